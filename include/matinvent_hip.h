@@ -1,0 +1,180 @@
+/*
+ * matinvent_hip.h -- C ABI of the MI355X (gfx950) hot path of MatInvent's RL-diffusion loop.
+ *
+ * The reference (schwallergroup/matinvent) has no FFI: its plug-in boundary is Python
+ * duck-typing.  These entry points are what a ctypes binding for that
+ * boundary binds; each one names the reference interface it replaces (path:line relative to
+ * the reference checkout).  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every `float*` / `int*` argument is a DEVICE pointer unless its name ends in `_host`;
+ *   - fp32 everywhere, indices int32, row-major, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it, nothing synchronises unless stated;
+ *   - every function returns 0 on success, a negative MI_E* code otherwise;
+ *     mi_last_error() returns a static, thread-local description;
+ *   - B crystals, N = sum(num_atoms) atoms, fully-connected edges E = sum(num_atoms^2),
+ *     H hidden width, L layers, F Fourier frequencies, TD time-embedding width,
+ *     A = 100 atom-type logits (MAX_ATOMIC_NUM, models/diffcsp/cspnet.py:9).
+ */
+#ifndef MATINVENT_HIP_H
+#define MATINVENT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument / unsupported hyper-parameter */
+#define MI_EHIP (-2)     /* a HIP runtime call failed */
+#define MI_ENOMEM (-3)
+#define MI_ESTATE (-4)   /* call order violated (e.g. forward before mi_net_set_params) */
+
+#define MI_NUM_TYPES 100
+
+typedef struct mi_net mi_net;       /* score network: hyper-parameters + packed weights   */
+typedef struct mi_batch mi_batch;   /* one batch of crystals: index tables + workspace    */
+
+const char* mi_last_error(void);
+int mi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Score network  --  replaces CSPNet (models/diffcsp/cspnet.py:94-294) as built by
+ * DiffCSPModule.__init__ (models/diffcsp/diffusion.py:73: smooth=True, pred_type=True,
+ * latent_dim += time_dim), fc edge style, dis_emb='sin', act 'silu', ip=True.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mi_net_config {
+    int hidden_dim;   /* H: 64, 128, 256 or 512                                  */
+    int num_layers;   /* L >= 1                                                  */
+    int num_freqs;    /* F >= 1                                                  */
+    int time_dim;     /* TD (latent_dim + time_dim of the reference), % 4 == 0   */
+    int ln;           /* 1: LayerNorm in every layer + final (cspnet.py:87,276)  */
+} mi_net_config;
+
+int mi_net_create(const mi_net_config* cfg, mi_net** out);
+void mi_net_destroy(mi_net* net);
+
+/* Number of fp32 parameters and the flat layout: the reference's `decoder.*` state_dict
+ * order (node_embedding.{weight,bias}, atom_latent_emb.{weight,bias}, per layer
+ * edge_mlp.0.{w,b}, edge_mlp.2.{w,b}, node_mlp.0.{w,b}, node_mlp.2.{w,b},
+ * layer_norm.{w,b}; coord_out.weight, lattice_out.weight, final_layer_norm.{w,b},
+ * type_out.{w,b}).  mi_net_param_offset fills offset/numel of the i-th tensor in that
+ * order and returns its name through a static string; returns MI_EINVAL past the end. */
+int64_t mi_net_num_params(const mi_net* net);
+int mi_net_num_tensors(const mi_net* net);
+int mi_net_param_info(const mi_net* net, int index, const char** name, int64_t* offset, int64_t* numel,
+                      int* rows, int* cols);
+
+/* Bind the flat parameter vector `theta` (device, mi_net_num_params floats, 16-byte aligned)
+ * and (re)build the MFMA-ready packed copies.  Must be called again after `theta` changes
+ * (i.e. after every optimizer step).  `fourier_freqs_host` = F floats, the table
+ * 2*pi*arange(F) of SinusoidsEmbedding (cspnet.py:16); copied on first call, may be NULL
+ * afterwards. */
+int mi_net_set_params(mi_net* net, const float* theta, const float* fourier_freqs_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Batch  --  replaces the PyG `Batch` bookkeeping the reference rebuilds on every decoder
+ * call: num_atoms -> node2graph (repeat_interleave, cspnet.py:269) and the fully connected
+ * edge list (block_diag + dense_to_sparse, cspnet.py:239-241, row-major incl. self loops).
+ * `node_offset`/`graph_offset` are the global indices of this shard's first atom / crystal
+ * (data-parallel sharding; they only enter the counter-based noise, so that a sharded run
+ * draws the same numbers as a single-GPU run).
+ * ------------------------------------------------------------------------------------- */
+int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset,
+                    int64_t graph_offset, mi_batch** out);
+void mi_batch_destroy(mi_batch* b);
+int mi_batch_num_nodes(const mi_batch* b);
+int64_t mi_batch_num_edges(const mi_batch* b);
+const int* mi_batch_node2graph(const mi_batch* b);   /* device, [N] */
+
+/* CSPNet.forward (cspnet.py:260-294).
+ *   t_emb [B,TD], atom_types [N,A] (continuous logits, smooth=True), frac [N,3],
+ *   lattices [B,3,3]  ->  lattice_out [B,3,3] (already multiplied by L, :289),
+ *   coord_out [N,3], type_out [N,A]. */
+int mi_cspnet_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types,
+                      const float* frac, const float* lattices, float* lattice_out, float* coord_out,
+                      float* type_out, void* stream);
+
+/* Debug / parity taps: copy out the node features after layer `layer` ([N,H]; layer = L
+ * means after the final LayerNorm) of the most recent forward on this batch. */
+int mi_cspnet_tap(mi_net* net, mi_batch* b, int layer, float* out, void* stream);
+
+/* SinusoidalTimeEmbeddings.forward (diffusion.py:53-66) for integer times.
+ * `freqs` = device table exp(arange(TD/2) * -log(1e4)/(TD/2-1)) (built by the host mirror
+ * with the same torch ops as the reference); times [B] int32 -> out [B,TD]. */
+int mi_time_embedding(const int* times, const float* freqs, int B, int time_dim, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Reverse sampler  --  replaces DiffCSPModule.sample (diffusion.py:273-399).
+ *
+ * `coef` is a host table [T+1][MI_NCOEF] of the per-step scalars the reference derives from
+ * its scheduler buffers at diffusion.py:297-343 (computed by the host mirror with the same
+ * fp32 ops):  see MI_C_* below.  The state (atom_types [N,A], frac [N,3], lattices [B,3,3])
+ * is updated in place from t = t_start down to t_stop+1; two network evaluations per step.
+ *
+ * Noise: if `noise` is NULL, draws come from the built-in counter-based Philox4x32-10 stream
+ * (key = seed, counter = (element>>2, 0, draw_id, step); DESIGN.md "RNG").  Otherwise
+ * `noise` points to caller-provided arrays (teacher-forced parity tests), indexed by step t.
+ * Recording: if `rec` is non-NULL, every field that the reference stores in traj[t]
+ * (diffusion.py:377-390) is written for each step.
+ * ------------------------------------------------------------------------------------- */
+#define MI_NCOEF 16
+#define MI_C_C0 0          /* 1/sqrt(alpha_t)                       diffusion.py:302 */
+#define MI_C_C1 1          /* (1-alpha_t)/sqrt(1-alphabar_t)        :303            */
+#define MI_C_SIGMA 2       /* beta_scheduler.sigmas[t]              :305            */
+#define MI_C_SQRT_SN 3     /* sqrt(sigmas_norm[t])                  :328            */
+#define MI_C_STEP_CORR 4   /* step_lr*(sigma_x/sigma_begin)^2       :324            */
+#define MI_C_STD_CORR 5    /* sqrt(2*step_corr)                     :325            */
+#define MI_C_STEP_PRED 6   /* sigma_x^2 - sigma_{x,t-1}^2           :342            */
+#define MI_C_STD_PRED 7    /* sqrt(adj^2*(sx^2-adj^2)/sx^2)         :343            */
+#define MI_C_STD_CORR_SQ 8 /* std_corr**2 (for log_prob_wn)         :26-28          */
+#define MI_C_STD_PRED_SQ 9 /* std_pred**2                                           */
+#define MI_C_SIGMA_SQ 10   /* sigma**2      (Normal.log_prob var)                   */
+#define MI_C_LOG_SIGMA 11  /* log(sigma)                                            */
+
+typedef struct mi_sampler_noise {   /* all device pointers; slice t of each array is used at step t */
+    const float* corr_x;   /* [T+1][N][3]   diffusion.py:322 */
+    const float* pred_l;   /* [T+1][B][9]   :337             */
+    const float* pred_t;   /* [T+1][N][A]   :338             */
+    const float* pred_x;   /* [T+1][N][3]   :339             */
+} mi_sampler_noise;
+
+typedef struct mi_sampler_record {  /* all device pointers, may individually be NULL */
+    float* atom_types;       /* [T+1][N][A]  traj[t]['atom_types']       */
+    float* frac_coords;      /* [T+1][N][3]  traj[t]['frac_coords']      */
+    float* lattices;         /* [T+1][B][9]  traj[t]['lattices']         */
+    float* frac_coords_mid;  /* [T+1][N][3]  traj[t]['frac_coords_mid']  (t > 1) */
+    float* log_prob_l;       /* [T+1][B]                                 (t > 1) */
+    float* log_prob_t;       /* [T+1][B]                                          */
+    float* log_prob_x;       /* [T+1][B]                                          */
+} mi_sampler_record;
+
+/* Initial state x_T ~ U[0,1), l_T, t_T ~ N(0,1) from the Philox stream (diffusion.py:277-279). */
+int mi_sampler_init_state(mi_batch* b, uint64_t seed, int T, float* atom_types, float* frac,
+                          float* lattices, void* stream);
+
+int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int t_start, int t_stop,
+                   const float* time_freqs, uint64_t seed, const mi_sampler_noise* noise,
+                   const mi_sampler_record* rec, float* atom_types, float* frac, float* lattices,
+                   void* stream);
+
+/* Fill `out` with n standard normals (uniform = 1: U[0,1)) of draw (step, draw_id), elements
+ * [elem_offset, elem_offset + n) -- exposes the noise contract for tests. */
+int mi_philox_fill(uint64_t seed, uint32_t step, uint32_t draw_id, int64_t elem_offset, int64_t n,
+                   int uniform, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Profiling hook used by bench.py: when enabled, the dominant kernel (edge-message MLP) is
+ * bracketed by hipEvents on its launch stream; mi_profile_read synchronises and returns the
+ * number of launches and their summed duration in milliseconds since the last reset.
+ * ------------------------------------------------------------------------------------- */
+int mi_profile_enable(mi_net* net, int on);
+int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATINVENT_HIP_H */

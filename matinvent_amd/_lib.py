@@ -1,0 +1,80 @@
+"""ctypes binding of include/matinvent_hip.h.  No fallback: if the HIP library is missing or
+a call fails, this raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmatinvent_hip.so")
+
+NCOEF = 16
+NUM_TYPES = 100
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("hidden_dim", C.c_int), ("num_layers", C.c_int), ("num_freqs", C.c_int), ("time_dim", C.c_int),
+                ("ln", C.c_int)]
+
+
+class SamplerNoise(C.Structure):
+    _fields_ = [("corr_x", C.c_void_p), ("pred_l", C.c_void_p), ("pred_t", C.c_void_p), ("pred_x", C.c_void_p)]
+
+
+class SamplerRecord(C.Structure):
+    _fields_ = [("atom_types", C.c_void_p), ("frac_coords", C.c_void_p), ("lattices", C.c_void_p),
+                ("frac_coords_mid", C.c_void_p), ("log_prob_l", C.c_void_p), ("log_prob_t", C.c_void_p),
+                ("log_prob_x", C.c_void_p)]
+
+
+_P, _I, _L, _U64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/matinvent_hip.h one to one
+SIGNATURES = {
+    "mi_last_error": (C.c_char_p, []),
+    "mi_version": (_I, []),
+    "mi_net_create": (_I, [C.POINTER(NetConfig), C.POINTER(_P)]),
+    "mi_net_destroy": (None, [_P]),
+    "mi_net_num_params": (_L, [_P]),
+    "mi_net_num_tensors": (_I, [_P]),
+    "mi_net_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I), C.POINTER(_I)]),
+    "mi_net_set_params": (_I, [_P, _P, C.POINTER(C.c_float), _P]),
+    "mi_batch_create": (_I, [_P, C.POINTER(_I), _I, _L, _L, C.POINTER(_P)]),
+    "mi_batch_destroy": (None, [_P]),
+    "mi_batch_num_nodes": (_I, [_P]),
+    "mi_batch_num_edges": (_L, [_P]),
+    "mi_batch_node2graph": (_P, [_P]),
+    "mi_cspnet_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_cspnet_tap": (_I, [_P, _P, _I, _P, _P]),
+    "mi_time_embedding": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mi_sampler_init_state": (_I, [_P, _U64, _I, _P, _P, _P, _P]),
+    "mi_sampler_run": (_I, [_P, _P, C.POINTER(C.c_float), _I, _I, _I, _P, _U64, C.POINTER(SamplerNoise),
+                            C.POINTER(SamplerRecord), _P, _P, _P, _P]),
+    "mi_philox_fill": (_I, [_U64, _U32, _U32, _L, _L, _I, _P, _P]),
+    "mi_profile_enable": (_I, [_P, _I]),
+    "mi_profile_read": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"matinvent_amd: HIP library not found at {LIB_PATH}; build it with `python -m matinvent_amd.build` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mi_last_error().decode(errors="replace")
+        raise RuntimeError(f"matinvent_hip {what} failed (code {rc}): {msg}")

@@ -1,0 +1,125 @@
+// Shared device/host helpers for the gfx950 hot path.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/matinvent_hip.h"
+
+namespace mi {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define MI_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            mi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                       \
+            return MI_EHIP;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define MI_CHECK(cond, code, ...)       \
+    do {                                \
+        if (!(cond)) {                  \
+            mi::set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+#define MI_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != MI_OK) return _r; \
+    } while (0)
+
+#define MI_KERNEL_CHECK() MI_HIP(hipGetLastError())
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device math ----------------------------------------------------------------------
+// torch.nn.functional.silu: x / (1 + exp(-x))
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// d silu / dx given x
+__device__ __forceinline__ float silu_grad(float x) {
+    float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+// python / torch `x % 1.` for floats (torch.remainder): result takes the sign of the divisor
+__device__ __forceinline__ float pymod1(float x) {
+    float r = fmodf(x, 1.0f);
+    if (r < 0.0f) r += 1.0f;
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- Philox4x32-10 (Random123), counter-based noise contract ---------------------------
+// key = (seed_lo, seed_hi); counter = (quad_lo, quad_hi, draw_id, step); element e of a draw
+// uses quad = e >> 2 and word e & 3.  Normals: Box-Muller on words (0,1) and (2,3).
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01_open_low(uint32_t x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-8f; }  // (0,1]
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }                    // [0,1)
+
+// the 4 normals of quad q of draw (step, draw_id)
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint32_t step, uint32_t draw, uint64_t quad, float out[4]) {
+    Philox4 r = philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), draw, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float r0 = sqrtf(-2.0f * logf(u01_open_low(r.x)));
+    float t0 = 6.2831853071795864769f * u01(r.y);
+    float r1 = sqrtf(-2.0f * logf(u01_open_low(r.z)));
+    float t1 = 6.2831853071795864769f * u01(r.w);
+    out[0] = r0 * cosf(t0);
+    out[1] = r0 * sinf(t0);
+    out[2] = r1 * cosf(t1);
+    out[3] = r1 * sinf(t1);
+}
+__device__ __forceinline__ float philox_normal1(uint64_t seed, uint32_t step, uint32_t draw, uint64_t elem) {
+    float z[4];
+    philox_normal4(seed, step, draw, elem >> 2, z);
+    return z[elem & 3];
+}
+__device__ __forceinline__ float philox_uniform1(uint64_t seed, uint32_t step, uint32_t draw, uint64_t elem) {
+    uint64_t quad = elem >> 2;
+    Philox4 r = philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), draw, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t w = (elem & 3) == 0 ? r.x : (elem & 3) == 1 ? r.y : (elem & 3) == 2 ? r.z : r.w;
+    return u01(w);
+}
+
+// draw ids (DESIGN.md "RNG"; mirrored in oracle/diffcsp_oracle.py for the checker)
+enum : uint32_t {
+    DRAW_X_T = 0, DRAW_L_T = 1, DRAW_T_T = 2,
+    DRAW_CORR_X = 3, DRAW_PRED_L = 4, DRAW_PRED_T = 5, DRAW_PRED_X = 6,
+    DRAW_FT_L = 7, DRAW_FT_X = 8, DRAW_FT_T = 9,
+};
+
+}  // namespace mi

@@ -1,0 +1,565 @@
+// CSPNet score network on gfx950: weight packing, node-level kernels, forward orchestration
+// and the mi_net / mi_batch C entry points.  Reference: models/diffcsp/cspnet.py.
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "edge_mlp.h"
+#include "gemm.h"
+#include "net.h"
+
+namespace mi {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// Packing kernels: theta (nn.Linear [out,in]) -> MFMA-ready layouts
+// ------------------------------------------------------------------------------------------
+// Whh[2H][H]: rows [0,H) = W1[f][0:H], rows [H,2H) = W1[f][H:2H]   (W1 row stride = edge_in)
+__global__ void pack_whh_kernel(const float* __restrict__ W1, int edge_in, int H, float* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * H * H) return;
+    int r = idx / H, k = idx % H;
+    out[idx] = r < H ? W1[(size_t)r * edge_in + k] : W1[(size_t)(r - H) * edge_in + H + k];
+}
+
+// Wff_p[m][t][lane][q]: feature f = 32t + (lane&31); pair s = 4m+q = c*F + k; hi = lane>>5 selects
+// the sin column (2H+9 + c*F + k) or the cos column (2H+9 + 3F + c*F + k) of W1.  Pads are zero.
+__global__ void pack_wff_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int KP, float* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int NT = H / 32;
+    int total = (KP / 4) * NT * 256;
+    if (idx >= total) return;
+    int q = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) % NT, m = (idx >> 8) / NT;
+    int s = 4 * m + q, f = 32 * t + (lane & 31), hi = lane >> 5;
+    float v = 0.f;
+    if (s < 3 * F) v = W1[(size_t)f * edge_in + 2 * H + 9 + (hi ? 3 * F : 0) + s];
+    out[idx] = v;
+}
+
+// W2_p[u][t][q][lane][c] = W2[32u + (lane&31)][32t + 8q + 4(lane>>5) + c]
+__global__ void pack_w2_kernel(const float* __restrict__ W2, int H, float* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int NT = H / 32;
+    if (idx >= H * H) return;
+    int c = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, t = (idx >> 10) % NT, u = (idx >> 10) / NT;
+    out[idx] = W2[(size_t)(32 * u + (lane & 31)) * H + 32 * t + 8 * q + 4 * (lane >> 5) + c];
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (one wave per row).  y has row stride ldy (writes into cat[:, :H]).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bsh, float* __restrict__ y, int ldy,
+                                                        float* __restrict__ stats, int N, int H) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = x + (size_t)row * H;
+    float v[8];
+    float s = 0.f;
+    int cnt = 0;
+    for (int c = lane; c < H; c += 64) {
+        v[cnt] = xr[c];
+        s += v[cnt++];
+    }
+    float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int k = 0; k < cnt; ++k) {
+        float d = v[k] - mean;
+        q += d * d;
+    }
+    float var = wave_sum(q) / (float)H;
+    float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float* yr = y + (size_t)row * ldy;
+    cnt = 0;
+    for (int c = lane; c < H; c += 64) yr[c] = (v[cnt++] - mean) * rstd * w[c] + bsh[c];
+    if (stats && lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int r = (int)(idx / H), c = (int)(idx % H);
+    y[(size_t)r * ldy + c] = x[idx];
+}
+
+// G[b][f] = b1[f] + sum_m (L L^T)[b].flat[m] * W1[f][2H + m]      (cspnet.py:68-72)
+__global__ void gram_term_kernel(const float* __restrict__ lattices, const float* __restrict__ W1, int edge_in,
+                                 const float* __restrict__ b1, float* __restrict__ G, int H) {
+    int b = blockIdx.x;
+    __shared__ float gram[9];
+    if (threadIdx.x < 9) {
+        int r = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float* Lm = lattices + (size_t)b * 9;
+        gram[threadIdx.x] = Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+        const float* w = W1 + (size_t)f * edge_in + 2 * H;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) s += gram[m] * w[m];
+        G[(size_t)b * H + f] = s + b1[f];
+    }
+}
+
+// agg[i] = (sum of this node's slots) / degree  -> cat[i][H:2H]       (scatter mean, cspnet.py:79)
+__global__ void finalize_agg_kernel(const float* __restrict__ part, const int* __restrict__ rowptr,
+                                    float* __restrict__ cat, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int i = (int)(idx / H), f = (int)(idx % H);
+    int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float s = 0.f;
+    if (e1 > e0) {
+        int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
+        for (int sl = 0; sl <= t1 - t0; ++sl) s += part[((size_t)sl * N + i) * H + f];
+        s = s / (float)(e1 - e0);
+    }
+    cat[(size_t)i * (2 * H) + H + f] = s;
+}
+
+// graph mean-pool + lattice head:  out[b] = reshape(Wl * mean_i hf_i, 3, 3) @ L_b  (cspnet.py:281-289)
+__global__ __launch_bounds__(256) void lattice_head_kernel(const float* __restrict__ hf, const int* __restrict__ node_off,
+                                                           const float* __restrict__ Wl, const float* __restrict__ lattices,
+                                                           float* __restrict__ out, float* __restrict__ gf_out, int H) {
+    int b = blockIdx.x;
+    extern __shared__ float sm[];  // H + 9
+    float* gf = sm;
+    float* lo = sm + H;
+    int n0 = node_off[b], n1 = node_off[b + 1];
+    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+        float s = 0.f;
+        for (int i = n0; i < n1; ++i) s += hf[(size_t)i * H + f];
+        float cnt = (float)(n1 - n0);
+        gf[f] = s / (cnt < 1.f ? 1.f : cnt);
+        if (gf_out) gf_out[(size_t)b * H + f] = gf[f];
+    }
+    __syncthreads();
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int m = wave; m < 9; m += 4) {
+        float s = 0.f;
+        for (int f = lane; f < H; f += 64) s += Wl[(size_t)m * H + f] * gf[f];
+        s = wave_sum(s);
+        if (lane == 0) lo[m] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        int r = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float* Lm = lattices + (size_t)b * 9;
+        out[(size_t)b * 9 + threadIdx.x] = lo[r * 3] * Lm[c] + lo[r * 3 + 1] * Lm[3 + c] + lo[r * 3 + 2] * Lm[6 + c];
+    }
+}
+
+template <typename T>
+int dev_alloc(mi_batch* b, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return MI_ENOMEM;
+    }
+    b->allocs.push_back(q);
+    *p = (T*)q;
+    return MI_OK;
+}
+template int dev_alloc<float>(mi_batch*, float**, size_t);
+template int dev_alloc<int>(mi_batch*, int**, size_t);
+
+static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, float* Z1, float* Z2, hipStream_t s) {
+    const std::string p = "csp_layer_" + std::to_string(layer) + ".";
+    EdgeFwdArgs a;
+    a.PQ = b->PQ;
+    a.G = b->G;
+    a.frac = frac;
+    a.src = b->src;
+    a.dst = b->dst;
+    a.node2graph = b->node2graph;
+    a.rowptr = b->rowptr;
+    a.freqs = net->freqs;
+    a.Wff_p = net->Wff_p + layer * net->wff_stride();
+    a.W2_p = net->W2_p + layer * net->w2_stride();
+    a.b2 = net->p(p + "edge_mlp.2.bias");
+    a.part = b->part;
+    a.Z1 = Z1;
+    a.Z2 = Z2;
+    a.E = b->E;
+    a.N = b->N;
+    a.F = net->F;
+    a.KP = net->KP;
+    if (b->E == 0) return MI_OK;
+    dim3 grid((unsigned)cdiv(b->E, 32)), block(64);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (net->prof) {
+        if (net->ev_used + 2 > net->ev.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t ev;
+                MI_HIP(hipEventCreate(&ev));
+                net->ev.push_back(ev);
+            }
+        }
+        e0 = net->ev[net->ev_used++];
+        e1 = net->ev[net->ev_used++];
+        MI_HIP(hipEventRecord(e0, s));
+    }
+    switch (net->H) {
+        case 64: hipLaunchKernelGGL(edge_mlp_fwd_kernel<64>, grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL(edge_mlp_fwd_kernel<128>, grid, block, 0, s, a); break;
+        case 256: hipLaunchKernelGGL(edge_mlp_fwd_kernel<256>, grid, block, 0, s, a); break;
+        case 512: hipLaunchKernelGGL(edge_mlp_fwd_kernel<512>, grid, block, 0, s, a); break;
+        default: set_error("unsupported hidden_dim %d", net->H); return MI_EINVAL;
+    }
+    MI_KERNEL_CHECK();
+    if (net->prof) MI_HIP(hipEventRecord(e1, s));
+    return MI_OK;
+}
+
+int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s) {
+    MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_cspnet_forward before mi_net_set_params");
+    const int H = net->H, L = net->L, N = b->N, B = b->B, TD = net->TD;
+    if (N == 0 || B == 0) return MI_OK;
+    const size_t NH = (size_t)N * H;
+    // ---- embedding (cspnet.py:265-271) ----
+    {
+        GemmEpilogue ep;
+        ep.bias = net->p("node_embedding.bias");
+        MI_TRY(gemm_nt(atom_types, MI_NUM_TYPES, net->p("node_embedding.weight"), MI_NUM_TYPES, b->x1, H, N, H, MI_NUM_TYPES, ep, s));
+        GemmEpilogue et;
+        et.bias = net->p("atom_latent_emb.bias");
+        MI_TRY(gemm_nt(t_emb, TD, net->p("atom_latent_emb.weight") + H, H + TD, b->tproj, H, B, H, TD, et, s));
+        GemmEpilogue eh;
+        eh.row_bias = b->tproj;
+        eh.row_group = b->node2graph;
+        eh.ld_row_bias = H;
+        MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s));
+    }
+    // ---- message-passing layers (cspnet.py:84-91) ----
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        const float* h_in = b->h + l * NH;
+        float* h_out = b->h + (l + 1) * NH;
+        if (net->cfg.ln) {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_in, net->p(p + "layer_norm.weight"),
+                               net->p(p + "layer_norm.bias"), b->cat, 2 * H, (float*)nullptr, N, H);
+        } else {
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, b->cat, 2 * H, N, H);
+        }
+        MI_KERNEL_CHECK();
+        MI_TRY(gemm_nt(b->cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
+        hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
+                           net->p(p + "edge_mlp.0.bias"), b->G, H);
+        MI_KERNEL_CHECK();
+        MI_TRY(launch_edge(net, b, l, frac, nullptr, nullptr, s));
+        hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, b->cat, N, H);
+        MI_KERNEL_CHECK();
+        GemmEpilogue e1;
+        e1.bias = net->p(p + "node_mlp.0.bias");
+        e1.act = ACT_SILU;
+        MI_TRY(gemm_nt(b->cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s));
+        GemmEpilogue e2;
+        e2.bias = net->p(p + "node_mlp.2.bias");
+        e2.act = ACT_SILU;
+        e2.residual = h_in;
+        e2.ld_res = H;
+        MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s));
+    }
+    // ---- heads (cspnet.py:276-291) ----
+    const float* h_last = b->h + (size_t)L * NH;
+    if (net->cfg.ln) {
+        hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_last, net->p("final_layer_norm.weight"),
+                           net->p("final_layer_norm.bias"), b->hf, H, (float*)nullptr, N, H);
+    } else {
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
+    }
+    MI_KERNEL_CHECK();
+    MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s));
+    GemmEpilogue et;
+    et.bias = net->p("type_out.bias");
+    MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s));
+    hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (H + 9) * sizeof(float), s, b->hf, b->node_off,
+                       net->p("lattice_out.weight"), lattices, lattice_out, (float*)nullptr, H);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+int64_t mi_net::off(const std::string& name) const {
+    for (const auto& p : params)
+        if (p.name == name) return p.off;
+    fprintf(stderr, "matinvent_hip: unknown parameter %s\n", name.c_str());
+    abort();
+}
+
+extern "C" {
+
+const char* mi_last_error(void) { return mi::g_err; }
+int mi_version(void) { return 1; }
+
+int mi_net_create(const mi_net_config* cfg, mi_net** out) {
+    MI_CHECK(cfg && out, MI_EINVAL, "null argument");
+    const int H = cfg->hidden_dim;
+    MI_CHECK(H == 64 || H == 128 || H == 256 || H == 512, MI_EINVAL, "hidden_dim must be 64/128/256/512, got %d", H);
+    MI_CHECK(cfg->num_layers >= 1 && cfg->num_freqs >= 1, MI_EINVAL, "num_layers/num_freqs must be >= 1");
+    MI_CHECK(cfg->time_dim > 0 && cfg->time_dim % 4 == 0, MI_EINVAL, "time_dim must be a positive multiple of 4");
+    mi_net* n = new mi_net();
+    n->cfg = *cfg;
+    n->H = H;
+    n->L = cfg->num_layers;
+    n->F = cfg->num_freqs;
+    n->TD = cfg->time_dim;
+    n->NT = H / 32;
+    n->KP = (3 * n->F + 3) / 4 * 4;
+    n->edge_in = 2 * H + 9 + 6 * n->F;
+    int64_t off = 0;
+    auto add = [&](const std::string& name, int rows, int cols) {
+        n->params.push_back(ParamInfo{name, off, (int64_t)rows * cols, rows, cols});
+        off += (int64_t)rows * cols;
+    };
+    add("node_embedding.weight", H, MI_NUM_TYPES);
+    add("node_embedding.bias", 1, H);
+    add("atom_latent_emb.weight", H, H + n->TD);
+    add("atom_latent_emb.bias", 1, H);
+    for (int l = 0; l < n->L; ++l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        add(p + "edge_mlp.0.weight", H, n->edge_in);
+        add(p + "edge_mlp.0.bias", 1, H);
+        add(p + "edge_mlp.2.weight", H, H);
+        add(p + "edge_mlp.2.bias", 1, H);
+        add(p + "node_mlp.0.weight", H, 2 * H);
+        add(p + "node_mlp.0.bias", 1, H);
+        add(p + "node_mlp.2.weight", H, H);
+        add(p + "node_mlp.2.bias", 1, H);
+        if (cfg->ln) {
+            add(p + "layer_norm.weight", 1, H);
+            add(p + "layer_norm.bias", 1, H);
+        }
+    }
+    add("coord_out.weight", 3, H);
+    add("lattice_out.weight", 9, H);
+    if (cfg->ln) {
+        add("final_layer_norm.weight", 1, H);
+        add("final_layer_norm.bias", 1, H);
+    }
+    add("type_out.weight", MI_NUM_TYPES, H);
+    add("type_out.bias", 1, MI_NUM_TYPES);
+    n->nparams = off;
+    *out = n;
+    return MI_OK;
+}
+
+void mi_net_destroy(mi_net* n) {
+    if (!n) return;
+    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p})
+        if (p) (void)hipFree(p);
+    for (auto e : n->ev) (void)hipEventDestroy(e);
+    delete n;
+}
+
+int64_t mi_net_num_params(const mi_net* n) { return n ? n->nparams : 0; }
+int mi_net_num_tensors(const mi_net* n) { return n ? (int)n->params.size() : 0; }
+
+int mi_net_param_info(const mi_net* n, int index, const char** name, int64_t* offset, int64_t* numel, int* rows, int* cols) {
+    MI_CHECK(n && index >= 0 && index < (int)n->params.size(), MI_EINVAL, "parameter index %d out of range", index);
+    const ParamInfo& p = n->params[index];
+    if (name) *name = p.name.c_str();
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (rows) *rows = p.rows;
+    if (cols) *cols = p.cols;
+    return MI_OK;
+}
+
+int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, void* stream) {
+    MI_CHECK(n && theta, MI_EINVAL, "null argument");
+    MI_CHECK((((uintptr_t)theta) & 15) == 0, MI_EINVAL, "theta must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = n->H;
+    if (!n->Whh) {
+        MI_HIP(hipMalloc((void**)&n->Whh, n->L * n->whh_stride() * sizeof(float)));
+        MI_HIP(hipMalloc((void**)&n->Wff_p, n->L * n->wff_stride() * sizeof(float)));
+        MI_HIP(hipMalloc((void**)&n->W2_p, n->L * n->w2_stride() * sizeof(float)));
+        MI_HIP(hipMalloc((void**)&n->freqs, n->F * sizeof(float)));
+    }
+    if (freqs_host) {
+        MI_HIP(hipMemcpyAsync(n->freqs, freqs_host, n->F * sizeof(float), hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));  // the host buffer may be transient
+        n->have_freqs = true;
+    }
+    MI_CHECK(n->have_freqs, MI_ESTATE, "fourier_freqs_host must be given on the first mi_net_set_params");
+    n->theta = theta;
+    for (int l = 0; l < n->L; ++l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        const float* W1 = n->p(p + "edge_mlp.0.weight");
+        const float* W2 = n->p(p + "edge_mlp.2.weight");
+        hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2 * H * H, 256)), dim3(256), 0, s, W1, n->edge_in, H,
+                           n->Whh + l * n->whh_stride());
+        hipLaunchKernelGGL(pack_wff_kernel, dim3(cdiv(n->wff_stride(), 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->KP,
+                           n->Wff_p + l * n->wff_stride());
+        hipLaunchKernelGGL(pack_w2_kernel, dim3(cdiv(H * H, 256)), dim3(256), 0, s, W2, H, n->W2_p + l * n->w2_stride());
+    }
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
+                    mi_batch** out) {
+    MI_CHECK(net && out && (num_atoms_host || B == 0) && B >= 0, MI_EINVAL, "bad argument");
+    mi_batch* b = new mi_batch();
+    b->B = B;
+    b->H = net->H;
+    b->L = net->L;
+    b->node_offset = node_offset;
+    b->graph_offset = graph_offset;
+    b->num_atoms_h.assign(num_atoms_host, num_atoms_host + B);
+    b->node_off_h.assign(B + 1, 0);
+    int64_t E = 0;
+    for (int g = 0; g < B; ++g) {
+        if (num_atoms_host[g] < 0) {
+            delete b;
+            set_error("num_atoms[%d] = %d is negative", g, num_atoms_host[g]);
+            return MI_EINVAL;
+        }
+        b->node_off_h[g + 1] = b->node_off_h[g] + num_atoms_host[g];
+        E += (int64_t)num_atoms_host[g] * num_atoms_host[g];
+    }
+    const int N = b->node_off_h[B];
+    b->N = N;
+    b->E = E;
+    if (E >= (int64_t)1 << 31) {
+        delete b;
+        set_error("edge count %lld exceeds int32", (long long)E);
+        return MI_EINVAL;
+    }
+    // fully connected edges, row-major incl. self loops (cspnet.py:239-241)
+    std::vector<int> n2g(N), src((size_t)E), dst((size_t)E), rowptr(N + 1, 0);
+    size_t e = 0;
+    int nslots = 1;
+    for (int g = 0; g < B; ++g) {
+        int n = num_atoms_host[g], o = b->node_off_h[g];
+        for (int i = 0; i < n; ++i) {
+            n2g[o + i] = g;
+            rowptr[o + i] = (int)e;
+            for (int j = 0; j < n; ++j) {
+                src[e] = o + i;
+                dst[e] = o + j;
+                ++e;
+            }
+            nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
+        }
+    }
+    rowptr[N] = (int)e;
+    b->nslots = nslots;
+    const int H = net->H, L = net->L;
+    const size_t NH = (size_t)N * H;
+    int rc = MI_OK;
+#define A_(p, n)                                   \
+    if (rc == MI_OK) rc = dev_alloc(b, &b->p, (n))
+    A_(num_atoms, B);
+    A_(node_off, B + 1);
+    A_(node2graph, N);
+    A_(src, (size_t)E);
+    A_(dst, (size_t)E);
+    A_(rowptr, N + 1);
+    A_(h, (L + 1) * NH);
+    A_(cat, 2 * NH);
+    A_(PQ, 2 * NH);
+    A_(G, (size_t)B * H);
+    A_(part, nslots * NH);
+    A_(X, NH);
+    A_(x1, NH);
+    A_(tproj, (size_t)B * H);
+    A_(hf, NH);
+    A_(temb, (size_t)B * net->TD);
+    A_(times, B);
+    A_(pred_l, (size_t)B * 9);
+    A_(pred_x, (size_t)N * 3);
+    A_(pred_t, (size_t)N * MI_NUM_TYPES);
+    A_(x_mid, (size_t)N * 3);
+    A_(lp_corr, B);
+#undef A_
+    if (rc != MI_OK) {
+        mi_batch_destroy(b);
+        return rc;
+    }
+    auto up = [&](int* d, const std::vector<int>& h) {
+        return h.empty() ? hipSuccess : hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+    };
+    hipError_t he = up(b->num_atoms, b->num_atoms_h);
+    if (he == hipSuccess) he = up(b->node_off, b->node_off_h);
+    if (he == hipSuccess) he = up(b->node2graph, n2g);
+    if (he == hipSuccess) he = up(b->src, src);
+    if (he == hipSuccess) he = up(b->dst, dst);
+    if (he == hipSuccess) he = up(b->rowptr, rowptr);
+    if (he != hipSuccess) {
+        set_error("index table upload failed: %s", hipGetErrorString(he));
+        mi_batch_destroy(b);
+        return MI_EHIP;
+    }
+    *out = b;
+    return MI_OK;
+}
+
+void mi_batch_destroy(mi_batch* b) {
+    if (!b) return;
+    for (void* p : b->allocs) (void)hipFree(p);
+    delete b;
+}
+
+int mi_batch_num_nodes(const mi_batch* b) { return b ? b->N : 0; }
+int64_t mi_batch_num_edges(const mi_batch* b) { return b ? b->E : 0; }
+const int* mi_batch_node2graph(const mi_batch* b) { return b ? b->node2graph : nullptr; }
+
+int mi_cspnet_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
+                      const float* lattices, float* lattice_out, float* coord_out, float* type_out, void* stream) {
+    MI_CHECK(net && b, MI_EINVAL, "null handle");
+    MI_CHECK(b->H == net->H && b->L == net->L, MI_EINVAL, "batch was created for a different network");
+    return net_forward(net, b, t_emb, atom_types, frac, lattices, lattice_out, coord_out, type_out, (hipStream_t)stream);
+}
+
+int mi_cspnet_tap(mi_net* net, mi_batch* b, int layer, float* out, void* stream) {
+    MI_CHECK(net && b && out, MI_EINVAL, "null argument");
+    MI_CHECK(layer >= 0 && layer <= net->L + 1, MI_EINVAL, "layer %d out of range", layer);
+    const size_t NH = (size_t)b->N * net->H;
+    const float* src = layer <= net->L ? b->h + (size_t)layer * NH : b->hf;
+    MI_HIP(hipMemcpyAsync(out, src, NH * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MI_OK;
+}
+
+int mi_profile_enable(mi_net* net, int on) {
+    MI_CHECK(net, MI_EINVAL, "null handle");
+    net->prof = on != 0;
+    net->ev_used = 0;
+    return MI_OK;
+}
+
+int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms) {
+    MI_CHECK(net && launches && total_ms, MI_EINVAL, "null argument");
+    double tot = 0;
+    int64_t n = 0;
+    for (size_t k = 0; k + 1 < net->ev_used; k += 2) {
+        MI_HIP(hipEventSynchronize(net->ev[k + 1]));
+        float ms = 0;
+        MI_HIP(hipEventElapsedTime(&ms, net->ev[k], net->ev[k + 1]));
+        tot += ms;
+        ++n;
+    }
+    *launches = n;
+    *total_ms = tot;
+    net->ev_used = 0;
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Host-side objects behind the opaque C handles.
+#pragma once
+#include "common.h"
+
+struct ParamInfo {
+    std::string name;
+    int64_t off, numel;
+    int rows, cols;
+};
+
+struct mi_net {
+    mi_net_config cfg;
+    int H, L, F, TD, KP, NT;  // KP: (sin,cos) pairs padded to a multiple of 4; NT = H/32
+    int edge_in;              // 2H + 9 + 6F
+    std::vector<ParamInfo> params;
+    int64_t nparams = 0;
+    const float* theta = nullptr;  // caller-owned flat parameters (device)
+    float* freqs = nullptr;        // [F] device
+    bool have_freqs = false;
+    // packed copies, rebuilt by mi_net_set_params
+    float* Whh = nullptr;    // [L][2H][H]   rows [0,H) = W1[:, :H], rows [H,2H) = W1[:, H:2H]
+    float* Wff_p = nullptr;  // [L][KP/4][NT][64][4]
+    float* W2_p = nullptr;   // [L][NT][NT][4][64][4]
+    // profiling of the dominant kernel
+    bool prof = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t ev_used = 0;
+
+    int64_t off(const std::string& name) const;
+    const float* p(const std::string& name) const { return theta + off(name); }
+    size_t whh_stride() const { return (size_t)2 * H * H; }
+    size_t wff_stride() const { return (size_t)(KP / 4) * NT * 256; }
+    size_t w2_stride() const { return (size_t)NT * NT * 4 * 256; }
+};
+
+struct mi_batch {
+    int B = 0, N = 0, H = 0, L = 0;
+    int64_t E = 0;
+    int nslots = 1;
+    int64_t node_offset = 0, graph_offset = 0;
+    std::vector<int> num_atoms_h, node_off_h;
+    // index tables (device)
+    int *num_atoms = nullptr, *node_off = nullptr /*[B+1]*/, *node2graph = nullptr, *src = nullptr, *dst = nullptr,
+        *rowptr = nullptr /*[N+1]*/;
+    // forward workspace (device)
+    float* h = nullptr;      // [L+1][N][H] node features before layer l / after the last
+    float* cat = nullptr;    // [N][2H]  (LN(h) | agg)
+    float* PQ = nullptr;     // [N][2H]
+    float* G = nullptr;      // [B][H]
+    float* part = nullptr;   // [nslots][N][H]
+    float* X = nullptr;      // [N][H] node-MLP hidden
+    float* x1 = nullptr;     // [N][H] node_embedding output
+    float* tproj = nullptr;  // [B][H]
+    float* hf = nullptr;     // [N][H] after the final LayerNorm
+    // sampler scratch
+    float* temb = nullptr;     // [B][TD]
+    int* times = nullptr;      // [B]
+    float* pred_l = nullptr;   // [B][9]
+    float* pred_x = nullptr;   // [N][3]
+    float* pred_t = nullptr;   // [N][100]
+    float* x_mid = nullptr;    // [N][3]
+    float* lp_corr = nullptr;  // [B]
+    float* coef = nullptr;     // [T+1][MI_NCOEF]
+    int coef_T = -1;
+    std::vector<void*> allocs;
+};
+
+namespace mi {
+int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s);
+template <typename T>
+int dev_alloc(mi_batch* b, T** p, size_t n);
+}  // namespace mi

@@ -1,0 +1,285 @@
+// Reverse-diffusion sampler on gfx950: DiffCSPModule.sample (models/diffcsp/diffusion.py:273-399).
+// Two score-network evaluations per step (corrector, predictor), state updates and the per-step
+// log-probabilities, with no host synchronisation inside the chain.
+//
+// The update arithmetic mirrors the reference's separately-rounded fp32 tensor ops, so
+// contraction into FMAs is disabled for this translation unit.
+#pragma clang fp contract(off)
+
+#include "net.h"
+
+namespace mi {
+
+// SinusoidalTimeEmbeddings.forward (diffusion.py:59-66): out[b] = [sin(t*f_k) | cos(t*f_k)]
+__global__ void time_embedding_kernel(const int* __restrict__ times, const float* __restrict__ freqs, float* __restrict__ out,
+                                      int B, int TD) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * TD) return;
+    int b = idx / TD, k = idx % TD, half = TD / 2;
+    float arg = (float)times[b] * freqs[k < half ? k : k - half];
+    out[idx] = k < half ? sinf(arg) : cosf(arg);
+}
+
+__global__ void fill_int_kernel(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void philox_fill_kernel(uint64_t seed, uint32_t step, uint32_t draw, int64_t off, int64_t n, int uniform,
+                                   float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t e = (uint64_t)(off + i);
+    out[i] = uniform ? philox_uniform1(seed, step, draw, e) : philox_normal1(seed, step, draw, e);
+}
+
+struct StepCoef {
+    float c0, c1, sigma, sqrt_sn, step_corr, std_corr, step_pred, std_pred, std_corr_sq, std_pred_sq, sigma_sq, log_sigma;
+};
+__device__ __forceinline__ StepCoef load_coef(const float* coef, int t) {
+    const float* c = coef + (size_t)t * MI_NCOEF;
+    return StepCoef{c[MI_C_C0], c[MI_C_C1], c[MI_C_SIGMA], c[MI_C_SQRT_SN], c[MI_C_STEP_CORR], c[MI_C_STD_CORR],
+                    c[MI_C_STEP_PRED], c[MI_C_STD_PRED], c[MI_C_STD_CORR_SQ], c[MI_C_STD_PRED_SQ], c[MI_C_SIGMA_SQ],
+                    c[MI_C_LOG_SIGMA]};
+}
+
+// log_prob_wn (diffusion.py:25-29): log sum_{i=-10..10} exp(-(x - mu + i)^2 / 2 / sigma^2)
+__device__ __forceinline__ float log_prob_wn(float x, float mu, float sigma_sq) {
+    float p = 0.f;
+    float d = x - mu;
+#pragma unroll
+    for (int i = -10; i <= 10; ++i) {
+        float v = d + (float)i;
+        p += expf(-(v * v) / 2.0f / sigma_sq);
+    }
+    return logf(p);
+}
+// torch.distributions.Normal(mu, sigma).log_prob(v)
+__device__ __forceinline__ float normal_log_prob(float v, float mu, float var, float log_sigma) {
+    float d = v - mu;
+    return -(d * d) / (2.0f * var) - log_sigma - 0.91893853320467274178f;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- corrector (diffusion.py:320-334): x_{t-1/2} = x_t - eps * s + sqrt(2 eps) z ---------------
+// one 64-lane block per crystal; also the corrector half of log_prob_x (:363-368)
+__global__ __launch_bounds__(64) void corrector_kernel(const float* __restrict__ x_t, const float* __restrict__ pred_x,
+                                                       const float* __restrict__ noise_x, const float* __restrict__ coef, int t,
+                                                       uint64_t seed, int64_t node_offset, const int* __restrict__ node_off,
+                                                       float* __restrict__ x_mid, float* __restrict__ lp_corr,
+                                                       float* __restrict__ rec_mid) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const StepCoef c = load_coef(coef, t);
+    const int n0 = node_off[b], n1 = node_off[b + 1];
+    float lp = 0.f;
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64) {
+        float z = 0.f;
+        if (t > 1) z = noise_x ? noise_x[idx] : philox_normal1(seed, (uint32_t)t, DRAW_CORR_X, (uint64_t)node_offset * 3 + idx);
+        float px = pred_x[idx] * c.sqrt_sn;
+        float drift = x_t[idx] - c.step_corr * px;
+        float xm = drift + c.std_corr * z;
+        x_mid[idx] = xm;
+        float xmw = pymod1(xm);
+        if (rec_mid && t > 1) rec_mid[idx] = xmw;
+        if (t > 1) lp += log_prob_wn(xmw, pymod1(drift), c.std_corr_sq);
+    }
+    lp = wave_sum(lp);
+    // mean over the 3 coordinates, then mean over the atoms of the crystal
+    if (lane == 0) lp_corr[b] = (n1 > n0) ? (lp / 3.0f) / (float)(n1 - n0) : 0.f;
+}
+
+// ---- predictor (diffusion.py:337-382) -------------------------------------------------------
+struct PredictorArgs {
+    const float *x_mid, *pred_x, *pred_l, *pred_t;
+    const float *noise_x, *noise_l, *noise_t;  // slices for step t, or NULL (Philox)
+    const float* coef;
+    const int* node_off;
+    const float* lp_corr;
+    float *frac, *lattices, *atom_types;  // state, updated in place
+    float *rec_types, *rec_frac, *rec_lat, *rec_lpl, *rec_lpt, *rec_lpx;  // slices (t-1 for state, t for log-probs)
+    uint64_t seed;
+    int64_t node_offset, graph_offset;
+    int t;
+};
+
+__global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = a.t;
+    const StepCoef c = load_coef(a.coef, t);
+    const int n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    const float cnt = (float)(n > 0 ? n : 1);
+
+    // lattice: l_{t-1} = c0 (l_t - c1 pred_l) + sigma z
+    float lp_l = 0.f;
+    if (tid < 9) {
+        int idx = b * 9 + tid;
+        float z = 0.f;
+        if (t > 1) z = a.noise_l ? a.noise_l[idx] : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_L, (uint64_t)a.graph_offset * 9 + idx);
+        float mu = c.c0 * (a.lattices[idx] - c.c1 * a.pred_l[idx]);
+        float v = mu + c.sigma * z;
+        a.lattices[idx] = v;
+        if (a.rec_lat) a.rec_lat[idx] = v;
+        if (t > 1) lp_l = normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+    }
+    lp_l = block_sum_256(lp_l, red);
+
+    // coordinates: x_{t-1} = (x_{t-1/2} - step * s + std z) % 1
+    float lp_x = 0.f;
+    for (int idx = n0 * 3 + tid; idx < n1 * 3; idx += 256) {
+        float z = 0.f;
+        if (t > 1) z = a.noise_x ? a.noise_x[idx] : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_X, (uint64_t)a.node_offset * 3 + idx);
+        float px = a.pred_x[idx] * c.sqrt_sn;
+        float drift = a.x_mid[idx] - c.step_pred * px;
+        float v = pymod1(drift + c.std_pred * z);
+        if (t > 1) lp_x += log_prob_wn(v, pymod1(drift), c.std_pred_sq);
+        v = pymod1(v);  // traj[t-1]['frac_coords'] = x_{t-1} % 1  (:386)
+        a.frac[idx] = v;
+        if (a.rec_frac) a.rec_frac[idx] = v;
+    }
+    lp_x = block_sum_256(lp_x, red);
+
+    // atom-type logits: one wave per atom
+    float lp_t = 0.f;
+    for (int i = n0 + wave; i < n1; i += 4) {
+        float s = 0.f;
+        for (int k = lane; k < MI_NUM_TYPES; k += 64) {
+            int64_t idx = (int64_t)i * MI_NUM_TYPES + k;
+            float z = 0.f;
+            if (t > 1)
+                z = a.noise_t ? a.noise_t[idx]
+                              : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_T, (uint64_t)a.node_offset * MI_NUM_TYPES + idx);
+            float mu = c.c0 * (a.atom_types[idx] - c.c1 * a.pred_t[idx]);
+            float v = mu + c.sigma * z;
+            a.atom_types[idx] = v;
+            if (a.rec_types) a.rec_types[idx] = v;
+            if (t > 1) s += normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+        }
+        s = wave_sum(s);
+        lp_t += s / (float)MI_NUM_TYPES;  // mean over the 100 logits (:358)
+    }
+    // every lane of a wave holds the same lp_t; add the four waves
+    __syncthreads();
+    if (lane == 0) red[wave] = lp_t;
+    __syncthreads();
+    if (tid == 0 && t > 1) {
+        float lpt = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+        if (a.rec_lpl) a.rec_lpl[b] = (lp_l / 3.0f) / 3.0f;  // .mean(-1).mean(-1) (:357)
+        if (a.rec_lpt) a.rec_lpt[b] = lpt;
+        if (a.rec_lpx) a.rec_lpx[b] = a.lp_corr[b] + (lp_x / 3.0f) / cnt;
+    }
+}
+
+__global__ void wrap_copy_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = pymod1(x[i]);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_time_embedding(const int* times, const float* freqs, int B, int time_dim, float* out, void* stream) {
+    MI_CHECK(times && freqs && out && time_dim % 2 == 0, MI_EINVAL, "bad argument");
+    if (B <= 0) return MI_OK;
+    hipLaunchKernelGGL(time_embedding_kernel, dim3(cdiv((int64_t)B * time_dim, 256)), dim3(256), 0, (hipStream_t)stream, times, freqs,
+                       out, B, time_dim);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_philox_fill(uint64_t seed, uint32_t step, uint32_t draw_id, int64_t elem_offset, int64_t n, int uniform, float* out,
+                   void* stream) {
+    MI_CHECK(out && n >= 0 && elem_offset >= 0, MI_EINVAL, "bad argument");
+    if (n == 0) return MI_OK;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, step, draw_id, elem_offset, n,
+                       uniform, out);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_sampler_init_state(mi_batch* b, uint64_t seed, int T, float* atom_types, float* frac, float* lattices, void* stream) {
+    MI_CHECK(b && atom_types && frac && lattices, MI_EINVAL, "null argument");
+    // diffusion.py:277-279; step field of the counter = T + 1
+    MI_TRY(mi_philox_fill(seed, (uint32_t)(T + 1), DRAW_X_T, b->node_offset * 3, (int64_t)b->N * 3, 1, frac, stream));
+    MI_TRY(mi_philox_fill(seed, (uint32_t)(T + 1), DRAW_L_T, b->graph_offset * 9, (int64_t)b->B * 9, 0, lattices, stream));
+    MI_TRY(mi_philox_fill(seed, (uint32_t)(T + 1), DRAW_T_T, b->node_offset * MI_NUM_TYPES, (int64_t)b->N * MI_NUM_TYPES, 0,
+                          atom_types, stream));
+    return MI_OK;
+}
+
+int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int t_start, int t_stop, const float* time_freqs,
+                   uint64_t seed, const mi_sampler_noise* noise, const mi_sampler_record* rec, float* atom_types, float* frac,
+                   float* lattices, void* stream) {
+    MI_CHECK(net && b && coef_host && time_freqs && atom_types && frac && lattices, MI_EINVAL, "null argument");
+    MI_CHECK(T >= 1 && t_start <= T && t_stop >= 0 && t_stop <= t_start, MI_EINVAL, "bad step range T=%d start=%d stop=%d", T,
+             t_start, t_stop);
+    hipStream_t s = (hipStream_t)stream;
+    const int N = b->N, B = b->B;
+    if (N == 0 || B == 0) return MI_OK;
+    if (b->coef_T != T) {
+        MI_TRY(dev_alloc(b, &b->coef, (size_t)(T + 1) * MI_NCOEF));
+        b->coef_T = T;
+    }
+    MI_HIP(hipMemcpyAsync(b->coef, coef_host, (size_t)(T + 1) * MI_NCOEF * sizeof(float), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));  // coef_host may be transient
+
+    const size_t n3 = (size_t)N * 3, nA = (size_t)N * MI_NUM_TYPES, b9 = (size_t)B * 9;
+    if (rec) {  // traj[t_start] = current state (diffusion.py:287-293)
+        if (rec->atom_types) MI_HIP(hipMemcpyAsync(rec->atom_types + t_start * nA, atom_types, nA * 4, hipMemcpyDeviceToDevice, s));
+        if (rec->lattices) MI_HIP(hipMemcpyAsync(rec->lattices + t_start * b9, lattices, b9 * 4, hipMemcpyDeviceToDevice, s));
+        if (rec->frac_coords)
+            hipLaunchKernelGGL(wrap_copy_kernel, dim3(cdiv(n3, 256)), dim3(256), 0, s, frac, rec->frac_coords + t_start * n3, (int64_t)n3);
+    }
+    for (int t = t_start; t > t_stop; --t) {
+        hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, b->times, t, B);
+        MI_TRY(mi_time_embedding(b->times, time_freqs, B, net->TD, b->temb, stream));
+        // corrector
+        MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s));
+        hipLaunchKernelGGL(corrector_kernel, dim3(B), dim3(64), 0, s, frac, b->pred_x, noise ? noise->corr_x + t * n3 : nullptr,
+                           b->coef, t, seed, b->node_offset, b->node_off, b->x_mid, b->lp_corr,
+                           (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr);
+        MI_KERNEL_CHECK();
+        // predictor
+        MI_TRY(net_forward(net, b, b->temb, atom_types, b->x_mid, lattices, b->pred_l, b->pred_x, b->pred_t, s));
+        PredictorArgs a;
+        a.x_mid = b->x_mid;
+        a.pred_x = b->pred_x;
+        a.pred_l = b->pred_l;
+        a.pred_t = b->pred_t;
+        a.noise_x = noise ? noise->pred_x + t * n3 : nullptr;
+        a.noise_l = noise ? noise->pred_l + t * b9 : nullptr;
+        a.noise_t = noise ? noise->pred_t + t * nA : nullptr;
+        a.coef = b->coef;
+        a.node_off = b->node_off;
+        a.lp_corr = b->lp_corr;
+        a.frac = frac;
+        a.lattices = lattices;
+        a.atom_types = atom_types;
+        a.rec_types = (rec && rec->atom_types) ? rec->atom_types + (t - 1) * nA : nullptr;
+        a.rec_frac = (rec && rec->frac_coords) ? rec->frac_coords + (t - 1) * n3 : nullptr;
+        a.rec_lat = (rec && rec->lattices) ? rec->lattices + (t - 1) * b9 : nullptr;
+        a.rec_lpl = (rec && rec->log_prob_l) ? rec->log_prob_l + (size_t)t * B : nullptr;
+        a.rec_lpt = (rec && rec->log_prob_t) ? rec->log_prob_t + (size_t)t * B : nullptr;
+        a.rec_lpx = (rec && rec->log_prob_x) ? rec->log_prob_x + (size_t)t * B : nullptr;
+        a.seed = seed;
+        a.node_offset = b->node_offset;
+        a.graph_offset = b->graph_offset;
+        a.t = t;
+        hipLaunchKernelGGL(predictor_kernel, dim3(B), dim3(256), 0, s, a);
+        MI_KERNEL_CHECK();
+    }
+    return MI_OK;
+}
+
+}  // extern "C"

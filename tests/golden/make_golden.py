@@ -41,6 +41,13 @@ from models.diffcsp import utils as ref_utils  # noqa: E402
 from torch_geometric.data import Data  # noqa: E402  (shim)
 
 
+def time_freqs(dim):
+    """diffusion.py:61-63 evaluated here (the module recomputes it on every forward)."""
+    import math
+    half = dim // 2
+    return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+
+
 def npz(name, **arrs):
     out = {}
     for k, v in arrs.items():
@@ -218,6 +225,9 @@ def g4_embeddings():
     t = torch.tensor([1, 2, 17, 500, 999, 1000])
     out["t"] = t
     out["time_256"] = ref_diffusion.SinusoidalTimeEmbeddings(256)(t)
+    # the frequency table as evaluated on the generating machine (torch.exp is libm-dependent:
+    # another host's CPU differs by 1 ulp in a few entries, which t <= 1000 amplifies to 6e-5)
+    out["time_freqs_256"] = time_freqs(256)
     npz("g4_embeddings", **out)
 
 
@@ -314,7 +324,7 @@ def g6_sample():
         noise["pred_x"][t] = torch.randn(N, 3, generator=g)
     with sampler_tape(noise, T, N, B):
         final, traj = m.sample(b, step_lr=5e-6)
-    out = dict(num_atoms=b.num_atoms, T=np.array(T), step_lr=np.array(5e-6),
+    out = dict(num_atoms=b.num_atoms, T=np.array(T), step_lr=np.array(5e-6), time_freqs=time_freqs(256),
                x_T=noise["x_T"], l_T=noise["l_T"], t_T=noise["t_T"])
     for t in range(T, 1, -1):
         for k in ("corr_x", "pred_l", "pred_t", "pred_x"):

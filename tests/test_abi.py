@@ -1,0 +1,57 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/matinvent_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+from matinvent_amd import _lib
+from matinvent_amd.build import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "matinvent_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build(verbose=False)
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/matinvent_hip.h but not exported"
+    # the ctypes table binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_host_only_entry_points():
+    lib = _lib.load()
+    assert lib.mi_version() == 1
+    h = ctypes.c_void_p()
+    bad = _lib.NetConfig(100, 2, 8, 256, 1)
+    assert lib.mi_net_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    assert b"hidden_dim" in lib.mi_last_error()
+    cfg = _lib.NetConfig(512, 6, 128, 256, 1)
+    _lib.check(lib.mi_net_create(ctypes.byref(cfg), ctypes.byref(h)))
+    assert lib.mi_net_num_params(h) == 12346468  # SURVEY.md section 8d [PROBE]
+    name, off, numel = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_int64()
+    r, c = ctypes.c_int(), ctypes.c_int()
+    total = 0
+    for i in range(lib.mi_net_num_tensors(h)):
+        _lib.check(lib.mi_net_param_info(h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(numel), ctypes.byref(r), ctypes.byref(c)))
+        assert off.value == total and off.value % 4 == 0
+        total += numel.value
+    assert total == 12346468
+    lib.mi_net_destroy(h)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmatinvent_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
