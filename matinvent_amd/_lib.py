@@ -61,6 +61,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: both must share ONE HIP runtime instance (torch bundles its own libamdhip64);
+    # device pointers and streams cross this boundary.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"matinvent_amd: HIP library not found at {LIB_PATH}; build it with `python -m matinvent_amd.build` "

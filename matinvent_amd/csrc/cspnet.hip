@@ -321,7 +321,7 @@ int mi_net_create(const mi_net_config* cfg, mi_net** out) {
     n->F = cfg->num_freqs;
     n->TD = cfg->time_dim;
     n->NT = H / 32;
-    n->KP = (3 * n->F + 3) / 4 * 4;
+    n->KP = (3 * n->F + 7) / 8 * 8;
     n->edge_in = 2 * H + 9 + 6 * n->F;
     int64_t off = 0;
     auto add = [&](const std::string& name, int rows, int cols) {

@@ -21,6 +21,8 @@
 // part[slot][node][:] with slot = tile - first tile of that node (deterministic; no float
 // atomics).  finalize_agg (cspnet.hip) adds the slots and divides by the degree.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mi {
@@ -35,7 +37,7 @@ struct EdgeFwdArgs {
     const int* rowptr;      // [N+1] first edge of every node
     const float* freqs;     // [F]  2*pi*k table
     const float* Wff_p;     // packed [KP/4][NT][64][4]
-    const float* W2_p;      // packed [NT][NT][4][64][4]
+    const float* W2_p;      // packed [NT(u)][NT(t)][4(q)][64][4]
     const float* b2;        // [H]
     float* part;            // [nslots][N][H]
     float* Z1;              // optional [E, H] pre-activation of linear 1 (saved for backward)
@@ -47,7 +49,13 @@ struct EdgeFwdArgs {
 template <int H>
 __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
     constexpr int NT = H / 32;
-    constexpr int UG = NT < 4 ? NT : 4;  // output tiles in flight in GEMM2
+#ifndef MI_UG
+#define MI_UG 4
+#endif
+#ifndef MI_RING
+#define MI_RING 4
+#endif
+    constexpr int UG = NT < MI_UG ? NT : MI_UG;  // output tiles in flight in GEMM2
     __shared__ __attribute__((aligned(16))) float tr[32 * 36];
 
     const int lane = threadIdx.x, e_l = lane & 31, hi = lane >> 5;
@@ -69,7 +77,8 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
         const float* pj = a.PQ + (size_t)j * (2 * H) + H + 4 * hi;
         const float* pg = a.G + (size_t)g * H + 4 * hi;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            if ((t & 1) == 0) __builtin_amdgcn_sched_barrier(0);  // two tiles (24 float4) in flight at a time
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 x = *reinterpret_cast<const f32x4*>(pi + 32 * t + 8 * q);
@@ -78,33 +87,57 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[t][4 * q + c] = (x[c] + y[c]) + z[c];
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- GEMM1: Z1^T += Wff * ff^T,  K = 2*KP, four k-steps per packed float4 -------------
+    // One wave per SIMD: nothing else hides memory latency, so the weight stream is software
+    // pipelined through two register buffers (the loads of step m+1 fly under the 64 MFMAs of
+    // step m); sched_barriers keep the compiler from hoisting or sinking the stream.
     {
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wff_p) + lane;
         int c = 0, k = 0;  // pair s = c*F + k
-        const int nm = a.KP / 4;
-        for (int m = 0; m < nm; ++m) {
-            f32x4 w4[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w4[t] = wp[((size_t)m * NT + t) * 64];
-            float bv[4];
+        const int nm = a.KP / 4;  // even (KP % 8 == 0)
+        auto fourier4 = [&](float (&bv)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float dc = c == 0 ? d0 : (c == 1 ? d1 : d2);
                 float arg = dc * a.freqs[k];  // emb = x * freq  (cspnet.py:21)
                 float sn, cs;
-                sincosf(arg, &sn, &cs);
+                sincos_bounded(arg, &sn, &cs);
                 bv[q] = hi ? cs : sn;         // hi = 0 lanes carry sin(c,k), hi = 1 lanes cos(c,k)
                 if (++k == a.F) { k = 0; ++c; }
                 if (c > 2) { c = 2; k = a.F - 1; }  // padding pairs: weights are zero
             }
+        };
+        f32x4 wa[NT], wb[NT];
+        float bv[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wa[t] = wp[(size_t)t * 64];
+        fourier4(bv);
+        for (int m = 0; m < nm; m += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wb[t] = wp[((size_t)(m + 1) * NT + t) * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[t][q], bv[q], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][q], bv[q], acc[t], 0, 0, 0);
+            fourier4(bv);
+            __builtin_amdgcn_sched_barrier(0);
+            const int mn = (m + 2 < nm) ? m + 2 : m;  // tail: harmless reload
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wa[t] = wp[((size_t)mn * NT + t) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t][q], bv[q], acc[t], 0, 0, 0);
+            fourier4(bv);
         }
     }
 
@@ -120,10 +153,6 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
                     *reinterpret_cast<f32x4*>(z + 32 * t + 8 * q) = v;
                 }
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = silu(acc[t][r]);
 
     // ---- segment structure of this tile (runs of equal src) -------------------------------
     const int i_prev = __shfl_up(i, 1, 64);
@@ -132,8 +161,16 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
     const int tile = (int)blockIdx.x;
 
     // ---- GEMM2: Z2^T = W2 * M1^T + b2, then SiLU and the per-node partial sums ------------
+    // Weight stream through a RING-deep register ring (one ring slot = the UG float4 of one
+    // (t,q) step = 4*UG MFMAs); SiLU of M1 tile t+1 is issued under the MFMAs of tile t during
+    // the first pass.
+    constexpr int RING = MI_RING, NSTEP = NT * 4;
     const f32x4* w2p = reinterpret_cast<const f32x4*>(a.W2_p) + lane;
-    for (int ug = 0; ug < NT; ug += UG) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = silu(acc[0][r]);
+
+    auto pass = [&](int ug, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         f32x16 o[UG];
 #pragma unroll
         for (int uu = 0; uu < UG; ++uu)
@@ -143,19 +180,33 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[uu][4 * q + c] = b[c];
             }
+        f32x4 ring[RING][UG];
+        auto wload = [&](int step, int uu) { return w2p[(((size_t)(ug + uu) * NT) * 4 + step) * 64]; };
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int st = 0; st < RING; ++st)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 w4[UG];
+            for (int uu = 0; uu < UG; ++uu) ring[st][uu] = wload(st, uu);
 #pragma unroll
-                for (int uu = 0; uu < UG; ++uu) w4[uu] = w2p[(((size_t)(ug + uu) * NT + t) * 4 + q) * 64];
+        for (int st = 0; st < NSTEP; ++st) {
+            const int t = st >> 2, q = st & 3;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int uu = 0; uu < UG; ++uu)
-                        o[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[uu][c], acc[t][4 * q + c], o[uu], 0, 0, 0);
+                for (int uu = 0; uu < UG; ++uu)
+                    o[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[st % RING][uu][c], acc[t][4 * q + c], o[uu], 0, 0, 0);
+            if constexpr (FIRST) {
+                if (t + 1 < NT) {  // SiLU of the next M1 tile, a quarter per step, under these MFMAs
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[t + 1][4 * q + c] = silu(acc[t + 1][4 * q + c]);
+                }
             }
+            if (st + RING < NSTEP) {
+#pragma unroll
+                for (int uu = 0; uu < UG; ++uu) ring[st % RING][uu] = wload(st + RING, uu);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
         for (int uu = 0; uu < UG; ++uu) {
@@ -193,7 +244,9 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
                 ++seg;
             }
         }
-    }
+    };
+    pass(0, std::true_type{});
+    for (int ug = UG; ug < NT; ug += UG) pass(ug, std::false_type{});
 }
 
 }  // namespace mi

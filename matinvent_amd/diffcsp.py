@@ -60,6 +60,17 @@ class DiffCSPModule(nn.Module):
     def device(self):
         return self.decoder.theta.device
 
+    def _coefficients(self, step_lr):
+        """Per-step scalar table, cached until a scheduler buffer changes (checkpoint load)."""
+        key = (float(step_lr),) + tuple(b._version for b in (self.beta_scheduler.alphas, self.beta_scheduler.alphas_cumprod,
+                                                              self.beta_scheduler.sigmas, self.sigma_scheduler.sigmas,
+                                                              self.sigma_scheduler.sigmas_norm))
+        cache = self.__dict__.setdefault("_coef_cache", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = sampler_coefficients(self.beta_scheduler, self.sigma_scheduler, step_lr).contiguous()
+        return cache[key]
+
     def crystal_batch(self, batch, node_offset=0, graph_offset=0) -> CrystalBatch:
         """Index tables for `batch` (anything with .num_atoms); cached on the object."""
         cb = getattr(batch, "_mi_batch", None)
@@ -97,7 +108,7 @@ class DiffCSPModule(nn.Module):
         else:
             x, l, a = (v.to(dev, torch.float32).contiguous().clone() for v in init)
         x = x % 1.0  # traj[T]['frac_coords'] = x_T % 1 (diffusion.py:289)
-        coef = sampler_coefficients(self.beta_scheduler, self.sigma_scheduler, step_lr).contiguous()
+        coef = self._coefficients(step_lr)
         nz = None
         if noise is not None:
             keep = {k: noise[k].to(dev, torch.float32).contiguous() for k in ("corr_x", "pred_l", "pred_t", "pred_x")}
