@@ -27,7 +27,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -47,6 +47,12 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- device math ----------------------------------------------------------------------
 // torch.nn.functional.silu: x / (1 + exp(-x))
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// SiLU on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): x * rcp(1 + 2^(-x log2 e)).
+// ~3 ulp from the IEEE-division form, far inside the stated fp32 tolerance; 5 VALU ops instead of ~30,
+// which keeps the unrolled edge kernel inside the instruction cache.
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 // d silu / dx given x
 __device__ __forceinline__ float silu_grad(float x) {
     float s = 1.0f / (1.0f + expf(-x));

@@ -29,8 +29,9 @@ __global__ void pack_whh_kernel(const float* __restrict__ W1, int edge_in, int H
     out[idx] = r < H ? W1[(size_t)r * edge_in + k] : W1[(size_t)(r - H) * edge_in + H + k];
 }
 
-// Wff_p[m][t][lane][q]: feature f = 32t + (lane&31); pair s = 4m+q = c*F + k; hi = lane>>5 selects
-// the sin column (2H+9 + c*F + k) or the cos column (2H+9 + 3F + c*F + k) of W1.  Pads are zero.
+// Wff_p[m][t][lane][q]: feature f = 32t + (lane&31); pair s = 4m+q = c*FP + k (FP = KP/3, k >= F is
+// zero padding); hi = lane>>5 selects the sin column (2H+9 + c*F + k) or the cos column
+// (2H+9 + 3F + c*F + k) of W1.
 __global__ void pack_wff_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int KP, float* __restrict__ out) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int NT = H / 32;
@@ -38,8 +39,9 @@ __global__ void pack_wff_kernel(const float* __restrict__ W1, int edge_in, int H
     if (idx >= total) return;
     int q = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) % NT, m = (idx >> 8) / NT;
     int s = 4 * m + q, f = 32 * t + (lane & 31), hi = lane >> 5;
+    int FP = KP / 3, c = s / FP, k = s % FP;
     float v = 0.f;
-    if (s < 3 * F) v = W1[(size_t)f * edge_in + 2 * H + 9 + (hi ? 3 * F : 0) + s];
+    if (k < F) v = W1[(size_t)f * edge_in + 2 * H + 9 + (hi ? 3 * F : 0) + c * F + k];
     out[idx] = v;
 }
 
@@ -185,13 +187,20 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     a.dst = b->dst;
     a.node2graph = b->node2graph;
     a.rowptr = b->rowptr;
-    a.freqs = net->freqs;
     a.Wff_p = net->Wff_p + layer * net->wff_stride();
     a.W2_p = net->W2_p + layer * net->w2_stride();
     a.b2 = net->p(p + "edge_mlp.2.bias");
     a.part = b->part;
     a.Z1 = Z1;
     a.Z2 = Z2;
+    a.dbg = nullptr;
+#ifdef MI_TIMING
+    static unsigned long long* g_dbg = nullptr;
+    static int g_count = 0;
+    const size_t ntile = (size_t)cdiv(b->E, 32);
+    if (!g_dbg) MI_HIP(hipMalloc((void**)&g_dbg, (size_t)1 << 24));
+    a.dbg = g_dbg;
+#endif
     a.E = b->E;
     a.N = b->N;
     a.F = net->F;
@@ -211,14 +220,40 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
         e1 = net->ev[net->ev_used++];
         MI_HIP(hipEventRecord(e0, s));
     }
+    const bool save = Z1 != nullptr;
+    MI_CHECK((Z1 == nullptr) == (Z2 == nullptr), MI_EINVAL, "Z1 and Z2 must be given together");
+#define MI_EDGE_LAUNCH(HH)                                                                   \
+    case HH:                                                                                 \
+        if (save) hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH, false>), grid, block, 0, s, a);     \
+        break;
     switch (net->H) {
-        case 64: hipLaunchKernelGGL(edge_mlp_fwd_kernel<64>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(edge_mlp_fwd_kernel<128>, grid, block, 0, s, a); break;
-        case 256: hipLaunchKernelGGL(edge_mlp_fwd_kernel<256>, grid, block, 0, s, a); break;
-        case 512: hipLaunchKernelGGL(edge_mlp_fwd_kernel<512>, grid, block, 0, s, a); break;
+        MI_EDGE_LAUNCH(64)
+        MI_EDGE_LAUNCH(128)
+        MI_EDGE_LAUNCH(256)
+        MI_EDGE_LAUNCH(512)
         default: set_error("unsupported hidden_dim %d", net->H); return MI_EINVAL;
     }
+#undef MI_EDGE_LAUNCH
     MI_KERNEL_CHECK();
+#ifdef MI_TIMING
+    if (++g_count == 40 && ntile * 128 <= ((size_t)1 << 24)) {
+        std::vector<unsigned long long> h(ntile * 16);
+        MI_HIP(hipStreamSynchronize(s));
+        MI_HIP(hipMemcpy(h.data(), g_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        const char* nm[8] = {"gemm1_A", "finish_A", "gemm1_B", "pass0_mfma", "pass0_epi", "pass1_mfma", "pass1_epi", "passes2.."};
+        const int lo[8] = {0, 1, 2, 3, 4, 5, 6, 7}, hiX[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) {
+            double sum = 0;
+            for (size_t t = 0; t < ntile; ++t) sum += (double)(h[t * 16 + hiX[k]] - h[t * 16 + lo[k]]);
+            fprintf(stderr, "[MI_TIMING] %-12s %10.0f clk/tile\n", nm[k], sum / ntile);
+        }
+        double whole = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t t = 0; t < ntile; ++t) { whole += (double)(h[t * 16 + 8] - h[t * 16]); tmin = std::min(tmin, h[t * 16]); tmax = std::max(tmax, h[t * 16 + 8]); }
+        fprintf(stderr, "[MI_TIMING] whole tile %10.0f clk; kernel span %llu clk; tiles %zu\n", whole / ntile, tmax - tmin, ntile);
+    }
+#endif
     if (net->prof) MI_HIP(hipEventRecord(e1, s));
     return MI_OK;
 }
@@ -321,7 +356,7 @@ int mi_net_create(const mi_net_config* cfg, mi_net** out) {
     n->F = cfg->num_freqs;
     n->TD = cfg->time_dim;
     n->NT = H / 32;
-    n->KP = (3 * n->F + 7) / 8 * 8;
+    n->KP = 3 * ((n->F + 7) / 8 * 8);
     n->edge_in = 2 * H + 9 + 6 * n->F;
     int64_t off = 0;
     auto add = [&](const std::string& name, int rows, int cols) {

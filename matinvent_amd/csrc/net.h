@@ -10,7 +10,7 @@ struct ParamInfo {
 
 struct mi_net {
     mi_net_config cfg;
-    int H, L, F, TD, KP, NT;  // KP: (sin,cos) pairs padded to a multiple of 8; NT = H/32
+    int H, L, F, TD, KP, NT;  // KP = 3*FP (sin,cos) pairs, FP = F rounded up to 8; NT = H/32
     int edge_in;              // 2H + 9 + 6F
     std::vector<ParamInfo> params;
     int64_t nparams = 0;
