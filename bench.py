@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     K, W = args.steps, args.warmup
-    assert 1 <= K and K + W <= T, f"steps + warmup must be <= T = {T}"
+    assert 1 <= K <= T and 0 <= W <= T, f"steps and warmup must be <= T = {T}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -152,13 +152,17 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    # initial state at t = T; W untimed steps, then exactly K timed steps of the same chain
-    final, _ = m.sample(cb, step_lr=STEP_LR, seed=SEED_NOISE, t_start=T, t_stop=T - W)
+    # W untimed denoising steps on a throwaway state, then exactly K timed steps of the chain that
+    # starts at t = T (its Philox initial state is generated outside the timed region: inputs resident)
+    if W > 0:
+        m.sample(cb, step_lr=STEP_LR, seed=SEED_NOISE + 1, t_start=T, t_stop=T - W)
+    final, _ = m.sample(cb, step_lr=STEP_LR, seed=SEED_NOISE, t_start=T, t_stop=T)
     state = (final["frac_coords"], final["lattices"], final["atom_types"])
+    m._coefficients(STEP_LR)
     barrier()
     _lib.check(lib.mi_profile_enable(m.decoder._h, 1))
     t0 = time.perf_counter()
-    final, _ = m.sample(cb, step_lr=STEP_LR, seed=SEED_NOISE, init=state, t_start=T - W, t_stop=T - W - K)
+    final, _ = m.sample(cb, step_lr=STEP_LR, seed=SEED_NOISE, init=state, t_start=T, t_stop=T - K)
     barrier()
     elapsed = time.perf_counter() - t0
     import ctypes as C
