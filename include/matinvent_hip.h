@@ -167,6 +167,38 @@ int mi_philox_fill(uint64_t seed, uint32_t step, uint32_t draw_id, int64_t elem_
                    int uniform, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fine-tune step  --  replaces the autograd pass, optimizer and noising that
+ * MatInvent.ft_step drives (pipeline/mat_invent.py:150-177).
+ *
+ * mi_cspnet_forward_train: CSPNet.forward that also keeps the activations its backward needs
+ *   (held by the batch; one pending backward per batch -- any later forward on the same batch
+ *   invalidates it).
+ * mi_cspnet_backward: given dLoss/d(lattice_out, coord_out, type_out) ACCUMULATES dLoss/dtheta
+ *   into grad_theta (flat, mi_net_num_params floats; `+=`, as `.backward()` does into `.grad`).
+ *   Gradients w.r.t. the noised inputs are not produced (ft_step never uses them).
+ * mi_adam_step: torch.optim.Adam with its defaults (mat_invent.py:136): bias-corrected, no weight
+ *   decay / amsgrad, on flat buffers; `step` is 1-based; the gradient is read as grad*grad_scale.
+ * mi_add_noise: DiffCSPModule.add_noise for one timestep (diffusion.py:81-119) with the per-step
+ *   scalars c0 = sqrt(alphabar), c1 = sqrt(1-alphabar), sigma, sigmas_norm passed in.
+ *   atom_types [N] int32 in 1..100.  rand_* = injected noise (rand_l [B,9], rand_x [N,3],
+ *   rand_t [N,A]) or NULL for the Philox stream (draw ids 7/8/9, counter step = `step`).
+ *   Outputs: noised lattice [B,9], frac [N,3], type logits [N,A]; targets tar_x [N,3] and the
+ *   noise actually used as lattice / type targets (out_rand_l [B,9], out_rand_t [N,A]).
+ * ------------------------------------------------------------------------------------- */
+int mi_cspnet_forward_train(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types,
+                            const float* frac, const float* lattices, float* lattice_out,
+                            float* coord_out, float* type_out, void* stream);
+int mi_cspnet_backward(mi_net* net, mi_batch* b, const float* d_lattice_out, const float* d_coord_out,
+                       const float* d_type_out, float* grad_theta, void* stream);
+int mi_adam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                 float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const float* frac0,
+                 const int* atom_types, float c0, float c1, float sigma, float sigma_norm, uint64_t seed,
+                 uint32_t step, const float* rand_l, const float* rand_x, const float* rand_t,
+                 float* in_lattice, float* in_frac, float* in_types, float* tar_x, float* out_rand_l,
+                 float* out_rand_t, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Profiling hook used by bench.py: when enabled, the dominant kernel (edge-message MLP) is
  * bracketed by hipEvents on its launch stream; mi_profile_read synchronises and returns the
  * number of launches and their summed duration in milliseconds since the last reset.

@@ -49,6 +49,11 @@ SIGNATURES = {
     "mi_sampler_run": (_I, [_P, _P, C.POINTER(C.c_float), _I, _I, _I, _P, _U64, C.POINTER(SamplerNoise),
                             C.POINTER(SamplerRecord), _P, _P, _P, _P]),
     "mi_philox_fill": (_I, [_U64, _U32, _U32, _L, _L, _I, _P, _P]),
+    "mi_cspnet_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_cspnet_backward": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "mi_adam_step": (_I, [_P, _P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "mi_add_noise": (_I, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _U64, _U32, _P, _P, _P, _P, _P, _P, _P,
+                          _P, _P, _P]),
     "mi_profile_enable": (_I, [_P, _I]),
     "mi_profile_read": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double)]),
 }

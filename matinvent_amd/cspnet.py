@@ -81,6 +81,8 @@ class CSPNet(nn.Module):
         n = int(lib.mi_net_num_params(h))
         device = torch.device(device if device is not None else "cuda")
         self.theta = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device))
+        self.theta._mi_owner = self
+        self._packed_version = -1
         self._freqs = fourier_freqs(num_freqs).float().contiguous()
         self._dirty = True
         self.reset_parameters()
@@ -131,14 +133,18 @@ class CSPNet(nn.Module):
         self._dirty = True
 
     def sync(self):
-        if self._dirty:
+        """(Re)build the packed weight copies if theta changed: explicitly marked dirty (FusedAdam,
+        load_state_dict) or bumped in place by a torch optimizer (tensor version counter)."""
+        if self._dirty or self._packed_version != self.theta._version:
             fr = self._freqs.numpy()
             _lib.check(self._lib.mi_net_set_params(self._h, _ptr(self.theta.data), fr.ctypes.data_as(C.POINTER(C.c_float)), _stream()),
                        "mi_net_set_params")
             self._dirty = False
+            self._packed_version = self.theta._version
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
+        self.theta._mi_owner = self
         self._dirty = True
         return r
 
@@ -148,16 +154,20 @@ class CSPNet(nn.Module):
 
     def forward(self, t, atom_types, frac_coords, lattices, num_atoms, node2graph=None, batch: CrystalBatch = None):
         """Same positional signature as the reference CSPNet.forward (cspnet.py:260); `batch`
-        carries the prebuilt index tables (built from num_atoms when absent).  Inference only:
-        the differentiable path is matinvent_amd.autograd (fine-tune step)."""
+        carries the prebuilt index tables (built from num_atoms when absent).  With grad enabled
+        and trainable parameters this is a differentiable op (matinvent_amd.autograd) whose
+        backward produces dLoss/dtheta; otherwise the inference entry point runs."""
         if batch is None:
             batch = self.make_batch(num_atoms)
-        self.sync()
         B, N = batch.num_graphs, batch.num_nodes
         dev = self.theta.device
         f = lambda x: x.detach().to(dev, torch.float32).contiguous()
         t, atom_types, frac_coords, lattices = f(t), f(atom_types), f(frac_coords), f(lattices)
         assert t.shape == (B, self.latent_dim) and atom_types.shape == (N, MAX_ATOMIC_NUM) and frac_coords.shape == (N, 3)
+        if torch.is_grad_enabled() and self.theta.requires_grad:
+            from .autograd import CSPNetFunction
+            return CSPNetFunction.apply(self.theta, self, batch, t, atom_types, frac_coords, lattices)
+        self.sync()
         lat_out = torch.empty(B, 3, 3, device=dev)
         coord_out = torch.empty(N, 3, device=dev)
         type_out = torch.empty(N, MAX_ATOMIC_NUM, device=dev)

@@ -1,0 +1,500 @@
+// Backward of the CSPNet score network (parameter gradients only: the fine-tune step never needs
+// gradients w.r.t. the noised inputs), fused Adam on the flat parameter vector, and forward
+// noising.  Reference: autograd through models/diffcsp/cspnet.py:260-294 as driven by
+// pipeline/mat_invent.py:150-177; torch.optim.Adam (:136); DiffCSPModule.add_noise
+// (models/diffcsp/diffusion.py:81-119).
+//
+// v1 structure: the edge stage is unfused -- dZ2, M1, dZ1 and the Fourier features are materialised
+// as [E,H] / [E,6F] scratch and pushed through the generic MFMA GEMMs (dgrad = gemm_nt against
+// pre-transposed weights, wgrad = gemm_tn with a fixed-order split reduction).  Deterministic: no
+// float atomics anywhere.
+#include "gemm.h"
+#include "net.h"
+
+namespace mi {
+
+__global__ void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    int c = idx / rows, r = idx % rows;  // dst[c][r]
+    dst[idx] = src[(size_t)r * ld_src + c];
+}
+
+// y = dy * silu'(z)   (in place allowed)
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dy[i] * silu_grad(z[i]);
+}
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+__global__ void silu_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = silu(z[i]);
+}
+
+// dZ2[e][f] = dagg[src(e)][f] / deg(src) * silu'(Z2[e][f])   (dagg = dcat[:, H:2H]); in place over Z2
+__global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __restrict__ src, const int* __restrict__ rowptr,
+                                float* __restrict__ Z2, int64_t E, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * H) return;
+    int64_t e = idx / H;
+    int f = (int)(idx % H);
+    int i = src[e];
+    float deg = (float)(rowptr[i + 1] - rowptr[i]);
+    Z2[idx] = (dcat[(size_t)i * (2 * H) + H + f] / deg) * silu_grad(Z2[idx]);
+}
+
+// FF[e][c*F+k] = sin(d_c * 2*pi*k), FF[e][3F + c*F+k] = cos(...)   (cspnet.py:20-24)
+__global__ void fourier_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
+                               float* __restrict__ FF, int64_t E, int F) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * 3 * F) return;
+    int64_t e = idx / (3 * F);
+    int ck = (int)(idx % (3 * F)), c = ck / F, k = ck % F;
+    float d = pymod1(frac[dst[e] * 3 + c] - frac[src[e] * 3 + c]);
+    float sn, cs;
+    sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
+    FF[e * (6 * F) + ck] = sn;
+    FF[e * (6 * F) + 3 * F + ck] = cs;
+}
+
+// dPQ[i][0:H]  = sum_j dZ1[(i,j)]      (row run of node i)
+// dPQ[j][H:2H] = sum_i dZ1[(i,j)]      (column of node j inside its fully connected crystal)
+__global__ void edge_dpq_kernel(const float* __restrict__ dZ1, const int* __restrict__ rowptr, const int* __restrict__ node2graph,
+                                const int* __restrict__ node_off, float* __restrict__ dPQ, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int i = (int)(idx / H), f = (int)(idx % H);
+    float s = 0.f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) s += dZ1[(size_t)e * H + f];
+    dPQ[(size_t)i * (2 * H) + f] = s;
+    int g = node2graph[i], n0 = node_off[g], n1 = node_off[g + 1], jl = i - n0;
+    float t = 0.f;
+    for (int ii = n0; ii < n1; ++ii) t += dZ1[(size_t)(rowptr[ii] + jl) * H + f];
+    dPQ[(size_t)i * (2 * H) + H + f] = t;
+}
+
+// out[g][f] = sum over the nodes of crystal g of X[i][f]  (X row stride ldx)
+__global__ void graph_sum_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ node_off, float* __restrict__ out,
+                                 int B, int H) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    int g = idx / H, f = idx % H;
+    float s = 0.f;
+    for (int i = node_off[g]; i < node_off[g + 1]; ++i) s += X[(size_t)i * ldx + f];
+    out[idx] = s;
+}
+
+// gram term backward: gW1[f][2H+m] += sum_b dG[b][f] * gram_b[m];  gb1[f] += sum_b dG[b][f]
+__global__ void gram_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ lattices, float* __restrict__ gW1,
+                                int edge_in, float* __restrict__ gb1, int B, int H) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= H) return;
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* Lm = lattices + (size_t)b * 9;
+        float d = dG[(size_t)b * H + f];
+        sb += d;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            int r = m / 3, c = m % 3;
+            acc[m] += d * (Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) gW1[(size_t)f * edge_in + 2 * H + m] += acc[m];
+    gb1[f] += sb;
+}
+
+// LayerNorm backward (one wave per row): dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w.
+// dx is ADDED to `dx_acc` when `accumulate` (residual stream), else written.  Per-block partial sums
+// of dw = sum dy*xhat and db = sum dy go to `part[blk][2H]` (reduced by tn_reduce_kernel).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int accumulate, float* __restrict__ part, int N,
+                                                            int H, int rows_per_block) {
+    extern __shared__ float sm[];  // [4][2H]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = sm + (size_t)wave * 2 * H;
+    for (int c = lane; c < 2 * H; c += 64) my[c] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float g[8], xh[8];
+        float s1 = 0.f, s2 = 0.f;
+        int cnt = 0;
+        for (int c = lane; c < H; c += 64) {
+            float d = dy[(size_t)row * ld_dy + c];
+            xh[cnt] = (x[(size_t)row * H + c] - mean) * rstd;
+            g[cnt] = d * w[c];
+            s1 += g[cnt];
+            s2 += g[cnt] * xh[cnt];
+            my[c] += d * xh[cnt];
+            my[H + c] += d;
+            ++cnt;
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        cnt = 0;
+        for (int c = lane; c < H; c += 64) {
+            float v = rstd * (g[cnt] - s1 - xh[cnt] * s2);
+            size_t o = (size_t)row * H + c;
+            dx[o] = accumulate ? dx[o] + v : v;
+            ++cnt;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256)
+        part[(size_t)blockIdx.x * 2 * H + c] = (sm[c] + sm[2 * H + c]) + (sm[4 * H + c] + sm[6 * H + c]);
+}
+
+// heads backward: dhf[i][f] = sum_a dT[i][a] Wt[a][f] + sum_c dX[i][c] Wc[c][f] + dgf[g(i)][f] / n_g
+__global__ void heads_bwd_kernel(const float* __restrict__ dT, const float* __restrict__ dX, const float* __restrict__ dgf,
+                                 const float* __restrict__ Wt, const float* __restrict__ Wc, const int* __restrict__ node2graph,
+                                 const int* __restrict__ node_off, float* __restrict__ dhf, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int i = (int)(idx / H), f = (int)(idx % H);
+    float s = 0.f;
+    const float* dt = dT + (size_t)i * MI_NUM_TYPES;
+    for (int a = 0; a < MI_NUM_TYPES; ++a) s += dt[a] * Wt[(size_t)a * H + f];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s += dX[i * 3 + c] * Wc[(size_t)c * H + f];
+    int g = node2graph[i];
+    s += dgf[(size_t)g * H + f] / (float)(node_off[g + 1] - node_off[g]);
+    dhf[idx] = s;
+}
+
+// lattice head backward (one block per crystal): out = reshape(lo,3,3) @ L  =>  dlo = dOut @ L^T;
+// dgf[b] = Wl^T dlo;  dlo stored for the wgrad gWl[m][f] += sum_b dlo[b][m] * gf[b][f]
+__global__ void lattice_head_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ lattices, const float* __restrict__ Wl,
+                                        float* __restrict__ dlo_out, float* __restrict__ dgf, int H) {
+    int b = blockIdx.x;
+    __shared__ float dlo[9];
+    if (threadIdx.x < 9) {
+        int r = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float* Lm = lattices + (size_t)b * 9;
+        const float* d = dOut + (size_t)b * 9;
+        float v = d[r * 3] * Lm[c * 3] + d[r * 3 + 1] * Lm[c * 3 + 1] + d[r * 3 + 2] * Lm[c * 3 + 2];
+        dlo[threadIdx.x] = v;
+        dlo_out[(size_t)b * 12 + threadIdx.x] = v;
+    }
+    if (threadIdx.x >= 9 && threadIdx.x < 12) dlo_out[(size_t)b * 12 + threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) s += dlo[m] * Wl[(size_t)m * H + f];
+        dgf[(size_t)b * H + f] = s;
+    }
+}
+
+// Adam (torch.optim.Adam defaults): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float eps, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * gscale;
+    float mi_ = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi_;
+    v[i] = vi;
+    p[i] -= lr_over_bc1 * (mi_ / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+static int alloc_tape(mi_net* net, mi_batch* b) {
+    if (b->tape.allocated) return MI_OK;
+    const size_t N = b->N, B = b->B, E = (size_t)b->E, H = net->H, L = net->L, F = net->F, TD = net->TD;
+    Tape& t = b->tape;
+    int rc = MI_OK;
+#define T_(p, n) \
+    if (rc == MI_OK) rc = dev_alloc(b, &t.p, (n))
+    T_(cat, L * N * 2 * H);
+    T_(Z1, L * E * H);
+    T_(Z2, L * E * H);
+    T_(Xpre, L * N * H);
+    T_(Ypre, L * N * H);
+    T_(lnstat, (L + 1) * N * 2);
+    T_(gf, B * H);
+    T_(atom_types, N * MI_NUM_TYPES);
+    T_(t_emb, B * TD);
+    T_(lattices, B * 9);
+    T_(frac, N * 3);
+    T_(dh, N * H);
+    T_(dY, N * H);
+    T_(dXa, N * H);
+    T_(Xa, N * H);
+    T_(dcat, N * 2 * H);
+    T_(dPQ, N * 2 * H);
+    T_(dG, B * H);
+    T_(dgf, B * H);
+    T_(dlo, B * 12);
+    T_(dtproj, B * H);
+    T_(M1, E * H);
+    T_(dM1, E * H);
+    T_(FF, E * 6 * F);
+    t.scratch_floats = std::max<size_t>((size_t)1 << 22, 16 * 2 * H * std::max<size_t>(2 * H, 6 * F + 64) + 1024 * 2 * H);
+    T_(scratch, t.scratch_floats);
+#undef T_
+    if (rc == MI_OK) t.allocated = true;
+    return rc;
+}
+
+int net_tape_prepare(mi_net* net, mi_batch* b) { return alloc_tape(net, b); }
+
+static inline dim3 g1(int64_t n) { return dim3((unsigned)cdiv(n, 256)); }
+
+int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s) {
+    MI_CHECK(b->tape.allocated && b->tape.valid, MI_ESTATE, "mi_cspnet_backward without a preceding training forward on this batch");
+    const int H = net->H, L = net->L, N = b->N, B = b->B, TD = net->TD, F = net->F;
+    const int64_t E = b->E;
+    if (N == 0 || B == 0) return MI_OK;
+    Tape& t = b->tape;
+    const size_t NH = (size_t)N * H;
+    auto G = [&](const std::string& name) { return grad + net->off(name); };
+    float* sc = t.scratch;
+    const size_t scf = t.scratch_floats;
+
+    // ---------------- heads ----------------
+    hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.lattices, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
+    MI_KERNEL_CHECK();
+    MI_TRY(gemm_tn_acc(t.dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
+    hipLaunchKernelGGL(heads_bwd_kernel, g1(NH), dim3(256), 0, s, d_type, d_coord, t.dgf, net->p("type_out.weight"),
+                       net->p("coord_out.weight"), b->node2graph, b->node_off, t.dY, N, H);  // dY = d hf
+    MI_KERNEL_CHECK();
+    MI_TRY(gemm_tn_acc(d_type, MI_NUM_TYPES, b->hf, H, G("type_out.weight"), H, N, MI_NUM_TYPES, H, sc, scf, s));
+    MI_TRY(colsum_acc(d_type, MI_NUM_TYPES, G("type_out.bias"), N, MI_NUM_TYPES, sc, scf, s));
+    MI_TRY(gemm_tn_acc(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
+
+    auto ln_bwd = [&](const float* dy, int ld_dy, const float* x, const float* stats, const std::string& wname, float* dx, int accumulate) {
+        const int rows_per_block = 64, nblk = cdiv(N, rows_per_block);
+        MI_CHECK((size_t)nblk * 2 * H <= scf, MI_ENOMEM, "LN scratch");
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 8 * H * sizeof(float), s, dy, ld_dy, x, stats, net->p(wname + ".weight"),
+                           dx, accumulate, sc, N, H, rows_per_block);
+        // part[blk][0:H] -> dw, [H:2H] -> db ; weight and bias are adjacent in theta (weight first)
+        hipLaunchKernelGGL(tn_reduce_kernel, g1(2 * H), dim3(256), 0, s, sc, nblk, 1, 2 * H, G(wname + ".weight"), 2 * H, 1, 2 * H, 1.0f);
+        MI_KERNEL_CHECK();
+        return MI_OK;
+    };
+    // final LayerNorm: d h_L
+    if (net->cfg.ln) {
+        MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)L * NH, t.lnstat + (size_t)L * N * 2, "final_layer_norm", t.dh, 0));
+    } else {
+        MI_HIP(hipMemcpyAsync(t.dh, t.dY, NH * 4, hipMemcpyDeviceToDevice, s));
+    }
+
+    // Fourier features are the same for every layer
+    if (E > 0) {
+        hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.frac, b->src, b->dst, t.FF, E, F);
+        MI_KERNEL_CHECK();
+    }
+
+    // ---------------- layers, last to first ----------------
+    for (int l = L - 1; l >= 0; --l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        const float* cat = t.cat + (size_t)l * N * 2 * H;
+        float* Z1 = t.Z1 + (size_t)l * E * H;
+        float* Z2 = t.Z2 + (size_t)l * E * H;
+        const float* Xpre = t.Xpre + (size_t)l * NH;
+        const float* Ypre = t.Ypre + (size_t)l * NH;
+        // node MLP (cspnet.py:80-82)
+        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, t.dY, (int64_t)NH);
+        hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, t.Xa, (int64_t)NH);
+        MI_KERNEL_CHECK();
+        MI_TRY(gemm_tn_acc(t.dY, H, t.Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
+        MI_TRY(colsum_acc(t.dY, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
+        MI_TRY(gemm_nt(t.dY, H, net->Wn2T + l * (size_t)H * H, H, t.dXa, H, N, H, H, GemmEpilogue(), s));
+        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dXa, Xpre, t.dXa, (int64_t)NH);
+        MI_KERNEL_CHECK();
+        MI_TRY(gemm_tn_acc(t.dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
+        MI_TRY(colsum_acc(t.dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
+        MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
+        // edge stage (cspnet.py:59-79)
+        if (E > 0) {
+            hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);  // Z2 := dZ2
+            hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
+            MI_KERNEL_CHECK();
+            MI_TRY(gemm_tn_acc(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
+            MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
+            MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
+            hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
+            MI_KERNEL_CHECK();
+            MI_TRY(gemm_tn_acc(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
+            hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
+            MI_KERNEL_CHECK();
+        } else {
+            MI_HIP(hipMemsetAsync(t.dPQ, 0, NH * 2 * 4, s));
+        }
+        hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dPQ, 2 * H, b->node_off, t.dG, B, H);
+        hipLaunchKernelGGL(gram_bwd_kernel, g1(H), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
+                           G(p + "edge_mlp.0.bias"), B, H);
+        MI_KERNEL_CHECK();
+        MI_TRY(gemm_tn_acc(t.dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_acc(t.dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
+        // d hn = dcat[:, :H] + dPQ * Whh   -> dY (reuse)
+        GemmEpilogue er;
+        er.residual = t.dcat;
+        er.ld_res = 2 * H;
+        MI_TRY(gemm_nt(t.dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s));
+        // LayerNorm + residual stream: dh_l = dh_{l+1} + LN'(d hn)
+        if (net->cfg.ln) {
+            MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)l * NH, t.lnstat + (size_t)l * N * 2, p + "layer_norm", t.dh, 1));
+        } else {
+            hipLaunchKernelGGL(axpy_kernel, g1(NH), dim3(256), 0, s, t.dY, t.dh, (int64_t)NH);
+            MI_KERNEL_CHECK();
+        }
+    }
+
+    // ---------------- embedding (cspnet.py:265-271) ----------------
+    const int WA = H + TD;
+    MI_TRY(gemm_tn_acc(t.dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
+    hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dh, H, b->node_off, t.dtproj, B, H);
+    MI_KERNEL_CHECK();
+    MI_TRY(gemm_tn_acc(t.dtproj, H, t.t_emb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
+    MI_TRY(colsum_acc(t.dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
+    MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s));
+    MI_TRY(gemm_tn_acc(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
+    MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
+    return MI_OK;
+}
+
+int net_pack_transposes(mi_net* n, hipStream_t s) {
+    const int H = n->H, L = n->L;
+    if (!n->W2T) {
+        MI_HIP(hipMalloc((void**)&n->W2T, (size_t)L * H * H * 4));
+        MI_HIP(hipMalloc((void**)&n->Wn2T, (size_t)L * H * H * 4));
+        MI_HIP(hipMalloc((void**)&n->Wn1T, (size_t)L * 2 * H * H * 4));
+        MI_HIP(hipMalloc((void**)&n->WhhT, (size_t)L * 2 * H * H * 4));
+        MI_HIP(hipMalloc((void**)&n->WaT, (size_t)H * H * 4));
+    }
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "edge_mlp.2.weight"), H, H, H, n->W2T + (size_t)l * H * H);
+        hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, n->Wn2T + (size_t)l * H * H);
+        hipLaunchKernelGGL(transpose_kernel, g1(2 * H * H), dim3(256), 0, s, n->p(p + "node_mlp.0.weight"), 2 * H, H, 2 * H,
+                           n->Wn1T + (size_t)l * 2 * H * H);
+        hipLaunchKernelGGL(transpose_kernel, g1(2 * H * H), dim3(256), 0, s, n->Whh + l * n->whh_stride(), H, 2 * H, H,
+                           n->WhhT + (size_t)l * 2 * H * H);
+    }
+    hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p("atom_latent_emb.weight"), H + n->TD, H, H, n->WaT);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+// ---- forward noising (diffusion.py:81-119) --------------------------------------------------------
+// lattice_params_to_matrix_torch (models/diffcsp/utils.py:68-96)
+__device__ __forceinline__ void lattice_matrix(const float* len, const float* ang, float* M) {
+    const float d2r = 0.017453292519943295f;
+    float c0 = cosf(ang[0] * d2r), c1 = cosf(ang[1] * d2r), c2 = cosf(ang[2] * d2r);
+    float s0 = sinf(ang[0] * d2r), s1 = sinf(ang[1] * d2r);
+    float val = (c0 * c1 - c2) / (s0 * s1);
+    val = fminf(1.f, fmaxf(-1.f, val));
+    float gs = acosf(val);
+    M[0] = len[0] * s1; M[1] = 0.f; M[2] = len[0] * c1;
+    M[3] = -len[1] * s0 * cosf(gs); M[4] = len[1] * s0 * sinf(gs); M[5] = len[1] * c0;
+    M[6] = 0.f; M[7] = 0.f; M[8] = len[2];
+}
+
+// d_log_p_wrapped_normal(x, sigma) (scheduler.py:39-43), 21 images
+__device__ __forceinline__ float d_log_p_wn(float x, float sigma) {
+    float num = 0.f, den = 0.f;
+    const float s2 = sigma * sigma;
+#pragma unroll
+    for (int i = -10; i <= 10; ++i) {
+        float v = x + (float)i;
+        float e = expf(-(v * v) / 2.0f / s2);
+        num += v / s2 * e;
+        den += e;
+    }
+    return num / den;
+}
+
+struct NoiseArgs {
+    const float *lengths, *angles, *frac0;
+    const int* atom_types;            // [N] 1..100
+    const float *rand_l, *rand_x, *rand_t;  // injected noise or NULL (Philox)
+    const int* node_off;
+    float *in_lat, *in_frac, *in_types, *tar_x;
+    float *out_rand_l, *out_rand_t;   // the targets rand_l / rand_t as used (copies of the noise)
+    float c0, c1, sigma, sigma_norm;
+    uint64_t seed;
+    uint32_t step;
+    int64_t node_offset, graph_offset;
+};
+
+__global__ __launch_bounds__(256) void add_noise_kernel(NoiseArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float Lm[9];
+    if (tid == 0) lattice_matrix(a.lengths + b * 3, a.angles + b * 3, Lm);
+    __syncthreads();
+    if (tid < 9) {
+        int idx = b * 9 + tid;
+        float z = a.rand_l ? a.rand_l[idx] : philox_normal1(a.seed, a.step, DRAW_FT_L, (uint64_t)a.graph_offset * 9 + idx);
+        a.out_rand_l[idx] = z;
+        a.in_lat[idx] = a.c0 * Lm[tid] + a.c1 * z;
+    }
+    const int n0 = a.node_off[b], n1 = a.node_off[b + 1];
+    for (int idx = n0 * 3 + tid; idx < n1 * 3; idx += 256) {
+        float z = a.rand_x ? a.rand_x[idx] : philox_normal1(a.seed, a.step, DRAW_FT_X, (uint64_t)a.node_offset * 3 + idx);
+        float sx = a.sigma * z;
+        a.in_frac[idx] = pymod1(a.frac0[idx] + sx);
+        a.tar_x[idx] = d_log_p_wn(sx, a.sigma) / sqrtf(a.sigma_norm);
+    }
+    for (int64_t idx = (int64_t)n0 * MI_NUM_TYPES + tid; idx < (int64_t)n1 * MI_NUM_TYPES; idx += 256) {
+        int i = (int)(idx / MI_NUM_TYPES), k = (int)(idx % MI_NUM_TYPES);
+        float z = a.rand_t ? a.rand_t[idx] : philox_normal1(a.seed, a.step, DRAW_FT_T, (uint64_t)a.node_offset * MI_NUM_TYPES + idx);
+        float onehot = (a.atom_types[i] - 1 == k) ? 1.f : 0.f;
+        a.out_rand_t[idx] = z;
+        a.in_types[idx] = a.c0 * onehot + a.c1 * z;
+    }
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_cspnet_forward_train(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
+                            const float* lattices, float* lattice_out, float* coord_out, float* type_out, void* stream) {
+    MI_CHECK(net && b, MI_EINVAL, "null handle");
+    MI_CHECK(b->H == net->H && b->L == net->L, MI_EINVAL, "batch was created for a different network");
+    MI_TRY(net_tape_prepare(net, b));
+    return net_forward(net, b, t_emb, atom_types, frac, lattices, lattice_out, coord_out, type_out, (hipStream_t)stream, true);
+}
+
+int mi_cspnet_backward(mi_net* net, mi_batch* b, const float* d_lattice_out, const float* d_coord_out, const float* d_type_out,
+                       float* grad_theta, void* stream) {
+    MI_CHECK(net && b && d_lattice_out && d_coord_out && d_type_out && grad_theta, MI_EINVAL, "null argument");
+    MI_CHECK(net->W2T != nullptr, MI_ESTATE, "mi_net_set_params must run before backward");
+    return net_backward(net, b, d_lattice_out, d_coord_out, d_type_out, grad_theta, (hipStream_t)stream);
+}
+
+int mi_adam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                 float beta2, float eps, float grad_scale, void* stream) {
+    MI_CHECK(theta && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, MI_EINVAL, "bad argument");
+    if (n == 0) return MI_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, theta, grad, exp_avg, exp_avg_sq, n,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const float* frac0, const int* atom_types, float c0, float c1,
+                 float sigma, float sigma_norm, uint64_t seed, uint32_t step, const float* rand_l, const float* rand_x, const float* rand_t,
+                 float* in_lattice, float* in_frac, float* in_types, float* tar_x, float* out_rand_l, float* out_rand_t, void* stream) {
+    MI_CHECK(b && lengths && angles && frac0 && atom_types && in_lattice && in_frac && in_types && tar_x && out_rand_l && out_rand_t,
+             MI_EINVAL, "null argument");
+    if (b->B == 0) return MI_OK;
+    NoiseArgs a{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, b->node_off, in_lattice, in_frac, in_types, tar_x,
+                out_rand_l, out_rand_t, c0, c1, sigma, sigma_norm, seed, step, b->node_offset, b->graph_offset};
+    hipLaunchKernelGGL(add_noise_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+}  // extern "C"

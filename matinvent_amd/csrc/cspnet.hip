@@ -259,11 +259,20 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
 }
 
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
-                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s) {
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train) {
     MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_cspnet_forward before mi_net_set_params");
     const int H = net->H, L = net->L, N = b->N, B = b->B, TD = net->TD;
     if (N == 0 || B == 0) return MI_OK;
     const size_t NH = (size_t)N * H;
+    Tape& tp = b->tape;
+    tp.valid = false;  // this forward overwrites h / hf / x1, which a pending backward would read
+    if (train) {
+        MI_CHECK(tp.allocated, MI_ESTATE, "training forward without tape");
+        MI_HIP(hipMemcpyAsync(tp.atom_types, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(tp.t_emb, t_emb, (size_t)B * TD * 4, hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(tp.lattices, lattices, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(tp.frac, frac, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
+    }
     // ---- embedding (cspnet.py:265-271) ----
     {
         GemmEpilogue ep;
@@ -283,36 +292,45 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
         float* h_out = b->h + (l + 1) * NH;
+        float* cat = train ? tp.cat + (size_t)l * N * 2 * H : b->cat;
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_in, net->p(p + "layer_norm.weight"),
-                               net->p(p + "layer_norm.bias"), b->cat, 2 * H, (float*)nullptr, N, H);
+                               net->p(p + "layer_norm.bias"), cat, 2 * H, train ? tp.lnstat + (size_t)l * N * 2 : (float*)nullptr, N, H);
         } else {
-            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, b->cat, 2 * H, N, H);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, cat, 2 * H, N, H);
         }
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_nt(b->cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
+        MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
         hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
                            net->p(p + "edge_mlp.0.bias"), b->G, H);
         MI_KERNEL_CHECK();
-        MI_TRY(launch_edge(net, b, l, frac, nullptr, nullptr, s));
-        hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, b->cat, N, H);
+        MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
+        hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
         MI_KERNEL_CHECK();
         GemmEpilogue e1;
         e1.bias = net->p(p + "node_mlp.0.bias");
         e1.act = ACT_SILU;
-        MI_TRY(gemm_nt(b->cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s));
+        if (train) {
+            e1.pre_act = tp.Xpre + (size_t)l * NH;
+            e1.ld_pre = H;
+        }
+        MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s));
         GemmEpilogue e2;
         e2.bias = net->p(p + "node_mlp.2.bias");
         e2.act = ACT_SILU;
         e2.residual = h_in;
         e2.ld_res = H;
+        if (train) {
+            e2.pre_act = tp.Ypre + (size_t)l * NH;
+            e2.ld_pre = H;
+        }
         MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s));
     }
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
     if (net->cfg.ln) {
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_last, net->p("final_layer_norm.weight"),
-                           net->p("final_layer_norm.bias"), b->hf, H, (float*)nullptr, N, H);
+                           net->p("final_layer_norm.bias"), b->hf, H, train ? tp.lnstat + (size_t)L * N * 2 : (float*)nullptr, N, H);
     } else {
         hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
     }
@@ -322,8 +340,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     et.bias = net->p("type_out.bias");
     MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s));
     hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (H + 9) * sizeof(float), s, b->hf, b->node_off,
-                       net->p("lattice_out.weight"), lattices, lattice_out, (float*)nullptr, H);
+                       net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
     MI_KERNEL_CHECK();
+    tp.valid = train;
     return MI_OK;
 }
 
@@ -397,7 +416,7 @@ int mi_net_create(const mi_net_config* cfg, mi_net** out) {
 
 void mi_net_destroy(mi_net* n) {
     if (!n) return;
-    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p})
+    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT})
         if (p) (void)hipFree(p);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
@@ -446,6 +465,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         hipLaunchKernelGGL(pack_w2_kernel, dim3(cdiv(H * H, 256)), dim3(256), 0, s, W2, H, n->W2_p + l * n->w2_stride());
     }
     MI_KERNEL_CHECK();
+    MI_TRY(net_pack_transposes(n, s));
     return MI_OK;
 }
 

@@ -8,6 +8,8 @@
 //
 // Tile: BM x BN outputs per 256-thread workgroup (4 waves as 2x2), BK = 32.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace mi {
@@ -143,6 +145,122 @@ inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, i
         dim3 grid(cdiv(N, 64), cdiv(M, 64));
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep);
     }
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM ("TN"):  C[Na, Kx] (+)= sum_m A[m, Na] * X[m, Kx]   (contraction over rows).
+// Both operands are read in their natural row-major layout; the contraction index is the slow one,
+// so LDS rows are m and the MFMA fragments are lane-contiguous reads (conflict-free ds_read_b32).
+// The row range is split into `nsplit` chunks (grid.z) whose 64x64 partial tiles go to a scratch
+// buffer; tn_reduce_kernel adds them in fixed order into the destination (deterministic; gradients
+// ACCUMULATE across micro-steps, so the destination is always += ).
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
+                                                      float* __restrict__ P, int M, int Na, int Kx, int rows_per_split) {
+    constexpr int BM = 32, LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[BM * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_vec = (lda % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
+    const bool x_vec = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+    for (int m0 = m_begin; m0 < m_end; m0 += BM) {
+        // 32 rows x 64 cols per operand = 512 float4 -> 2 per thread
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            int f = tid + v * 256, r = f >> 4, c = (f & 15) * 4;
+            int gm = m0 + r;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+            if (gm < m_end) {
+                const float* pa = A + (size_t)gm * lda + n0 + c;
+                const float* px = X + (size_t)gm * ldx + k0 + c;
+                if (a_vec && n0 + c + 3 < Na) va = *reinterpret_cast<const f32x4*>(pa);
+                else
+                    for (int u = 0; u < 4; ++u) va[u] = (n0 + c + u < Na) ? pa[u] : 0.f;
+                if (x_vec && k0 + c + 3 < Kx) vx = *reinterpret_cast<const f32x4*>(px);
+                else
+                    for (int u = 0; u < 4; ++u) vx[u] = (k0 + c + u < Kx) ? px[u] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&As[r * LD + c]) = va;
+            *reinterpret_cast<f32x4*>(&Xs[r * LD + c]) = vx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BM / 2; ++s) {
+            float av = As[(2 * s + hi) * LD + wn * 32 + l31];
+            float xv = Xs[(2 * s + hi) * LD + wk * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // partial tile: P[split][n][k] over the padded [gridDim.y*64][gridDim.x*64] matrix
+    const int PK = gridDim.x * 64;
+    float* Pt = P + (size_t)blockIdx.z * (gridDim.y * 64) * PK;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk * 32 + l31;
+        Pt[(size_t)n * PK + k] = acc[r];
+    }
+}
+
+static __global__ void tn_reduce_kernel(const float* __restrict__ P, int nsplit, int PN, int PK, float* __restrict__ C, int ldc, int Na,
+                                 int Kx, float scale) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Na * Kx) return;
+    int n = idx / Kx, k = idx % Kx;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += P[((size_t)z * PN + n) * PK + k];
+    C[(size_t)n * ldc + k] += s * scale;
+}
+
+// C[Na,Kx] (ldc) += A^T X.  `scratch` must hold nsplit * ceil64(Na) * ceil64(Kx) floats.
+inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+                       size_t scratch_floats, hipStream_t s) {
+    if (M <= 0 || Na <= 0 || Kx <= 0) return MI_OK;
+    const int gy = cdiv(Na, 64), gx = cdiv(Kx, 64);
+    int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(1024, gx * gy)));
+    while (nsplit > 1 && (size_t)nsplit * gy * 64 * gx * 64 > scratch_floats) --nsplit;
+    MI_CHECK((size_t)nsplit * gy * 64 * gx * 64 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
+    int rows = cdiv(cdiv(M, nsplit), 32) * 32;
+    nsplit = cdiv(M, rows);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, nsplit), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 64, gx * 64, C, ldc,
+                       Na, Kx, 1.0f);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+// out[c] += sum_m A[m][c]   (bias gradients), two stages through `scratch` like gemm_tn_acc
+static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ P, int M, int Nc,
+                                                     int rows_per_split) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int m_begin = blockIdx.y * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    float s = 0.f;
+    if (c < Nc)
+        for (int m = m_begin + rg; m < m_end; m += 4) s += A[(size_t)m * lda + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < Nc) P[(size_t)blockIdx.y * (gridDim.x * 64) + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s) {
+    if (M <= 0 || Nc <= 0) return MI_OK;
+    const int gx = cdiv(Nc, 64);
+    int nsplit = std::max(1, std::min(cdiv(M, 64), 64));
+    MI_CHECK((size_t)nsplit * gx * 64 <= scratch_floats, MI_ENOMEM, "colsum scratch too small");
+    int rows = cdiv(M, nsplit);
+    nsplit = cdiv(M, rows);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(Nc, 256)), dim3(256), 0, s, scratch, nsplit, 1, gx * 64, out, Nc, 1, Nc, 1.0f);
     MI_KERNEL_CHECK();
     return MI_OK;
 }

@@ -21,6 +21,12 @@ struct mi_net {
     float* Whh = nullptr;    // [L][2H][H]   rows [0,H) = W1[:, :H], rows [H,2H) = W1[:, H:2H]
     float* Wff_p = nullptr;  // [L][KP/4][NT][64][4]
     float* W2_p = nullptr;   // [L][NT][NT][4][64][4]
+    // transposed copies for the data-gradient GEMMs (training), rebuilt with the packs
+    float* W2T = nullptr;    // [L][H][H]
+    float* Wn2T = nullptr;   // [L][H][H]
+    float* Wn1T = nullptr;   // [L][2H][H]
+    float* WhhT = nullptr;   // [L][H][2H]
+    float* WaT = nullptr;    // [H][H]   (atom_latent_emb.weight[:, :H])^T
     // profiling of the dominant kernel
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -31,6 +37,16 @@ struct mi_net {
     size_t whh_stride() const { return (size_t)2 * H * H; }
     size_t wff_stride() const { return (size_t)(KP / 4) * NT * 256; }
     size_t w2_stride() const { return (size_t)NT * NT * 4 * 256; }
+};
+
+// Saved activations of one training forward + backward scratch (allocated on first use).
+struct Tape {
+    bool allocated = false, valid = false;
+    float *cat = nullptr, *Z1 = nullptr, *Z2 = nullptr, *Xpre = nullptr, *Ypre = nullptr, *lnstat = nullptr, *gf = nullptr;
+    float *atom_types = nullptr, *t_emb = nullptr, *lattices = nullptr, *frac = nullptr;
+    float *dh = nullptr, *dY = nullptr, *dXa = nullptr, *Xa = nullptr, *dcat = nullptr, *dPQ = nullptr, *dG = nullptr, *dgf = nullptr,
+          *dlo = nullptr, *dtproj = nullptr, *M1 = nullptr, *dM1 = nullptr, *FF = nullptr, *scratch = nullptr;
+    size_t scratch_floats = 0;
 };
 
 struct mi_batch {
@@ -62,12 +78,16 @@ struct mi_batch {
     float* lp_corr = nullptr;  // [B]
     float* coef = nullptr;     // [T+1][MI_NCOEF]
     int coef_T = -1;
+    Tape tape;
     std::vector<void*> allocs;
 };
 
 namespace mi {
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
-                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s);
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train = false);
+int net_tape_prepare(mi_net* net, mi_batch* b);
+int net_pack_transposes(mi_net* net, hipStream_t s);
+int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s);
 template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
 }  // namespace mi

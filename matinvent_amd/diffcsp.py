@@ -15,6 +15,13 @@ from .cspnet import CSPNet, CrystalBatch, MAX_ATOMIC_NUM, _ptr, _stream
 from .schedules import BetaScheduler, SigmaScheduler, sampler_coefficients, time_embedding_freqs
 
 
+def _scatter_mean(src, index, dim_size):
+    """torch_scatter.scatter(..., reduce='mean') on the device: sum / max(count, 1)."""
+    out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
+    return out / cnt.clamp(min=1)
+
+
 def _cfg(d, drop=("_target_",)):
     return {k: v for k, v in dict(d).items() if k not in drop}
 
@@ -72,14 +79,99 @@ class DiffCSPModule(nn.Module):
         return cache[key]
 
     def crystal_batch(self, batch, node_offset=0, graph_offset=0) -> CrystalBatch:
-        """Index tables for `batch` (anything with .num_atoms); cached on the object."""
-        cb = getattr(batch, "_mi_batch", None)
-        if cb is None or cb.num_atoms_list != [int(x) for x in batch.num_atoms.tolist()]:
-            cb = self.decoder.make_batch(batch.num_atoms, node_offset, graph_offset)
+        """Index tables + workspace for `batch` (anything with .num_atoms); cached on the object
+        PER MODULE (agent and frozen prior must not share workspace: a forward of one would
+        clobber the activations the other's pending backward reads)."""
+        cache = getattr(batch, "_mi_batches", None)
+        if cache is None:
+            cache = {}
             try:
-                batch._mi_batch = cb
+                batch._mi_batches = cache
             except AttributeError:
                 pass
+        key = (id(self), node_offset, graph_offset)
+        cb = cache.get(key)
+        if cb is None or cb.num_atoms_list != [int(x) for x in batch.num_atoms.tolist()]:
+            cb = self.decoder.make_batch(batch.num_atoms, node_offset, graph_offset)
+            cache[key] = cb
+        return cb
+
+    # ---- fine-tune surface (pipeline/mat_invent.py:152-161) ------------------------------------
+    def add_noise(self, batch, time=None, noise=None, seed=None):
+        """DiffCSPModule.add_noise (diffusion.py:81-119) for an explicit timestep index
+        (`time` in 0..T-1 -> diffusion time T - time, :86-87).  Returns the reference's triple
+        (noised_input, noises, batch.batch).  Fresh Gaussian noise per call from the Philox
+        stream (seed, running call counter) unless `noise` = (rand_l, rand_x, rand_t)."""
+        if time is None:
+            raise NotImplementedError("add_noise without an explicit timestep is not used by the pipeline and not built")
+        lib = _lib.load()
+        dev = self.device
+        T = self.beta_scheduler.timesteps
+        t = T - int(time)
+        cb = self._batch_for(batch.num_atoms)
+        B, N = cb.num_graphs, cb.num_nodes
+        times = torch.full((B,), t, device=dev)
+        time_emb = self.time_embedding(times)
+        ac = self.beta_scheduler.alphas_cumprod[t]
+        c0, c1 = float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac))
+        sig, sn = float(self.sigma_scheduler.sigmas[t]), float(self.sigma_scheduler.sigmas_norm[t])
+        f = lambda x: x.to(dev, torch.float32).contiguous()
+        lengths, angles, frac0 = f(batch.lengths), f(batch.angles), f(batch.frac_coords)
+        at = batch.atom_types.to(dev, torch.int32).contiguous()
+        in_lat, in_frac = torch.empty(B, 3, 3, device=dev), torch.empty(N, 3, device=dev)
+        in_types, tar_x = torch.empty(N, MAX_ATOMIC_NUM, device=dev), torch.empty(N, 3, device=dev)
+        rand_l, rand_t = torch.empty(B, 3, 3, device=dev), torch.empty(N, MAX_ATOMIC_NUM, device=dev)
+        nz = (None, None, None) if noise is None else tuple(f(x) for x in noise)
+        self._noise_calls = getattr(self, "_noise_calls", 0) + 1
+        seed = getattr(self, "noise_seed", 0) if seed is None else seed
+        _lib.check(lib.mi_add_noise(cb._h, _ptr(lengths), _ptr(angles), _ptr(frac0), _ptr(at), c0, c1, sig, sn, seed,
+                                    self._noise_calls & 0xFFFFFFFF, _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), _ptr(in_lat), _ptr(in_frac),
+                                    _ptr(in_types), _ptr(tar_x), _ptr(rand_l), _ptr(rand_t), _stream()), "mi_add_noise")
+        noised_input = (time_emb, in_types, in_frac, in_lat, cb.num_atoms, cb.batch)
+        return noised_input, (rand_l, tar_x, rand_t), cb.batch
+
+    def calc_sample_loss(self, input_all):
+        """diffusion.py:121-138: per-crystal cost_lattice*mse_l + cost_coord*mse_x + cost_type*mse_t."""
+        noised_input, (rand_l, tar_x, rand_t), node2graph = input_all
+        time_emb, atom_types, frac, lattices, num_atoms, _ = noised_input
+        B = lattices.shape[0]
+        cb = self._batch_for(num_atoms)
+        pred_l, pred_x, pred_t = self.decoder(time_emb, atom_types, frac, lattices, num_atoms, node2graph, batch=cb)
+        loss_lattice = torch.pow(pred_l - rand_l, 2).mean(dim=(1, 2))
+        loss_coord = _scatter_mean(torch.pow(pred_x - tar_x, 2).mean(dim=1), node2graph, B)
+        loss_type = _scatter_mean(torch.pow(pred_t - rand_t, 2).mean(dim=1), node2graph, B)
+        loss = self.cost_lattice * loss_lattice + self.cost_coord * loss_coord + self.cost_type * loss_type
+        return loss, (pred_l, pred_x, pred_t)
+
+    def calc_kl_reg(self, agent_pred, prior_pred, batch):
+        """diffusion.py:140-149: per-crystal sum of three mean-squared agent-prior differences."""
+        pl, px, pt = agent_pred
+        plp, pxp, ptp = (p.detach() for p in prior_pred)
+        node2graph = batch.batch if hasattr(batch, "batch") else batch
+        node2graph = node2graph.to(pl.device)
+        B = pl.shape[0]
+        k0 = torch.pow(pl - plp, 2).mean(dim=(1, 2))
+        k1 = _scatter_mean(torch.pow(px - pxp, 2).mean(dim=1), node2graph, B)
+        k2 = _scatter_mean(torch.pow(pt - ptp, 2).mean(dim=1), node2graph, B)
+        return k0 + k1 + k2
+
+    def forward(self, noised_input):
+        time_emb, atom_types, frac, lattices, num_atoms, node2graph = noised_input
+        return self.decoder(time_emb, atom_types, frac, lattices, num_atoms, node2graph, batch=self._batch_for(num_atoms))
+
+    def _batch_for(self, num_atoms):
+        """CrystalBatch of THIS module for a num_atoms tensor (small cache keyed by the atom counts and
+        the shard offsets `self.shard_offsets` = (first global atom, first global crystal), which only
+        enter the noise counters)."""
+        off = getattr(self, "shard_offsets", (0, 0))
+        key = (tuple(int(x) for x in num_atoms.tolist()), off)
+        cache = self.__dict__.setdefault("_nb_cache", {})
+        cb = cache.get(key)
+        if cb is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            cb = self.decoder.make_batch(list(key[0]), off[0], off[1])
+            cache[key] = cb
         return cb
 
     @torch.no_grad()
