@@ -155,3 +155,45 @@ def test_fused_adam_matches_torch_adam():
         o1.step()
         o2.step()
     assert float((p1 - p2).detach().abs().max()) < 2e-6
+
+
+def test_ft_step_end_to_end_vs_oracle():
+    """matinvent_amd.finetune.ft_step (device-side loss accumulation, fused Adam, flat gradient) vs
+    the oracle's literal restatement of pipeline/mat_invent.py:125-189: 2 epochs x 6 timesteps,
+    accum 3 -> 4 optimizer steps, injected noise."""
+    from matinvent_amd.data import CrystalData
+    from matinvent_amd.finetune import ft_step
+    hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
+    P0, Q0 = O.init_params(hp, seed=3), O.init_params(hp, seed=3)
+    gen = torch.Generator().manual_seed(9)
+    for k in P0:
+        P0[k] = P0[k] + 0.01 * torch.randn(P0[k].shape, generator=gen)
+    sn = torch.cat([torch.ones(1), 0.5 + torch.rand(1000, generator=gen)])
+    agent, prior = make_module(64, 2, 8, 1000, P0, sigmas_norm=sn), make_module(64, 2, 8, 1000, Q0, sigmas_norm=sn)
+    prior.requires_grad_(False)
+    na = [4, 2, 6, 3]
+    data = [CrystalData(torch.rand(n, 3, generator=gen), torch.randint(1, 95, (n,), generator=gen), 4 + 6 * torch.rand(1, 3, generator=gen),
+                        70 + 40 * torch.rand(1, 3, generator=gen)) for n in na]
+    rewards = torch.rand(len(na), generator=gen).numpy()
+    B, N = len(na), sum(na)
+    noises = {(e, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
+              for e in range(2) for t in range(6)}
+    cfg = dict(lr=1e-4, accum_steps=3, epochs=2, timesteps=6, sigma=0.025)
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)])
+    # oracle side
+    sch = O.Schedules.make(1000, sigmas_norm=sn)
+    sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
+    batch = dict(num_atoms=torch.tensor(na), lengths=torch.cat([d.lengths for d in data]), angles=torch.cat([d.angles for d in data]),
+                 frac_coords=torch.cat([d.frac_coords for d in data]), atom_types=torch.cat([d.atom_types for d in data]))
+    A = {k: v.clone() for k, v in P0.items()}
+    rec = {}
+    O.ft_step(A, Q0, hp, sch, O.Costs(), batch, torch.from_numpy(rewards).float(),
+              lambda e, t: dict(zip(("rand_l", "rand_x", "rand_t"), noises[(e, t)])), lr=1e-4, timesteps=6, accum_steps=3, sigma=0.025,
+              epochs=2, record=rec)
+    for k, w in agent.decoder.views().items():
+        d = (w.detach().cpu() - A["decoder." + k]).abs()
+        assert float(d.max()) <= 1.2e-4, f"{k}: {float(d.max())}"          # 4 Adam steps of lr = 1e-4 each
+        assert float(d.flatten().kthvalue(max(1, int(0.98 * d.numel()))).values) <= 1e-5, k
+    # logged epoch loss = mean over timesteps of the per-step loss (mat_invent.py:168-172)
+    ref_loss0 = float(torch.stack(rec["loss"][:6]).sum() * 3 / 6)
+    assert abs(stats[0]["loss"] - ref_loss0) <= 1e-4 * max(1.0, abs(ref_loss0))

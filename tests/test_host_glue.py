@@ -1,0 +1,133 @@
+"""CPU-only checks of the host glue against reference-generated fixtures (g3, g9) and a
+world_size-2 gloo run of the data-parallel fine-tune arithmetic."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_atom_count_prior_and_step_lr(golden):
+    from matinvent_amd.sampling import ATOM_DIST, DEFAULT_STEP_LR, SampleDataset
+    g = golden("g9_host_glue")
+    np.testing.assert_array_equal(np.array(ATOM_DIST["mp_20"]), g["atom_dist_mp20"])
+    assert DEFAULT_STEP_LR["gen"]["mp_20"] == float(g["step_lr_gen_mp20"])
+    np.random.seed(0)
+    assert SampleDataset(8).num_atoms.tolist() == g["num_atoms_seed0_8"].tolist()
+    np.random.seed(0)
+    assert SampleDataset(64).num_atoms.tolist() == g["num_atoms_seed0_64"].tolist()
+
+
+def test_lattices_to_params_shape(golden):
+    from matinvent_amd.data import lattices_to_params_shape
+    g = golden("g3_lattice")
+    l, a = lattices_to_params_shape(torch.from_numpy(g["rnd"]))
+    np.testing.assert_array_equal(l.numpy(), g["rnd_lengths"])
+    np.testing.assert_array_equal(a.numpy(), g["rnd_angles"])
+
+
+def test_collate_and_dataset():
+    from matinvent_amd.data import CrystalBatchData, CrystalData, CrystalDataset, CrystalLoader
+    items = [CrystalData(torch.rand(n, 3), torch.randint(1, 95, (n,)), torch.rand(1, 3) + 4, torch.full((1, 3), 90.0)) for n in (3, 1, 5)]
+    ds = CrystalDataset(items, rewards=np.array([0.1, 0.5, 0.9]))
+    b = CrystalBatchData([ds[i] for i in range(3)])
+    assert b.num_graphs == 3 and b.num_nodes == 9 and b.batch.tolist() == [0, 0, 0, 1, 2, 2, 2, 2, 2]
+    assert b.reward.tolist() == [np.float32(0.1), np.float32(0.5), np.float32(0.9)]
+    assert b.lengths.shape == (3, 3) and b.atom_types.dtype == torch.long
+    torch.manual_seed(0)
+    batches = list(CrystalLoader(ds, batch_size=2, shuffle=True))
+    assert sum(x.num_graphs for x in batches) == 3 and len(batches) == 2
+
+
+def test_shard_range_partitions():
+    from matinvent_amd.dist import shard_range
+    for n in (0, 1, 7, 18, 256, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_schedules_match_reference_fixture(golden):
+    from matinvent_amd.schedules import BetaScheduler, SigmaScheduler, sampler_coefficients
+    g = golden("g2_schedulers")
+    for Tn in (20, 1000):
+        b = BetaScheduler(Tn, "cosine")
+        for k in ("betas", "alphas", "alphas_cumprod", "sigmas"):
+            np.testing.assert_allclose(getattr(b, k).numpy(), g[f"T{Tn}_beta_{k}"], rtol=2e-6, atol=1e-7)
+        torch.manual_seed(1234)
+        s = SigmaScheduler(Tn, 0.005, 0.5)
+        np.testing.assert_allclose(s.sigmas.numpy(), g[f"T{Tn}_sigma_sigmas"], rtol=1e-7)
+        np.testing.assert_allclose(s.sigmas_norm.numpy(), g[f"T{Tn}_sigma_sigmas_norm"], rtol=1e-5)
+    for mode in ("linear", "quadratic", "sigmoid"):
+        np.testing.assert_allclose(BetaScheduler(50, mode).betas.numpy(), g[f"T50_{mode}_betas"], rtol=1e-6, atol=1e-9)
+    coef = sampler_coefficients(BetaScheduler(20, "cosine"), SigmaScheduler(20, 0.005, 0.5, sigmas_norm=torch.ones(21)), 5e-6)
+    assert coef.shape == (21, 16) and torch.isfinite(coef[2:]).all()
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from oracle import diffcsp_oracle as O
+from matinvent_amd.dist import shard_range, allreduce_flat_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.set_num_threads(2)
+hp = O.CSPNetHParams(hidden_dim=64, num_layers=1, num_freqs=8)
+P = O.init_params(hp, seed=0)
+sch = O.Schedules.make(50, sigmas_norm=torch.ones(51))
+g = torch.Generator().manual_seed(1)
+na = torch.tensor([3, 5, 2, 4, 6])
+B, N = len(na), int(na.sum())
+full = dict(num_atoms=na, lengths=4 + 6 * torch.rand(B, 3, generator=g), angles=70 + 40 * torch.rand(B, 3, generator=g),
+            frac_coords=torch.rand(N, 3, generator=g), atom_types=torch.randint(1, 95, (N,), generator=g))
+rewards = torch.rand(B, generator=g)
+noise = dict(rand_l=torch.randn(B, 3, 3, generator=g), rand_x=torch.randn(N, 3, generator=g), rand_t=torch.randn(N, 100, generator=g))
+accum, sigma = 2, 0.025
+names = list(P)
+
+def grad_of(batch, rw, nz, denom):
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    noised = O.add_noise(hp, sch, batch, 7, nz)
+    loss_b, pred = O.calc_sample_loss(Pg, hp, O.Costs(), noised)
+    with torch.no_grad():
+        _, pp = O.calc_sample_loss({k: v * 1.01 for k, v in P.items()}, hp, O.Costs(), noised)
+    kl = O.calc_kl_reg(pred, pp, noised[2], len(rw))
+    loss = (rw * loss_b + kl * (1.1 - rw) * sigma).sum() / denom
+    gs = torch.autograd.grad(loss, [Pg[k] for k in names])
+    return torch.cat([x.reshape(-1) for x in gs])
+
+lo, hi = shard_range(B, rank, world)
+off = [0] + torch.cumsum(na, 0).tolist()
+sl = slice(off[lo], off[hi])
+shard = dict(num_atoms=na[lo:hi], lengths=full["lengths"][lo:hi], angles=full["angles"][lo:hi],
+             frac_coords=full["frac_coords"][sl], atom_types=full["atom_types"][sl])
+nz = dict(rand_l=noise["rand_l"][lo:hi], rand_x=noise["rand_x"][sl], rand_t=noise["rand_t"][sl])
+# local sum / (B_global * accum), then ONE flat all-reduce  == reference .mean() / accum on the whole batch
+flat = grad_of(shard, rewards[lo:hi], nz, B * accum)
+allreduce_flat_(flat)
+ref = grad_of(full, rewards, noise, B * accum)
+err = float((flat - ref).abs().max() / ref.abs().max())
+assert err < 2e-5, err
+if rank == 0:
+    print("DP_OK", err)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_gradient_equals_full_batch_gloo(tmp_path):
+    """world_size 2 over gloo: sharding by crystal with sum/(B_global*accum) scaling and one flat
+    all-reduce reproduces the full-batch gradient of the reference's `.mean()/accum` loss."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DP_OK" in out.stdout
