@@ -115,13 +115,69 @@ def _oracle_steps(O, P, hp, sch, na, noise, t_from, t_to):
     return O.sample(P, hp, s, na, noise, step_lr=STEP_LR, t_stop=t_to, keep_traj=False)
 
 
+def main_ft(args):
+    """Secondary metric (BASELINE configs[2]/[3]): crystal-timesteps / second of the fine-tune loop
+    (noise + agent fwd + frozen-prior fwd + agent bwd per timestep, fused Adam every 50), ft set =
+    256 synthetic crystals x 20 atoms per GPU, reward ~ U[0,1] (stands in for reward=hhi)."""
+    K, W = (args.steps if args.steps != 1000 else 100), args.warmup
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    from matinvent_amd.data import CrystalData
+    from matinvent_amd.finetune import ft_step
+    agent, prior = build_module(dev), build_module(dev)
+    prior.requires_grad_(False)
+    g = torch.Generator().manual_seed(7)
+    nglob = B * world
+    data = [CrystalData(torch.rand(NATOM, 3, generator=g), torch.randint(1, 95, (NATOM,), generator=g), 4 + 6 * torch.rand(1, 3, generator=g),
+                        70 + 40 * torch.rand(1, 3, generator=g)) for _ in range(nglob)]
+    rewards = torch.rand(nglob, generator=g).numpy()
+    cfg = dict(lr=1e-4, accum_steps=50, epochs=1, sigma=0.025)
+
+    def run(n):
+        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    run(max(W, 1))
+    t0 = time.perf_counter()
+    run(K)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        flops = 4 * 5.893e9 * nglob * K  # SURVEY 8d: agent fwd + prior fwd + 2x for backward
+        print(json.dumps({"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
+                          "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps, 256 crystals x 20 atoms per GPU, "
+                                                 "synthetic reward, accum_steps=50, fused Adam, flat-gradient all-reduce when N>1"},
+                          "end_to_end": {"tflops_section8d": flops / elapsed / 1e12}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["sample", "ft"], default="sample",
+                    help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
+    if args.mode == "ft":
+        return main_ft(args)
     K, W = args.steps, args.warmup
     assert 1 <= K <= T and 0 <= W <= T, f"steps and warmup must be <= T = {T}"
 

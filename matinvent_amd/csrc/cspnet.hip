@@ -45,6 +45,36 @@ __global__ void pack_wff_kernel(const float* __restrict__ W1, int edge_in, int H
     out[idx] = v;
 }
 
+// Fourier operand of the edge kernel, once per network evaluation, in B-fragment order:
+// FFp[tile][m][lane][q] = hi ? cos(arg) : sin(arg), arg = ((x_j - x_i) % 1)_c * (2*pi*k), pair 4m+q = c*FP + k,
+// lane = (edge-in-tile, hi).  SinusoidsEmbedding (cspnet.py:12-24); frequency table 2*pi*k in fp32 (:16).
+__global__ void fourier_pack_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
+                                    float* __restrict__ FFp, int64_t E, int F, int KP) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+    const int nm = KP / 4, FP = KP / 3;
+    const int64_t total = ((E + 31) / 32) * nm * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), m = (int)((idx >> 6) % nm);
+    const int64_t tile = (idx >> 6) / nm;
+    int64_t e = tile * 32 + (lane & 31);
+    if (e >= E) e = E - 1;
+    const int hi = lane >> 5, i = src[e], j = dst[e];
+    f32x4 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = 4 * m + q, c = s / FP, k = s % FP;
+        float v = 0.f;
+        if (k < F) {
+            const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);  // cspnet.py:242
+            float sn, cs;
+            sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
+            v = hi ? cs : sn;
+        }
+        out[q] = v;
+    }
+    reinterpret_cast<f32x4*>(FFp)[idx] = out;
+}
+
 // W2_p[u][t][q][lane][c] = W2[32u + (lane&31)][32t + 8q + 4(lane>>5) + c]
 __global__ void pack_w2_kernel(const float* __restrict__ W2, int H, float* __restrict__ out) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,7 +212,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     EdgeFwdArgs a;
     a.PQ = b->PQ;
     a.G = b->G;
-    a.frac = frac;
+    a.FFp = b->FFp;
     a.src = b->src;
     a.dst = b->dst;
     a.node2graph = b->node2graph;
@@ -286,6 +316,13 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         eh.row_group = b->node2graph;
         eh.ld_row_bias = H;
         MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s));
+    }
+    // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
+    if (b->E > 0) {
+        const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
+        hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->src, b->dst, b->FFp, b->E, net->F,
+                           net->KP);
+        MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
     for (int l = 0; l < L; ++l) {
@@ -533,6 +570,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
     A_(PQ, 2 * NH);
     A_(G, (size_t)B * H);
     A_(part, nslots * NH);
+    A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);

@@ -37,12 +37,12 @@ namespace mi {
 struct EdgeFwdArgs {
     const float* PQ;        // [N, 2H]  cols [0,H) = P_i, cols [H,2H) = P_j
     const float* G;         // [B, H]   gram term + b1
-    const float* frac;      // [N, 3]
     const int* src;         // [E] row node i (sorted ascending)
     const int* dst;         // [E] col node j
     const int* node2graph;  // [N]
     const int* rowptr;      // [N+1] first edge of every node
     const float* Wff_p;     // packed [KP/4][NT][64][4], pair s = c*FP + k
+    const float* FFp;       // [tiles][KP/4][64][4] Fourier operand in B-fragment order (built once per evaluation)
     const float* W2_p;      // packed [NT(u)][NT(t)][4(q)][64][4]
     const float* b2;        // [H]
     float* part;            // [nslots][N][H]
@@ -67,14 +67,11 @@ struct EdgeFwdArgs {
 #define MI_STAMP(k) do { } while (0)
 #endif
 
-#ifndef MI_ABL
-#define MI_ABL 0
-#endif
 #ifndef MI_UG
-#define MI_UG 4
+#define MI_UG 2
 #endif
 #ifndef MI_RING
-#define MI_RING 2
+#define MI_RING 4
 #endif
 
 template <int H, bool SAVE>
@@ -91,11 +88,6 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
     const int i = a.src[e], j = a.dst[e];
     const int g = a.node2graph[i];
 
-    // fractional difference (x_j - x_i) % 1   (cspnet.py:242)
-    const float d0 = pymod1(a.frac[j * 3 + 0] - a.frac[i * 3 + 0]);
-    const float d1 = pymod1(a.frac[j * 3 + 1] - a.frac[i * 3 + 1]);
-    const float d2 = pymod1(a.frac[j * 3 + 2] - a.frac[i * 3 + 2]);
-
     const float* pi = a.PQ + (size_t)i * (2 * H) + 4 * hi;
     const float* pj = a.PQ + (size_t)j * (2 * H) + H + 4 * hi;
     const float* pg = a.G + (size_t)g * H + 4 * hi;
@@ -105,10 +97,9 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
     // ---- GEMM1 half: Z1^T[32*(T0+t) .. ] = Wff * ff^T for NTH feature tiles --------------------
     // K runs over (coordinate c, frequency k) pairs, FP = F rounded up to 8 per coordinate (zero
     // weights on the pads), four pairs per packed float4 -> 2*4 k-values per m-step.  Software
-    // pipeline, all in registers: weights of step m+1 are loaded under the MFMAs of step m, and the
-    // Fourier operand of step m+1 (4 sincos) is computed BETWEEN the MFMAs of step m -- a single
-    // in-order wave only overlaps VALU with the matrix pipe when they alternate in program order,
-    // which the sched_group_barrier ladder enforces.
+    // pipeline, all in registers: weights AND the Fourier operand of step m+1 are loaded under the
+    // MFMAs of step m.  (An earlier version generated sin/cos in the loop: on gfx950 VALU work does
+    // not overlap f32 MFMAs, so the 12x per-evaluation recomputation cost 13 % of the kernel.)
     auto gemm1_half = [&](auto t0_tag, f32x16 (&acc)[NTH]) {
         constexpr int T0 = decltype(t0_tag)::value;
 #pragma unroll
@@ -116,67 +107,35 @@ __global__ __launch_bounds__(64, 1) void edge_mlp_fwd_kernel(EdgeFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wff_p) + (size_t)T0 * 64 + lane;
-        const int nmc = a.KP / 12;  // m-steps per coordinate (even: FP % 8 == 0)
-        auto fourier4 = [&](float dc, int kbase, float (&bv)[4]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // emb = x * freq, freq = 2*pi*k evaluated in fp32 exactly like the reference table (cspnet.py:16,21)
-                const float arg = dc * ((float)(kbase + q) * 6.28318530717958647692f);
-                float sn, cs;
-                sincos_bounded(arg, &sn, &cs);
-                bv[q] = hi ? cs : sn;  // hi = 0 lanes carry sin(c,k), hi = 1 lanes cos(c,k)
-            }
-        };
-        auto mfma_block = [&](const f32x4 (&w)[NTH], const float (&bv)[4]) {
+        // Fourier operand: precomputed once per network evaluation in fragment order (fourier_pack_kernel,
+        // cspnet.hip): FFp[tile][m][lane] = float4 of the four pairs of m-step m for lane (edge, hi).
+        const f32x4* fp = reinterpret_cast<const f32x4*>(a.FFp) + ((size_t)blockIdx.x * (a.KP / 4)) * 64 + lane;
+        const int nm = a.KP / 4;  // even
+        auto mfma_block = [&](const f32x4 (&w)[NTH], const f32x4& bv) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int t = 0; t < NTH; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][q], bv[q], acc[t], 0, 0, 0);
         };
-        auto interleave = [&]() {  // 1 MFMA : 5 VALU, for the 4*NTH MFMAs of a block
-#pragma unroll
-            for (int x = 0; x < 4 * NTH; ++x) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-        };
-        f32x4 wa[NTH], wb[NTH];
-        float bva[4], bvb[4];
+        f32x4 wa[NTH], wb[NTH], bva, bvb;
 #pragma unroll
         for (int t = 0; t < NTH; ++t) wa[t] = wp[(size_t)t * 64];
-        fourier4(d0, 0, bva);
+        bva = fp[0];
+        for (int m = 0; m < nm; m += 2) {
+            MI_PIN();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float dc = c == 0 ? d0 : (c == 1 ? d1 : d2);
-            const float dn = c == 0 ? d1 : d2;  // next coordinate (unused after the last)
-            for (int mm = 0; mm < nmc; mm += 2) {
-                const int mg = c * nmc + mm;  // global m-step
-                MI_PIN();
+            for (int t = 0; t < NTH; ++t) wb[t] = wp[((size_t)(m + 1) * NT + t) * 64];
+            bvb = fp[(size_t)(m + 1) * 64];
+            MI_PIN();
+            mfma_block(wa, bva);
+            MI_PIN();
+            const int mn = (m + 2 < nm) ? m + 2 : m;  // last step: harmless reload
 #pragma unroll
-                for (int t = 0; t < NTH; ++t) wb[t] = wp[((size_t)(mg + 1) * NT + t) * 64];
-                MI_PIN();
-                mfma_block(wa, bva);
-#if MI_ABL != 1
-                fourier4(dc, 4 * (mm + 1), bvb);
-                interleave();
-#else
-                bvb[0] = bva[1]; bvb[1] = bva[2]; bvb[2] = bva[3]; bvb[3] = bva[0];
-#endif
-                MI_PIN();
-                const bool last = mm + 2 >= nmc;
-                const int mn = (c == 2 && last) ? mg : mg + 2;  // very last step: harmless reload
-#pragma unroll
-                for (int t = 0; t < NTH; ++t) wa[t] = wp[((size_t)mn * NT + t) * 64];
-                MI_PIN();
-                mfma_block(wb, bvb);
-#if MI_ABL != 1
-                fourier4(last ? dn : dc, last ? 0 : 4 * (mm + 2), bva);
-                interleave();
-#else
-                bva[0] = bvb[1]; bva[1] = bvb[2]; bva[2] = bvb[3]; bva[3] = bvb[0];
-#endif
-            }
+            for (int t = 0; t < NTH; ++t) wa[t] = wp[((size_t)mn * NT + t) * 64];
+            bva = fp[(size_t)mn * 64];
+            MI_PIN();
+            mfma_block(wb, bvb);
         }
         MI_PIN();
     };

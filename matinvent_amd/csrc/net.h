@@ -64,6 +64,7 @@ struct mi_batch {
     float* PQ = nullptr;     // [N][2H]
     float* G = nullptr;      // [B][H]
     float* part = nullptr;   // [nslots][N][H]
+    float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
