@@ -1,0 +1,122 @@
+"""Model plug-in API (models/suite/{base,diffcsp}.py of the reference): the drop-in boundary the
+pipeline talks to.  `load_model / get_sampler / get_dataloader / save_model` keep their names,
+arguments and error behaviour."""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import config as C
+from .data import CrystalDataset, CrystalLoader
+from .diffcsp import DiffCSPModule
+from .sampling import DiffCSPSampler
+
+# public DiffCSP mp_20 generation hyper-parameters (the hub's hparams.yaml is unreachable offline;
+# SURVEY.md section 8d): used only for `random_init: true` runs (benchmarks, smoke tests)
+DEFAULT_DIFFCSP_HPARAMS = dict(
+    decoder=dict(hidden_dim=512, num_layers=6, max_atoms=100, act_fn="silu", dis_emb="sin", num_freqs=128, edge_style="fc",
+                 ln=True, ip=True),
+    beta_scheduler=dict(timesteps=1000, scheduler_mode="cosine"),
+    sigma_scheduler=dict(timesteps=1000, sigma_begin=0.005, sigma_end=0.5),
+    latent_dim=0, time_dim=256, cost_lattice=1.0, cost_coord=1.0, cost_type=20.0)
+
+
+def get_device(device=None):
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    return torch.device(device)
+
+
+class ModelSuite:
+    """models/suite/base.py:30-59."""
+
+    def __init__(self, model_name, sample_cfg, finetune_cfg, model_path=None, config_overrides=[], device=None, **kwargs):
+        self.model_name = model_name
+        self.sample_cfg = C.create(sample_cfg)
+        self.finetune_cfg = C.create(finetune_cfg)
+        self.model_path = model_path
+        self.config_overrides = config_overrides
+        self.device = get_device(device)
+        self.cfg = C.create(kwargs)
+
+    def load_model(self):
+        raise NotImplementedError
+
+    def get_sampler(self):
+        raise NotImplementedError
+
+    def get_dataloader(self):
+        raise NotImplementedError
+
+    def save_model(self):
+        raise NotImplementedError
+
+
+class DiffCSPSuite(ModelSuite):
+    """models/suite/diffcsp.py:25-145."""
+
+    def load_model(self):
+        """A fresh model per call (the pipeline loads agent and prior separately, mat_invent.py:63-64).
+        `model_path` = directory with `hparams.yaml` (key `model`) and `last.ckpt`
+        ({"state_dict", ...}); without it the reference downloads from the HF hub, which is not
+        possible offline: pass `random_init: true` (+ optional `hparams`) for synthetic runs."""
+        if self.model_path is None:
+            if not self.cfg.get("random_init", False):
+                raise RuntimeError("DiffCSPSuite.load_model: no model_path and no network access to jwchen25/MatInvent; "
+                                   "give model_path=<dir with hparams.yaml + last.ckpt> or random_init=true")
+            hp = C.merge(C.create(DEFAULT_DIFFCSP_HPARAMS), self.cfg.get("hparams"))
+            cfg = C.create({"model": hp})
+            sn = os.path.join(os.path.dirname(__file__), "data", "sigmas_norm_T1000_b0.005_e0.5_seed1234.npy")
+            ss = dict(hp["sigma_scheduler"])
+            if (ss.get("timesteps"), ss.get("sigma_begin"), ss.get("sigma_end")) == (1000, 0.005, 0.5):
+                ss["sigmas_norm"] = np.load(sn)
+            torch.manual_seed(int(self.cfg.get("seed", 0)))
+            model = DiffCSPModule(**{**C.to_container(hp), "sigma_scheduler": ss}, device=self.device)
+            scale = float(self.cfg.get("head_scale", 1.0))
+            if scale != 1.0:
+                with torch.no_grad():
+                    v = model.decoder.views()
+                    for k in ("coord_out.weight", "lattice_out.weight", "type_out.weight", "type_out.bias"):
+                        v[k].mul_(scale)
+                model.decoder.mark_dirty()
+        else:
+            model_path = Path(os.path.abspath(self.model_path))
+            cfg = C.load(str(model_path / "hparams.yaml"))
+            hp = C.to_container(cfg["model"] if "model" in cfg else cfg, resolve=True)
+            hp.pop("_target_", None)
+            hp.pop("optim", None)
+            model = DiffCSPModule(**hp, device=self.device)
+            ckpts = sorted(model_path.glob("*.ckpt"))
+            if ckpts:
+                last = [c for c in ckpts if "last" in c.name]
+                ck = torch.load(str(last[0] if last else ckpts[-1]), map_location="cpu", weights_only=False)
+                model.load_state_dict(ck["state_dict"], strict=False)
+        model.config = cfg
+        return model
+
+    def get_sampler(self):
+        return DiffCSPSampler(batch_size=self.sample_cfg.batch_size, num_batches=self.sample_cfg.num_batches)
+
+    def get_dataloader(self, samples, rewards, batch_size=None, shuffle=True):
+        if batch_size is None:
+            batch_size = self.finetune_cfg.batch_size
+        return CrystalLoader(CrystalDataset(samples, rewards), batch_size=batch_size, shuffle=shuffle)
+
+    def save_model(self, model, save_dir):
+        """Same artefacts as the reference: last.ckpt = {"state_dict", "config"} + hparams.yaml."""
+        os.makedirs(save_dir, exist_ok=True)
+        cfg = model.config
+        torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "config": C.to_container(cfg, resolve=True)},
+                   os.path.join(save_dir, "last.ckpt"))
+        C.save(cfg, os.path.join(save_dir, "hparams.yaml"))
+
+
+class MatterGenSuite(ModelSuite):
+    """models/suite/mattergen.py: the GemNet-T denoiser, corruptions and sampler live in the un-vendored
+    pip package `mattergen @ 5bb2b397` (parity unpinned) -- not built."""
+
+    def load_model(self):
+        raise NotImplementedError("MatterGenSuite: the MatterGen arithmetic is an un-vendored dependency of the reference and is "
+                                  "not part of this build; use model=diffcsp")
+    get_sampler = get_dataloader = save_model = load_model

@@ -1,0 +1,87 @@
+"""CPU-only: the hydra-compatible front-end (matinvent_amd.config) on the example tree and, when the
+reference checkout is present (build container only), on the reference's own configs/."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from matinvent_amd import config as C  # noqa: E402
+
+EXAMPLE = os.path.join(ROOT, "dropin", "configs")
+REF = "/root/reference/configs"
+
+
+class Dummy:
+    def __init__(self, **kw):
+        self.kw = kw
+
+
+def test_compose_interpolation_resolver_and_overrides():
+    cfg = C.compose(EXAMPLE, "base", ["expname=run7", "eval_size=8", "model.finetune_cfg.lr=0.5", "+extra.flag=true", "device=cuda:1"])
+    r = C.resolved(cfg)
+    assert r.model.sample_cfg.batch_size == 96            # ${calc:'${eval_size} * 12'}
+    assert r.model.finetune_cfg.batch_size == 8 and r.model.finetune_cfg.lr == 0.5
+    assert r.pipeline.sample_cfg == {"num_batches": 1, "max_num": 8}   # whole-node ${sample_cfg}
+    assert r.pipeline.device == "cuda:1" and r.model.device == "cuda:1"
+    assert r.extra.flag is True
+    assert C.run_dir(cfg) == "exp_res/run7"
+    with pytest.raises(KeyError):
+        C.compose(EXAMPLE, "base", ["nonexistent=1"])
+    # group selection
+    cfg2 = C.compose(EXAMPLE, "base", ["pipeline=baseline", "+sample_size=4"])
+    assert C.resolved(cfg2).pipeline._target_ == "pipeline.baseline.Baseline"
+    assert C.resolved(cfg2).pipeline.sample_cfg.batch_size == 4
+
+
+def test_merge_and_container_roundtrip(tmp_path):
+    a = C.create({"x": 1, "n": {"a": 1, "b": [1, 2]}})
+    b = C.create({"n": {"b": [3], "c": 2}})
+    m = C.merge(a, b)
+    assert m == {"x": 1, "n": {"a": 1, "b": [3], "c": 2}} and a.n.b == [1, 2]
+    assert m.n.c == 2 and "zz" not in m and m.get("zz") is None
+    p = tmp_path / "c.yaml"
+    C.save(m, str(p))
+    assert C.load(str(p)) == m
+
+
+def test_instantiate_recursive_partial_and_kwargs():
+    cfg = C.create({"_target_": "tests.test_config_frontend.Dummy", "a": 1,
+                    "child": {"_target_": "tests.test_config_frontend.Dummy", "b": 2},
+                    "items": [{"_target_": "tests.test_config_frontend.Dummy", "c": 3}, 5], "plain": {"k": "v"}})
+    obj = C.instantiate(cfg, extra={"_target_": "tests.test_config_frontend.Dummy", "d": 4}, a=10)
+    assert isinstance(obj, Dummy) and obj.kw["a"] == 10
+    assert isinstance(obj.kw["child"], Dummy) and obj.kw["child"].kw == {"b": 2}
+    assert isinstance(obj.kw["items"][0], Dummy) and obj.kw["items"][1] == 5
+    assert isinstance(obj.kw["extra"], Dummy) and obj.kw["plain"].k == "v"
+    raw = C.instantiate(C.merge(cfg, {"_recursive_": False}))
+    assert isinstance(raw.kw["child"], dict)
+    part = C.instantiate(C.create({"_target_": "tests.test_config_frontend.Dummy", "_partial_": True, "a": 1}))
+    assert part(b=2).kw == {"a": 1, "b": 2}
+
+
+def test_dropin_import_paths_resolve():
+    """Every `_target_` the example (= the reference's) configs name resolves through dropin/."""
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        for t in ("models.suite.DiffCSPSuite", "models.suite.MatterGenSuite", "pipeline.mat_invent.MatInvent", "pipeline.baseline.Baseline",
+                  "pipeline.utils.logger.CSVLogger", "pipeline.filters.opt_filter.OptFilter", "models.diffcsp.diffusion.DiffCSPModule",
+                  "models.diffcsp.cspnet.CSPNet", "models.diffcsp.scheduler.BetaScheduler", "models.diffcsp.sample.DiffCSPSampler",
+                  "models.diffcsp.finetune.DiffCSPDataset", "rewards.synthetic.SyntheticReward"):
+            assert C._locate(t) is not None, t
+    finally:
+        sys.path.remove(os.path.join(ROOT, "dropin"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
+def test_reference_config_tree_composes_unchanged():
+    """The reference's configs/ and its documented command line (scripts/run_rl.sh:8-15, README) compose."""
+    cfg = C.compose(REF, "base", ["expname=t", "pipeline=mat_invent", "model=diffcsp", "reward=hhi", "logger=csv", "device=cuda:0"])
+    r = C.resolved(cfg)
+    assert r.model._target_ == "models.suite.DiffCSPSuite" and r.model.sample_cfg.batch_size == 16 * 12
+    assert r.pipeline._target_ == "pipeline.mat_invent.MatInvent" and r.pipeline.finetune_cfg.accum_steps == 50
+    assert r.pipeline.sample_cfg.filter._target_ == "pipeline.filters.opt_filter.OptFilter" and r.pipeline.sample_cfg.max_num == 16
+    assert r.reward.prop_cfg[0].calculator._target_ == "rewards.calculators.PyMatGen"
+    assert r.logger._target_ == "pipeline.utils.logger.CSVLogger" and C.run_dir(cfg) == "exp_res/t"
+    for reward in sorted(f[:-5] for f in os.listdir(os.path.join(REF, "reward"))):
+        C.resolved(C.compose(REF, "base", [f"reward={reward}", "model=mattergen"]))
