@@ -203,6 +203,26 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
  * bracketed by hipEvents on its launch stream; mi_profile_read synchronises and returns the
  * number of launches and their summed duration in milliseconds since the last reset.
  * ------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------
+ * Arithmetic paths.  Both reproduce the reference to fp32 round-off (tests state the bounds).
+ *   GEMM mode (process-wide): MI_GEMM_SPLIT (default) evaluates every fp32 product on the bf16 matrix
+ *     pipe from three bf16 planes per operand (six terms; measured max error below the f32 MFMA's);
+ *     MI_GEMM_F32 uses v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (1/16 the bf16 rate).
+ *   Edge mode (per network): MI_EDGE_GEMM (default) runs the per-edge MLP as two tiled GEMMs over
+ *     the edge list with gather / SiLU epilogues; MI_EDGE_FUSED_F32 is the register-chained
+ *     f32-MFMA kernel that keeps the intermediate in registers.
+ * ------------------------------------------------------------------------------------- */
+#define MI_GEMM_F32 0
+#define MI_GEMM_SPLIT 1
+#define MI_EDGE_FUSED_F32 0
+#define MI_EDGE_GEMM 1
+int mi_set_gemm_mode(int mode);
+int mi_net_set_edge_mode(mi_net* net, int mode);
+
+/* Diagnostics: C[M,N] = A[M,K] W[N,K]^T through the node-level GEMM kernels.  kind 0 = f32-input MFMA,
+ * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe. */
+int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M,
+                  int N, int K, void* stream);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms);
 

@@ -29,6 +29,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def set_gemm_mode(mode: str):
+    """Process-wide matrix path of every node-/edge-level GEMM: 'split' (default; three bf16 planes,
+    six product terms on the bf16 matrix pipe, fp32-class accuracy) or 'f32' (f32-input MFMA)."""
+    _lib.check(_lib.load().mi_set_gemm_mode({"f32": 0, "split": 1}[mode]), "mi_set_gemm_mode")
+
+
 class CrystalBatch:
     """Index tables + workspace of one batch of crystals (mi_batch).  Replaces the PyG Batch
     bookkeeping (`num_atoms`, `batch`) and the per-call edge enumeration of gen_edges."""
@@ -147,6 +153,13 @@ class CSPNet(nn.Module):
         self.theta._mi_owner = self
         self._dirty = True
         return r
+
+    # ---- arithmetic path ------------------------------------------------------------------------
+    def set_edge_mode(self, mode: str):
+        """'gemm' (default): per-edge MLP as two tiled GEMMs; 'fused_f32': register-chained f32-MFMA kernel."""
+        code = {"fused_f32": 0, "gemm": 1}[mode]
+        _lib.check(self._lib.mi_net_set_edge_mode(self._h, code), "mi_net_set_edge_mode")
+        self.edge_mode = mode
 
     # ---- forward ------------------------------------------------------------------------------
     def make_batch(self, num_atoms, node_offset=0, graph_offset=0) -> CrystalBatch:

@@ -8,7 +8,7 @@
 // as [E,H] / [E,6F] scratch and pushed through the generic MFMA GEMMs (dgrad = gemm_nt against
 // pre-transposed weights, wgrad = gemm_tn with a fixed-order split reduction).  Deterministic: no
 // float atomics anywhere.
-#include "gemm.h"
+#include "gemm_split.h"
 #include "net.h"
 
 namespace mi {
@@ -46,19 +46,8 @@ __global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __res
     Z2[idx] = (dcat[(size_t)i * (2 * H) + H + f] / deg) * silu_grad(Z2[idx]);
 }
 
-// FF[e][c*F+k] = sin(d_c * 2*pi*k), FF[e][3F + c*F+k] = cos(...)   (cspnet.py:20-24)
 __global__ void fourier_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
-                               float* __restrict__ FF, int64_t E, int F) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= E * 3 * F) return;
-    int64_t e = idx / (3 * F);
-    int ck = (int)(idx % (3 * F)), c = ck / F, k = ck % F;
-    float d = pymod1(frac[dst[e] * 3 + c] - frac[src[e] * 3 + c]);
-    float sn, cs;
-    sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
-    FF[e * (6 * F) + ck] = sn;
-    FF[e * (6 * F) + 3 * F + ck] = cs;
-}
+                               float* __restrict__ FF, int64_t E, int F);
 
 // dPQ[i][0:H]  = sum_j dZ1[(i,j)]      (row run of node i)
 // dPQ[j][H:2H] = sum_i dZ1[(i,j)]      (column of node j inside its fully connected crystal)
@@ -495,6 +484,28 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
     hipLaunchKernelGGL(add_noise_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, a);
     MI_KERNEL_CHECK();
     return MI_OK;
+}
+
+int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, void* stream) {
+    MI_CHECK(A && W && C, MI_EINVAL, "null argument");
+    if (kind == 2) {  // split both operands into tile-blocked bf16 planes (cached scratch), then the plane GEMM
+        static u16 *pa = nullptr, *pw = nullptr;
+        static size_t na = 0, nw = 0;
+        hipStream_t s = (hipStream_t)stream;
+        if (planes_elems(M, K) > na) { if (pa) (void)hipFree(pa); na = planes_elems(M, K); MI_HIP(hipMalloc((void**)&pa, na * 2)); }
+        if (planes_elems(N, K) > nw) { if (pw) (void)hipFree(pw); nw = planes_elems(N, K); MI_HIP(hipMalloc((void**)&pw, nw * 2)); }
+        Planes PA = make_planes(pa, K), PW = make_planes(pw, K);
+        if (ldc >= 0) {
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((M + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, M, K, PA);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((N + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, N, K, PW);
+        }
+        PlanesEpilogue pe;
+        pe.C = C;
+        pe.ldc = ldc < 0 ? -ldc : ldc;
+        return gemm_planes(PA, PW, M, N, K, pe, s);
+    }
+    return kind == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream)
+                     : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -5,10 +5,12 @@
 #include <algorithm>
 
 #include "edge_mlp.h"
-#include "gemm.h"
+#include "gemm_split.h"
 #include "net.h"
 
 namespace mi {
+
+int g_gemm_mode = 1;  // MI_GEMM_SPLIT
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -73,6 +75,71 @@ __global__ void fourier_pack_kernel(const float* __restrict__ frac, const int* _
         out[q] = v;
     }
     reinterpret_cast<f32x4*>(FFp)[idx] = out;
+}
+
+// FF[e][c*F+k] = sin(d_c * 2*pi*k), FF[e][3F + c*F+k] = cos(...)   (cspnet.py:20-24)
+__global__ void fourier_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
+                               float* __restrict__ FF, int64_t E, int F) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * 3 * F) return;
+    int64_t e = idx / (3 * F);
+    int ck = (int)(idx % (3 * F)), c = ck / F, k = ck % F;
+    float d = pymod1(frac[dst[e] * 3 + c] - frac[src[e] * 3 + c]);
+    float sn, cs;
+    sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
+    FF[e * (6 * F) + ck] = sn;
+    FF[e * (6 * F) + 3 * F + ck] = cs;
+}
+
+// Fourier features written directly as a tile-blocked bf16 plane set (the A operand of the first edge GEMM).
+// One thread per (edge, column pair); columns = [sin(3F) | cos(3F)] in the reference order (cspnet.py:20-24),
+// pad columns (>= 6F) and pad rows (>= E) are written as zero.
+__global__ void fourier_planes_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst, Planes FF,
+                                      int64_t E, int F) {
+    const int cp = FF.KT * 16;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows_pad = (E + 127) / 128 * 128;
+    if (idx >= rows_pad * cp) return;
+    const int64_t e = idx / cp;
+    const int c0 = (int)(idx % cp) * 2;
+    float v[2] = {0.f, 0.f};
+    if (e < E) {
+        const int i = src[e], j = dst[e];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = c0 + u;
+            if (col < 6 * F) {
+                const int ck = col < 3 * F ? col : col - 3 * F, c = ck / F, k = ck % F;
+                const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+                float sn, cs;
+                sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
+                v[u] = col < 3 * F ? sn : cs;
+            }
+        }
+    }
+    unsigned p[3];
+    split3_pair(v[0], v[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, c0, k)) = p[k];
+}
+
+// Wff[f][0:6F] = W1[f][2H+9 : 2H+9+6F]  (contiguous, 16-byte aligned rows for the GEMM path)
+__global__ void pack_wff_plain_kernel(const float* __restrict__ W1, int edge_in, int H, int F6, float* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * F6) return;
+    int f = idx / F6, k = idx % F6;
+    out[idx] = W1[(size_t)f * edge_in + 2 * H + 9 + k];
+}
+
+// agg[i] = mean over the edge run of node i of M2[e]  -> cat[i][H:2H]     (scatter mean, cspnet.py:79)
+__global__ void segment_mean_kernel(const float* __restrict__ M2, const int* __restrict__ rowptr, float* __restrict__ cat, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int i = (int)(idx / H), f = (int)(idx % H);
+    int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float s = 0.f;
+    for (int e = e0; e < e1; ++e) s += M2[(size_t)e * H + f];
+    cat[(size_t)i * (2 * H) + H + f] = e1 > e0 ? s / (float)(e1 - e0) : 0.f;
 }
 
 // W2_p[u][t][q][lane][c] = W2[32u + (lane&31)][32t + 8q + 4(lane>>5) + c]
@@ -206,6 +273,26 @@ int dev_alloc(mi_batch* b, T** p, size_t n) {
 }
 template int dev_alloc<float>(mi_batch*, float**, size_t);
 template int dev_alloc<int>(mi_batch*, int**, size_t);
+template int dev_alloc<unsigned short>(mi_batch*, unsigned short**, size_t);
+
+// bench.py's roofline hook: bracket the dominant stage (the per-edge MLP of one layer) with events
+static int prof_begin(mi_net* net, hipStream_t s) {
+    if (!net->prof) return MI_OK;
+    if (net->ev_used + 2 > net->ev.size())
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t ev;
+            MI_HIP(hipEventCreate(&ev));
+            net->ev.push_back(ev);
+        }
+    MI_HIP(hipEventRecord(net->ev[net->ev_used], s));
+    return MI_OK;
+}
+static int prof_end(mi_net* net, hipStream_t s) {
+    if (!net->prof) return MI_OK;
+    MI_HIP(hipEventRecord(net->ev[net->ev_used + 1], s));
+    net->ev_used += 2;
+    return MI_OK;
+}
 
 static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, float* Z1, float* Z2, hipStream_t s) {
     const std::string p = "csp_layer_" + std::to_string(layer) + ".";
@@ -237,19 +324,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     a.KP = net->KP;
     if (b->E == 0) return MI_OK;
     dim3 grid((unsigned)cdiv(b->E, 32)), block(64);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (net->prof) {
-        if (net->ev_used + 2 > net->ev.size()) {
-            for (int k = 0; k < 2; ++k) {
-                hipEvent_t ev;
-                MI_HIP(hipEventCreate(&ev));
-                net->ev.push_back(ev);
-            }
-        }
-        e0 = net->ev[net->ev_used++];
-        e1 = net->ev[net->ev_used++];
-        MI_HIP(hipEventRecord(e0, s));
-    }
+    MI_TRY(prof_begin(net, s));
     const bool save = Z1 != nullptr;
     MI_CHECK((Z1 == nullptr) == (Z2 == nullptr), MI_EINVAL, "Z1 and Z2 must be given together");
 #define MI_EDGE_LAUNCH(HH)                                                                   \
@@ -266,6 +341,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     }
 #undef MI_EDGE_LAUNCH
     MI_KERNEL_CHECK();
+    MI_TRY(prof_end(net, s));
 #ifdef MI_TIMING
     if (++g_count == 40 && ntile * 128 <= ((size_t)1 << 24)) {
         std::vector<unsigned long long> h(ntile * 16);
@@ -284,7 +360,6 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
         fprintf(stderr, "[MI_TIMING] whole tile %10.0f clk; kernel span %llu clk; tiles %zu\n", whole / ntile, tmax - tmin, ntile);
     }
 #endif
-    if (net->prof) MI_HIP(hipEventRecord(e1, s));
     return MI_OK;
 }
 
@@ -318,10 +393,18 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s));
     }
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
-    if (b->E > 0) {
+    if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
         hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->src, b->dst, b->FFp, b->E, net->F,
                            net->KP);
+        MI_KERNEL_CHECK();
+    } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
+        Planes ffp = make_planes(b->FFpl, 6 * net->F);
+        const int64_t nthr = (b->E + 127) / 128 * 128 * (int64_t)ffp.KT * 16;
+        hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->src, b->dst, ffp, b->E, net->F);
+        MI_KERNEL_CHECK();
+    } else if (b->E > 0) {
+        hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)cdiv(b->E * 3 * net->F, 256)), dim3(256), 0, s, frac, b->src, b->dst, b->FF, b->E, net->F);
         MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
@@ -341,9 +424,60 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
                            net->p(p + "edge_mlp.0.bias"), b->G, H);
         MI_KERNEL_CHECK();
-        MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
-        hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
-        MI_KERNEL_CHECK();
+        if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
+            MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+            MI_KERNEL_CHECK();
+        } else if (b->E > 0) {      // two tiled GEMMs over the edge list with gather / SiLU epilogues
+            const int E = (int)b->E, F6 = 6 * net->F;
+            MI_TRY(prof_begin(net, s));
+            GemmEpilogue g1e;       // Z1 = FF Wff^T + P_i[src] + P_j[dst] + G[graph];  M1 = SiLU(Z1)
+            g1e.row_bias = b->PQ;
+            g1e.row_group = b->src;
+            g1e.ld_row_bias = 2 * H;
+            g1e.row_bias2 = b->PQ + H;
+            g1e.row_group2 = b->dst;
+            g1e.ld_row_bias2 = 2 * H;
+            g1e.row_bias3 = b->G;
+            g1e.row_group3 = b->edge_graph;
+            g1e.ld_row_bias3 = H;
+            g1e.act = ACT_SILU;
+            if (train) {
+                g1e.pre_act = tp.Z1 + (size_t)l * b->E * H;
+                g1e.ld_pre = H;
+            }
+            GemmEpilogue g2e;       // M2 = SiLU(M1 W2^T + b2)
+            g2e.bias = net->p(p + "edge_mlp.2.bias");
+            g2e.act = ACT_SILU;
+            if (train) {
+                g2e.pre_act = tp.Z2 + (size_t)l * b->E * H;
+                g2e.ld_pre = H;
+            }
+            if (g_gemm_mode == MI_GEMM_SPLIT) {  // operands pre-split into bf16 planes: pure bf16 GEMMs
+                Planes ffp = make_planes(b->FFpl, F6);
+                Planes wffp = make_planes(net->Wffpl + (size_t)l * planes_elems(H, F6), F6);
+                Planes m1p = make_planes(b->M1pl, H);
+                Planes w2p = make_planes(net->W2pl + (size_t)l * planes_elems(H, H), H);
+                PlanesEpilogue pe1;
+                pe1.ep = g1e;
+                pe1.Cp = m1p;
+                MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
+                PlanesEpilogue pe2;
+                pe2.ep = g2e;
+                pe2.C = b->M2;
+                pe2.ldc = H;
+                MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
+            } else {
+                MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
+                MI_TRY(gemm_nt(b->M1, H, net->p(p + "edge_mlp.2.weight"), H, b->M2, H, E, H, H, g2e, s));
+            }
+            MI_TRY(prof_end(net, s));
+            hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->M2, b->rowptr, cat, N, H);
+            MI_KERNEL_CHECK();
+        } else {
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+            MI_KERNEL_CHECK();
+        }
         GemmEpilogue e1;
         e1.bias = net->p(p + "node_mlp.0.bias");
         e1.act = ACT_SILU;
@@ -453,8 +587,10 @@ int mi_net_create(const mi_net_config* cfg, mi_net** out) {
 
 void mi_net_destroy(mi_net* n) {
     if (!n) return;
-    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT})
+    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->Wff, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT})
         if (p) (void)hipFree(p);
+    if (n->Wffpl) (void)hipFree(n->Wffpl);
+    if (n->W2pl) (void)hipFree(n->W2pl);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
 }
@@ -483,6 +619,9 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Wff_p, n->L * n->wff_stride() * sizeof(float)));
         MI_HIP(hipMalloc((void**)&n->W2_p, n->L * n->w2_stride() * sizeof(float)));
         MI_HIP(hipMalloc((void**)&n->freqs, n->F * sizeof(float)));
+        MI_HIP(hipMalloc((void**)&n->Wff, (size_t)n->L * H * 6 * n->F * sizeof(float)));
+        MI_HIP(hipMalloc((void**)&n->Wffpl, (size_t)n->L * planes_elems(H, 6 * n->F) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->W2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
     }
     if (freqs_host) {
         MI_HIP(hipMemcpyAsync(n->freqs, freqs_host, n->F * sizeof(float), hipMemcpyHostToDevice, s));
@@ -500,6 +639,15 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         hipLaunchKernelGGL(pack_wff_kernel, dim3(cdiv(n->wff_stride(), 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->KP,
                            n->Wff_p + l * n->wff_stride());
         hipLaunchKernelGGL(pack_w2_kernel, dim3(cdiv(H * H, 256)), dim3(256), 0, s, W2, H, n->W2_p + l * n->w2_stride());
+        hipLaunchKernelGGL(pack_wff_plain_kernel, dim3(cdiv(H * 6 * n->F, 256)), dim3(256), 0, s, W1, n->edge_in, H, 6 * n->F,
+                           n->Wff + (size_t)l * H * 6 * n->F);
+        {
+            const int F6 = 6 * n->F, Hp = (H + 127) / 128 * 128;
+            Planes wffp = make_planes(n->Wffpl + (size_t)l * planes_elems(H, F6), F6);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wffp.KT * 16, 256)), dim3(256), 0, s, W1 + 2 * H + 9, n->edge_in, H, F6, wffp);
+            Planes w2p = make_planes(n->W2pl + (size_t)l * planes_elems(H, H), H);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * w2p.KT * 16, 256)), dim3(256), 0, s, W2, H, H, H, w2p);
+        }
     }
     MI_KERNEL_CHECK();
     MI_TRY(net_pack_transposes(n, s));
@@ -536,7 +684,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
         return MI_EINVAL;
     }
     // fully connected edges, row-major incl. self loops (cspnet.py:239-241)
-    std::vector<int> n2g(N), src((size_t)E), dst((size_t)E), rowptr(N + 1, 0);
+    std::vector<int> n2g(N), src((size_t)E), dst((size_t)E), rowptr(N + 1, 0), egraph((size_t)E);
     size_t e = 0;
     int nslots = 1;
     for (int g = 0; g < B; ++g) {
@@ -547,6 +695,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
             for (int j = 0; j < n; ++j) {
                 src[e] = o + i;
                 dst[e] = o + j;
+                egraph[e] = g;
                 ++e;
             }
             nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
@@ -564,6 +713,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
     A_(node2graph, N);
     A_(src, (size_t)E);
     A_(dst, (size_t)E);
+    A_(edge_graph, (size_t)E);
     A_(rowptr, N + 1);
     A_(h, (L + 1) * NH);
     A_(cat, 2 * NH);
@@ -571,6 +721,11 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
     A_(G, (size_t)B * H);
     A_(part, nslots * NH);
     A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
+    A_(FF, (size_t)E * 6 * net->F);
+    A_(M1, (size_t)E * H);
+    A_(M2, (size_t)E * H);
+    A_(FFpl, planes_elems(E, 6 * net->F));
+    A_(M1pl, planes_elems(E, H));
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);
@@ -587,6 +742,12 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
         mi_batch_destroy(b);
         return rc;
     }
+    // M1 planes: the GEMM epilogue only writes rows < E; the row padding of the last tile must be finite
+    if (hipMemset(b->M1pl, 0, planes_elems(E, H) * sizeof(unsigned short)) != hipSuccess) {
+        mi_batch_destroy(b);
+        set_error("hipMemset failed");
+        return MI_EHIP;
+    }
     auto up = [&](int* d, const std::vector<int>& h) {
         return h.empty() ? hipSuccess : hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
     };
@@ -595,6 +756,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
     if (he == hipSuccess) he = up(b->node2graph, n2g);
     if (he == hipSuccess) he = up(b->src, src);
     if (he == hipSuccess) he = up(b->dst, dst);
+    if (he == hipSuccess) he = up(b->edge_graph, egraph);
     if (he == hipSuccess) he = up(b->rowptr, rowptr);
     if (he != hipSuccess) {
         set_error("index table upload failed: %s", hipGetErrorString(he));
@@ -628,6 +790,18 @@ int mi_cspnet_tap(mi_net* net, mi_batch* b, int layer, float* out, void* stream)
     const size_t NH = (size_t)b->N * net->H;
     const float* src = layer <= net->L ? b->h + (size_t)layer * NH : b->hf;
     MI_HIP(hipMemcpyAsync(out, src, NH * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MI_OK;
+}
+
+int mi_set_gemm_mode(int mode) {
+    MI_CHECK(mode == MI_GEMM_F32 || mode == MI_GEMM_SPLIT, MI_EINVAL, "unknown gemm mode %d", mode);
+    mi::g_gemm_mode = mode;
+    return MI_OK;
+}
+
+int mi_net_set_edge_mode(mi_net* net, int mode) {
+    MI_CHECK(net && (mode == MI_EDGE_FUSED_F32 || mode == MI_EDGE_GEMM), MI_EINVAL, "unknown edge mode %d", mode);
+    net->edge_mode = mode;
     return MI_OK;
 }
 

@@ -21,12 +21,33 @@ struct GemmEpilogue {
     const float* row_bias = nullptr;  // [G, ld_row_bias]; row r gets row_bias[row_group[r]]
     const int* row_group = nullptr;   // [M]
     int ld_row_bias = 0;
+    const float* row_bias2 = nullptr;  // second / third row-gathered addends (edge stage: P_j[dst], G[graph])
+    const int* row_group2 = nullptr;
+    int ld_row_bias2 = 0;
+    const float* row_bias3 = nullptr;
+    const int* row_group3 = nullptr;
+    int ld_row_bias3 = 0;
     const float* residual = nullptr;  // [M, ld_res] added AFTER the activation
     int ld_res = 0;
     int act = ACT_NONE;
     float* pre_act = nullptr;         // optional [M, ld_pre]: value before the activation (saved for backward)
     int ld_pre = 0;
 };
+
+// value after the accumulator + per-column bias: row-gathered addends, optional pre-activation save,
+// activation, residual
+__device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, int row, int col) {
+    if (ep.row_bias) {
+        float g = ep.row_bias[(size_t)ep.row_group[row] * ep.ld_row_bias + col];
+        if (ep.row_bias2) g += ep.row_bias2[(size_t)ep.row_group2[row] * ep.ld_row_bias2 + col];
+        if (ep.row_bias3) g += ep.row_bias3[(size_t)ep.row_group3[row] * ep.ld_row_bias3 + col];
+        v += g;
+    }
+    if (ep.pre_act) ep.pre_act[(size_t)row * ep.ld_pre + col] = v;
+    if (ep.act == ACT_SILU) v = silu(v);
+    if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];
+    return v;
+}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
@@ -122,18 +143,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                 int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row >= M) continue;
                 float v = acc[i][j][r] + bcol;
-                if (ep.row_bias) v += ep.row_bias[(size_t)ep.row_group[row] * ep.ld_row_bias + col];
-                if (ep.pre_act) ep.pre_act[(size_t)row * ep.ld_pre + col] = v;
-                if (ep.act == ACT_SILU) v = silu(v);
-                if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];
+                v = apply_epilogue(ep, v, row, col);
                 C[(size_t)row * ldc + col] = v;
             }
         }
 }
 
 // host launcher.  Requirements: K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, 16-byte aligned bases.
-inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                   const GemmEpilogue& ep, hipStream_t s) {
+inline int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                       const GemmEpilogue& ep, hipStream_t s) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt: K/lda/ldw must be multiples of 4 (%d,%d,%d)", K, lda, ldw);
     MI_CHECK((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, MI_EINVAL, "gemm_nt: operands must be 16-byte aligned");
     if (M <= 0 || N <= 0) return MI_OK;

@@ -21,6 +21,10 @@ struct mi_net {
     float* Whh = nullptr;    // [L][2H][H]   rows [0,H) = W1[:, :H], rows [H,2H) = W1[:, H:2H]
     float* Wff_p = nullptr;  // [L][KP/4][NT][64][4]
     float* W2_p = nullptr;   // [L][NT][NT][4][64][4]
+    float* Wff = nullptr;    // [L][H][6F]  Fourier column block of edge_mlp.0, contiguous (GEMM edge path)
+    int edge_mode = 1;       // MI_EDGE_GEMM (default) or MI_EDGE_FUSED_F32
+    unsigned short* Wffpl = nullptr;  // [L][3][H][ld(6F)] bf16 planes of Wff
+    unsigned short* W2pl = nullptr;   // [L][3][H][H]      bf16 planes of edge_mlp.2.weight
     // transposed copies for the data-gradient GEMMs (training), rebuilt with the packs
     float* W2T = nullptr;    // [L][H][H]
     float* Wn2T = nullptr;   // [L][H][H]
@@ -57,14 +61,19 @@ struct mi_batch {
     std::vector<int> num_atoms_h, node_off_h;
     // index tables (device)
     int *num_atoms = nullptr, *node_off = nullptr /*[B+1]*/, *node2graph = nullptr, *src = nullptr, *dst = nullptr,
-        *rowptr = nullptr /*[N+1]*/;
+        *rowptr = nullptr /*[N+1]*/, *edge_graph = nullptr /*[E]*/;
     // forward workspace (device)
     float* h = nullptr;      // [L+1][N][H] node features before layer l / after the last
     float* cat = nullptr;    // [N][2H]  (LN(h) | agg)
     float* PQ = nullptr;     // [N][2H]
     float* G = nullptr;      // [B][H]
     float* part = nullptr;   // [nslots][N][H]
-    float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order
+    float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order (fused path)
+    float* FF = nullptr;     // [E][6F] Fourier features, reference column order (GEMM path)
+    float* M1 = nullptr;     // [E][H]
+    float* M2 = nullptr;     // [E][H]
+    unsigned short* FFpl = nullptr;  // [3][E][ld(6F)] bf16 planes of the Fourier features
+    unsigned short* M1pl = nullptr;  // [3][E][H]      bf16 planes of M1
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]

@@ -12,9 +12,23 @@ from tests.gpu_util import load_decoder, params_from_golden
 pytestmark = pytest.mark.gpu
 
 
-def _net(H, L, F, P=None):
+# arithmetic paths: (gemm mode, edge mode).  Default = bf16-split GEMMs everywhere; the other two keep
+# the f32-input MFMA (exact fp32 fma chains) with either edge-stage formulation.
+PATHS = [("split", "gemm"), ("f32", "gemm"), ("f32", "fused_f32")]
+
+
+@pytest.fixture(params=PATHS, ids=lambda p: f"{p[0]}-{p[1]}")
+def path(request):
+    from matinvent_amd.cspnet import set_gemm_mode
+    set_gemm_mode(request.param[0])
+    yield request.param
+    set_gemm_mode("split")
+
+
+def _net(H, L, F, P=None, path=("split", "gemm")):
     from matinvent_amd.cspnet import CSPNet
     net = CSPNet(hidden_dim=H, num_layers=L, num_freqs=F, latent_dim=256, ln=True, smooth=True, pred_type=True, device="cuda")
+    net.set_edge_mode(path[1])
     if P is not None:
         load_decoder(net, P)
     return net
@@ -52,9 +66,9 @@ def test_time_embedding_golden(golden):
     _close(emb(torch.from_numpy(g["t"])), g["time_256"], 2e-6, "time embedding, pinned table")
 
 
-def test_forward_tiny_golden(golden):
+def test_forward_tiny_golden(golden, path):
     g = golden("g5a_cspnet_tiny")
-    net = _net(64, 2, 8, params_from_golden(g))
+    net = _net(64, 2, 8, params_from_golden(g), path)
     T = lambda k: torch.from_numpy(g[k]).cuda()
     b = net.make_batch(g["num_atoms"])
     assert b.num_edges == g["edges"].shape[1]
@@ -66,12 +80,12 @@ def test_forward_tiny_golden(golden):
     _close(pt, g["pred_t"], 2e-5, "pred_t")
 
 
-def test_forward_north_star_hparams_golden(golden):
+def test_forward_north_star_hparams_golden(golden, path):
     """H=512, L=6, F=128: weights rebuilt from seed 0 (same construction order as the
     reference, checksummed), outputs produced by the reference code."""
     g = golden("g5b_cspnet_ns")
     torch.manual_seed(0)
-    net = _net(512, 6, 128)
+    net = _net(512, 6, 128, path=path)
     sd = net.state_dict()
     assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
     for name, s, a in zip(g["param_names"].tolist(), g["param_sum"], g["param_abs_sum"]):
@@ -90,7 +104,7 @@ def test_forward_north_star_hparams_golden(golden):
     (256, 2, 16, [20] * 9 + [3]),
     (64, 1, 8, [40, 33, 2]),                      # node runs spanning three 32-edge tiles
 ])
-def test_forward_vs_oracle_ragged(H, L, F, num_atoms):
+def test_forward_vs_oracle_ragged(H, L, F, num_atoms, path):
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P = O.init_params(hp, seed=3)
     # non-trivial LayerNorm affine so that its parameters are exercised
@@ -98,7 +112,7 @@ def test_forward_vs_oracle_ragged(H, L, F, num_atoms):
     for k in P:
         if "layer_norm" in k:
             P[k] = P[k] + 0.1 * torch.randn(P[k].shape, generator=g)
-    net = _net(H, L, F, P)
+    net = _net(H, L, F, P, path)
     na = torch.tensor(num_atoms)
     B, N = len(num_atoms), int(na.sum())
     n2g = torch.repeat_interleave(torch.arange(B), na)
@@ -113,7 +127,7 @@ def test_forward_vs_oracle_ragged(H, L, F, num_atoms):
     _close(pt, ot, 3e-5, "pred_t")
 
 
-def test_forward_full_size_properties():
+def test_forward_full_size_properties(path):
     """BASELINE config-2 shape (B=256, n=20, H=512, L=6, F=128): size-independent properties.
     (1) bit-reproducible run to run (fixed reduction order, no float atomics);
     (2) a crystal's outputs do not depend on which other crystals share the batch
@@ -121,7 +135,7 @@ def test_forward_full_size_properties():
     (3) a lattice-vector translation of all atoms of a crystal leaves the scores unchanged
         up to round-off (only (x_j - x_i) % 1 enters the network)."""
     torch.manual_seed(0)
-    net = _net(512, 6, 128)
+    net = _net(512, 6, 128, path=path)
     B, n = 256, 20
     g = torch.Generator().manual_seed(5)
     na = [n] * B
