@@ -462,18 +462,23 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe1.ep = g1e;
                 pe1.Cp = m1p;
                 MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
-                PlanesEpilogue pe2;
+                PlanesEpilogue pe2;   // M2 never reaches HBM: the edge -> node sum happens in the epilogue
                 pe2.ep = g2e;
-                pe2.C = b->M2;
-                pe2.ldc = H;
+                pe2.seg_part = b->part;
+                pe2.seg_src = b->src;
+                pe2.seg_rowptr = b->rowptr;
+                pe2.seg_nodes = N;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
+                MI_TRY(prof_end(net, s));
+                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+                MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
                 MI_TRY(gemm_nt(b->M1, H, net->p(p + "edge_mlp.2.weight"), H, b->M2, H, E, H, H, g2e, s));
+                MI_TRY(prof_end(net, s));
+                hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->M2, b->rowptr, cat, N, H);
+                MI_KERNEL_CHECK();
             }
-            MI_TRY(prof_end(net, s));
-            hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->M2, b->rowptr, cat, N, H);
-            MI_KERNEL_CHECK();
         } else {
             hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
             MI_KERNEL_CHECK();

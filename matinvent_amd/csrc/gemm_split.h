@@ -231,14 +231,31 @@ struct PlanesEpilogue {
     float* C = nullptr;    // optional fp32 output [M][ldc]
     int ldc = 0;
     Planes Cp;             // optional plane-set output (the A operand of the next GEMM)
+    // optional fused segmented sum over rows (edge -> node aggregation, cspnet.py:79): rows are edges sorted by
+    // `seg_src`; every 32-row block writes the partial sum of each node run it contains to
+    // seg_part[slot][node][col], slot = block - first block of that node (fixed order, no atomics);
+    // finalize_agg_kernel adds the slots and divides by the degree.
+    float* seg_part = nullptr;
+    const int* seg_src = nullptr;
+    const int* seg_rowptr = nullptr;
+    int seg_nodes = 0;
 };
 
 // C = epi(A W^T) with both operands given as tile-blocked plane sets; main loop = loads + ds + MFMA only.
+//
+// LDS image per plane: 128 rows x 64 B, unpadded, 16-byte chunk index XOR-swizzled with (row >> 2) & 3:
+//   chunk c of row r lives at r*64 + ((c ^ ((r >> 2) & 3)) * 16).
+// Fragment reads (ds_read_b128, 16-lane groups of rows distinct mod 16, same chunk) and staging writes
+// (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
+// was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
+// Global -> register prefetch runs TWO k-tiles ahead (the A operand streams from HBM/MALL).
+// This is the 128x128-tile, two-barriers-per-k-step structure: ~870 TF/s of bf16 MFMA issue (35 % of peak),
+// which is its known ceiling on this chip; a 256x256 multi-phase schedule is the next step.
 static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe) {
-    constexpr int BM = 128, BN = 128, BK = 32, ROWB = 80, TM = 2, TN = 2;
+    constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Ws = smem + 3 * BM * ROWB;
+    unsigned char* Ws = smem + 3 * PLB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
     const int rt = blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
@@ -252,8 +269,8 @@ static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Plane
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // a plane tile = 128 rows x 64 B = 512 chunks of 16 B; two per thread per plane
-    u32x4 ra[3][2], rw[3][2];
-    auto load_tiles = [&](int kt) {
+    u32x4 ra0[3][2], rw0[3][2], ra1[3][2], rw1[3][2];
+    auto load_tiles = [&](int kt, u32x4 (&ra)[3][2], u32x4 (&rw)[3][2]) {
         const u32x4* ga = reinterpret_cast<const u32x4*>(A.base + A.tile(rt, kt));
         const u32x4* gw = reinterpret_cast<const u32x4*>(W.base + W.tile(ct, kt));
 #pragma unroll
@@ -264,40 +281,37 @@ static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Plane
                 rw[p][v] = gw[p * 512 + v * 256 + tid];
             }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const u32x4 (&ra)[3][2], const u32x4 (&rw)[3][2]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                int f = v * 256 + tid, r = f >> 2, cb = (f & 3) * 16;
-                *reinterpret_cast<u32x4*>(As + ((size_t)p * BM + r) * ROWB + cb) = ra[p][v];
-                *reinterpret_cast<u32x4*>(Ws + ((size_t)p * BN + r) * ROWB + cb) = rw[p][v];
+                const int f = v * 256 + tid, r = f >> 2, c = (f & 3) ^ ((r >> 2) & 3);
+                *reinterpret_cast<u32x4*>(As + p * PLB + r * 64 + c * 16) = ra[p][v];
+                *reinterpret_cast<u32x4*>(Ws + p * PLB + r * 64 + c * 16) = rw[p][v];
             }
     };
-
-    const int KT = (K + 31) / 32;
-    load_tiles(0);
-    for (int kt = 0; kt < KT; ++kt) {
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < KT) load_tiles(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + ((size_t)pl * BM + (wm * TM + i) * 32 + l31) * ROWB + (16 * s + 8 * kg) * 2);
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLB + r * 64 + c * 16);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                const int r = (wn * TN + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Ws + ((size_t)pl * BN + (wn * TN + j) * 32 + l31) * ROWB + (16 * s + 8 * kg) * 2);
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * PLB + r * 64 + c * 16);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    // smallest terms first, so that they are not lost against a large accumulator
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
@@ -306,38 +320,92 @@ static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Plane
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    const int KT = (K + 31) / 32;
+    load_tiles(0, ra0, rw0);
+    if (KT > 1) load_tiles(1, ra1, rw1);
+    for (int kt = 0; kt < KT; kt += 2) {
+        store_tiles(ra0, rw0);
         __syncthreads();
+        if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
+        compute();
+        __syncthreads();
+        if (kt + 1 < KT) {
+            store_tiles(ra1, rw1);
+            __syncthreads();
+            if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
+            compute();
+            __syncthreads();
+        }
     }
 
     const GemmEpilogue& ep = pe.ep;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int rb = row0 + (wm * TM + i) * 32;  // first row of this 32-row block
+        // segment structure of the block (runs of equal seg_src), wave-uniform
+        uint32_t starts = 0;
+        int srcv = 0, nvalid = 0;
+        if (pe.seg_part) {
+            nvalid = M - rb < 32 ? (M - rb > 0 ? M - rb : 0) : 32;
+            srcv = nvalid > 0 ? pe.seg_src[rb + (l31 < nvalid ? l31 : nvalid - 1)] : 0;
+            const int prev = __shfl_up(srcv, 1, 64);
+            starts = (uint32_t)__ballot(kg == 0 && l31 < nvalid && (l31 == 0 || srcv != prev));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            int col = col0 + (wn * TN + j) * 32 + l31;
-            if (col >= N) continue;
-            float bcol = ep.bias ? ep.bias[col] : 0.f;
+            const int col = col0 + (wn * TN + j) * 32 + l31;
+            const bool col_ok = col < N;
+            const float bcol = (ep.bias && col_ok) ? ep.bias[col] : 0.f;
+            float val[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (row >= M) continue;
-                float v = apply_epilogue(ep, acc[i][j][r] + bcol, row, col);
-                if (pe.C) pe.C[(size_t)row * pe.ldc + col] = v;
-                if (pe.Cp.base) {
-                    u16 p0, p1, p2;
-                    split3(v, p0, p1, p2);
-                    pe.Cp.base[pe.Cp.elem(row, col, 0)] = p0;
-                    pe.Cp.base[pe.Cp.elem(row, col, 1)] = p1;
-                    pe.Cp.base[pe.Cp.elem(row, col, 2)] = p2;
+                const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                float v = 0.f;
+                if (row < M && col_ok) {
+                    v = apply_epilogue(ep, acc[i][j][r] + bcol, row, col);
+                    if (pe.C) pe.C[(size_t)row * pe.ldc + col] = v;
+                    if (pe.Cp.base) {
+                        u16 p0, p1, p2;
+                        split3(v, p0, p1, p2);
+                        pe.Cp.base[pe.Cp.elem(row, col, 0)] = p0;
+                        pe.Cp.base[pe.Cp.elem(row, col, 1)] = p1;
+                        pe.Cp.base[pe.Cp.elem(row, col, 2)] = p2;
+                    }
+                }
+                val[r] = v;
+            }
+            if (pe.seg_part) {
+                uint32_t rem = starts;
+                while (rem) {
+                    const int sg = __builtin_ctz(rem);
+                    rem &= rem - 1;
+                    const int end = rem ? __builtin_ctz(rem) : nvalid;
+                    const int node = __builtin_amdgcn_readlane(srcv, sg);
+                    // rows this lane holds: c + 4*kg for the 16 compile-time offsets c; in-range test as one unsigned compare
+                    const unsigned lo = (unsigned)(sg - 4 * kg), span = (unsigned)(end - sg);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned c = (unsigned)((r & 3) + 8 * (r >> 2));
+                        sum += (c - lo < span) ? val[r] : 0.f;
+                    }
+                    sum += __shfl_xor(sum, 32, 64);
+                    if (kg == 0 && col_ok) {
+                        const int slot = (rb >> 5) - (pe.seg_rowptr[node] >> 5);
+                        pe.seg_part[((size_t)slot * pe.seg_nodes + node) * N + col] = sum;
+                    }
                 }
             }
         }
+    }
 }
 
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
     MI_CHECK(A.KT == (K + 31) / 32 && W.KT == A.KT, MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
-    hipLaunchKernelGGL(gemm_planes_kernel, dim3(cdiv(N, 128), cdiv(M, 128)), dim3(256), 3 * 256 * 80, s, A, W, M, N, K, pe);
+    hipLaunchKernelGGL(gemm_planes_kernel, dim3(cdiv(N, 128), cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
