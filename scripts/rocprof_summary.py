@@ -17,7 +17,7 @@ def main():
         lines += ["", f"## PMC pass `{p}` (per-dispatch averages)", "", "| kernel | counter | dispatches | avg value |", "|---|---|---|---|"]
         q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
              "group by kernel_name, counter_name order by sum(value) desc")
-        rows = [r for r in cur.execute(q) if "edge_mlp" in r[0] or "gemm_nt" in r[0]]
+        rows = [r for r in cur.execute(q) if any(t in r[0] for t in ("edge_mlp", "gemm_nt", "gemm_planes"))]
         for k, c, n, v in rows:
             lines.append(f"| `{k[:60]}` | {c} | {n} | {v:.6g} |")
     open(out, "w").write("\n".join(lines) + "\n")
