@@ -124,11 +124,16 @@ def main_ft(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = bool(os.environ.get("MI_BENCH_SHARE_GPU"))  # test-only: N ranks on ONE GPU over gloo
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     from matinvent_amd.data import CrystalData
@@ -146,14 +151,14 @@ def main_ft(args):
         ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if share else dist.barrier(device_ids=[local_rank])
 
     run(max(W, 1))
     t0 = time.perf_counter()
     run(K)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
@@ -192,8 +197,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("MI_BENCH_SHARE_GPU"):   # test-only: N ranks on ONE GPU over gloo, to exercise the control flow
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -212,7 +221,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if os.environ.get("MI_BENCH_SHARE_GPU") else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     # W untimed denoising steps on a throwaway state, then exactly K timed steps of the chain that
@@ -235,7 +244,7 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for v in (final["frac_coords"], final["lattices"], final["atom_types"]))
 
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if os.environ.get("MI_BENCH_SHARE_GPU") else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -280,7 +289,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -23,7 +23,12 @@ def shard_range(n: int, rank: int, world: int):
 def allreduce_flat_(buf: torch.Tensor):
     """In-place SUM all-reduce of one flat buffer (the whole gradient: 4P bytes, one message)."""
     if is_dist() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if buf.is_cuda and dist.get_backend() == "gloo":  # CPU-backend test runs: stage through the host
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 

@@ -1,0 +1,28 @@
+"""The three GEMM kernels behind every linear of the path, against fp64: the bf16 three-plane split
+(on-the-fly and pre-split/tile-blocked) must be at least as accurate as the f32-input MFMA."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 100, 100), (5120, 512, 1024), (20000, 512, 768), (129, 512, 48)])
+def test_gemm_kernels_vs_fp64(M, N, K):
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    ref = A.double() @ W.double().t()
+    scale = ref.abs().max().item()
+    errs = {}
+    for kind in (0, 1, 2):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.mi_debug_gemm(kind, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+        torch.cuda.synchronize()
+        errs[kind] = (out.double() - ref).abs().max().item() / scale
+        assert errs[kind] < 3e-6, (kind, errs)
+    # fp32-class: the split paths are not worse than the f32 MFMA by more than round-off noise
+    assert errs[1] <= 1.5 * errs[0] + 1e-7 and errs[2] <= 1.5 * errs[0] + 1e-7, errs
