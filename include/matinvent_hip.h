@@ -203,6 +203,23 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
  * bracketed by hipEvents on its launch stream; mi_profile_read synchronises and returns the
  * number of launches and their summed duration in milliseconds since the last reset.
  * ------------------------------------------------------------------------------------- */
+/* One fine-tune timestep of MatInvent.ft_step (pipeline/mat_invent.py:152-164) enqueued end to end:
+ * add_noise -> agent forward (kept) -> frozen-prior forward -> fused per-sample loss / anchor penalty /
+ * reward weighting + gradient seeds -> agent backward, i.e.
+ *     grad_theta += d/dtheta [ sum_b ( r_b L_b + kl_sigma (1.1 - r_b) KL_b ) / (b_global * accum_steps) ].
+ * `t` = diffusion time (T - timestep index, diffusion.py:86-87); c0/c1/sigma_t/sigma_norm as for mi_add_noise;
+ * `reward` [B] device; rand_* optional injected noise.  `stats` (device, 3 floats, may be NULL) accumulates
+ * the three quantities the reference logs (:168-170): the accum-normalised loss, sum_b r_b L_b,
+ * sum_b (1.1-r_b) KL_b.  out_sample_loss / out_kl ([B], may be NULL) receive L_b / KL_b.
+ * `ab` / `pb` must be distinct batch handles of the agent / prior networks for the same crystals. */
+int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths,
+                     const float* angles, const float* frac0, const int* atom_types, const float* reward,
+                     const float* time_freqs, int t, float c0, float c1, float sigma_t, float sigma_norm,
+                     uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
+                     const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma,
+                     int b_global, int accum_steps, float* grad_theta, float* stats, float* out_sample_loss,
+                     float* out_kl, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Arithmetic paths.  Both reproduce the reference to fp32 round-off (tests state the bounds).
  *   GEMM mode (process-wide): MI_GEMM_SPLIT (default) evaluates every fp32 product on the bf16 matrix

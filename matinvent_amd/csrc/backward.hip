@@ -25,6 +25,10 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __res
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = dy[i] * silu_grad(z[i]);
 }
+__global__ void fill_int_kernel2(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];
@@ -225,6 +229,17 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
     T_(M1, E * H);
     T_(dM1, E * H);
     T_(FF, E * 6 * F);
+    T_(nz_lat, B * 9);
+    T_(nz_frac, N * 3);
+    T_(nz_types, N * MI_NUM_TYPES);
+    T_(tar_x, N * 3);
+    T_(rnd_l, B * 9);
+    T_(rnd_t, N * MI_NUM_TYPES);
+    T_(d_l, B * 9);
+    T_(d_x, N * 3);
+    T_(d_t, N * MI_NUM_TYPES);
+    T_(Lb, B);
+    T_(KLb, B);
     t.scratch_floats = std::max<size_t>((size_t)1 << 22, 16 * 2 * H * std::max<size_t>(2 * H, 6 * F + 64) + 1024 * 2 * H);
     T_(scratch, t.scratch_floats);
 #undef T_
@@ -259,7 +274,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     MI_TRY(gemm_tn_acc(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
 
     auto ln_bwd = [&](const float* dy, int ld_dy, const float* x, const float* stats, const std::string& wname, float* dx, int accumulate) {
-        const int rows_per_block = 64, nblk = cdiv(N, rows_per_block);
+        const int rows_per_block = N >= 16384 ? 64 : (N >= 2048 ? 16 : 4), nblk = cdiv(N, rows_per_block);  // >= ~256 blocks when possible
         MI_CHECK((size_t)nblk * 2 * H <= scf, MI_ENOMEM, "LN scratch");
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 8 * H * sizeof(float), s, dy, ld_dy, x, stats, net->p(wname + ".weight"),
                            dx, accumulate, sc, N, H, rows_per_block);
@@ -348,6 +363,74 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     MI_TRY(gemm_tn_acc(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
     return MI_OK;
+}
+
+// ---- fused per-sample loss, prior-anchor penalty, reward weighting and gradient seeds (K14) -------------
+// DiffCSPModule.calc_sample_loss (diffusion.py:126-136), calc_kl_reg (:143-148) and the reward weighting of
+// MatInvent.ft_step (mat_invent.py:158-163) in one kernel, one block per crystal:
+//   L_b  = cl*mean9((pl-rl)^2) + cx*mean_i mean3((px-tx)^2) + ct*mean_i mean100((pt-rt)^2)
+//   KL_b = mean9((pl-plp)^2) + mean_i mean3((px-pxp)^2) + mean_i mean100((pt-ptp)^2)
+//   total = inv_denom * sum_b ( r_b L_b + sigma (1.1 - r_b) KL_b )          (inv_denom = 1/(B_global*accum))
+// and writes d total / d(pl, px, pt) -- the upstream gradients of the network backward.
+struct LossArgs {
+    const float *pl, *px, *pt, *plp, *pxp, *ptp, *rl, *tx, *rt, *reward;
+    const int* node_off;
+    float *dl, *dx, *dt, *Lb, *KLb;
+    float cl, cx, ct, sigma, inv_denom;
+};
+__global__ __launch_bounds__(256) void ft_loss_kernel(LossArgs a) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    const float r = a.reward[b], w1 = r * a.inv_denom, w2 = a.sigma * (1.1f - r) * a.inv_denom;
+    const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
+    float sl = 0.f, skl = 0.f;
+    if (tid < 9) {
+        const int i = b * 9 + tid;
+        const float e = a.pl[i] - a.rl[i], k = a.pl[i] - a.plp[i];
+        sl = e * e;
+        skl = k * k;
+        a.dl[i] = (w1 * a.cl * 2.0f * e + w2 * 2.0f * k) / 9.0f;
+    }
+    float sx = 0.f, skx = 0.f;
+    for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
+        const float e = a.px[i] - a.tx[i], k = a.px[i] - a.pxp[i];
+        sx += e * e;
+        skx += k * k;
+        a.dx[i] = (w1 * a.cx * 2.0f * e + w2 * 2.0f * k) * inv_n / 3.0f;
+    }
+    float st = 0.f, skt = 0.f;
+    for (int64_t i = (int64_t)n0 * MI_NUM_TYPES + tid; i < (int64_t)n1 * MI_NUM_TYPES; i += 256) {
+        const float e = a.pt[i] - a.rt[i], k = a.pt[i] - a.ptp[i];
+        st += e * e;
+        skt += k * k;
+        a.dt[i] = (w1 * a.ct * 2.0f * e + w2 * 2.0f * k) * inv_n / (float)MI_NUM_TYPES;
+    }
+    auto bsum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    sl = bsum(sl); skl = bsum(skl); sx = bsum(sx); skx = bsum(skx); st = bsum(st); skt = bsum(skt);
+    if (tid == 0) {
+        a.Lb[b] = a.cl * sl / 9.0f + a.cx * sx * inv_n / 3.0f + a.ct * st * inv_n / (float)MI_NUM_TYPES;
+        a.KLb[b] = skl / 9.0f + skx * inv_n / 3.0f + skt * inv_n / (float)MI_NUM_TYPES;
+    }
+}
+// stats[0] += accum-normalised loss, stats[1] += sum_b r_b L_b, stats[2] += sum_b (1.1 - r_b) KL_b  (mat_invent.py:168-170)
+__global__ void ft_stats_kernel(const float* __restrict__ Lb, const float* __restrict__ KLb, const float* __restrict__ reward, int B,
+                                float sigma, float inv_bglobal, float* __restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float d = 0.f, k = 0.f;
+    for (int b = 0; b < B; ++b) {
+        d += reward[b] * Lb[b];
+        k += (1.1f - reward[b]) * KLb[b];
+    }
+    stats[0] += (d + sigma * k) * inv_bglobal;
+    stats[1] += d;
+    stats[2] += k;
 }
 
 int net_pack_transposes(mi_net* n, hipStream_t s) {
@@ -484,6 +567,37 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
     hipLaunchKernelGGL(add_noise_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, a);
     MI_KERNEL_CHECK();
     return MI_OK;
+}
+
+int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,
+                     const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int t, float c0, float c1,
+                     float sigma_t, float sigma_norm, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
+                     const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global, int accum_steps,
+                     float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream) {
+    MI_CHECK(agent && ab && prior && pb && lengths && angles && frac0 && atom_types && reward && time_freqs && grad_theta, MI_EINVAL,
+             "null argument");
+    MI_CHECK(ab != pb, MI_EINVAL, "agent and prior need separate batch handles (separate workspace)");
+    MI_CHECK(ab->B == pb->B && ab->N == pb->N && b_global >= ab->B && accum_steps >= 1, MI_EINVAL, "inconsistent batch arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ab->B, N = ab->N;
+    if (B == 0 || N == 0) return MI_OK;
+    MI_TRY(net_tape_prepare(agent, ab));
+    Tape& tp = ab->tape;
+    hipLaunchKernelGGL(fill_int_kernel2, dim3(cdiv(B, 256)), dim3(256), 0, s, ab->times, t, B);
+    MI_TRY(mi_time_embedding(ab->times, time_freqs, B, agent->TD, ab->temb, stream));
+    MI_TRY(mi_add_noise(ab, lengths, angles, frac0, atom_types, c0, c1, sigma_t, sigma_norm, seed, noise_step, rand_l, rand_x, rand_t,
+                        tp.nz_lat, tp.nz_frac, tp.nz_types, tp.tar_x, tp.rnd_l, tp.rnd_t, stream));
+    MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
+    MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
+    LossArgs la{ab->pred_l, ab->pred_x, ab->pred_t, pb->pred_l, pb->pred_x, pb->pred_t, tp.rnd_l, tp.tar_x, tp.rnd_t, reward, ab->node_off,
+                tp.d_l, tp.d_x, tp.d_t, tp.Lb, tp.KLb, cost_lattice, cost_coord, cost_type, kl_sigma,
+                1.0f / ((float)b_global * (float)accum_steps)};
+    hipLaunchKernelGGL(ft_loss_kernel, dim3(B), dim3(256), 0, s, la);
+    if (stats) hipLaunchKernelGGL(ft_stats_kernel, dim3(1), dim3(64), 0, s, tp.Lb, tp.KLb, reward, B, kl_sigma, 1.0f / (float)b_global, stats);
+    MI_KERNEL_CHECK();
+    if (out_sample_loss) MI_HIP(hipMemcpyAsync(out_sample_loss, tp.Lb, B * 4, hipMemcpyDeviceToDevice, s));
+    if (out_kl) MI_HIP(hipMemcpyAsync(out_kl, tp.KLb, B * 4, hipMemcpyDeviceToDevice, s));
+    return net_backward(agent, ab, tp.d_l, tp.d_x, tp.d_t, grad_theta, s);
 }
 
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, void* stream) {

@@ -50,6 +50,9 @@ struct Tape {
     float *atom_types = nullptr, *t_emb = nullptr, *lattices = nullptr, *frac = nullptr;
     float *dh = nullptr, *dY = nullptr, *dXa = nullptr, *Xa = nullptr, *dcat = nullptr, *dPQ = nullptr, *dG = nullptr, *dgf = nullptr,
           *dlo = nullptr, *dtproj = nullptr, *M1 = nullptr, *dM1 = nullptr, *FF = nullptr, *scratch = nullptr;
+    // fused fine-tune micro-step: noised inputs, targets, gradient seeds, per-crystal losses
+    float *nz_lat = nullptr, *nz_frac = nullptr, *nz_types = nullptr, *tar_x = nullptr, *rnd_l = nullptr, *rnd_t = nullptr, *d_l = nullptr,
+          *d_x = nullptr, *d_t = nullptr, *Lb = nullptr, *KLb = nullptr;
     size_t scratch_floats = 0;
 };
 

@@ -157,7 +157,8 @@ def test_fused_adam_matches_torch_adam():
     assert float((p1 - p2).detach().abs().max()) < 2e-6
 
 
-def test_ft_step_end_to_end_vs_oracle():
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-micro-step", "autograd-surface"])
+def test_ft_step_end_to_end_vs_oracle(fused):
     """matinvent_amd.finetune.ft_step (device-side loss accumulation, fused Adam, flat gradient) vs
     the oracle's literal restatement of pipeline/mat_invent.py:125-189: 2 epochs x 6 timesteps,
     accum 3 -> 4 optimizer steps, injected noise."""
@@ -179,7 +180,7 @@ def test_ft_step_end_to_end_vs_oracle():
     noises = {(e, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
               for e in range(2) for t in range(6)}
     cfg = dict(lr=1e-4, accum_steps=3, epochs=2, timesteps=6, sigma=0.025)
-    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)])
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=fused)
     # oracle side
     sch = O.Schedules.make(1000, sigmas_norm=sn)
     sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
@@ -197,3 +198,8 @@ def test_ft_step_end_to_end_vs_oracle():
     # logged epoch loss = mean over timesteps of the per-step loss (mat_invent.py:168-172)
     ref_loss0 = float(torch.stack(rec["loss"][:6]).sum() * 3 / 6)
     assert abs(stats[0]["loss"] - ref_loss0) <= 1e-4 * max(1.0, abs(ref_loss0))
+    rw = torch.from_numpy(rewards).float()
+    ref_diff0 = float(sum((rw * l).sum() for l in rec["sample_loss"][:6]) / 6 / len(na))
+    ref_kl0 = float(sum(((1.1 - rw) * k).sum() for k in rec["kl"][:6]) / 6 / len(na))
+    assert abs(stats[0]["loss_diff"] - ref_diff0) <= 1e-4 * max(1.0, abs(ref_diff0))
+    assert abs(stats[0]["loss_kl"] - ref_kl0) <= 2e-4 * max(1e-3, abs(ref_kl0))
