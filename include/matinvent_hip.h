@@ -85,6 +85,22 @@ int mi_net_set_params(mi_net* net, const float* theta, const float* fourier_freq
  * ------------------------------------------------------------------------------------- */
 int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset,
                     int64_t graph_offset, mi_batch** out);
+/* knn edge style (K17): the batch owns a periodic neighbour list that every forward rebuilds on the device from
+ * (frac, lattices) -- CSPNet.gen_edges knn branch (cspnet.py:243-257) -> radius_graph_pbc (utils.py:335-514, 27 images,
+ * cutoff = smallest inter-plane spacing + 0.01) + get_max_neighbors_mask (utils.py:517-601, `max_neighbors` with the
+ * +0.01 band on d^2) + reorder_symmetric_edges (cspnet.py:159-234).  `edge_cap_per_node` bounds the kept, mask-selected
+ * neighbours per centre atom (buffers are sized for 2 * N * cap edges; exceeding it is an MI_ENOMEM error, never a
+ * silent truncation).  At most 64 atoms per crystal. */
+int mi_batch_create_knn(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
+                        int max_neighbors, int edge_cap_per_node, mi_batch** out);
+/* Build the list for the given coordinates without running the network (one host synchronisation); *num_edges = E''. */
+int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* stream, int64_t* num_edges);
+/* Copy out the current list: edges [2][E''] int32 (row 0 = aggregation/source node, row 1 = neighbour) and
+ * edge_vec [E''][3] (the `frac_diff` CSPNet.forward consumes).  MI_EDGE_ORDER_REFERENCE reproduces gen_edges' order
+ * bit for bit; MI_EDGE_ORDER_CSR is the source-sorted order the kernels iterate in.  Either pointer may be NULL. */
+#define MI_EDGE_ORDER_REFERENCE 0
+#define MI_EDGE_ORDER_CSR 1
+int mi_knn_graph_read(const mi_batch* b, int* edges, float* edge_vec, int order, void* stream);
 void mi_batch_destroy(mi_batch* b);
 int mi_batch_num_nodes(const mi_batch* b);
 int64_t mi_batch_num_edges(const mi_batch* b);

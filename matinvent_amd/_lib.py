@@ -38,6 +38,9 @@ SIGNATURES = {
     "mi_net_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I), C.POINTER(_I)]),
     "mi_net_set_params": (_I, [_P, _P, C.POINTER(C.c_float), _P]),
     "mi_batch_create": (_I, [_P, C.POINTER(_I), _I, _L, _L, C.POINTER(_P)]),
+    "mi_batch_create_knn": (_I, [_P, C.POINTER(_I), _I, _L, _L, _I, _I, C.POINTER(_P)]),
+    "mi_knn_graph": (_I, [_P, _P, _P, _P, C.POINTER(_L)]),
+    "mi_knn_graph_read": (_I, [_P, _P, _P, _I, _P]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),
     "mi_batch_num_edges": (_L, [_P]),

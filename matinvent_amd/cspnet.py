@@ -39,7 +39,8 @@ class CrystalBatch:
     """Index tables + workspace of one batch of crystals (mi_batch).  Replaces the PyG Batch
     bookkeeping (`num_atoms`, `batch`) and the per-call edge enumeration of gen_edges."""
 
-    def __init__(self, net: "CSPNet", num_atoms, node_offset: int = 0, graph_offset: int = 0):
+    def __init__(self, net: "CSPNet", num_atoms, node_offset: int = 0, graph_offset: int = 0, edge_style: str = "fc",
+                 max_neighbors: int = 20, edge_cap_per_node: int = 48):
         lib = _lib.load()
         na = [int(x) for x in (num_atoms.tolist() if torch.is_tensor(num_atoms) else num_atoms)]
         self.num_atoms_list = na
@@ -47,13 +48,37 @@ class CrystalBatch:
         self.num_nodes = sum(na)
         arr = (C.c_int * max(len(na), 1))(*na)
         h = C.c_void_p()
-        _lib.check(lib.mi_batch_create(net._h, arr, len(na), node_offset, graph_offset, C.byref(h)), "mi_batch_create")
+        self.edge_style = edge_style
+        if edge_style == "knn":
+            _lib.check(lib.mi_batch_create_knn(net._h, arr, len(na), node_offset, graph_offset, max_neighbors, edge_cap_per_node, C.byref(h)),
+                       "mi_batch_create_knn")
+        else:
+            _lib.check(lib.mi_batch_create(net._h, arr, len(na), node_offset, graph_offset, C.byref(h)), "mi_batch_create")
         self._h = h
+        self._dev = net.theta.device
         self._lib = lib
         dev = net.theta.device
         self.num_atoms = torch.tensor(na, dtype=torch.long, device=dev)
         self.batch = torch.repeat_interleave(torch.arange(len(na), device=dev), self.num_atoms)
         self.num_edges = int(lib.mi_batch_num_edges(h))
+
+    # ---- knn edge style (gen_edges knn branch, cspnet.py:243-257) ----
+    def build_graph(self, frac_coords, lattices) -> int:
+        """Rebuild the periodic neighbour list for these coordinates (the forward does this itself); returns E''."""
+        f = lambda x: x.detach().to(self._dev, torch.float32).contiguous()
+        n = C.c_int64()
+        fr, lat = f(frac_coords), f(lattices)  # keep both alive across the call
+        _lib.check(self._lib.mi_knn_graph(self._h, _ptr(fr), _ptr(lat), _stream(), C.byref(n)), "mi_knn_graph")
+        self.num_edges = int(n.value)
+        return self.num_edges
+
+    def edges(self, order: str = "reference"):
+        """(edges [2,E''] int64, frac_diff [E'',3]) of the current list, as gen_edges returns them."""
+        E = int(self._lib.mi_batch_num_edges(self._h))
+        ei = torch.empty(2, E, dtype=torch.int32, device=self._dev)
+        ev = torch.empty(E, 3, dtype=torch.float32, device=self._dev)
+        _lib.check(self._lib.mi_knn_graph_read(self._h, _ptr(ei), _ptr(ev), {"reference": 0, "csr": 1}[order], _stream()), "mi_knn_graph_read")
+        return ei.long(), ev
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -69,8 +94,11 @@ class CSPNet(nn.Module):
         if not (smooth and pred_type) or pred_scalar or act_fn != "silu" or dis_emb != "sin" or not ip or max_atoms != MAX_ATOMIC_NUM:
             raise NotImplementedError("HIP CSPNet implements the DiffCSPModule configuration: smooth=True, pred_type=True, "
                                       "act_fn='silu', dis_emb='sin', ip=True, max_atoms=100")
-        if edge_style != "fc":
-            raise NotImplementedError("edge_style='knn' is not on the HIP path yet (fc is the reference default)")
+        if edge_style not in ("fc", "knn"):
+            raise NotImplementedError(f"edge_style={edge_style!r}")
+        # `cutoff` is accepted and, as in the reference, has no effect: radius_graph_pbc overwrites it with the smallest
+        # inter-plane spacing + 0.01 (utils.py:463-471)
+        self.edge_style, self.cutoff, self.max_neighbors = edge_style, cutoff, max_neighbors
         self.hidden_dim, self.latent_dim, self.num_layers, self.num_freqs, self.ln = hidden_dim, latent_dim, num_layers, num_freqs, ln
         lib = _lib.load()
         self._lib = lib
@@ -163,7 +191,7 @@ class CSPNet(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     def make_batch(self, num_atoms, node_offset=0, graph_offset=0) -> CrystalBatch:
-        return CrystalBatch(self, num_atoms, node_offset, graph_offset)
+        return CrystalBatch(self, num_atoms, node_offset, graph_offset, edge_style=self.edge_style, max_neighbors=self.max_neighbors)
 
     def forward(self, t, atom_types, frac_coords, lattices, num_atoms, node2graph=None, batch: CrystalBatch = None):
         """Same positional signature as the reference CSPNet.forward (cspnet.py:260); `batch`

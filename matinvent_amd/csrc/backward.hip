@@ -50,8 +50,8 @@ __global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __res
     Z2[idx] = (dcat[(size_t)i * (2 * H) + H + f] / deg) * silu_grad(Z2[idx]);
 }
 
-__global__ void fourier_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
-                               float* __restrict__ FF, int64_t E, int F);
+__global__ void fourier_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
+                               const int* __restrict__ dst, float* __restrict__ FF, int64_t E, int F);
 
 // dPQ[i][0:H]  = sum_j dZ1[(i,j)]      (row run of node i)
 // dPQ[j][H:2H] = sum_i dZ1[(i,j)]      (column of node j inside its fully connected crystal)
@@ -66,6 +66,21 @@ __global__ void edge_dpq_kernel(const float* __restrict__ dZ1, const int* __rest
     int g = node2graph[i], n0 = node_off[g], n1 = node_off[g + 1], jl = i - n0;
     float t = 0.f;
     for (int ii = n0; ii < n1; ++ii) t += dZ1[(size_t)(rowptr[ii] + jl) * H + f];
+    dPQ[(size_t)i * (2 * H) + H + f] = t;
+}
+
+// general edge lists (knn branch): out-edges of i are its CSR row, in-edges are listed in `inedge` at the same offsets
+__global__ void edge_dpq_csr_kernel(const float* __restrict__ dZ1, const int* __restrict__ rowptr, const int* __restrict__ inedge,
+                                    float* __restrict__ dPQ, int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * H) return;
+    int i = (int)(idx / H), f = (int)(idx % H);
+    float s = 0.f, t = 0.f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        s += dZ1[(size_t)e * H + f];
+        t += dZ1[(size_t)inedge[e] * H + f];
+    }
+    dPQ[(size_t)i * (2 * H) + f] = s;
     dPQ[(size_t)i * (2 * H) + H + f] = t;
 }
 
@@ -200,7 +215,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 static int alloc_tape(mi_net* net, mi_batch* b) {
     if (b->tape.allocated) return MI_OK;
-    const size_t N = b->N, B = b->B, E = (size_t)b->E, H = net->H, L = net->L, F = net->F, TD = net->TD;
+    const size_t N = b->N, B = b->B, E = (size_t)b->E_cap, H = net->H, L = net->L, F = net->F, TD = net->TD;
     Tape& t = b->tape;
     int rc = MI_OK;
 #define T_(p, n) \
@@ -292,7 +307,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 
     // Fourier features are the same for every layer
     if (E > 0) {
-        hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.frac, b->src, b->dst, t.FF, E, F);
+        hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.frac, b->fd, b->src, b->dst, t.FF, E, F);
         MI_KERNEL_CHECK();
     }
 
@@ -327,7 +342,8 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
             MI_KERNEL_CHECK();
             MI_TRY(gemm_tn_acc(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
-            hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
+            if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
+            else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
             MI_KERNEL_CHECK();
         } else {
             MI_HIP(hipMemsetAsync(t.dPQ, 0, NH * 2 * 4, s));

@@ -50,7 +50,12 @@ __global__ void pack_wff_kernel(const float* __restrict__ W1, int edge_in, int H
 // Fourier operand of the edge kernel, once per network evaluation, in B-fragment order:
 // FFp[tile][m][lane][q] = hi ? cos(arg) : sin(arg), arg = ((x_j - x_i) % 1)_c * (2*pi*k), pair 4m+q = c*FP + k,
 // lane = (edge-in-tile, hi).  SinusoidsEmbedding (cspnet.py:12-24); frequency table 2*pi*k in fp32 (:16).
-__global__ void fourier_pack_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
+// frac_diff of edge e, coordinate c: explicit (knn branch) or (x_dst - x_src) % 1 (fc branch, cspnet.py:242)
+__device__ __forceinline__ float edge_diff(const float* __restrict__ frac, const float* __restrict__ fd, int64_t e, int i, int j, int c) {
+    return fd ? fd[e * 3 + c] : pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+}
+
+__global__ void fourier_pack_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src, const int* __restrict__ dst,
                                     float* __restrict__ FFp, int64_t E, int F, int KP) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
     const int nm = KP / 4, FP = KP / 3;
@@ -67,7 +72,7 @@ __global__ void fourier_pack_kernel(const float* __restrict__ frac, const int* _
         const int s = 4 * m + q, c = s / FP, k = s % FP;
         float v = 0.f;
         if (k < F) {
-            const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);  // cspnet.py:242
+            const float d = edge_diff(frac, fd, e, i, j, c);
             float sn, cs;
             sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
             v = hi ? cs : sn;
@@ -78,13 +83,13 @@ __global__ void fourier_pack_kernel(const float* __restrict__ frac, const int* _
 }
 
 // FF[e][c*F+k] = sin(d_c * 2*pi*k), FF[e][3F + c*F+k] = cos(...)   (cspnet.py:20-24)
-__global__ void fourier_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst,
-                               float* __restrict__ FF, int64_t E, int F) {
+__global__ void fourier_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
+                               const int* __restrict__ dst, float* __restrict__ FF, int64_t E, int F) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * 3 * F) return;
     int64_t e = idx / (3 * F);
     int ck = (int)(idx % (3 * F)), c = ck / F, k = ck % F;
-    float d = pymod1(frac[dst[e] * 3 + c] - frac[src[e] * 3 + c]);
+    float d = edge_diff(frac, fd, e, src[e], dst[e], c);
     float sn, cs;
     sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
     FF[e * (6 * F) + ck] = sn;
@@ -94,8 +99,8 @@ __global__ void fourier_kernel(const float* __restrict__ frac, const int* __rest
 // Fourier features written directly as a tile-blocked bf16 plane set (the A operand of the first edge GEMM).
 // One thread per (edge, column pair); columns = [sin(3F) | cos(3F)] in the reference order (cspnet.py:20-24),
 // pad columns (>= 6F) and pad rows (>= E) are written as zero.
-__global__ void fourier_planes_kernel(const float* __restrict__ frac, const int* __restrict__ src, const int* __restrict__ dst, Planes FF,
-                                      int64_t E, int F) {
+__global__ void fourier_planes_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
+                                      const int* __restrict__ dst, Planes FF, int64_t E, int F) {
     const int cp = FF.KT * 16;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rows_pad = (E + 127) / 128 * 128;
@@ -110,7 +115,7 @@ __global__ void fourier_planes_kernel(const float* __restrict__ frac, const int*
             const int col = c0 + u;
             if (col < 6 * F) {
                 const int ck = col < 3 * F ? col : col - 3 * F, c = ck / F, k = ck % F;
-                const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+                const float d = edge_diff(frac, fd, e, i, j, c);
                 float sn, cs;
                 sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn, &cs);
                 v[u] = col < 3 * F ? sn : cs;
@@ -371,6 +376,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     const size_t NH = (size_t)N * H;
     Tape& tp = b->tape;
     tp.valid = false;  // this forward overwrites h / hf / x1, which a pending backward would read
+    if (b->knn) MI_TRY(knn_build(b, frac, lattices, s));  // cspnet.py:243-257: the edge list follows the coordinates
     if (train) {
         MI_CHECK(tp.allocated, MI_ESTATE, "training forward without tape");
         MI_HIP(hipMemcpyAsync(tp.atom_types, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
@@ -395,16 +401,16 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
-        hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->src, b->dst, b->FFp, b->E, net->F,
+        hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FFp, b->E, net->F,
                            net->KP);
         MI_KERNEL_CHECK();
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
         Planes ffp = make_planes(b->FFpl, 6 * net->F);
         const int64_t nthr = (b->E + 127) / 128 * 128 * (int64_t)ffp.KT * 16;
-        hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->src, b->dst, ffp, b->E, net->F);
+        hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
         MI_KERNEL_CHECK();
     } else if (b->E > 0) {
-        hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)cdiv(b->E * 3 * net->F, 256)), dim3(256), 0, s, frac, b->src, b->dst, b->FF, b->E, net->F);
+        hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)cdiv(b->E * 3 * net->F, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FF, b->E, net->F);
         MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
@@ -659,8 +665,8 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
     return MI_OK;
 }
 
-int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
-                    mi_batch** out) {
+static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset, bool knn,
+                             int max_neighbors, int cap_per_node, mi_batch** out) {
     MI_CHECK(net && out && (num_atoms_host || B == 0) && B >= 0, MI_EINVAL, "bad argument");
     mi_batch* b = new mi_batch();
     b->B = B;
@@ -682,28 +688,38 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
     }
     const int N = b->node_off_h[B];
     b->N = N;
-    b->E = E;
+    if (knn) {  // edge list built on the device by every forward; buffers sized for the capacity
+        int rck = knn_alloc(b, max_neighbors, cap_per_node);
+        if (rck != MI_OK) {
+            mi_batch_destroy(b);
+            return rck;
+        }
+        E = b->E_cap;
+    }
+    b->E = knn ? 0 : E;
+    b->E_cap = E;
     if (E >= (int64_t)1 << 31) {
         delete b;
         set_error("edge count %lld exceeds int32", (long long)E);
         return MI_EINVAL;
     }
     // fully connected edges, row-major incl. self loops (cspnet.py:239-241)
-    std::vector<int> n2g(N), src((size_t)E), dst((size_t)E), rowptr(N + 1, 0), egraph((size_t)E);
+    const size_t Efc = knn ? 0 : (size_t)E;
+    std::vector<int> n2g(N), src(Efc), dst(Efc), rowptr(N + 1, 0), egraph(Efc);
     size_t e = 0;
-    int nslots = 1;
+    int nslots = knn ? b->deg_cap / 32 + 2 : 1;
     for (int g = 0; g < B; ++g) {
         int n = num_atoms_host[g], o = b->node_off_h[g];
         for (int i = 0; i < n; ++i) {
             n2g[o + i] = g;
             rowptr[o + i] = (int)e;
-            for (int j = 0; j < n; ++j) {
+            for (int j = 0; j < n && !knn; ++j) {
                 src[e] = o + i;
                 dst[e] = o + j;
                 egraph[e] = g;
                 ++e;
             }
-            nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
+            if (!knn) nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
         }
     }
     rowptr[N] = (int)e;
@@ -776,6 +792,15 @@ void mi_batch_destroy(mi_batch* b) {
     if (!b) return;
     for (void* p : b->allocs) (void)hipFree(p);
     delete b;
+}
+
+int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset, mi_batch** out) {
+    return batch_create_impl(net, num_atoms_host, B, node_offset, graph_offset, false, 0, 0, out);
+}
+
+int mi_batch_create_knn(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset, int max_neighbors,
+                        int edge_cap_per_node, mi_batch** out) {
+    return batch_create_impl(net, num_atoms_host, B, node_offset, graph_offset, true, max_neighbors, edge_cap_per_node, out);
 }
 
 int mi_batch_num_nodes(const mi_batch* b) { return b ? b->N : 0; }

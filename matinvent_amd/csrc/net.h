@@ -58,8 +58,16 @@ struct Tape {
 
 struct mi_batch {
     int B = 0, N = 0, H = 0, L = 0;
-    int64_t E = 0;
+    int64_t E = 0;      // edges of the current graph (fixed for fc; rewritten by every forward for knn)
+    int64_t E_cap = 0;  // edge capacity every per-edge buffer is sized for (= E for fc)
     int nslots = 1;
+    // knn edge style (CSPNet.gen_edges knn branch, graph.hip)
+    int knn = 0, max_neighbors = 0, cap_per_node = 0, deg_cap = 0, nmax = 0;
+    float* fd = nullptr;    // [E][3] explicit frac_diff per edge (CSR order); nullptr = fc: (x_dst - x_src) % 1
+    int* inedge = nullptr;  // [E] edge ids grouped by destination node, node v at rowptr[v]..rowptr[v+1] (degrees are symmetric)
+    int *kn_ent = nullptr, *kn_acnt = nullptr, *kn_deg = nullptr, *kn_mcount = nullptr, *kn_eoff = nullptr, *kn_meta = nullptr,
+        *kn_refpos = nullptr, *r_src = nullptr, *r_dst = nullptr;
+    float* r_vec = nullptr;  // reference-order copy of the list: edges (r_src, r_dst), attribute r_vec
     int64_t node_offset = 0, graph_offset = 0;
     std::vector<int> num_atoms_h, node_off_h;
     // index tables (device)
@@ -103,4 +111,6 @@ int net_pack_transposes(mi_net* net, hipStream_t s);
 int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s);
 template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
+int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);
+int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
 }  // namespace mi

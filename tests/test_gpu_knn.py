@@ -1,0 +1,189 @@
+"""GPU parity of the periodic neighbour graph (K17) and of the score network on top of it:
+CSPNet.gen_edges knn branch = radius_graph_pbc + get_max_neighbors_mask + reorder_symmetric_edges
+(models/diffcsp/cspnet.py:159-257, models/diffcsp/utils.py:335-601).  The edge list and its attribute are index /
+exactly-rounded work: compared bit for bit, in the reference's order.  Network outputs: fp32 round-off."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffcsp_oracle as O
+from tests.gpu_util import load_decoder, params_from_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(H, L, F, P=None, seed=0):
+    from matinvent_amd.cspnet import CSPNet
+    torch.manual_seed(seed)
+    net = CSPNet(hidden_dim=H, num_layers=L, num_freqs=F, latent_dim=256, ln=True, smooth=True, pred_type=True, edge_style="knn",
+                 max_neighbors=20, device="cuda")
+    if P is not None:
+        load_decoder(net, P)
+    return net
+
+
+def _close(a, b, tol, what):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+def _check_csr(batch, edges_ref, vec_ref, N):
+    """The source-sorted list the kernels iterate over is a permutation of the reference list."""
+    ec, vc = batch.edges("csr")
+    ec, vc = ec.cpu(), vc.cpu()
+    assert bool((ec[0][1:] >= ec[0][:-1]).all()), "CSR order must be sorted by source node"
+    key = lambda e, v: sorted(zip(e[0].tolist(), e[1].tolist(), map(tuple, v.tolist())))
+    assert key(ec, vc) == key(edges_ref, vec_ref)
+
+
+def test_knn_graph_golden(golden):
+    g = golden("g5c_knn")
+    net = _net(64, 2, 8)
+    b = net.make_batch(g["num_atoms"])
+    E = b.build_graph(torch.from_numpy(g["frac"]), torch.from_numpy(g["lattices"]))
+    assert E == g["edges"].shape[1]
+    edges, vec = b.edges("reference")
+    assert edges.cpu().tolist() == g["edges"].tolist()
+    np.testing.assert_array_equal(vec.cpu().numpy(), g["edge_vec"])  # exactly rounded: bit for bit
+    _check_csr(b, torch.from_numpy(g["edges"]), torch.from_numpy(g["edge_vec"]), int(g["num_atoms"].sum()))
+
+
+def test_knn_forward_golden(golden):
+    g = golden("g5c_knn")
+    net = _net(64, 2, 8, params_from_golden(g))
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    b = net.make_batch(g["num_atoms"])
+    for mode, edge in (("split", "gemm"), ("f32", "gemm"), ("f32", "fused_f32")):
+        from matinvent_amd.cspnet import set_gemm_mode
+        set_gemm_mode(mode)
+        net.set_edge_mode(edge)
+        try:
+            pl, px, pt = net(T("t_emb"), T("atom_types"), T("frac"), T("lattices"), None, batch=b)
+        finally:
+            set_gemm_mode("split")
+        assert b._lib.mi_batch_num_edges(b._h) == g["edges"].shape[1]
+        _close(pl, g["pred_l"], 2e-5, f"pred_l [{mode}-{edge}]")
+        _close(px, g["pred_x"], 2e-5, f"pred_x [{mode}-{edge}]")
+        _close(pt, g["pred_t"], 2e-5, f"pred_t [{mode}-{edge}]")
+
+
+def _random_crystals(seed, num_atoms, lo=3.5, hi=9.0, ang=(65.0, 115.0)):
+    g = torch.Generator().manual_seed(seed)
+    B, N = len(num_atoms), sum(num_atoms)
+    lengths = lo + (hi - lo) * torch.rand(B, 3, generator=g)
+    angles = ang[0] + (ang[1] - ang[0]) * torch.rand(B, 3, generator=g)
+    lat = O.lattice_params_to_matrix(lengths, angles)
+    frac = torch.rand(N, 3, generator=g)
+    return frac, lat
+
+
+@pytest.mark.parametrize("seed,num_atoms", [(1, [1, 2, 3, 20, 7]), (2, [20] * 6), (3, [5, 1, 1, 12, 30, 2, 9]), (4, [64, 3]),
+                                            (5, [16, 16, 16, 8])])
+def test_knn_graph_vs_oracle(seed, num_atoms):
+    """Ragged batches incl. single-atom crystals (self-image edges only), dense cells where the max-neighbour trim
+    is active, and the 64-atom limit."""
+    frac, lat = _random_crystals(seed, num_atoms)
+    na = torch.tensor(num_atoms)
+    edges_ref, vec_ref = O.knn_edges(frac, lat, na, 20)
+    net = _net(64, 1, 4)
+    b = net.make_batch(num_atoms)
+    E = b.build_graph(frac, lat)
+    assert E == edges_ref.shape[1]
+    edges, vec = b.edges("reference")
+    assert edges.cpu().tolist() == edges_ref.tolist()
+    np.testing.assert_array_equal(vec.cpu().numpy(), vec_ref.numpy())
+    _check_csr(b, edges_ref, vec_ref, sum(num_atoms))
+
+
+def test_knn_graph_symmetric_cells():
+    """High-symmetry input: cubic cells with atoms on a 1/4 grid -> many exactly degenerate distances, shells that straddle
+    the max-neighbour rank (the +0.01 band keeps whole shells), self-image edges at exactly the lattice constant."""
+    num_atoms = [8, 4, 2, 1]
+    lat = torch.stack([torch.eye(3) * a for a in (4.0, 5.5, 3.0, 2.5)])
+    g = torch.Generator().manual_seed(11)
+    frac = torch.randint(0, 4, (sum(num_atoms), 3), generator=g).float() / 4
+    # distinct sites inside each crystal
+    frac = torch.cat([torch.tensor([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5], [.25, .25, .25], [.75, .75, .25], [.75, .25, .75],
+                                    [.25, .75, .75]]), torch.tensor([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]),
+                      torch.tensor([[0, 0, 0], [.5, .5, .5]]), torch.tensor([[.1, .2, .3]])]).float()
+    na = torch.tensor(num_atoms)
+    edges_ref, vec_ref = O.knn_edges(frac, lat, na, 20)
+    net = _net(64, 1, 4)
+    b = net.make_batch(num_atoms)
+    b.build_graph(frac, lat)
+    edges, vec = b.edges("reference")
+    assert edges.cpu().tolist() == edges_ref.tolist()
+    np.testing.assert_array_equal(vec.cpu().numpy(), vec_ref.numpy())
+
+
+def test_knn_capacity_error():
+    """Exceeding the per-atom capacity raises; it never truncates silently."""
+    from matinvent_amd.cspnet import CrystalBatch
+    net = _net(64, 1, 4)
+    frac, lat = _random_crystals(2, [20] * 2)
+    b = CrystalBatch(net, [20, 20], edge_style="knn", max_neighbors=20, edge_cap_per_node=4)
+    with pytest.raises(RuntimeError, match="capacity"):
+        b.build_graph(frac, lat)
+
+
+def test_knn_forward_and_grads_vs_oracle():
+    """Forward outputs and dLoss/dtheta through the knn graph (general CSR edge list: gathers, segmented mean,
+    in-edge sums of the backward) against the oracle's autograd."""
+    H, L, F = 64, 2, 8
+    num_atoms = [6, 20, 1, 11]
+    frac, lat = _random_crystals(21, num_atoms)
+    na = torch.tensor(num_atoms)
+    B, N = len(num_atoms), sum(num_atoms)
+    g = torch.Generator().manual_seed(5)
+    at = torch.randn(N, 100, generator=g)
+    t_emb = torch.randn(B, 256, generator=g)
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F, edge_style="knn")
+    P = O.init_params(hp, seed=3)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    n2g = torch.repeat_interleave(torch.arange(B), na)
+    pl, px, pt = O.cspnet_forward(Pg, hp, t_emb, at, frac, lat, na, n2g)
+    wl, wx, wt = torch.randn(pl.shape, generator=g), torch.randn(px.shape, generator=g), torch.randn(pt.shape, generator=g)
+    loss = (pl * wl).sum() + (px * wx).sum() + (pt * wt).sum()
+    loss.backward()
+
+    net = _net(H, L, F, P)
+    net.theta.requires_grad_(True)
+    b = net.make_batch(num_atoms)
+    with torch.enable_grad():
+        ql, qx, qt = net(t_emb.cuda(), at.cuda(), frac.cuda(), lat.cuda(), None, batch=b)
+        (ql * wl.cuda()).sum().add((qx * wx.cuda()).sum()).add((qt * wt.cuda()).sum()).backward()
+    _close(ql, pl, 2e-5, "pred_l")
+    _close(qx, px, 2e-5, "pred_x")
+    _close(qt, pt, 2e-5, "pred_t")
+    gv = {k: net.theta.grad[o:o + n].view(shape).cpu() for k, (o, n, shape) in net.layout.items()}
+    for k, v in gv.items():
+        ref = Pg["decoder." + k].grad
+        scale = max(float(ref.abs().max()), 1e-3)
+        err = float((v - ref).abs().max())
+        assert err <= 5e-4 * scale, f"grad {k}: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_knn_sample_chain_vs_oracle():
+    """Free-running reverse chain with the graph rebuilt before every network evaluation (counter-based noise shared
+    with the oracle).  The chain starts from N(0,1) lattices, i.e. arbitrary skewed cells."""
+    from matinvent_amd.diffcsp import DiffCSPModule
+    from tests.gpu_util import Box, wrap_dist
+    T, seed = 8, 77
+    hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8, edge_style="knn")
+    P = O.init_params(hp, seed=1, head_scale=0.1)
+    sn = torch.cat([torch.ones(1), 0.5 + torch.rand(T, generator=torch.Generator().manual_seed(3))])
+    m = DiffCSPModule(decoder=dict(hidden_dim=64, num_layers=2, num_freqs=8, ln=True, edge_style="knn", max_neighbors=20),
+                      beta_scheduler=dict(timesteps=T, scheduler_mode="cosine"),
+                      sigma_scheduler=dict(timesteps=T, sigma_begin=0.005, sigma_end=0.5, sigmas_norm=sn), device="cuda")
+    load_decoder(m.decoder, P)
+    sch = O.Schedules.make(T, sigmas_norm=sn)
+    na = torch.tensor([4, 9, 2, 12])
+    noise = O.philox_sampler_noise(seed, na, T)
+    of, _ = O.sample(P, hp, sch, na, noise, step_lr=5e-6)
+    final, _ = m.sample(Box(na), step_lr=5e-6, seed=seed)
+    assert wrap_dist(final["frac_coords"].cpu().numpy(), of["frac_coords"].numpy()).max() < 3e-4
+    np.testing.assert_allclose(final["lattices"].cpu().numpy(), of["lattices"].numpy(), rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(final["atom_types"].cpu().numpy(), of["atom_types"].numpy(), rtol=3e-4, atol=3e-4)
