@@ -618,7 +618,7 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
 
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, void* stream) {
     MI_CHECK(A && W && C, MI_EINVAL, "null argument");
-    if (kind == 2) {  // split both operands into tile-blocked bf16 planes (cached scratch), then the plane GEMM
+    if (kind == 2 || kind == 3) {  // split both operands into tile-blocked bf16 planes (cached scratch), then the plane GEMM (3: 256-row variant)
         static u16 *pa = nullptr, *pw = nullptr;
         static size_t na = 0, nw = 0;
         hipStream_t s = (hipStream_t)stream;
@@ -632,7 +632,11 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
         PlanesEpilogue pe;
         pe.C = C;
         pe.ldc = ldc < 0 ? -ldc : ldc;
-        return gemm_planes(PA, PW, M, N, K, pe, s);
+        const int saved = g_planes_variant;
+        g_planes_variant = kind == 3;
+        const int rc = gemm_planes(PA, PW, M, N, K, pe, s);
+        g_planes_variant = saved;
+        return rc;
     }
     return kind == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream)
                      : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream);

@@ -11,6 +11,7 @@
 namespace mi {
 
 int g_gemm_mode = 1;  // MI_GEMM_SPLIT
+int g_planes_variant = 1;
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {

@@ -11,6 +11,7 @@
 //
 // Tile: 128 x 128 outputs per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles), BK = 32.
 #pragma once
+#include <type_traits>
 #include "gemm.h"
 
 namespace mi {
@@ -162,6 +163,7 @@ inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float
 //   MI_GEMM_SPLIT (default): three-plane bf16 split, six terms -- fp32-class accuracy, bf16 matrix pipe
 //   MI_GEMM_F32            : v_mfma_f32_32x32x2_f32 -- bit-for-bit an fp32 fma chain
 extern int g_gemm_mode;
+extern int g_planes_variant;  // 0 = 128x128 tiles, 1 = 256x128 double-buffered (large M)
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                    hipStream_t s) {
     return g_gemm_mode == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, ep, s) : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
@@ -226,6 +228,14 @@ static __global__ void split_planes_kernel(const float* __restrict__ src, int ld
     for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(r, c, k)) = p[k];
 }
 
+// buffer descriptor over [p, p + bytes) with every field forced into scalar registers (the compiler otherwise
+// treats block-uniform pointer arithmetic as divergent and wraps each buffer load in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 struct PlanesEpilogue {
     GemmEpilogue ep;       // bias / gathers / pre_act / act / residual as for the fp32 kernels
     float* C = nullptr;    // optional fp32 output [M][ldc]
@@ -241,109 +251,15 @@ struct PlanesEpilogue {
     int seg_nodes = 0;
 };
 
-// C = epi(A W^T) with both operands given as tile-blocked plane sets; main loop = loads + ds + MFMA only.
-//
-// LDS image per plane: 128 rows x 64 B, unpadded, 16-byte chunk index XOR-swizzled with (row >> 2) & 3:
-//   chunk c of row r lives at r*64 + ((c ^ ((r >> 2) & 3)) * 16).
-// Fragment reads (ds_read_b128, 16-lane groups of rows distinct mod 16, same chunk) and staging writes
-// (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
-// was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
-// Global -> register prefetch runs TWO k-tiles ahead (the A operand streams from HBM/MALL).
-// This is the 128x128-tile, two-barriers-per-k-step structure: ~870 TF/s of bf16 MFMA issue (35 % of peak),
-// which is its known ceiling on this chip; a 256x256 multi-phase schedule is the next step.
-static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe) {
-    constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;
-    unsigned char* Ws = smem + 3 * PLB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
-    const int rt = blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // a plane tile = 128 rows x 64 B = 512 chunks of 16 B; two per thread per plane
-    u32x4 ra0[3][2], rw0[3][2], ra1[3][2], rw1[3][2];
-    auto load_tiles = [&](int kt, u32x4 (&ra)[3][2], u32x4 (&rw)[3][2]) {
-        const u32x4* ga = reinterpret_cast<const u32x4*>(A.base + A.tile(rt, kt));
-        const u32x4* gw = reinterpret_cast<const u32x4*>(W.base + W.tile(ct, kt));
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                ra[p][v] = ga[p * 512 + v * 256 + tid];
-                rw[p][v] = gw[p * 512 + v * 256 + tid];
-            }
-    };
-    auto store_tiles = [&](const u32x4 (&ra)[3][2], const u32x4 (&rw)[3][2]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int f = v * 256 + tid, r = f >> 2, c = (f & 3) ^ ((r >> 2) & 3);
-                *reinterpret_cast<u32x4*>(As + p * PLB + r * 64 + c * 16) = ra[p][v];
-                *reinterpret_cast<u32x4*>(Ws + p * PLB + r * 64 + c * 16) = rw[p][v];
-            }
-    };
-    auto compute = [&]() {
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLB + r * 64 + c * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = (wn * TN + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * PLB + r * 64 + c * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // smallest terms first, so that they are not lost against a large accumulator
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    const int KT = (K + 31) / 32;
-    load_tiles(0, ra0, rw0);
-    if (KT > 1) load_tiles(1, ra1, rw1);
-    for (int kt = 0; kt < KT; kt += 2) {
-        store_tiles(ra0, rw0);
-        __syncthreads();
-        if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
-        compute();
-        __syncthreads();
-        if (kt + 1 < KT) {
-            store_tiles(ra1, rw1);
-            __syncthreads();
-            if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
-            compute();
-            __syncthreads();
-        }
-    }
-
+// Epilogue of one wave's TM x TN block of 32x32 accumulator tiles whose first row / column are row_w / col_w:
+// bias, gathers, activation, optional fp32 / plane-set stores and the fused segmented row sum.
+template <int TM, int TN>
+__device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N, int l31,
+                                                int kg) {
     const GemmEpilogue& ep = pe.ep;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int rb = row0 + (wm * TM + i) * 32;  // first row of this 32-row block
+        const int rb = row_w + i * 32;  // first row of this 32-row block
         // segment structure of the block (runs of equal seg_src), wave-uniform
         uint32_t starts = 0;
         int srcv = 0, nvalid = 0;
@@ -355,7 +271,7 @@ static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Plane
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = col0 + (wn * TN + j) * 32 + l31;
+            const int col = col_w + j * 32 + l31;
             const bool col_ok = col < N;
             const float bcol = (ep.bias && col_ok) ? ep.bias[col] : 0.f;
             float val[16];
@@ -402,10 +318,336 @@ static __global__ __launch_bounds__(256) void gemm_planes_kernel(Planes A, Plane
     }
 }
 
+// Row-major variant of the epilogue for GEMMs that write a plane set (the first edge GEMM).  In the MFMA result layout a lane
+// owns ONE column of 16 rows, so the three row-gathered addends cost 48 four-byte loads and the plane output 48 two-byte
+// stores per 32x32 tile and lane.  Here each tile goes through a per-wave LDS patch (32 x 36 floats) and comes back as
+// 8 consecutive columns of one row per lane: every gather, the optional pre-activation save and the three plane stores are
+// 16-byte accesses (12 loads + 6..8 stores per tile and lane).  Needs N % 8 == 0; `stage` = this wave's 4608-byte patch.
+template <int TM, int TN>
+__device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N,
+                                                     int lane, float* stage) {
+    const GemmEpilogue& ep = pe.ep;
+    const int l31 = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = row_w + i * 32, cb = col_w + j * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = lane + 64 * u, rl = q >> 2, c8 = (q & 3) * 8;
+                const int row = rb + rl, col = cb + c8;
+                const f32x4 z0 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8);
+                const f32x4 z1 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8 + 4);
+                if (row < M && col < N) {
+                    float v[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+                    auto add8 = [&](float (&dst)[8], const float* src) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            dst[k] += a[k];
+                            dst[4 + k] += b[k];
+                        }
+                    };
+                    if (ep.bias) add8(v, ep.bias + col);
+                    if (ep.row_bias) {
+                        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        add8(g, ep.row_bias + (size_t)ep.row_group[row] * ep.ld_row_bias + col);
+                        if (ep.row_bias2) add8(g, ep.row_bias2 + (size_t)ep.row_group2[row] * ep.ld_row_bias2 + col);
+                        if (ep.row_bias3) add8(g, ep.row_bias3 + (size_t)ep.row_group3[row] * ep.ld_row_bias3 + col);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += g[k];
+                    }
+                    if (ep.pre_act) {
+                        float* d = ep.pre_act + (size_t)row * ep.ld_pre + col;
+                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                    if (ep.act == ACT_SILU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = silu(v[k]);
+                    }
+                    if (pe.C) {
+                        float* d = pe.C + (size_t)row * pe.ldc + col;
+                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                    if (pe.Cp.base) {
+                        u32x4 o[3];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            unsigned pr[3];
+                            split3_pair(v[2 * k], v[2 * k + 1], pr);
+                            o[0][k] = pr[0];
+                            o[1][k] = pr[1];
+                            o[2][k] = pr[2];
+                        }
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(row, col, pl)) = o[pl];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+// whether the row-major epilogue applies (otherwise the result-layout one, which also carries the fused segmented sum)
+__device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
+    return pe.Cp.base != nullptr && pe.seg_part == nullptr && pe.ep.residual == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 &&
+           (pe.ep.ld_pre & 3) == 0 && (pe.ep.ld_row_bias & 3) == 0 && (pe.ep.ld_row_bias2 & 3) == 0 && (pe.ep.ld_row_bias3 & 3) == 0;
+}
+
+// C = epi(A W^T) with both operands given as tile-blocked plane sets; main loop = loads + ds + MFMA only.
+//
+// LDS image per plane: 128 rows x 64 B, unpadded, 16-byte chunk index XOR-swizzled with (row >> 2) & 3:
+//   chunk c of row r lives at r*64 + ((c ^ ((r >> 2) & 3)) * 16).
+// Fragment reads (ds_read_b128, 16-lane groups of rows distinct mod 16, same chunk) and staging writes
+// (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
+// was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
+// Global -> register prefetch runs TWO k-tiles ahead (the A operand streams from HBM/MALL).
+// This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU), used when M is too small to fill
+// the chip with 256-row tiles; the double-buffered kernel below takes the large edge-level products.
+template <int V>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe) {
+    constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Ws = smem + 3 * PLB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    const int rt = blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // a plane tile = 128 rows x 64 B = 512 chunks of 16 B; two per thread per plane.  Buffer loads: the descriptor covers
+    // this block's row tile (uniform), the per-thread offset is constant and every tile/plane offset is scalar, so the
+    // loop carries no per-load vector address arithmetic.
+    u32x4 ra0[3][2], rw0[3][2], ra1[3][2], rw1[3][2];
+    const int KT = (K + 31) / 32;
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(rt, 0), KT * 24576);
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(W.base + W.tile(ct, 0), KT * 24576);
+    auto load_tiles = [&](int kt, u32x4 (&ra)[3][2], u32x4 (&rw)[3][2]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                ra[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, kt * 24576 + p * 8192 + v * 4096, 0);
+                rw[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, kt * 24576 + p * 8192 + v * 4096, 0);
+            }
+    };
+    auto store_tiles = [&](const u32x4 (&ra)[3][2], const u32x4 (&rw)[3][2]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int f = v * 256 + tid, r = f >> 2, c = (f & 3) ^ ((r >> 2) & 3);
+                *reinterpret_cast<u32x4*>(As + p * PLB + r * 64 + c * 16) = ra[p][v];
+                *reinterpret_cast<u32x4*>(Ws + p * PLB + r * 64 + c * 16) = rw[p][v];
+            }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLB + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = (wn * TN + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * PLB + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest terms first, so that they are not lost against a large accumulator
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    load_tiles(0, ra0, rw0);
+    if (KT > 1) load_tiles(1, ra1, rw1);
+    int kt = 0;
+    for (; kt + 2 <= KT; kt += 2) {  // k-tiles in pairs: the accumulators never cross a conditional
+        store_tiles(ra0, rw0);
+        __syncthreads();
+        if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
+        compute();
+        __syncthreads();
+        store_tiles(ra1, rw1);
+        __syncthreads();
+        if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
+        compute();
+        __syncthreads();
+    }
+    if (kt < KT) {
+        store_tiles(ra0, rw0);
+        __syncthreads();
+        compute();
+        __syncthreads();
+    }
+
+    if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
+        __syncthreads();                   // the staging patches overlay the operand tiles
+        planes_epilogue_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    } else {
+        planes_epilogue<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, l31, kg);
+    }
+}
+
+// The same contraction on a 256 x 128 tile with 8 waves and DOUBLE-BUFFERED LDS (2 x 72 KiB): one barrier per k-tile instead
+// of two, and the staging writes of tile k+1 / the global loads of tile k+2 sit between the two MFMA halves of tile k, so the
+// matrix pipe only idles at that one barrier.  One workgroup per CU (LDS), two waves per SIMD as before.
+constexpr int GEMM_DB_LDS = 2 * (3 * 256 * 64 + 3 * 128 * 64);
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_db_kernel(Planes A, Planes W, int M, int N,
+                                                                                                              int K, PlanesEpilogue pe) {
+    constexpr int TM = 2, TN = 2, PLA = 256 * 64, PLW = 128 * 64, BUF = 3 * PLA + 3 * PLW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    // Workgroups are dispatched round-robin over the 8 XCDs (id % 8), each with its own L2.  Map ids so that all column tiles
+    // of one 256-row tile run on the SAME XCD at about the same time: the streamed A operand then crosses the fabric once
+    // instead of once per column tile.
+    const int nct = (N + 127) / 128, id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int ct = slot % nct, rt2 = (slot / nct) * 8 + xcd;
+    if (rt2 * 256 >= M) return;
+    const int row0 = rt2 * 256, col0 = ct * 128;
+    const int KT = (K + 31) / 32, RT = (M + 127) / 128;
+    const int rowtile_bytes = (KT * 12288 + 2048) * 2;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // 72 KiB per k-tile = 9 x 16 B per thread: six of A (two 128-row tiles x three planes), three of W
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(2 * rt2, 0), (2 * rt2 + 1 < RT ? 2 : 1) * rowtile_bytes);
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(W.base + W.tile(ct, 0), KT * 24576);
+    u32x4 ra[6], rw[3];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, kt * 24576 + p * 8192, 0);
+            ra[3 + p] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, rowtile_bytes + kt * 24576 + p * 8192, 0);
+            rw[p] = __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, kt * 24576 + p * 8192, 0);
+        }
+    };
+    const int sr = tid >> 2, sc = ((tid & 3) ^ ((sr >> 2) & 3)) * 16;
+    auto store_tiles = [&](unsigned char* buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<u32x4*>(buf + p * PLA + sr * 64 + sc) = ra[p];
+            *reinterpret_cast<u32x4*>(buf + p * PLA + (128 + sr) * 64 + sc) = ra[3 + p];
+            *reinterpret_cast<u32x4*>(buf + 3 * PLA + p * PLW + sr * 64 + sc) = rw[p];
+        }
+    };
+    // fragment sets are software-pipelined: while the MFMAs of one 16-wide k-half run, the ds_reads of the next half
+    // (and the staging writes / global loads) are already in flight
+    struct Frag {
+        bf16x8 a[TM][3], b[TN][3];
+    };
+    auto read_frag = [&](Frag& f, const unsigned char* buf, int s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f.a[i][pl] = *reinterpret_cast<const bf16x8*>(buf + pl * PLA + r * 64 + c * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = (wn * TN + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f.b[j][pl] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLA + pl * PLW + r * 64 + c * 16);
+        }
+    };
+    // the six product terms of one k-half, smallest first (they must not be lost against a large accumulator).  Consecutive
+    // MFMAs go to DIFFERENT accumulators: a filler between two dependent MFMAs costs the accumulator-forwarding fast path.
+    auto mfma_terms = [&](const Frag& f, int t0, int t1) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+            const int pa = t == 0 ? 2 : (t == 1 || t == 4 || t == 5) ? 0 : 1;   // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+            const int pb = t == 0 ? 0 : t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[j][pb], acc[i][j], 0, 0, 0);
+        }
+    };
+    Frag f0, f1;
+    // one k-tile.  On entry: f0 = first-half fragments of tile kt (from `cur`), registers = tile kt+1 (if any).
+    // Half 0: second-half fragments of tile kt are fetched and tile kt+1 is staged into `nxt` under the first 24 MFMAs;
+    // barrier; half 1: tile kt+2 is requested and the first-half fragments of tile kt+1 are fetched under the other 24.
+    auto step = [&](int kt, auto has_next, auto has_next2) {
+        const unsigned char* cur = smem + (kt & 1) * BUF;
+        unsigned char* nxt = smem + ((kt & 1) ^ 1) * BUF;
+        // every wave is past the previous barrier, so nobody still reads `nxt`: stage tile kt+1 at once and re-issue the
+        // registers for tile kt+2 -- its loads get a whole k-tile of MFMAs to land
+        if constexpr (decltype(has_next)::value) store_tiles(nxt);
+        if constexpr (decltype(has_next2)::value) load_tiles(kt + 2);
+        read_frag(f1, cur, 1);
+        mfma_terms(f0, 0, 6);
+        __syncthreads();
+        if constexpr (decltype(has_next)::value) read_frag(f0, nxt, 0);
+        mfma_terms(f1, 0, 6);
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    load_tiles(0);
+    store_tiles(smem);
+    if (KT > 1) load_tiles(1);
+    __syncthreads();
+    read_frag(f0, smem, 0);
+    int kt = 0;
+    for (; kt + 2 < KT; ++kt) step(kt, yes(), yes());  // steady state: branch-free
+    if (kt + 1 < KT) {
+        step(kt, yes(), no());
+        ++kt;
+    }
+    step(kt, no(), no());
+    if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
+        __syncthreads();                   // the staging patches overlay the operand tiles
+        planes_epilogue_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    } else {
+        planes_epilogue<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, l31, kg);
+    }
+}
+
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
     MI_CHECK(A.KT == (K + 31) / 32 && W.KT == A.KT, MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
-    hipLaunchKernelGGL(gemm_planes_kernel, dim3(cdiv(N, 128), cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe);
+    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 512) {  // enough 256-row tiles to fill the chip twice over
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_planes_db_kernel, dim3(cdiv(N, 128) * ((cdiv(M, 256) + 7) / 8 * 8)), dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe);
+    } else {
+        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(cdiv(N, 128), cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe);
+    }
     MI_KERNEL_CHECK();
     return MI_OK;
 }
