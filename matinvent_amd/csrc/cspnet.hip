@@ -98,10 +98,45 @@ __global__ void fourier_kernel(const float* __restrict__ frac, const float* __re
 }
 
 // Fourier features written directly as a tile-blocked bf16 plane set (the A operand of the first edge GEMM).
-// One thread per (edge, column pair); columns = [sin(3F) | cos(3F)] in the reference order (cspnet.py:20-24),
-// pad columns (>= 6F) and pad rows (>= E) are written as zero.
+// Columns = [sin(3F) | cos(3F)] in the reference order (cspnet.py:20-24).  One thread per (edge, pair of sin columns): the
+// sine and cosine of an argument are produced together and stored to column ck and column 3F + ck.  Pad columns (>= 6F)
+// and pad rows (>= E) are written as zero.  Needs 3F even (F even); the per-column kernel below covers odd F.
 __global__ void fourier_planes_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
                                       const int* __restrict__ dst, Planes FF, int64_t E, int F) {
+    const int F3 = 3 * F, np = F3 / 2, npad = (FF.KT * 32 - 2 * F3) / 2, per_row = np + npad;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows_pad = (E + 127) / 128 * 128;
+    if (idx >= rows_pad * per_row) return;
+    const int64_t e = idx / per_row;
+    const int m = (int)(idx % per_row);
+    if (m >= np) {  // zero padding of the K direction
+        const int col = 2 * F3 + 2 * (m - np);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, col, k)) = 0u;
+        return;
+    }
+    float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+    if (e < E) {
+        const int i = src[e], j = dst[e];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ck = 2 * m + u, c = ck / F, k = ck - c * F;
+            const float d = edge_diff(frac, fd, e, i, j, c);
+            sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn[u], &cs[u]);
+        }
+    }
+    unsigned p[3];
+    split3_pair(sn[0], sn[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
+    split3_pair(cs[0], cs[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, F3 + 2 * m, k)) = p[k];
+}
+
+// per-column-pair form (any F)
+__global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
+                                           const int* __restrict__ dst, Planes FF, int64_t E, int F) {
     const int cp = FF.KT * 16;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rows_pad = (E + 127) / 128 * 128;
@@ -407,8 +442,14 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_KERNEL_CHECK();
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
         Planes ffp = make_planes(b->FFpl, 6 * net->F);
-        const int64_t nthr = (b->E + 127) / 128 * 128 * (int64_t)ffp.KT * 16;
-        hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
+        const int64_t rows_pad = (b->E + 127) / 128 * 128;
+        if (net->F % 2 == 0) {
+            const int64_t nthr = rows_pad * (int64_t)(ffp.KT * 16 - 3 * net->F / 2);
+            hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
+        } else {
+            const int64_t nthr = rows_pad * (int64_t)ffp.KT * 16;
+            hipLaunchKernelGGL(fourier_planes_cols_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
+        }
         MI_KERNEL_CHECK();
     } else if (b->E > 0) {
         hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)cdiv(b->E * 3 * net->F, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FF, b->E, net->F);

@@ -36,6 +36,7 @@ struct GemmEpilogue {
 
 // value after the accumulator + per-column bias: row-gathered addends, optional pre-activation save,
 // activation, residual
+template <bool FAST = false>
 __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, int row, int col) {
     if (ep.row_bias) {
         float g = ep.row_bias[(size_t)ep.row_group[row] * ep.ld_row_bias + col];
@@ -44,7 +45,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
         v += g;
     }
     if (ep.pre_act) ep.pre_act[(size_t)row * ep.ld_pre + col] = v;
-    if (ep.act == ACT_SILU) v = silu(v);
+    if (ep.act == ACT_SILU) v = FAST ? silu_fast(v) : silu(v);
     if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];
     return v;
 }

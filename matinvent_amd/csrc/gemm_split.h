@@ -36,6 +36,22 @@ __device__ __forceinline__ void split3(float x, u16& p0, u16& p1, u16& p2) {
     p2 = f2bf(r);
 }
 
+// RNE fp32 -> bf16 pair in one instruction (gfx950 v_cvt_pk_bf16_f32): result = bf16(lo) | bf16(hi) << 16
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// three-plane split of two values at once: p[k] = plane k of (x, y) packed as (x | y << 16)
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) {
+    p[0] = cvt_pk_bf16(x, y);
+    float rx = x - __uint_as_float(p[0] << 16), ry = y - __uint_as_float(p[0] & 0xFFFF0000u);
+    p[1] = cvt_pk_bf16(rx, ry);
+    rx -= __uint_as_float(p[1] << 16);
+    ry -= __uint_as_float(p[1] & 0xFFFF0000u);
+    p[2] = cvt_pk_bf16(rx, ry);
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                             float* __restrict__ C, int ldc, int M, int N, int K, GemmEpilogue ep) {
@@ -77,12 +93,12 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
     };
     auto store_split = [&](unsigned char* base, int rows, const f32x4& val, int f) {
         int r = f >> 3, c = (f & 7) * 4;
-        u16 p[3][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) split3(val[u], p[0][u], p[1][u], p[2][u]);
+        unsigned lo[3], hi[3];
+        split3_pair(val[0], val[1], lo);
+        split3_pair(val[2], val[3], hi);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            uint2 pk = {(unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16), (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16)};
+            uint2 pk = {lo[pl], hi[pl]};
             *reinterpret_cast<uint2*>(base + ((size_t)pl * rows + r) * ROWB + c * 2) = pk;
         }
     };
@@ -197,22 +213,6 @@ struct Planes {
 static inline size_t planes_elems(int64_t rows, int cols) { return (size_t)((rows + 127) / 128) * ((size_t)((cols + 31) / 32) * 12288 + 2048); }
 static inline Planes make_planes(u16* base, int cols) { return Planes{base, (cols + 31) / 32}; }
 
-// RNE fp32 -> bf16 pair in one instruction (gfx950 v_cvt_pk_bf16_f32): result = bf16(lo) | bf16(hi) << 16
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// three-plane split of two values at once: p[k] = plane k of (x, y) packed as (x | y << 16)
-__device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) {
-    p[0] = cvt_pk_bf16(x, y);
-    float rx = x - __uint_as_float(p[0] << 16), ry = y - __uint_as_float(p[0] & 0xFFFF0000u);
-    p[1] = cvt_pk_bf16(rx, ry);
-    rx -= __uint_as_float(p[1] << 16);
-    ry -= __uint_as_float(p[1] & 0xFFFF0000u);
-    p[2] = cvt_pk_bf16(rx, ry);
-}
-
 // fp32 [rows][cols] (row stride ld_src) -> plane set (pads written as zero); one thread per column pair
 static __global__ void split_planes_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, Planes dst) {
     const int cp = dst.KT * 16;  // column pairs per padded row
@@ -280,7 +280,7 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
                 const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 float v = 0.f;
                 if (row < M && col_ok) {
-                    v = apply_epilogue(ep, acc[i][j][r] + bcol, row, col);
+                    v = apply_epilogue<true>(ep, acc[i][j][r] + bcol, row, col);
                     if (pe.C) pe.C[(size_t)row * pe.ldc + col] = v;
                     if (pe.Cp.base) {
                         u16 p0, p1, p2;
@@ -366,9 +366,9 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     }
-                    if (ep.act == ACT_SILU) {
+                    if (ep.act == ACT_SILU) {  // hardware exp2/rcp form (~3 ulp): E*H activations per launch, not hidden behind MFMAs
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = silu(v[k]);
+                        for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
                     }
                     if (pe.C) {
                         float* d = pe.C + (size_t)row * pe.ldc + col;
