@@ -74,21 +74,23 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr int A_V = BM * BK / 4 / 256, W_V = BN * BK / 4 / 256;
-    f32x4 ra[A_V], rw[W_V];
-    auto load_tiles = [&](int k0) {
+    // two register stages: the fp32 tiles of k-step t+2 are requested while step t is split, staged and multiplied, so a
+    // lone workgroup on a CU (node-level products) is not serialised on the global-load latency
+    f32x4 ra[2][A_V], rw[2][W_V];
+    auto load_tiles = [&](int k0, f32x4 (&qa)[A_V], f32x4 (&qw)[W_V]) {
 #pragma unroll
         for (int v = 0; v < A_V; ++v) {
             int f = tid + v * 256, r = f >> 3, c = (f & 7) * 4, gr = row0 + r, gk = k0 + c;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (gr < M && gk < K) val = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
-            ra[v] = val;
+            qa[v] = val;
         }
 #pragma unroll
         for (int v = 0; v < W_V; ++v) {
             int f = tid + v * 256, r = f >> 3, c = (f & 7) * 4, gr = col0 + r, gk = k0 + c;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (gr < N && gk < K) val = *reinterpret_cast<const f32x4*>(W + (size_t)gr * ldw + gk);
-            rw[v] = val;
+            qw[v] = val;
         }
     };
     auto store_split = [&](unsigned char* base, int rows, const f32x4& val, int f) {
@@ -102,15 +104,13 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
             *reinterpret_cast<uint2*>(base + ((size_t)pl * rows + r) * ROWB + c * 2) = pk;
         }
     };
-
-    load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    auto step = [&](int k0, f32x4 (&qa)[A_V], f32x4 (&qw)[W_V]) {
 #pragma unroll
-        for (int v = 0; v < A_V; ++v) store_split(As, BM, ra[v], tid + v * 256);
+        for (int v = 0; v < A_V; ++v) store_split(As, BM, qa[v], tid + v * 256);
 #pragma unroll
-        for (int v = 0; v < W_V; ++v) store_split(Ws, BN, rw[v], tid + v * 256);
+        for (int v = 0; v < W_V; ++v) store_split(Ws, BN, qw[v], tid + v * 256);
         __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);
+        load_tiles(k0 + 2 * BK, qa, qw);  // past-the-end tiles load as zeros
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 a[TM][3], b[TN][3];
@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
                 }
         }
         __syncthreads();
+    };
+
+    load_tiles(0, ra[0], rw[0]);
+    load_tiles(BK, ra[1], rw[1]);
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {  // steps in pairs (an odd last step multiplies a zero tile)
+        step(k0, ra[0], rw[0]);
+        step(k0 + BK, ra[1], rw[1]);
     }
 
 #pragma unroll
@@ -410,14 +417,15 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU), used when M is too small to fill
 // the chip with 256-row tiles; the double-buffered kernel below takes the large edge-level products.
 template <int V>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe) {
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
+                                                                                                         int rt_base) {
     constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
     unsigned char* Ws = smem + 3 * PLB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
-    const int rt = blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
+    const int rt = rt_base + blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -519,7 +527,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // matrix pipe only idles at that one barrier.  One workgroup per CU (LDS), two waves per SIMD as before.
 constexpr int GEMM_DB_LDS = 2 * (3 * 256 * 64 + 3 * 128 * 64);
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_db_kernel(Planes A, Planes W, int M, int N,
-                                                                                                              int K, PlanesEpilogue pe) {
+                                                                                                              int K, PlanesEpilogue pe, int Mlim) {
     constexpr int TM = 2, TN = 2, PLA = 256 * 64, PLW = 128 * 64, BUF = 3 * PLA + 3 * PLW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,7 +537,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // instead of once per column tile.
     const int nct = (N + 127) / 128, id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int ct = slot % nct, rt2 = (slot / nct) * 8 + xcd;
-    if (rt2 * 256 >= M) return;
+    if (rt2 * 256 >= Mlim) return;  // this launch covers rows [0, Mlim)
     const int row0 = rt2 * 256, col0 = ct * 128;
     const int KT = (K + 31) / 32, RT = (M + 127) / 128;
     const int rowtile_bytes = (KT * 12288 + 2048) * 2;
@@ -638,15 +646,22 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
     MI_CHECK(A.KT == (K + 31) / 32 && W.KT == A.KT, MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
-    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * cdiv(N, 128) >= 512) {  // enough 256-row tiles to fill the chip twice over
-        static bool attr_set = false;
-        if (!attr_set) {
+    const int nct = cdiv(N, 128);
+    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= 512) {  // enough 256-row tiles to fill the chip twice over
+        static int num_cu = 0;
+        if (num_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            MI_HIP(hipGetDevice(&dev));
+            MI_HIP(hipGetDeviceProperties(&prop, dev));
+            num_cu = prop.multiProcessorCount;
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
-            attr_set = true;
         }
-        hipLaunchKernelGGL(gemm_planes_db_kernel, dim3(cdiv(N, 128) * ((cdiv(M, 256) + 7) / 8 * 8)), dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe);
+        // (measured: peeling the partial last round off to half-size tiles does not pay -- workgroups are dispatched
+        // dynamically, so the remainder overlaps the stragglers of the last full round)
+        hipLaunchKernelGGL(gemm_planes_db_kernel, dim3(nct * ((cdiv(M, 256) + 7) / 8 * 8)), dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else {
-        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(cdiv(N, 128), cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe);
+        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(nct, cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     }
     MI_KERNEL_CHECK();
     return MI_OK;
