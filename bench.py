@@ -262,6 +262,14 @@ def main():
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
             issued, peak, dtype = fp32_equiv, PEAK_F32_MFMA_TFLOPS, "f32"
         y_eval = bytes_per_crystal_eval(NATOM)
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+        # separate passes, corrected as the MI355X guide prescribes; scripts/rocprof_summary.py writes the file).  bench.py cannot
+        # read hardware counters itself, so the figure is the profiled one and carries its provenance; absent file -> null.
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_rocprofv3_summary_traffic.json")
+        if args.path == "split-gemm" and world == 1 and os.path.exists(tpath):
+            tr = json.load(open(tpath))
+            traffic = tr["bytes_per_dispatch"] * tr["dispatches_per_bench_launch"]
         out = {
             "metric": "crystal structures/sec (1000-step reverse diffusion)", "value": value, "unit": "structures/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
@@ -272,7 +280,7 @@ def main():
                        "batch_per_gpu": B, "atoms_per_cell": NATOM, "T": T, "evals_per_step": 2, "path": args.path,
                        "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": issued, "peak": peak,
-                         "unit": "TFLOP/s", "frac": issued / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,
                          "launches": int(n_launch.value), "avg_launch_ms": avg_ms,
                          "achieved_fp32_equivalent": fp32_equiv,
                          "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg,

@@ -101,6 +101,11 @@ int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* st
 #define MI_EDGE_ORDER_REFERENCE 0
 #define MI_EDGE_ORDER_CSR 1
 int mi_knn_graph_read(const mi_batch* b, int* edges, float* edge_vec, int order, void* stream);
+/* K18: geometric validity quantities of a batch of structures (the step right after the sampler): per crystal
+ * out[b][4] = { longest cell edge (A) -- the reference keeps structures with max(abc) < 25, pipeline/filters/opt_filter.py:53-55;
+ * shortest interatomic distance over all pairs and 27 periodic images (A); cell volume |det L| (A^3); atom count }.
+ * The thresholds of the external `structure_validity` check (distance / volume) are applied by the caller. */
+int mi_structure_check(const mi_batch* b, const float* frac, const float* lattices, float* out, void* stream);
 void mi_batch_destroy(mi_batch* b);
 int mi_batch_num_nodes(const mi_batch* b);
 int64_t mi_batch_num_edges(const mi_batch* b);

@@ -270,6 +270,57 @@ __global__ __launch_bounds__(256) void knn_emit_kernel(const float* __restrict__
     }
 }
 
+// K18 -- geometric validity pre-filter of sampled structures, straight off the sampler's final state: the cell test of
+// pipeline/filters/opt_filter.py:53-55 (max cell edge < 25 A is applied by the caller on `max_len`) and the quantities the
+// external structure_validity check thresholds (shortest interatomic distance incl. periodic images, cell volume).
+// out[b] = {longest cell edge, shortest distance, |det L|, number of atoms}.  One workgroup per crystal; pairs x 27 images.
+__global__ __launch_bounds__(256) void structure_check_kernel(const float* __restrict__ frac, const float* __restrict__ lattices,
+                                                              const int* __restrict__ node_off, float* __restrict__ out) {
+    __shared__ float red[256];
+    __shared__ float offs[81];
+    const int b = blockIdx.x, n0 = node_off[b], n = node_off[b + 1] - n0, tid = threadIdx.x;
+    const float* Lm = lattices + (size_t)b * 9;
+    if (tid < 27) {
+        const float ua = (float)(tid / 9 - 1), ub = (float)((tid / 3) % 3 - 1), uc = (float)(tid % 3 - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) offs[tid * 3 + c] = (Lm[c] * ua + Lm[3 + c] * ub) + Lm[6 + c] * uc;
+    }
+    __syncthreads();
+    float best = __builtin_inff();
+    const int64_t total = (int64_t)n * n * 27;
+    for (int64_t w = tid; w < total; w += 256) {
+        const int c = (int)(w % 27), j = (int)((w / 27) % n), i = (int)(w / (27 * (int64_t)n));
+        if (j < i || (j == i && c == 13)) continue;  // unordered pairs; an atom and its own home image is not a pair
+        float d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] = frac[(size_t)(n0 + j) * 3 + a] - frac[(size_t)(n0 + i) * 3 + a];
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = ((d[0] * Lm[a] + d[1] * Lm[3 + a]) + d[2] * Lm[6 + a]) + offs[c * 3 + a];
+            s += x * x;
+        }
+        best = fminf(best, s);
+    }
+    red[tid] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fminf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float len = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) len = fmaxf(len, sqrtf((Lm[r * 3] * Lm[r * 3] + Lm[r * 3 + 1] * Lm[r * 3 + 1]) + Lm[r * 3 + 2] * Lm[r * 3 + 2]));
+        float c23[3];
+        cross3(Lm + 3, Lm + 6, c23);
+        out[b * 4 + 0] = len;
+        out[b * 4 + 1] = sqrtf(red[0]);
+        out[b * 4 + 2] = fabsf((Lm[0] * c23[0] + Lm[1] * c23[1]) + Lm[2] * c23[2]);
+        out[b * 4 + 3] = (float)n;
+    }
+}
+
 static size_t select_lds(int nmax) { return (size_t)(3 * nmax + 81 + 2 * nmax + 4) * 4 + (size_t)4 * 27 * nmax * (4 + 2); }
 static size_t emit_lds(int nmax, int cap) { return (size_t)(nmax + 1 + (size_t)nmax * cap) * 4; }
 
@@ -339,6 +390,14 @@ int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* st
     MI_CHECK(b && frac && lattices, MI_EINVAL, "null argument");
     MI_TRY(knn_build(b, frac, lattices, (hipStream_t)stream));
     if (num_edges) *num_edges = b->E;
+    return MI_OK;
+}
+
+int mi_structure_check(const mi_batch* b, const float* frac, const float* lattices, float* out, void* stream) {
+    MI_CHECK(b && frac && lattices && out, MI_EINVAL, "null argument");
+    if (b->B == 0) return MI_OK;
+    hipLaunchKernelGGL(structure_check_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, frac, lattices, b->node_off, out);
+    MI_KERNEL_CHECK();
     return MI_OK;
 }
 

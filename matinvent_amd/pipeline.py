@@ -11,8 +11,10 @@ import torch
 
 from . import config as C
 from .dist import broadcast_object, rank_world
+from .filters import invalid_filter
 from .finetune import ft_step as _ft_step
 from .memory import ReplayBuffer
+from .structure import write_extxyz
 from .suite import get_device
 
 
@@ -66,10 +68,17 @@ class MatInvent(ReinL):
         self.prior.to(self.device)
 
     def sample_step(self):
-        """mat_invent.py:74-123 without the out-of-scope validity / MLIP / SUN filters."""
+        """mat_invent.py:74-123: sample, geometric validity pre-filter (device-side quantities), save the valid set as
+        extxyz, optional filter callable, max_num.  MLIP relaxation / SUN metrics are out of scope."""
         rank, world = rank_world()
-        kw = {k: v for k, v in self.sample_cfg.items() if k not in ("filter", "mlip_opt")}
+        kw = {k: v for k, v in self.sample_cfg.items() if k not in ("filter", "mlip_opt", "geometric_filter")}
         data, strucs = self.sampler.generate(model=self.agent, rank=rank, world_size=world, **kw)
+        if self.sample_cfg.get("geometric_filter", True):  # the reference always filters (mat_invent.py:78-79)
+            n_all = len(data)
+            data, strucs = invalid_filter(data, strucs)
+            logging.info(f"geometric pre-filter kept {len(data)} of {n_all} samples")
+        if rank == 0 and getattr(self, "sample_dir", None):
+            write_extxyz(strucs, os.path.join(self.sample_dir, f"step_{self.step:0>4d}_valid.extxyz"))
         flt = self.sample_cfg.get("filter")
         metrics = {}
         if callable(flt):
@@ -87,6 +96,9 @@ class MatInvent(ReinL):
         rank, world = rank_world()
         logging.info(f"*****   LOOP {self.step} START   *****")
         data, strucs, xyz, metrics = self.sample_step()
+        if len(data) == 0:  # (the reference would fail inside reward scoring; identical on every rank, so no rank diverges)
+            logging.warning("no sample passed the validity pre-filter; skipping scoring and fine-tuning for this loop")
+            return
         if rank == 0:  # scoring / ranking / replay are rank-0 CPU bookkeeping; the chosen set is broadcast
             data, strucs, rewards, props = self.reward_step(data, strucs, xyz, f"step_{self.step:0>4d}")
             log = {f"{k} mean": v.mean() for k, v in props.items()}
@@ -127,7 +139,7 @@ class Baseline(ReinL):
         self.agent = self.model_suite.load_model().to(self.device)
 
     def rl_step(self):
-        kw = {k: v for k, v in self.sample_cfg.items() if k not in ("filter", "mlip_opt")}
+        kw = {k: v for k, v in self.sample_cfg.items() if k not in ("filter", "mlip_opt", "geometric_filter")}
         data, strucs = self.sampler.generate(model=self.agent, **kw)
         data, strucs, rewards, props = self.reward_step(data, strucs, None, f"step_{self.step:0>4d}")
         if self.logger is not None:

@@ -60,7 +60,11 @@ class DiffCSPSampler:
             lo, hi = shard_range(len(na), rank, world)
             node_off = int(np.sum(na[:lo]))
             self.seed += 1
-            outputs, _ = model.sample(_AtomCounts(na[lo:hi]), step_lr=step_lr, seed=self.seed, node_offset=node_off, graph_offset=lo)
+            counts = _AtomCounts(na[lo:hi])
+            outputs, _ = model.sample(counts, step_lr=step_lr, seed=self.seed, node_offset=node_off, graph_offset=lo)
+        # geometric validity quantities of the final state, computed where it lives (K18); the filter step thresholds them
+        from .structure import check_structures
+        geom = check_structures(model.crystal_batch(counts, node_off, lo), outputs["frac_coords"], outputs["lattices"]).cpu()
         frac_coords = outputs["frac_coords"].detach().cpu()
         num_atoms = outputs["num_atoms"].detach().cpu()
         atom_types = outputs["atom_types"].detach().cpu()
@@ -72,6 +76,7 @@ class DiffCSPSampler:
         for i in range(len(num_atoms)):
             d = CrystalData(frac_coords=frac_coords[offset[i]:offset[i + 1]], atom_types=atom_types[offset[i]:offset[i + 1]],
                             lengths=lengths[i].view(1, -1), angles=angles[i].view(1, -1), num_atoms=int(num_atoms[i]))
+            d.geometry = {"max_cell_edge": float(geom[i, 0]), "min_distance": float(geom[i, 1]), "volume": float(geom[i, 2])}
             data_list.append(d)
             struc_list.append(data2struc(d))
         if world > 1:

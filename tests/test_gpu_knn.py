@@ -187,3 +187,19 @@ def test_knn_sample_chain_vs_oracle():
     assert wrap_dist(final["frac_coords"].cpu().numpy(), of["frac_coords"].numpy()).max() < 3e-4
     np.testing.assert_allclose(final["lattices"].cpu().numpy(), of["lattices"].numpy(), rtol=3e-4, atol=3e-4)
     np.testing.assert_allclose(final["atom_types"].cpu().numpy(), of["atom_types"].numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_structure_check_vs_oracle():
+    """K18: longest cell edge / shortest interatomic distance over 27 images / volume per crystal, against the oracle,
+    incl. single-atom crystals (only self images) and the mask thresholds of the validity pre-filter."""
+    from matinvent_amd.structure import check_structures, geometric_mask
+    num_atoms = [1, 2, 20, 7, 33]
+    frac, lat = _random_crystals(8, num_atoms, lo=2.0, hi=30.0)
+    frac[1] = frac[2] + torch.tensor([0.01, 0.0, 0.0])  # crystal 1: an overlapping pair
+    net = _net(64, 1, 4)
+    b = net.make_batch(num_atoms)
+    out = check_structures(b, frac.cuda(), lat.cuda()).cpu()
+    ref = O.structure_check(frac, lat, torch.tensor(num_atoms))
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-5, atol=1e-6)
+    assert geometric_mask(out).tolist() == geometric_mask(ref).tolist()
+    assert not bool(geometric_mask(out)[1])

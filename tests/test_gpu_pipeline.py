@@ -22,7 +22,9 @@ def test_main_runs_rl_loops_and_saves_reference_style_checkpoint(tmp_path):
         tiny = ["+model.hparams.decoder.hidden_dim=64", "+model.hparams.decoder.num_layers=2", "+model.hparams.decoder.num_freqs=8",
                 "+model.hparams.beta_scheduler.timesteps=20", "+model.hparams.sigma_scheduler.timesteps=20", "model.head_scale=0.1"]
         rl = dropin_main.main(["expname=e2e", "eval_size=4", "rl_epoch=2", "model.finetune_cfg.timesteps=6",
-                               "pipeline.finetune_cfg.accum_steps=3", "pipeline.finetune_cfg.epochs=1", "device=cuda:0"] + tiny)
+                               "pipeline.finetune_cfg.accum_steps=3", "pipeline.finetune_cfg.epochs=1", "device=cuda:0",
+                               # a random-init network samples overlapping atoms: keep them so that the loop has data to train on
+                               "+sample_cfg.geometric_filter=false"] + tiny)
         run = tmp_path / "exp_res" / "e2e"
         assert (run / "hparams.yaml").exists() and (run / "metrics.csv").exists()
         rows = (run / "metrics.csv").read_text().strip().splitlines()
