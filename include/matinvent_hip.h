@@ -261,8 +261,12 @@ int mi_net_set_edge_mode(mi_net* net, int mode);
  * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe. */
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M,
                   int N, int K, void* stream);
+/* bench.py's roofline hook: HIP events bracket the dominant stage (the per-edge MLP of one layer) on the stream it is
+ * launched on.  mi_profile_read returns the number of bracketed launches, the sum of their durations and (optional) the
+ * UNION of their execution intervals -- with several chains running concurrently on different streams the launches overlap,
+ * and total flops / union time is the rate the stage sustains while at least one instance is executing. */
 int mi_profile_enable(mi_net* net, int on);
-int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms);
+int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mi_net_set_edge_mode": (_I, [_P, _I]),
     "mi_debug_gemm": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "mi_profile_enable": (_I, [_P, _I]),
-    "mi_profile_read": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double)]),
+    "mi_profile_read": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

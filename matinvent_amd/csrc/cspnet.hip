@@ -317,21 +317,29 @@ template int dev_alloc<int>(mi_batch*, int**, size_t);
 template int dev_alloc<unsigned short>(mi_batch*, unsigned short**, size_t);
 
 // bench.py's roofline hook: bracket the dominant stage (the per-edge MLP of one layer) with events
-static int prof_begin(mi_net* net, hipStream_t s) {
+struct ProfSlot {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+static int prof_begin(mi_net* net, hipStream_t s, ProfSlot* slot) {
+    *slot = ProfSlot();
     if (!net->prof) return MI_OK;
-    if (net->ev_used + 2 > net->ev.size())
-        for (int k = 0; k < 2; ++k) {
-            hipEvent_t ev;
-            MI_HIP(hipEventCreate(&ev));
-            net->ev.push_back(ev);
-        }
-    MI_HIP(hipEventRecord(net->ev[net->ev_used], s));
+    {
+        std::lock_guard<std::mutex> g(net->prof_mu);
+        if (net->ev_used + 2 > net->ev.size())
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t ev;
+                MI_HIP(hipEventCreate(&ev));
+                net->ev.push_back(ev);
+            }
+        slot->e0 = net->ev[net->ev_used];
+        slot->e1 = net->ev[net->ev_used + 1];
+        net->ev_used += 2;
+    }
+    MI_HIP(hipEventRecord(slot->e0, s));
     return MI_OK;
 }
-static int prof_end(mi_net* net, hipStream_t s) {
-    if (!net->prof) return MI_OK;
-    MI_HIP(hipEventRecord(net->ev[net->ev_used + 1], s));
-    net->ev_used += 2;
+static int prof_end(mi_net* net, hipStream_t s, const ProfSlot& slot) {
+    if (slot.e1) MI_HIP(hipEventRecord(slot.e1, s));
     return MI_OK;
 }
 
@@ -365,7 +373,8 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     a.KP = net->KP;
     if (b->E == 0) return MI_OK;
     dim3 grid((unsigned)cdiv(b->E, 32)), block(64);
-    MI_TRY(prof_begin(net, s));
+    ProfSlot ps;
+    MI_TRY(prof_begin(net, s, &ps));
     const bool save = Z1 != nullptr;
     MI_CHECK((Z1 == nullptr) == (Z2 == nullptr), MI_EINVAL, "Z1 and Z2 must be given together");
 #define MI_EDGE_LAUNCH(HH)                                                                   \
@@ -382,7 +391,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     }
 #undef MI_EDGE_LAUNCH
     MI_KERNEL_CHECK();
-    MI_TRY(prof_end(net, s));
+    MI_TRY(prof_end(net, s, ps));
 #ifdef MI_TIMING
     if (++g_count == 40 && ntile * 128 <= ((size_t)1 << 24)) {
         std::vector<unsigned long long> h(ntile * 16);
@@ -478,7 +487,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             MI_KERNEL_CHECK();
         } else if (b->E > 0) {      // two tiled GEMMs over the edge list with gather / SiLU epilogues
             const int E = (int)b->E, F6 = 6 * net->F;
-            MI_TRY(prof_begin(net, s));
+            ProfSlot ps;
+            MI_TRY(prof_begin(net, s, &ps));
             GemmEpilogue g1e;       // Z1 = FF Wff^T + P_i[src] + P_j[dst] + G[graph];  M1 = SiLU(Z1)
             g1e.row_bias = b->PQ;
             g1e.row_group = b->src;
@@ -517,13 +527,13 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_rowptr = b->rowptr;
                 pe2.seg_nodes = N;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
-                MI_TRY(prof_end(net, s));
+                MI_TRY(prof_end(net, s, ps));
                 hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
                 MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
                 MI_TRY(gemm_nt(b->M1, H, net->p(p + "edge_mlp.2.weight"), H, b->M2, H, E, H, H, g2e, s));
-                MI_TRY(prof_end(net, s));
+                MI_TRY(prof_end(net, s, ps));
                 hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->M2, b->rowptr, cat, N, H);
                 MI_KERNEL_CHECK();
             }
@@ -879,21 +889,48 @@ int mi_net_set_edge_mode(mi_net* net, int mode) {
 
 int mi_profile_enable(mi_net* net, int on) {
     MI_CHECK(net, MI_EINVAL, "null handle");
+    std::lock_guard<std::mutex> g(net->prof_mu);
     net->prof = on != 0;
     net->ev_used = 0;
+    if (on) {
+        if (!net->ev_origin) MI_HIP(hipEventCreate(&net->ev_origin));
+        MI_HIP(hipEventRecord(net->ev_origin, nullptr));
+    }
     return MI_OK;
 }
 
-int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms) {
+int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms) {
     MI_CHECK(net && launches && total_ms, MI_EINVAL, "null argument");
+    std::lock_guard<std::mutex> g(net->prof_mu);
     double tot = 0;
     int64_t n = 0;
+    std::vector<std::pair<float, float>> iv;
     for (size_t k = 0; k + 1 < net->ev_used; k += 2) {
         MI_HIP(hipEventSynchronize(net->ev[k + 1]));
         float ms = 0;
         MI_HIP(hipEventElapsedTime(&ms, net->ev[k], net->ev[k + 1]));
         tot += ms;
         ++n;
+        if (union_ms && net->ev_origin) {
+            float t0 = 0;
+            MI_HIP(hipEventElapsedTime(&t0, net->ev_origin, net->ev[k]));
+            iv.emplace_back(t0, t0 + ms);
+        }
+    }
+    if (union_ms) {  // time during which at least one bracketed stage was executing (launches on concurrent streams overlap)
+        std::sort(iv.begin(), iv.end());
+        double u = 0, lo = 0, hi = -1;
+        for (auto& x : iv) {
+            if (hi < 0 || x.first > hi) {
+                if (hi >= 0) u += hi - lo;
+                lo = x.first;
+                hi = x.second;
+            } else if (x.second > hi) {
+                hi = x.second;
+            }
+        }
+        if (hi >= 0) u += hi - lo;
+        *union_ms = u;
     }
     *launches = n;
     *total_ms = tot;

@@ -1,5 +1,7 @@
 // Host-side objects behind the opaque C handles.
 #pragma once
+#include <mutex>
+
 #include "common.h"
 
 struct ParamInfo {
@@ -31,10 +33,12 @@ struct mi_net {
     float* Wn1T = nullptr;   // [L][2H][H]
     float* WhhT = nullptr;   // [L][H][2H]
     float* WaT = nullptr;    // [H][H]   (atom_latent_emb.weight[:, :H])^T
-    // profiling of the dominant kernel
+    // profiling of the dominant kernel (event pairs; launches may come from several host threads / streams)
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs
     size_t ev_used = 0;
+    hipEvent_t ev_origin = nullptr;
+    std::mutex prof_mu;
 
     int64_t off(const std::string& name) const;
     const float* p(const std::string& name) const { return theta + off(name); }

@@ -42,6 +42,13 @@ class SinusoidalTimeEmbeddings(nn.Module):
         return out
 
 
+class _Counts:
+    """Atom counts of a contiguous group of crystals (what `sample` needs of a batch)."""
+
+    def __init__(self, num_atoms):
+        self.num_atoms = torch.as_tensor(num_atoms, dtype=torch.long)
+
+
 class DiffCSPModule(nn.Module):
     def __init__(self, decoder, beta_scheduler, sigma_scheduler, latent_dim=0, time_dim=256, cost_lattice=1.0,
                  cost_coord=1.0, cost_type=20.0, device=None, **kwargs):
@@ -176,8 +183,80 @@ class DiffCSPModule(nn.Module):
 
     @torch.no_grad()
     def sample(self, batch, diff_ratio=1.0, step_lr=1e-5, seed=0, noise=None, init=None, record=False, t_start=None,
-               t_stop=0, node_offset=0, graph_offset=0):
+               t_stop=0, node_offset=0, graph_offset=0, streams=None):
         """DiffCSPModule.sample (diffusion.py:273-399).
+
+        `streams` > 1 splits the crystals into that many contiguous groups and runs their chains CONCURRENTLY on separate
+        HIP streams (crystals never interact, and the counter-based noise is indexed by global atom / crystal id, so the
+        samples are the same as those of the unsplit batch): the node-level kernels and the partial last round of one
+        group's edge GEMMs overlap the other group's edge GEMMs.  None = automatic (2 for large batches).
+        """
+        if isinstance(batch, CrystalBatch):
+            return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
+        na = [int(v) for v in batch.num_atoms.tolist()]
+        if streams is None:
+            streams = 2 if sum(v * v for v in na) >= 65536 else 1
+        streams = max(1, min(int(streams), len(na)))
+        if streams == 1:
+            return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
+        import threading
+        key = ("split", streams, tuple(na))
+        parts = getattr(batch, "_mi_split", {}).get(key)
+        if parts is None:  # contiguous crystal groups, cached on the batch object like its CrystalBatch
+            cuts = [len(na) * k // streams for k in range(streams + 1)]
+            parts = [_Counts(na[cuts[k]:cuts[k + 1]]) for k in range(streams)]
+            try:
+                batch._mi_split = {key: parts}
+            except AttributeError:
+                pass
+        g0 = [0]
+        n0 = [0]
+        for p_ in parts:
+            g0.append(g0[-1] + len(p_.num_atoms))
+            n0.append(n0[-1] + int(p_.num_atoms.sum()))
+        self.decoder.sync()
+        self._coefficients(step_lr)
+        cur = torch.cuda.current_stream()
+        ready = cur.record_event()
+        pool = self.__dict__.setdefault("_sample_streams", [])
+        while len(pool) < streams:
+            pool.append(torch.cuda.Stream(device=self.device))
+        out, err = [None] * streams, [None] * streams
+
+        def run(k):
+            try:
+                with torch.cuda.stream(pool[k]):
+                    pool[k].wait_event(ready)
+                    ini = None if init is None else (init[0][n0[k]:n0[k + 1]], init[1][g0[k]:g0[k + 1]], init[2][n0[k]:n0[k + 1]])
+                    nz = None if noise is None else {"corr_x": noise["corr_x"][:, n0[k]:n0[k + 1]], "pred_x": noise["pred_x"][:, n0[k]:n0[k + 1]],
+                                                     "pred_t": noise["pred_t"][:, n0[k]:n0[k + 1]], "pred_l": noise["pred_l"][:, g0[k]:g0[k + 1]]}
+                    out[k] = self._sample_one(parts[k], step_lr, seed, nz, ini, record, t_start, t_stop, node_offset + n0[k], graph_offset + g0[k])
+                    cur.wait_event(pool[k].record_event())
+            except BaseException as e:  # re-raised on the caller's thread
+                err[k] = e
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(streams)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for e in err:
+            if e is not None:
+                raise e
+
+        def merge(ds):
+            m = {}
+            for name in ds[0]:
+                if name == "batch_idx":
+                    m[name] = torch.cat([d[name] + g0[k] for k, d in enumerate(ds)])
+                else:
+                    m[name] = torch.cat([d[name] for d in ds])
+            return m
+        traj = {t: merge([o[1][t] for o in out]) for t in out[0][1]}
+        return traj[t_stop], traj
+
+    def _sample_one(self, batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset):
+        """One chain over one CrystalBatch on the current stream.
 
         Returns (traj[t_stop], traj) like the reference.  `traj` holds every step only when
         record=True (the reference keeps all T+1 states alive on the device); otherwise it
