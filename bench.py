@@ -148,7 +148,7 @@ def main_ft(args):
     cfg = dict(lr=1e-4, accum_steps=50, epochs=1, sigma=0.025)
 
     def run(n):
-        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None)
+        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None, groups=args.ft_groups)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier() if share else dist.barrier(device_ids=[local_rank])
@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ft-groups", type=int, default=None, help="--mode ft: crystal groups fine-tuned concurrently (default: automatic)")
     ap.add_argument("--streams", type=int, default=2, help="crystal groups of the batch sampled concurrently on separate HIP "
                     "streams (same samples: the noise is indexed by global ids)")
     ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused"], default="split-gemm",

@@ -265,6 +265,9 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
  * launched on.  mi_profile_read returns the number of bracketed launches, the sum of their durations and (optional) the
  * UNION of their execution intervals -- with several chains running concurrently on different streams the launches overlap,
  * and total flops / union time is the rate the stage sustains while at least one instance is executing. */
+/* One wave busy-waiting ~`cycles` shader clocks on `stream`: lets the host side test whether two HIP streams really execute
+ * concurrently (streams may share a hardware queue, which serialises them). */
+int mi_debug_spin(long long cycles, void* stream);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 

@@ -20,6 +20,14 @@ __global__ void time_embedding_kernel(const int* __restrict__ times, const float
     out[idx] = k < half ? sinf(arg) : cosf(arg);
 }
 
+// busy-wait for ~`cycles` shader clocks on one wave (stream-concurrency probe, mi_debug_spin)
+__global__ void spin_kernel(long long cycles, int* sink) {
+    const long long t0 = __builtin_readcyclecounter();
+    int k = 0;
+    while (__builtin_readcyclecounter() - t0 < cycles) ++k;
+    if (sink && k == -1) *sink = k;
+}
+
 __global__ void fill_int_kernel(int* p, int v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -279,6 +287,12 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         hipLaunchKernelGGL(predictor_kernel, dim3(B), dim3(256), 0, s, a);
         MI_KERNEL_CHECK();
     }
+    return MI_OK;
+}
+
+int mi_debug_spin(long long cycles, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cycles, (int*)nullptr);
+    MI_KERNEL_CHECK();
     return MI_OK;
 }
 

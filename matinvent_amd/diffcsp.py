@@ -218,9 +218,8 @@ class DiffCSPModule(nn.Module):
         self._coefficients(step_lr)
         cur = torch.cuda.current_stream()
         ready = cur.record_event()
-        pool = self.__dict__.setdefault("_sample_streams", [])
-        while len(pool) < streams:
-            pool.append(torch.cuda.Stream(device=self.device))
+        from .streams import concurrent_streams
+        pool = concurrent_streams(streams, self.device)
         out, err = [None] * streams, [None] * streams
 
         def run(k):

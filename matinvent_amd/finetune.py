@@ -19,8 +19,9 @@ from .dist import allreduce_flat_, rank_world, shard_range
 from .optim import FusedAdam
 
 
-def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats):
-    """One timestep through mi_ft_micro_step; accumulates into `grad` (+=) and `stats` (device, 3 floats)."""
+def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats, call_id=None):
+    """One timestep through mi_ft_micro_step on the current stream; accumulates into `grad` (+=) and `stats` (device, 3
+    floats).  `call_id` = the noise-stream call counter (one value per timestep, shared by every crystal group)."""
     import ctypes as C
     from . import _lib
     from .cspnet import _ptr, _stream
@@ -40,21 +41,28 @@ def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, acc
         cache.update(lengths=f(batch.lengths), angles=f(batch.angles), frac=f(batch.frac_coords),
                      types=batch.atom_types.to(dev, torch.int32).contiguous(), reward=f(batch.reward))
     nz = (None, None, None) if noise is None else tuple(x.to(dev, torch.float32).contiguous() for x in noise)
-    agent._noise_calls = getattr(agent, "_noise_calls", 0) + 1
+    if call_id is None:
+        agent._noise_calls = getattr(agent, "_noise_calls", 0) + 1
+        call_id = agent._noise_calls
     _lib.check(lib.mi_ft_micro_step(agent.decoder._h, ab._h, prior.decoder._h, pb._h, _ptr(cache["lengths"]), _ptr(cache["angles"]),
                                     _ptr(cache["frac"]), _ptr(cache["types"]), _ptr(cache["reward"]), _ptr(agent.time_embedding.freqs), t,
-                                    c0, c1, sig, sn, getattr(agent, "noise_seed", 0), agent._noise_calls & 0xFFFFFFFF, _ptr(nz[0]),
+                                    c0, c1, sig, sn, getattr(agent, "noise_seed", 0), call_id & 0xFFFFFFFF, _ptr(nz[0]),
                                     _ptr(nz[1]), _ptr(nz[2]), agent.cost_lattice, agent.cost_coord, agent.cost_type, sigma, n_global,
                                     accum_steps, _ptr(grad), _ptr(stats), None, None, _stream()), "mi_ft_micro_step")
 
 
-def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, log=logging.info, fused=True):
+def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, log=logging.info, fused=True, groups=None):
     """cfg needs: lr, accum_steps, epochs, timesteps, sigma (attribute or key access).
     `noise_fn(epoch, t)` -> (rand_l, rand_x, rand_t) injects noise (parity tests); default Philox.
     fused=True (default) enqueues each timestep through mi_ft_micro_step (noise, both forwards, the fused
     loss / penalty / gradient-seed kernel and the backward in one C call, no autograd graph); fused=False
     drives the same arithmetic through the reference's module surface (add_noise / calc_sample_loss /
-    calc_kl_reg + autograd), which is what the parity tests compare it with."""
+    calc_kl_reg + autograd), which is what the parity tests compare it with.
+    `groups` (fused path): the local fine-tune set is cut into that many contiguous crystal groups whose micro-steps are
+    enqueued on separate HIP streams and run concurrently, each accumulating into its own gradient buffer (summed before
+    the optimizer step) -- the same arithmetic as data-parallel ranks, inside one GPU: one group's node-level and
+    reduction kernels overlap the other's large GEMMs.  None = automatic (2-3 for large sets; measured at 256 x 20 atoms:
+    7.5k -> 9.0k / 9.3k / 8.9k crystal-timesteps/s with 2 / 3 / 4 groups)."""
     get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
     lr, accum_steps, epochs, timesteps, sigma = get("lr"), int(get("accum_steps")), int(get("epochs")), int(get("timesteps")), get("sigma")
     device = device or agent.device
@@ -67,6 +75,13 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     node_lo = sum(d.num_atoms for d in dataset.data_list[:lo])
     agent.shard_offsets = prior.shard_offsets = (node_lo, lo)
     theta = agent.decoder.theta
+    if groups is None:
+        e_total = sum(d.num_atoms ** 2 for d in dataset.data_list[lo:hi])
+        groups = (3 if e_total >= 90000 else 2 if e_total >= 40000 else 1) if fused else 1
+    groups = max(1, min(int(groups), hi - lo)) if fused else 1
+    if groups > 1:
+        return _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, lr, accum_steps, epochs, timesteps, sigma, device,
+                                noise_fn, log, rank)
     optimizer = FusedAdam([theta], lr=lr)  # fresh every call (:136)
     stats = []
     for epoch in range(epochs):
@@ -111,4 +126,75 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
         stats.append(d)
         if rank == 0:
             log(f"Epoch {epoch}: " + ", ".join(f"{k}: {v:.4f}" for k, v in d.items()))
+    return stats
+
+
+def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, lr, accum_steps, epochs, timesteps, sigma, device, noise_fn,
+                     log, rank):
+    """ft_step's fused path with the local set cut into `groups` crystal groups on concurrent streams (see ft_step)."""
+    theta = agent.decoder.theta
+    cuts = [lo + (hi - lo) * k // groups for k in range(groups + 1)]
+    nodes = [node_lo]
+    for k in range(groups):
+        nodes.append(nodes[-1] + sum(d.num_atoms for d in dataset.data_list[cuts[k]:cuts[k + 1]]))
+    batches = [CrystalBatchData([dataset[i] for i in range(cuts[k], cuts[k + 1])]).to(device) for k in range(groups)]
+    offs = [(nodes[k], cuts[k]) for k in range(groups)]
+    main = torch.cuda.current_stream()
+    from .streams import concurrent_streams
+    streams = concurrent_streams(groups, device)
+    if theta.grad is None:
+        theta.grad = torch.zeros_like(theta)
+    grads = [theta.grad] + [torch.zeros_like(theta) for _ in range(groups - 1)]
+    optimizer = FusedAdam([theta], lr=lr)  # fresh every call (:136)
+    stats = []
+
+    def optimizer_step():
+        for k in range(groups):  # the optimizer consumes every group's gradient
+            main.wait_event(streams[k].record_event())
+        for g in grads[1:]:
+            theta.grad.add_(g)
+            g.zero_()
+        allreduce_flat_(theta.grad)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=False)
+        agent.decoder.sync()  # repack the updated weights once, on the main stream, before any group reads them
+        ready = main.record_event()
+        for st in streams:
+            st.wait_event(ready)
+
+    for epoch in range(epochs):
+        agent.train()
+        theta.grad.zero_()
+        accs = [torch.zeros(3, device=device) for _ in range(groups)]
+        agent.decoder.sync()
+        prior.decoder.sync()
+        ready = main.record_event()
+        for st in streams:
+            st.wait_event(ready)
+        t = -1
+        for t in range(timesteps):
+            noise = None if noise_fn is None else noise_fn(epoch, t)
+            agent._noise_calls = getattr(agent, "_noise_calls", 0) + 1
+            for k in range(groups):
+                nz = None
+                if noise is not None:  # (rand_l [B,3,3], rand_x [N,3], rand_t [N,100]) of the local set -> this group's rows
+                    g0, g1, n0, n1 = cuts[k] - lo, cuts[k + 1] - lo, nodes[k] - node_lo, nodes[k + 1] - node_lo
+                    nz = (noise[0][g0:g1], noise[1][n0:n1], noise[2][n0:n1])
+                agent.shard_offsets = prior.shard_offsets = offs[k]
+                with torch.cuda.stream(streams[k]):
+                    _fused_micro_step(agent, prior, batches[k], t, nz, sigma, n_global, accum_steps, grads[k], accs[k], call_id=agent._noise_calls)
+            if (t + 1) % accum_steps == 0:
+                optimizer_step()
+        if (t + 1) % accum_steps != 0:
+            optimizer_step()
+        for k in range(groups):
+            main.wait_event(streams[k].record_event())
+        acc = torch.stack(accs).sum(0)
+        allreduce_flat_(acc)
+        a = acc.tolist()  # the only host sync of the epoch
+        d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
+        stats.append(d)
+        if rank == 0:
+            log(f"Epoch {epoch}: " + ", ".join(f"{k}: {v:.4f}" for k, v in d.items()))
+    agent.shard_offsets = prior.shard_offsets = (node_lo, lo)
     return stats

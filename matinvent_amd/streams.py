@@ -1,0 +1,52 @@
+"""HIP streams that really run concurrently.
+
+Two HIP streams may be mapped to the same hardware queue, in which case their kernels serialise (measured: the fine-tune
+step on two fresh streams ran 8 % SLOWER than on one, on three 20 % faster).  The mapping policy is the runtime's business,
+so it is probed instead of assumed: a one-wave busy-wait kernel is launched on two candidate streams and the pair is
+accepted when both finish in about the time of one."""
+import ctypes as C
+import time
+
+import torch
+
+_CACHE = {}
+
+
+def _pair_is_concurrent(lib, a, b, cycles=400_000):
+    def run(streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in streams:
+            lib.mi_debug_spin(cycles, C.c_void_p(s.cuda_stream))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run([a])
+    one = min(run([a]) for _ in range(2))
+    two = min(run([a, b]) for _ in range(2))
+    return two < 1.5 * one
+
+
+def concurrent_streams(n: int, device=None):
+    """`n` streams of `device` that were measured to overlap pairwise (cached per device); falls back to whatever the pool
+    offers when fewer independent hardware queues exist."""
+    from . import _lib
+    dev = torch.device(device if device is not None else "cuda", torch.cuda.current_device()) if not isinstance(device, torch.device) else device
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = dev.index
+    chosen = _CACHE.setdefault(key, [])
+    if len(chosen) >= n:
+        return chosen[:n]
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        pool = [torch.cuda.Stream(device=dev) for _ in range(12)]
+        for cand in pool:
+            if len(chosen) >= n:
+                break
+            if all(_pair_is_concurrent(lib, c, cand) for c in chosen):
+                chosen.append(cand)
+        k = 0
+        while len(chosen) < n:  # not enough independent queues: reuse
+            chosen.append(pool[k % len(pool)])
+            k += 1
+    return chosen[:n]

@@ -157,11 +157,13 @@ def test_fused_adam_matches_torch_adam():
     assert float((p1 - p2).detach().abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused-micro-step", "autograd-surface"])
-def test_ft_step_end_to_end_vs_oracle(fused):
+@pytest.mark.parametrize("fused,groups", [(True, 1), (True, 2), (True, 3), (False, 1)],
+                         ids=["fused-micro-step", "fused-2-concurrent-groups", "fused-3-concurrent-groups", "autograd-surface"])
+def test_ft_step_end_to_end_vs_oracle(fused, groups):
     """matinvent_amd.finetune.ft_step (device-side loss accumulation, fused Adam, flat gradient) vs
     the oracle's literal restatement of pipeline/mat_invent.py:125-189: 2 epochs x 6 timesteps,
-    accum 3 -> 4 optimizer steps, injected noise."""
+    accum 3 -> 4 optimizer steps, injected noise.  `groups` > 1: the set is cut into crystal groups whose
+    micro-steps run concurrently on separate streams with separate gradient buffers (ragged: 4 crystals in 3 groups)."""
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import ft_step
     hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
@@ -180,7 +182,7 @@ def test_ft_step_end_to_end_vs_oracle(fused):
     noises = {(e, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
               for e in range(2) for t in range(6)}
     cfg = dict(lr=1e-4, accum_steps=3, epochs=2, timesteps=6, sigma=0.025)
-    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=fused)
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=fused, groups=groups)
     # oracle side
     sch = O.Schedules.make(1000, sigmas_norm=sn)
     sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
