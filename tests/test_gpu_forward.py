@@ -160,3 +160,29 @@ def test_forward_full_size_properties(path):
     o3 = net(t_emb, at, (fr + shift) % 1.0, lat, None, batch=bt)
     for a, b, w in zip(o1, o3, ("pred_l", "pred_x", "pred_t")):
         _close(b, a, 2e-4, w + " translation")
+
+
+def test_full_size_paths_agree():
+    """BASELINE config-2 shape: the default path (pre-split bf16 planes, 256x128 double-buffered GEMM with the row-major and the
+    fused segmented-sum epilogues) against the independent f32-input MFMA path on the same inputs -- the full-size check of the
+    kernels the small oracle cases cannot reach (they only engage above ~33k edges)."""
+    from matinvent_amd.cspnet import set_gemm_mode
+    torch.manual_seed(0)
+    B, n = 256, 20
+    g = torch.Generator().manual_seed(11)
+    N = B * n
+    t_emb = O.time_embedding(torch.full((B,), 321), 256).cuda()
+    at = torch.randn(N, 100, generator=g).cuda()
+    fr = torch.rand(N, 3, generator=g).cuda()
+    lat = (4 * torch.eye(3) + torch.randn(B, 3, 3, generator=g)).cuda()
+    outs = {}
+    net = _net(512, 6, 128, path=("split", "gemm"))
+    bt = net.make_batch([n] * B)
+    for mode in ("split", "f32"):
+        set_gemm_mode(mode)
+        try:
+            outs[mode] = [x.clone() for x in net(t_emb, at, fr, lat, None, batch=bt)]
+        finally:
+            set_gemm_mode("split")
+    for a, b, w in zip(outs["split"], outs["f32"], ("pred_l", "pred_x", "pred_t")):
+        _close(a, b, 2e-5, w + " split vs f32")

@@ -26,3 +26,23 @@ def test_gemm_kernels_vs_fp64(M, N, K):
         assert errs[kind] < 3e-6, (kind, errs)
     # fp32-class: the split paths are not worse than the f32 MFMA by more than round-off noise
     assert errs[1] <= 1.5 * errs[0] + 1e-7 and errs[2] <= 1.5 * errs[0] + 1e-7, errs
+
+
+@pytest.mark.parametrize("M,N,K", [(33333, 512, 768), (66000, 512, 96), (33000, 512, 48), (140000, 64, 64)])
+def test_double_buffered_plane_gemm_vs_fp64(M, N, K):
+    """The 256x128 double-buffered kernel (kind 3) on shapes that engage it: ragged M (not a multiple of 256 or 128, odd number
+    of 128-row tiles), odd and padded k-tile counts, a single narrow column tile."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    ref = A.double() @ W.double().t()
+    scale = ref.abs().max().item()
+    errs = {}
+    for kind in (2, 3):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.mi_debug_gemm(kind, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+        torch.cuda.synchronize()
+        errs[kind] = (out.double() - ref).abs().max().item() / scale
+        assert errs[kind] < 3e-6, (kind, errs)
