@@ -39,11 +39,14 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the spa
 PEAK_HBM_TBPS = 8.0
 
 
-def edge_flops_per_edge():
+def edge_flops_per_edge(pairs=True):
     """fp32 flops per edge per layer in the edge-message stage.
-    executed:    Fourier block (K = 6F) + second linear (K = H) on MFMA -- what the kernel issues;
+    executed:    Fourier block (K = 6F) + second linear (K = H) on MFMA -- what the kernels issue.  On the default path the
+                 Fourier block runs once per unordered atom pair (the reversed edge sees -sin / +cos of the same arguments):
+                 n(n-1)/2 operand rows per crystal instead of n*n, self edges are a constant;
     algorithmic: SURVEY.md section 8(d): 2*(2H+9+6F)*H + 2*H*H (the reference's concat-GEMM form)."""
-    executed = 2 * (6 * F) * H + 2 * H * H
+    rows = (NATOM - 1) / (2.0 * NATOM) if pairs else 1.0     # Fourier-GEMM rows per directed edge
+    executed = rows * 2 * (6 * F) * H + 2 * H * H
     algorithmic = 2 * (2 * H + 9 + 6 * F) * H + 2 * H * H
     return executed, algorithmic
 
@@ -259,7 +262,7 @@ def main():
     if rank == 0:
         value = world * B * K / (T * elapsed)
         E = (B // S) * NATOM * NATOM                               # edges one bracketed launch processes (one stream's group)
-        f_exec, f_alg = edge_flops_per_edge()
+        f_exec, f_alg = edge_flops_per_edge(pairs=args.path == "split-gemm")
         avg_ms = tot_ms.value / max(1, n_launch.value)             # plain per-launch duration (what rocprofv3 --stats shows)
         # S chains run concurrently, so launches overlap: the rate the stage sustains = all its flops / the time during which
         # at least one instance was executing (= sum of durations when S = 1)
@@ -267,7 +270,7 @@ def main():
         fp32_equiv = n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12   # TFLOP/s of fp32 multiply-adds the stage delivers
         if args.path == "split-gemm":
             # every fp32 product is issued as SIX bf16 MFMA products: price the matrix pipe with what it executes
-            kernel, issued, peak, dtype = "gemm_planes_db_kernel x2 (edge MLP of one layer: Fourier-block GEMM + second-linear GEMM)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
+            kernel, issued, peak, dtype = "gemm_planes_db_kernel<pair> + gemm_planes_db_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
                 "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"

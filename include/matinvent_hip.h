@@ -256,6 +256,9 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
 #define MI_EDGE_GEMM 1
 int mi_set_gemm_mode(int mode);
 int mi_net_set_edge_mode(mi_net* net, int mode);
+/* fc edge style on the plane-GEMM path: run the Fourier-block GEMM over unordered node pairs (default on).  The reversed edge's
+ * features are (-sin, +cos) of the same arguments, so one operand row yields both directed edges; off = one row per edge. */
+int mi_set_edge_pairs(int on);
 
 /* Diagnostics: C[M,N] = A[M,K] W[N,K]^T through the node-level GEMM kernels.  kind 0 = f32-input MFMA,
  * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe. */

@@ -35,6 +35,12 @@ def set_gemm_mode(mode: str):
     _lib.check(_lib.load().mi_set_gemm_mode({"f32": 0, "split": 1}[mode]), "mi_set_gemm_mode")
 
 
+def set_edge_pairs(on: bool):
+    """fc edge style, plane-GEMM edge stage: evaluate the Fourier block once per unordered node pair (default) or once per
+    directed edge."""
+    _lib.check(_lib.load().mi_set_edge_pairs(int(bool(on))), "mi_set_edge_pairs")
+
+
 class CrystalBatch:
     """Index tables + workspace of one batch of crystals (mi_batch).  Replaces the PyG Batch
     bookkeeping (`num_atoms`, `batch`) and the per-call edge enumeration of gen_edges."""

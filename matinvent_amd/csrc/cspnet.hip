@@ -12,6 +12,7 @@ namespace mi {
 
 int g_gemm_mode = 1;  // MI_GEMM_SPLIT
 int g_planes_variant = 1;
+int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -162,6 +163,87 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
     split3_pair(v[0], v[1], p);
 #pragma unroll
     for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, c0, k)) = p[k];
+}
+
+// Pair-mode Fourier operand: rows = unordered pairs (i, j), columns = [sin(3F) | 0 .. Kh) | cos(3F) | 0 .. 2Kh) of
+// d = (x_j - x_i) % 1.  One thread per (row, sine column pair); pad rows / pad columns are written as zero.
+__global__ void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi, const int* __restrict__ pj, Planes FF,
+                                           int64_t Np, int F, int Kh) {
+    const int F3 = 3 * F, per_row = Kh / 2;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows_pad = (Np + 127) / 128 * 128;
+    if (idx >= rows_pad * per_row) return;
+    const int64_t e = idx / per_row;
+    const int m = (int)(idx % per_row);
+    float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+    if (e < Np) {
+        const int i = pi[e], j = pj[e];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ck = 2 * m + u;
+            if (ck < F3) {
+                const int c = ck / F, k = ck - c * F;
+                const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+                sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn[u], &cs[u]);
+            }
+        }
+    }
+    unsigned p[3];
+    split3_pair(sn[0], sn[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
+    split3_pair(cs[0], cs[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, Kh + 2 * m, k)) = p[k];
+}
+
+// plane set of the Fourier block of edge_mlp.0 in the pair-mode column layout; C0[f] = sum of its cosine block
+__global__ void pack_wff_pair_planes_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int Kh, Planes dst) {
+    const int F3 = 3 * F, per_row = Kh;  // column pairs per row over 2*Kh columns
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows_pad = (int64_t)(H + 127) / 128 * 128;
+    if (idx >= rows_pad * per_row) return;
+    const int f = (int)(idx / per_row), col = (int)(idx % per_row) * 2;
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = col + u, blk = c >= Kh, cc = blk ? c - Kh : c;
+        if (f < H && cc < F3) v[u] = W1[(size_t)f * edge_in + 2 * H + 9 + blk * F3 + cc];
+    }
+    unsigned p[3];
+    split3_pair(v[0], v[1], p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(f, col, k)) = p[k];
+}
+__global__ void wff_cos_rowsum_kernel(const float* __restrict__ W1, int edge_in, int H, int F, float* __restrict__ C0) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= H) return;
+    const float* w = W1 + (size_t)f * edge_in + 2 * H + 9 + 3 * F;
+    float s = 0.f;
+    for (int k = 0; k < 3 * F; ++k) s += w[k];
+    C0[f] = s;
+}
+
+// Self edges (i, i) of the fc list in pair mode: d = 0, so the Fourier term is the constant C0:
+//   Z1 = P_i[i] + P_j[i] + G[graph] + C0;  M1 = SiLU(Z1) written as planes at row e_diag[i]  (cspnet.py:59-79)
+__global__ void edge_diag_kernel(const float* __restrict__ PQ, const float* __restrict__ G, const float* __restrict__ C0,
+                                 const int* __restrict__ node2graph, const int* __restrict__ e_diag, float* __restrict__ pre_act, Planes M1,
+                                 int N, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * (H / 2)) return;
+    const int i = (int)(idx / (H / 2)), f = (int)(idx % (H / 2)) * 2, e = e_diag[i], g = node2graph[i];
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        v[u] = C0[f + u] + ((PQ[(size_t)i * 2 * H + f + u] + PQ[(size_t)i * 2 * H + H + f + u]) + G[(size_t)g * H + f + u]);
+    if (pre_act) {
+        pre_act[(size_t)e * H + f] = v[0];
+        pre_act[(size_t)e * H + f + 1] = v[1];
+    }
+    unsigned p[3];
+    split3_pair(silu_fast(v[0]), silu_fast(v[1]), p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(M1.base + M1.elem(e, f, k)) = p[k];
 }
 
 // Wff[f][0:6F] = W1[f][2H+9 : 2H+9+6F]  (contiguous, 16-byte aligned rows for the GEMM path)
@@ -449,6 +531,14 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FFp, b->E, net->F,
                            net->KP);
         MI_KERNEL_CHECK();
+    } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn) {
+        if (b->Np > 0) {  // pair mode: one operand row per unordered pair
+            Planes ffp = make_planes(b->FFpl, 2 * net->Kh);
+            const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 2);
+            hipLaunchKernelGGL(fourier_pair_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np,
+                               net->F, net->Kh);
+            MI_KERNEL_CHECK();
+        }
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
         Planes ffp = make_planes(b->FFpl, 6 * net->F);
         const int64_t rows_pad = (b->E + 127) / 128 * 128;
@@ -519,7 +609,24 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 PlanesEpilogue pe1;
                 pe1.ep = g1e;
                 pe1.Cp = m1p;
-                MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
+                if (g_edge_pairs && !b->knn) {
+                    // symmetric edge list: sin(2 pi k (1 - d)) = -sin(2 pi k d), cos unchanged, so one operand row per unordered
+                    // pair yields both directed edges (half the MFMA work of this GEMM); self edges (d = 0) are a constant
+                    const int Kp = 2 * net->Kh;
+                    pe1.pair_i = b->pair_i;
+                    pe1.pair_j = b->pair_j;
+                    pe1.pair_e1 = b->pair_e1;
+                    pe1.pair_e2 = b->pair_e2;
+                    pe1.pair_graph = b->pair_graph;
+                    if (b->Np > 0)
+                        MI_TRY(gemm_planes(make_planes(b->FFpl, Kp), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
+                                           pe1, s));
+                    hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G,
+                                       net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H);
+                    MI_KERNEL_CHECK();
+                } else {
+                    MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
+                }
                 PlanesEpilogue pe2;   // M2 never reaches HBM: the edge -> node sum happens in the epilogue
                 pe2.ep = g2e;
                 pe2.seg_part = b->part;
@@ -653,6 +760,8 @@ void mi_net_destroy(mi_net* n) {
     for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->Wff, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT})
         if (p) (void)hipFree(p);
     if (n->Wffpl) (void)hipFree(n->Wffpl);
+    if (n->Wffpl_pair) (void)hipFree(n->Wffpl_pair);
+    if (n->C0) (void)hipFree(n->C0);
     if (n->W2pl) (void)hipFree(n->W2pl);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
@@ -685,6 +794,9 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Wff, (size_t)n->L * H * 6 * n->F * sizeof(float)));
         MI_HIP(hipMalloc((void**)&n->Wffpl, (size_t)n->L * planes_elems(H, 6 * n->F) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->W2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
+        n->Kh = (3 * n->F + 31) / 32 * 32;
+        MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
     }
     if (freqs_host) {
         MI_HIP(hipMemcpyAsync(n->freqs, freqs_host, n->F * sizeof(float), hipMemcpyHostToDevice, s));
@@ -710,6 +822,9 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wffp.KT * 16, 256)), dim3(256), 0, s, W1 + 2 * H + 9, n->edge_in, H, F6, wffp);
             Planes w2p = make_planes(n->W2pl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * w2p.KT * 16, 256)), dim3(256), 0, s, W2, H, H, H, w2p);
+            Planes wpp = make_planes(n->Wffpl_pair + (size_t)l * planes_elems(H, 2 * n->Kh), 2 * n->Kh);
+            hipLaunchKernelGGL(pack_wff_pair_planes_kernel, dim3(cdiv((int64_t)Hp * n->Kh, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->Kh, wpp);
+            hipLaunchKernelGGL(wff_cos_rowsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->C0 + (size_t)l * H);
         }
     }
     MI_KERNEL_CHECK();
@@ -757,7 +872,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     }
     // fully connected edges, row-major incl. self loops (cspnet.py:239-241)
     const size_t Efc = knn ? 0 : (size_t)E;
-    std::vector<int> n2g(N), src(Efc), dst(Efc), rowptr(N + 1, 0), egraph(Efc);
+    std::vector<int> n2g(N), src(Efc), dst(Efc), rowptr(N + 1, 0), egraph(Efc), pr_i, pr_j, pr_e1, pr_e2, pr_g, ediag(knn ? 0 : N);
     size_t e = 0;
     int nslots = knn ? b->deg_cap / 32 + 2 : 1;
     for (int g = 0; g < B; ++g) {
@@ -773,7 +888,20 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
             }
             if (!knn) nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
         }
+        if (!knn) {  // unordered pairs i < j and self edges of this crystal; edge (a -> b) sits at rowptr[a] + b_local
+            for (int i = 0; i < n; ++i) {
+                ediag[o + i] = rowptr[o + i] + i;
+                for (int j = i + 1; j < n; ++j) {
+                    pr_i.push_back(o + i);
+                    pr_j.push_back(o + j);
+                    pr_e1.push_back(rowptr[o + i] + j);
+                    pr_e2.push_back(rowptr[o + j] + i);
+                    pr_g.push_back(g);
+                }
+            }
+        }
     }
+    b->Np = (int64_t)pr_i.size();
     rowptr[N] = (int)e;
     b->nslots = nslots;
     const int H = net->H, L = net->L;
@@ -797,7 +925,13 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(FF, (size_t)E * 6 * net->F);
     A_(M1, (size_t)E * H);
     A_(M2, (size_t)E * H);
-    A_(FFpl, planes_elems(E, 6 * net->F));
+    A_(FFpl, std::max(planes_elems(E, 6 * net->F), planes_elems(b->Np, 2 * ((3 * net->F + 31) / 32 * 32))));
+    A_(pair_i, (size_t)b->Np);
+    A_(pair_j, (size_t)b->Np);
+    A_(pair_e1, (size_t)b->Np);
+    A_(pair_e2, (size_t)b->Np);
+    A_(pair_graph, (size_t)b->Np);
+    A_(e_diag, knn ? 0 : N);
     A_(M1pl, planes_elems(E, H));
     A_(X, NH);
     A_(x1, NH);
@@ -831,6 +965,12 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     if (he == hipSuccess) he = up(b->dst, dst);
     if (he == hipSuccess) he = up(b->edge_graph, egraph);
     if (he == hipSuccess) he = up(b->rowptr, rowptr);
+    if (he == hipSuccess) he = up(b->pair_i, pr_i);
+    if (he == hipSuccess) he = up(b->pair_j, pr_j);
+    if (he == hipSuccess) he = up(b->pair_e1, pr_e1);
+    if (he == hipSuccess) he = up(b->pair_e2, pr_e2);
+    if (he == hipSuccess) he = up(b->pair_graph, pr_g);
+    if (he == hipSuccess) he = up(b->e_diag, ediag);
     if (he != hipSuccess) {
         set_error("index table upload failed: %s", hipGetErrorString(he));
         mi_batch_destroy(b);
@@ -878,6 +1018,11 @@ int mi_cspnet_tap(mi_net* net, mi_batch* b, int layer, float* out, void* stream)
 int mi_set_gemm_mode(int mode) {
     MI_CHECK(mode == MI_GEMM_F32 || mode == MI_GEMM_SPLIT, MI_EINVAL, "unknown gemm mode %d", mode);
     mi::g_gemm_mode = mode;
+    return MI_OK;
+}
+
+int mi_set_edge_pairs(int on) {
+    g_edge_pairs = on != 0;
     return MI_OK;
 }
 

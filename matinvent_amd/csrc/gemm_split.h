@@ -256,6 +256,16 @@ struct PlanesEpilogue {
     const int* seg_src = nullptr;
     const int* seg_rowptr = nullptr;
     int seg_nodes = 0;
+    // optional PAIR mode (first edge GEMM over a symmetric edge list): rows are unordered node pairs (i, j); the first half of
+    // K holds the sine features, the second half the cosine features of d = x_j - x_i.  The reversed edge sees 1 - d, i.e.
+    // -sin and +cos, so ONE row of MFMA work yields both edges:  Z(i->j) = C + S + ...,  Z(j->i) = C - S + ...
+    // (S, C = the two half-K sums).  pair_e1 / pair_e2 = output rows (edge ids) of the two directions; row-gathered addends:
+    // ep.row_bias [pair_i] + ep.row_bias2 [pair_j] for i->j and the swapped pair for j->i, plus ep.row_bias3 [pair_graph].
+    const int* pair_i = nullptr;
+    const int* pair_j = nullptr;
+    const int* pair_e1 = nullptr;
+    const int* pair_e2 = nullptr;
+    const int* pair_graph = nullptr;
 };
 
 // Epilogue of one wave's TM x TN block of 32x32 accumulator tiles whose first row / column are row_w / col_w:
@@ -400,6 +410,97 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
             __builtin_amdgcn_wave_barrier();
         }
 }
+// PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major
+// through two per-wave LDS patches; each lane handles 8 consecutive columns of one pair and emits BOTH directed edges.
+template <int TM, int TN>
+__device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, f32x16 (&accS)[TM][TN], f32x16 (&accC)[TM][TN], int row_w,
+                                                      int col_w, int M, int N, int lane, float* stage) {
+    const GemmEpilogue& ep = pe.ep;
+    const int l31 = lane & 31, kg = lane >> 5;
+    float* stS = stage;
+    float* stC = stage + 1152;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = row_w + i * 32, cb = col_w + j * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31;
+                stS[o] = accS[i][j][r];
+                stC[o] = accC[i][j][r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = lane + 64 * u, rl = q >> 2, c8 = (q & 3) * 8;
+                const int row = rb + rl, col = cb + c8;
+                if (row < M && col < N) {
+                    float sv[8], cv[8];
+                    {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(stS + rl * 36 + c8), b = *reinterpret_cast<const f32x4*>(stS + rl * 36 + c8 + 4);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(stC + rl * 36 + c8), d = *reinterpret_cast<const f32x4*>(stC + rl * 36 + c8 + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            sv[k] = a[k];
+                            sv[4 + k] = b[k];
+                            cv[k] = c[k];
+                            cv[4 + k] = d[k];
+                        }
+                    }
+                    const int ni = pe.pair_i[row], nj = pe.pair_j[row], gr = pe.pair_graph[row];
+                    auto ld8 = [&](float (&dst)[8], const float* src) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            dst[k] = a[k];
+                            dst[4 + k] = b[k];
+                        }
+                    };
+                    float pii[8], pjj[8], pij[8], pji[8], gg[8], bb[8];
+                    ld8(pii, ep.row_bias + (size_t)ni * ep.ld_row_bias + col);    // P_i[i]
+                    ld8(pjj, ep.row_bias2 + (size_t)nj * ep.ld_row_bias2 + col);  // P_j[j]
+                    ld8(pij, ep.row_bias + (size_t)nj * ep.ld_row_bias + col);    // P_i[j]
+                    ld8(pji, ep.row_bias2 + (size_t)ni * ep.ld_row_bias2 + col);  // P_j[i]
+                    ld8(gg, ep.row_bias3 + (size_t)gr * ep.ld_row_bias3 + col);
+                    if (ep.bias) ld8(bb, ep.bias + col);
+#pragma unroll
+                    for (int dir = 0; dir < 2; ++dir) {
+                        const int erow = dir == 0 ? pe.pair_e1[row] : pe.pair_e2[row];
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float acc = dir == 0 ? cv[k] + sv[k] : cv[k] - sv[k];
+                            const float g = dir == 0 ? (pii[k] + pjj[k]) + gg[k] : (pij[k] + pji[k]) + gg[k];
+                            v[k] = (ep.bias ? acc + bb[k] : acc) + g;
+                        }
+                        if (ep.pre_act) {
+                            float* d = ep.pre_act + (size_t)erow * ep.ld_pre + col;
+                            *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        }
+                        if (ep.act == ACT_SILU) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
+                        }
+                        u32x4 o[3];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            unsigned pr[3];
+                            split3_pair(v[2 * k], v[2 * k + 1], pr);
+                            o[0][k] = pr[0];
+                            o[1][k] = pr[1];
+                            o[2][k] = pr[2];
+                        }
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
 // whether the row-major epilogue applies (otherwise the result-layout one, which also carries the fused segmented sum)
 __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
     return pe.Cp.base != nullptr && pe.seg_part == nullptr && pe.ep.residual == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 &&
@@ -492,6 +593,29 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
 
+    if constexpr (V == 1) {  // PAIR mode (small problems only: plain one-tile-per-iteration loop)
+        f32x16 accS[TM][TN];
+        const int half = KT / 2;
+        for (int kt2 = 0; kt2 < KT; ++kt2) {
+            if (kt2 == half) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        accS[i][j] = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    }
+            }
+            load_tiles(kt2, ra0, rw0);
+            store_tiles(ra0, rw0);
+            __syncthreads();
+            compute();
+            __syncthreads();
+        }
+        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
+        return;
+    }
     load_tiles(0, ra0, rw0);
     if (KT > 1) load_tiles(1, ra1, rw1);
     int kt = 0;
@@ -526,6 +650,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // of two, and the staging writes of tile k+1 / the global loads of tile k+2 sit between the two MFMA halves of tile k, so the
 // matrix pipe only idles at that one barrier.  One workgroup per CU (LDS), two waves per SIMD as before.
 constexpr int GEMM_DB_LDS = 2 * (3 * 256 * 64 + 3 * 128 * 64);
+template <bool PAIR>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_db_kernel(Planes A, Planes W, int M, int N,
                                                                                                               int K, PlanesEpilogue pe, int Mlim) {
     constexpr int TM = 2, TN = 2, PLA = 256 * 64, PLW = 128 * 64, BUF = 3 * PLA + 3 * PLW;
@@ -629,12 +754,31 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     __syncthreads();
     read_frag(f0, smem, 0);
     int kt = 0;
-    for (; kt + 2 < KT; ++kt) step(kt, yes(), yes());  // steady state: branch-free
-    if (kt + 1 < KT) {
-        step(kt, yes(), no());
-        ++kt;
+    auto advance = [&](int kend) {
+        for (; kt < kend && kt + 2 < KT; ++kt) step(kt, yes(), yes());  // steady state: branch-free
+        for (; kt < kend; ++kt) {
+            if (kt + 1 < KT) step(kt, yes(), no());
+            else step(kt, no(), no());
+        }
+    };
+    if constexpr (PAIR) {  // sine half of K into one accumulator set, cosine half into the other (see PlanesEpilogue)
+        f32x16 accS[TM][TN];
+        advance(KT / 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                accS[i][j] = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        advance(KT);
+        __syncthreads();  // the staging patches overlay the operand tiles
+        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
+        return;
+    } else {
+        advance(KT);
     }
-    step(kt, no(), no());
     if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
         __syncthreads();                   // the staging patches overlay the operand tiles
         planes_epilogue_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
@@ -646,20 +790,24 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
     MI_CHECK(A.KT == (K + 31) / 32 && W.KT == A.KT, MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
+    const bool pair = pe.pair_i != nullptr;
+    MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
+             "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);
     if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= 512) {  // enough 256-row tiles to fill the chip twice over
-        static int num_cu = 0;
-        if (num_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            MI_HIP(hipGetDevice(&dev));
-            MI_HIP(hipGetDeviceProperties(&prop, dev));
-            num_cu = prop.multiProcessorCount;
-            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
+            attr_set = true;
         }
         // (measured: peeling the partial last round off to half-size tiles does not pay -- workgroups are dispatched
         // dynamically, so the remainder overlaps the stragglers of the last full round)
-        hipLaunchKernelGGL(gemm_planes_db_kernel, dim3(nct * ((cdiv(M, 256) + 7) / 8 * 8)), dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
+        const dim3 grid(nct * ((cdiv(M, 256) + 7) / 8 * 8));
+        if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
+        else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
+    } else if (pair) {
+        hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(nct, cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     } else {
         hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(nct, cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     }

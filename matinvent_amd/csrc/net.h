@@ -27,6 +27,11 @@ struct mi_net {
     int edge_mode = 1;       // MI_EDGE_GEMM (default) or MI_EDGE_FUSED_F32
     unsigned short* Wffpl = nullptr;  // [L][3][H][ld(6F)] bf16 planes of Wff
     unsigned short* W2pl = nullptr;   // [L][3][H][H]      bf16 planes of edge_mlp.2.weight
+    // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],
+    // Kh = 3F rounded up to 32, so that each block is a whole number of k-tiles
+    int Kh = 0;
+    unsigned short* Wffpl_pair = nullptr;  // [L] plane sets of the Fourier block of edge_mlp.0 in that column layout
+    float* C0 = nullptr;                   // [L][H] sum of the cosine-block weights = the Fourier term of a self edge (d = 0)
     // transposed copies for the data-gradient GEMMs (training), rebuilt with the packs
     float* W2T = nullptr;    // [L][H][H]
     float* Wn2T = nullptr;   // [L][H][H]
@@ -67,6 +72,10 @@ struct mi_batch {
     int nslots = 1;
     // knn edge style (CSPNet.gen_edges knn branch, graph.hip)
     int knn = 0, max_neighbors = 0, cap_per_node = 0, deg_cap = 0, nmax = 0;
+    // pair tables of the fc edge list (unordered node pairs i < j of each crystal): the first edge GEMM runs over pairs
+    int64_t Np = 0;
+    int *pair_i = nullptr, *pair_j = nullptr, *pair_e1 = nullptr /*edge i->j*/, *pair_e2 = nullptr /*edge j->i*/, *pair_graph = nullptr,
+        *e_diag = nullptr /*[N] self edge of node i*/;
     float* fd = nullptr;    // [E][3] explicit frac_diff per edge (CSR order); nullptr = fc: (x_dst - x_src) % 1
     int* inedge = nullptr;  // [E] edge ids grouped by destination node, node v at rowptr[v]..rowptr[v+1] (degrees are symmetric)
     int *kn_ent = nullptr, *kn_acnt = nullptr, *kn_deg = nullptr, *kn_mcount = nullptr, *kn_eoff = nullptr, *kn_meta = nullptr,

@@ -14,15 +14,19 @@ pytestmark = pytest.mark.gpu
 
 # arithmetic paths: (gemm mode, edge mode).  Default = bf16-split GEMMs everywhere; the other two keep
 # the f32-input MFMA (exact fp32 fma chains) with either edge-stage formulation.
-PATHS = [("split", "gemm"), ("f32", "gemm"), ("f32", "fused_f32")]
+# The default additionally evaluates the Fourier block once per unordered node pair (the reversed edge sees -sin / +cos of the
+# same arguments); "per-edge" switches that off.
+PATHS = [("split", "gemm"), ("split", "gemm", "per-edge"), ("f32", "gemm"), ("f32", "fused_f32")]
 
 
-@pytest.fixture(params=PATHS, ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.fixture(params=PATHS, ids=lambda p: "-".join(p))
 def path(request):
-    from matinvent_amd.cspnet import set_gemm_mode
+    from matinvent_amd.cspnet import set_edge_pairs, set_gemm_mode
     set_gemm_mode(request.param[0])
+    set_edge_pairs(len(request.param) < 3)
     yield request.param
     set_gemm_mode("split")
+    set_edge_pairs(True)
 
 
 def _net(H, L, F, P=None, path=("split", "gemm")):
