@@ -271,6 +271,8 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
 /* One wave busy-waiting ~`cycles` shader clocks on `stream`: lets the host side test whether two HIP streams really execute
  * concurrently (streams may share a hardware queue, which serialises them). */
 int mi_debug_spin(long long cycles, void* stream);
+/* Tuning knob: smallest number of 256-row tiles for which the double-buffered plane GEMM is used (default 256). */
+int mi_debug_set_db_min_tiles(int n);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mi_structure_check": (_I, [_P, _P, _P, _P, _P]),
     "mi_debug_spin": (_I, [C.c_longlong, _P]),
     "mi_set_edge_pairs": (_I, [_I]),
+    "mi_debug_set_db_min_tiles": (_I, [_I]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),
     "mi_batch_num_edges": (_L, [_P]),

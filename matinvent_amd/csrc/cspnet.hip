@@ -12,6 +12,8 @@ namespace mi {
 
 int g_gemm_mode = 1;  // MI_GEMM_SPLIT
 int g_planes_variant = 1;
+int g_planes_db_min_tiles = 512;
+int g_pair_kernel = 0;
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 
 static thread_local char g_err[512] = "";
@@ -1018,6 +1020,12 @@ int mi_cspnet_tap(mi_net* net, mi_batch* b, int layer, float* out, void* stream)
 int mi_set_gemm_mode(int mode) {
     MI_CHECK(mode == MI_GEMM_F32 || mode == MI_GEMM_SPLIT, MI_EINVAL, "unknown gemm mode %d", mode);
     mi::g_gemm_mode = mode;
+    return MI_OK;
+}
+
+int mi_debug_set_db_min_tiles(int n) {
+    if (n < 0) g_pair_kernel = 1;  // negative: also let pair-mode GEMMs pick the kernel by size
+    g_planes_db_min_tiles = n < 0 ? -n : n;
     return MI_OK;
 }
 

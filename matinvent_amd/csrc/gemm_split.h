@@ -187,6 +187,8 @@ inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float
 //   MI_GEMM_F32            : v_mfma_f32_32x32x2_f32 -- bit-for-bit an fp32 fma chain
 extern int g_gemm_mode;
 extern int g_planes_variant;  // 0 = 128x128 tiles, 1 = 256x128 double-buffered (large M)
+extern int g_planes_db_min_tiles;
+extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                    hipStream_t s) {
     return g_gemm_mode == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, ep, s) : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
@@ -593,44 +595,56 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
 
-    if constexpr (V == 1) {  // PAIR mode (small problems only: plain one-tile-per-iteration loop)
-        f32x16 accS[TM][TN];
-        const int half = KT / 2;
-        for (int kt2 = 0; kt2 < KT; ++kt2) {
-            if (kt2 == half) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        accS[i][j] = acc[i][j];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                    }
-            }
-            load_tiles(kt2, ra0, rw0);
+    load_tiles(0, ra0, rw0);
+    if (KT > 1) load_tiles(1, ra1, rw1);
+    int kt = 0;
+    // k-tiles kt .. kend-1 (kend - kt even), two per iteration so that the accumulators never cross a conditional; the register
+    // prefetch keeps running across calls
+    auto run_pairs = [&](int kend) {
+        for (; kt + 2 <= kend; kt += 2) {
             store_tiles(ra0, rw0);
             __syncthreads();
+            if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
             compute();
             __syncthreads();
+            store_tiles(ra1, rw1);
+            __syncthreads();
+            if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
+            compute();
+            __syncthreads();
+        }
+    };
+    if constexpr (V == 1) {  // PAIR mode: sine half of K into one accumulator set, cosine half into the other (see PlanesEpilogue)
+        f32x16 accS[TM][TN];
+        const int half = KT / 2;
+        auto swap_acc = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    accS[i][j] = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        };
+        if ((half & 1) == 0) {
+            run_pairs(half);
+            swap_acc();
+            run_pairs(KT);
+        } else {  // odd half (tiny K): plain one-tile-per-iteration loop
+            for (int k2 = 0; k2 < KT; ++k2) {
+                if (k2 == half) swap_acc();
+                load_tiles(k2, ra0, rw0);
+                store_tiles(ra0, rw0);
+                __syncthreads();
+                compute();
+                __syncthreads();
+            }
         }
         planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
         return;
     }
-    load_tiles(0, ra0, rw0);
-    if (KT > 1) load_tiles(1, ra1, rw1);
-    int kt = 0;
-    for (; kt + 2 <= KT; kt += 2) {  // k-tiles in pairs: the accumulators never cross a conditional
-        store_tiles(ra0, rw0);
-        __syncthreads();
-        if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
-        compute();
-        __syncthreads();
-        store_tiles(ra1, rw1);
-        __syncthreads();
-        if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
-        compute();
-        __syncthreads();
-    }
+    run_pairs(KT);
     if (kt < KT) {
         store_tiles(ra0, rw0);
         __syncthreads();
@@ -794,7 +808,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);
-    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= 512) {  // enough 256-row tiles to fill the chip twice over
+    // pair mode has twice the epilogue per row of MFMA work: two workgroups per CU (128-row kernel) hide it behind each other's main
+    // loop, which measured faster than the one-workgroup-per-CU kernel at every size tried
+    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= g_planes_db_min_tiles && !(pair && g_pair_kernel == 0)) {
         static bool attr_set = false;
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));

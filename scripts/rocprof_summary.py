@@ -27,14 +27,16 @@ def main():
     traffic = {}
     for p in pmcs:
         cur = sqlite3.connect(p).cursor()
-        q = ("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%gemm_planes_db%' "
-             "and counter_name in ('FETCH_SIZE', 'WRITE_SIZE') group by counter_name")
+        # the two kernels of one bench 'launch' (pair-mode Fourier GEMM + second-linear GEMM): equally many dispatches each,
+        # so the average over both x 2 = bytes per launch
+        q = ("select counter_name, count(*), avg(value) from counters_collection where (kernel_name like '%gemm_planes_db%' "
+             "or kernel_name like '%gemm_planes_kernel%') and counter_name in ('FETCH_SIZE', 'WRITE_SIZE') group by counter_name")
         for c, n, v in cur.execute(q):
             traffic[c] = {"dispatches": n, "avg_reported_KiB": v}
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         fetch = 2.0 * traffic["FETCH_SIZE"]["avg_reported_KiB"] * 1024.0
         write = traffic["WRITE_SIZE"]["avg_reported_KiB"] * 1024.0
-        rec = {"kernel": "gemm_planes_db_kernel", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
+        rec = {"kernel": "gemm_planes_kernel<pair> + gemm_planes_db_kernel", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
                "write_bytes_per_dispatch": write, "dispatches_per_bench_launch": 2, "counters": traffic,
                "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
         json.dump(rec, open(out.rsplit(".", 1)[0] + "_traffic.json", "w"), indent=1)
