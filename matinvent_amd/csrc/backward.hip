@@ -12,6 +12,10 @@
 #include "net.h"
 
 namespace mi {
+extern int g_edge_pairs;
+}
+
+namespace mi {
 
 __global__ void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,6 +71,25 @@ __global__ void edge_dpq_kernel(const float* __restrict__ dZ1, const int* __rest
     float t = 0.f;
     for (int ii = n0; ii < n1; ++ii) t += dZ1[(size_t)(rowptr[ii] + jl) * H + f];
     dPQ[(size_t)i * (2 * H) + H + f] = t;
+}
+
+// pair-mode weight gradient of the Fourier block (fc edge list): with S = sin, C = cos of the pair's arguments,
+//   dW_sin += sum_p (dZ1[i->j] - dZ1[j->i])^T S_p,   dW_cos += sum_p (dZ1[i->j] + dZ1[j->i])^T C_p  (+ the self edges, cos = 1)
+__global__ void pair_combine_kernel(const float* __restrict__ dZ1, const int* __restrict__ e1, const int* __restrict__ e2,
+                                    float* __restrict__ Dm, float* __restrict__ Dp, int64_t Np, int H) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Np * (H / 4)) return;
+    const int64_t p = idx / (H / 4);
+    const int f = (int)(idx % (H / 4)) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(dZ1 + (size_t)e1[p] * H + f), b = *reinterpret_cast<const f32x4*>(dZ1 + (size_t)e2[p] * H + f);
+    *reinterpret_cast<f32x4*>(Dm + (size_t)p * H + f) = a - b;
+    *reinterpret_cast<f32x4*>(Dp + (size_t)p * H + f) = a + b;
+}
+// gW[f][c] += v[f] for c < ncols   (self edges: every cosine feature is 1)
+__global__ void row_broadcast_add_kernel(const float* __restrict__ v, float* __restrict__ gW, int ld, int H, int ncols) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * ncols) return;
+    gW[(size_t)(idx / ncols) * ld + idx % ncols] += v[idx / ncols];
 }
 
 // general edge lists (knn branch): out-edges of i are its CSR row, in-edges are listed in `inedge` at the same offsets
@@ -305,8 +328,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_HIP(hipMemcpyAsync(t.dh, t.dY, NH * 4, hipMemcpyDeviceToDevice, s));
     }
 
-    // Fourier features are the same for every layer
-    if (E > 0) {
+    // Fourier features are the same for every layer; in pair mode one row per unordered atom pair
+    const bool pairs = g_edge_pairs && !b->knn && H % 4 == 0;
+    const int64_t Np = b->Np;
+    if (pairs && Np > 0) {
+        hipLaunchKernelGGL(fourier_kernel, g1(Np * 3 * F), dim3(256), 0, s, t.frac, (const float*)nullptr, b->pair_i, b->pair_j, t.FF, Np, F);
+        MI_KERNEL_CHECK();
+    } else if (!pairs && E > 0) {
         hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.frac, b->fd, b->src, b->dst, t.FF, E, F);
         MI_KERNEL_CHECK();
     }
@@ -341,7 +369,23 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
             hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
             MI_KERNEL_CHECK();
-            MI_TRY(gemm_tn_acc(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
+            if (pairs) {  // t.M1 is free again (its weight gradient is done): Dm | Dp live there
+                float* gWff = G(p + "edge_mlp.0.weight") + 2 * H + 9;
+                if (Np > 0) {
+                    float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
+                    hipLaunchKernelGGL(pair_combine_kernel, g1(Np * (H / 4)), dim3(256), 0, s, t.dM1, b->pair_e1, b->pair_e2, Dm, Dp, Np, H);
+                    MI_KERNEL_CHECK();
+                    MI_TRY(gemm_tn_acc(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
+                    MI_TRY(gemm_tn_acc(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
+                }
+                float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
+                MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
+                MI_TRY(colsum_acc(t.dM1, H, dsum, N, H, sc, scf - H, s, b->e_diag));
+                hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
+                MI_KERNEL_CHECK();
+            } else {
+                MI_TRY(gemm_tn_acc(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
+            }
             if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
             else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
             MI_KERNEL_CHECK();

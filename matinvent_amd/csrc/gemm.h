@@ -259,26 +259,27 @@ inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* 
 
 // out[c] += sum_m A[m][c]   (bias gradients), two stages through `scratch` like gemm_tn_acc
 static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ P, int M, int Nc,
-                                                     int rows_per_split) {
+                                                     int rows_per_split, const int* __restrict__ row_idx = nullptr) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const int m_begin = blockIdx.y * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     float s = 0.f;
     if (c < Nc)
-        for (int m = m_begin + rg; m < m_end; m += 4) s += A[(size_t)m * lda + c];
+        for (int m = m_begin + rg; m < m_end; m += 4) s += A[(size_t)(row_idx ? row_idx[m] : m) * lda + c];
     red[rg][threadIdx.x & 63] = s;
     __syncthreads();
     if (rg == 0 && c < Nc) P[(size_t)blockIdx.y * (gridDim.x * 64) + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s) {
+inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s,
+                      const int* row_idx = nullptr) {
     if (M <= 0 || Nc <= 0) return MI_OK;
     const int gx = cdiv(Nc, 64);
     int nsplit = std::max(1, std::min(cdiv(M, 64), 64));
     MI_CHECK((size_t)nsplit * gx * 64 <= scratch_floats, MI_ENOMEM, "colsum scratch too small");
     int rows = cdiv(M, nsplit);
     nsplit = cdiv(M, rows);
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows, row_idx);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(Nc, 256)), dim3(256), 0, s, scratch, nsplit, 1, gx * 64, out, Nc, 1, Nc, 1.0f);
     MI_KERNEL_CHECK();
     return MI_OK;

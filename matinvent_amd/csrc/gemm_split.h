@@ -528,7 +528,13 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     unsigned char* Ws = smem + 3 * PLB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
-    const int rt = rt_base + blockIdx.y, ct = blockIdx.x, row0 = rt * BM, col0 = ct * BN;
+    // XCD-aware tile mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all column tiles of one row tile run
+    // on the same XCD, so the streamed A operand crosses the fabric once (measured on the pair-mode GEMM: FETCH_SIZE 4x the
+    // operand size without it)
+    const int nct_ = (N + BN - 1) / BN, id_ = blockIdx.x, slot_ = id_ >> 3;
+    const int ct = slot_ % nct_, rt = rt_base + (slot_ / nct_) * 8 + (id_ & 7);
+    if (rt * BM >= M) return;
+    const int row0 = rt * BM, col0 = ct * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -823,9 +829,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else if (pair) {
-        hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(nct, cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     } else {
-        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(nct, cdiv(M, 128)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     }
     MI_KERNEL_CHECK();
     return MI_OK;
