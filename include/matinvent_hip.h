@@ -232,14 +232,16 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
  * `reward` [B] device; rand_* optional injected noise.  `stats` (device, 3 floats, may be NULL) accumulates
  * the three quantities the reference logs (:168-170): the accum-normalised loss, sum_b r_b L_b,
  * sum_b (1.1-r_b) KL_b.  out_sample_loss / out_kl ([B], may be NULL) receive L_b / KL_b.
- * `ab` / `pb` must be distinct batch handles of the agent / prior networks for the same crystals. */
+ * `ab` / `pb` must be distinct batch handles of the agent / prior networks for the same crystals.
+ * `aux_stream` (may be NULL): a second stream onto which the frozen prior's forward is forked, so that it overlaps the agent's
+ * forward (worthwhile for small fine-tune sets, which leave most of the chip idle); joined before the loss. */
 int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths,
                      const float* angles, const float* frac0, const int* atom_types, const float* reward,
                      const float* time_freqs, int t, float c0, float c1, float sigma_t, float sigma_norm,
                      uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
                      const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma,
                      int b_global, int accum_steps, float* grad_theta, float* stats, float* out_sample_loss,
-                     float* out_kl, void* stream);
+                     float* out_kl, void* stream, void* aux_stream);
 
 /* ---------------------------------------------------------------------------------------
  * Arithmetic paths.  Both reproduce the reference to fp32 round-off (tests state the bounds).

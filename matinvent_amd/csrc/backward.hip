@@ -633,7 +633,7 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
                      const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int t, float c0, float c1,
                      float sigma_t, float sigma_norm, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
                      const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global, int accum_steps,
-                     float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream) {
+                     float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream, void* aux_stream) {
     MI_CHECK(agent && ab && prior && pb && lengths && angles && frac0 && atom_types && reward && time_freqs && grad_theta, MI_EINVAL,
              "null argument");
     MI_CHECK(ab != pb, MI_EINVAL, "agent and prior need separate batch handles (separate workspace)");
@@ -647,8 +647,24 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
     MI_TRY(mi_time_embedding(ab->times, time_freqs, B, agent->TD, ab->temb, stream));
     MI_TRY(mi_add_noise(ab, lengths, angles, frac0, atom_types, c0, c1, sigma_t, sigma_norm, seed, noise_step, rand_l, rand_x, rand_t,
                         tp.nz_lat, tp.nz_frac, tp.nz_types, tp.tar_x, tp.rnd_l, tp.rnd_t, stream));
-    MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
-    MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
+    if (aux_stream && aux_stream != stream) {
+        // the frozen prior's forward is independent of the agent's: fork it onto the auxiliary stream (small fine-tune sets leave
+        // most of the chip idle, so the two forwards overlap), join before the loss kernel reads both predictions
+        hipStream_t s2 = (hipStream_t)aux_stream;
+        if (!pb->ev_fork) {
+            MI_HIP(hipEventCreateWithFlags(&pb->ev_fork, hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&pb->ev_join, hipEventDisableTiming));
+        }
+        MI_HIP(hipEventRecord(pb->ev_fork, s));
+        MI_HIP(hipStreamWaitEvent(s2, pb->ev_fork, 0));
+        MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s2, false));
+        MI_HIP(hipEventRecord(pb->ev_join, s2));
+        MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
+        MI_HIP(hipStreamWaitEvent(s, pb->ev_join, 0));
+    } else {
+        MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
+        MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
+    }
     LossArgs la{ab->pred_l, ab->pred_x, ab->pred_t, pb->pred_l, pb->pred_x, pb->pred_t, tp.rnd_l, tp.tar_x, tp.rnd_t, reward, ab->node_off,
                 tp.d_l, tp.d_x, tp.d_t, tp.Lb, tp.KLb, cost_lattice, cost_coord, cost_type, kl_sigma,
                 1.0f / ((float)b_global * (float)accum_steps)};

@@ -984,6 +984,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
 
 void mi_batch_destroy(mi_batch* b) {
     if (!b) return;
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     for (void* p : b->allocs) (void)hipFree(p);
     delete b;
 }

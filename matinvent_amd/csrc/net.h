@@ -113,6 +113,7 @@ struct mi_batch {
     float* coef = nullptr;     // [T+1][MI_NCOEF]
     int coef_T = -1;
     Tape tape;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // fork / join of work put on an auxiliary stream (mi_ft_micro_step)
     std::vector<void*> allocs;
 };
 

@@ -19,7 +19,7 @@ from .dist import allreduce_flat_, rank_world, shard_range
 from .optim import FusedAdam
 
 
-def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats, call_id=None):
+def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats, call_id=None, aux_stream=None):
     """One timestep through mi_ft_micro_step on the current stream; accumulates into `grad` (+=) and `stats` (device, 3
     floats).  `call_id` = the noise-stream call counter (one value per timestep, shared by every crystal group)."""
     import ctypes as C
@@ -48,7 +48,8 @@ def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, acc
                                     _ptr(cache["frac"]), _ptr(cache["types"]), _ptr(cache["reward"]), _ptr(agent.time_embedding.freqs), t,
                                     c0, c1, sig, sn, getattr(agent, "noise_seed", 0), call_id & 0xFFFFFFFF, _ptr(nz[0]),
                                     _ptr(nz[1]), _ptr(nz[2]), agent.cost_lattice, agent.cost_coord, agent.cost_type, sigma, n_global,
-                                    accum_steps, _ptr(grad), _ptr(stats), None, None, _stream()), "mi_ft_micro_step")
+                                    accum_steps, _ptr(grad), _ptr(stats), None, None, _stream(),
+                                    C.c_void_p(aux_stream.cuda_stream) if aux_stream is not None else None), "mi_ft_micro_step")
 
 
 def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, log=logging.info, fused=True, groups=None):
@@ -84,6 +85,10 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
                                 noise_fn, log, rank)
     optimizer = FusedAdam([theta], lr=lr)  # fresh every call (:136)
     stats = []
+    aux = None
+    if fused:  # a single (small) group: fork the frozen prior's forward onto a second, really concurrent stream
+        from .streams import concurrent_streams
+        aux = concurrent_streams(2, device)[1]
     for epoch in range(epochs):
         agent.train()
         optimizer.zero_grad(set_to_none=False) if theta.grad is not None else None
@@ -94,7 +99,7 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
             if fused:
                 if theta.grad is None:
                     theta.grad = torch.zeros_like(theta)
-                _fused_micro_step(agent, prior, batch, t, noise, sigma, n_global, accum_steps, theta.grad, acc)
+                _fused_micro_step(agent, prior, batch, t, noise, sigma, n_global, accum_steps, theta.grad, acc, aux_stream=aux)
                 if (t + 1) % accum_steps == 0:
                     allreduce_flat_(theta.grad)
                     optimizer.step()

@@ -24,6 +24,29 @@ def main():
         rows = [r for r in cur.execute(q) if any(t in r[0] for t in ("edge_mlp", "gemm_nt", "gemm_planes"))]
         for k, c, n, v in rows:
             lines.append(f"| `{k[:60]}` | {c} | {n} | {v:.6g} |")
+    # HBM-side traffic and achieved bandwidth of every kernel (north_star: "achieved HBM GB/s against the chip's peak")
+    dur = {}
+    cur = sqlite3.connect(trace).cursor()
+    for name, calls, tot, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        dur[name.split("(")[0]] = (avg, calls)   # avg in ns
+    per = {}
+    for p in pmcs:
+        cur = sqlite3.connect(p).cursor()
+        for k, c, v in cur.execute("select kernel_name, counter_name, avg(value) from counters_collection where counter_name in "
+                                   "('FETCH_SIZE', 'WRITE_SIZE') group by kernel_name, counter_name"):
+            per.setdefault(k.split("(")[0], {})[c] = v
+    rows = []
+    for k, d in per.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d and k in dur:
+            fetch, write = 2.0 * d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0
+            avg_us = dur[k][0] / 1e3
+            rows.append((dur[k][0] * dur[k][1], k, avg_us, fetch, write, (fetch + write) / (avg_us * 1e-6) / 1e9))
+    if rows:
+        lines += ["", "## HBM-side traffic per dispatch (FETCH_SIZE x2 correction, WRITE_SIZE as reported) and achieved bandwidth", "",
+                  "Durations from the kernel trace, bytes from the PMC passes of the same command; peak 8000 GB/s.", "",
+                  "| kernel | avg us | fetch MB | write MB | GB/s | % of peak |", "|---|---|---|---|---|---|"]
+        for _, k, us, f, w, gbs in sorted(rows, reverse=True)[:14]:
+            lines.append(f"| `{k[:70]}` | {us:.1f} | {f / 1e6:.1f} | {w / 1e6:.1f} | {gbs:.0f} | {gbs / 80:.1f} |")
     traffic = {}
     for p in pmcs:
         cur = sqlite3.connect(p).cursor()
