@@ -353,12 +353,12 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_KERNEL_CHECK();
         MI_TRY(gemm_tn_acc(t.dY, H, t.Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
         MI_TRY(colsum_acc(t.dY, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
-        MI_TRY(gemm_nt(t.dY, H, net->Wn2T + l * (size_t)H * H, H, t.dXa, H, N, H, H, GemmEpilogue(), s));
+        MI_TRY(gemm_nt(t.dY, H, net->Wn2T + l * (size_t)H * H, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
         hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dXa, Xpre, t.dXa, (int64_t)NH);
         MI_KERNEL_CHECK();
         MI_TRY(gemm_tn_acc(t.dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
         MI_TRY(colsum_acc(t.dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
-        MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
+        MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         // edge stage (cspnet.py:59-79)
         if (E > 0) {
             hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);  // Z2 := dZ2
@@ -402,7 +402,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         GemmEpilogue er;
         er.residual = t.dcat;
         er.ld_res = 2 * H;
-        MI_TRY(gemm_nt(t.dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s));
+        MI_TRY(gemm_nt(t.dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s, &b->sk));
         // LayerNorm + residual stream: dh_l = dh_{l+1} + LN'(d hn)
         if (net->cfg.ln) {
             MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)l * NH, t.lnstat + (size_t)l * N * 2, p + "layer_norm", t.dh, 1));
@@ -419,7 +419,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     MI_KERNEL_CHECK();
     MI_TRY(gemm_tn_acc(t.dtproj, H, t.t_emb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
     MI_TRY(colsum_acc(t.dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
-    MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s));
+    MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
     MI_TRY(gemm_tn_acc(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
     return MI_OK;

@@ -517,15 +517,15 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     {
         GemmEpilogue ep;
         ep.bias = net->p("node_embedding.bias");
-        MI_TRY(gemm_nt(atom_types, MI_NUM_TYPES, net->p("node_embedding.weight"), MI_NUM_TYPES, b->x1, H, N, H, MI_NUM_TYPES, ep, s));
+        MI_TRY(gemm_nt(atom_types, MI_NUM_TYPES, net->p("node_embedding.weight"), MI_NUM_TYPES, b->x1, H, N, H, MI_NUM_TYPES, ep, s, &b->sk));
         GemmEpilogue et;
         et.bias = net->p("atom_latent_emb.bias");
-        MI_TRY(gemm_nt(t_emb, TD, net->p("atom_latent_emb.weight") + H, H + TD, b->tproj, H, B, H, TD, et, s));
+        MI_TRY(gemm_nt(t_emb, TD, net->p("atom_latent_emb.weight") + H, H + TD, b->tproj, H, B, H, TD, et, s, &b->sk));
         GemmEpilogue eh;
         eh.row_bias = b->tproj;
         eh.row_group = b->node2graph;
         eh.ld_row_bias = H;
-        MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s));
+        MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s, &b->sk));
     }
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
@@ -569,7 +569,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, cat, 2 * H, N, H);
         }
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s));
+        MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
                            net->p(p + "edge_mlp.0.bias"), b->G, H);
         MI_KERNEL_CHECK();
@@ -657,7 +657,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             e1.pre_act = tp.Xpre + (size_t)l * NH;
             e1.ld_pre = H;
         }
-        MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s));
+        MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s, &b->sk));
         GemmEpilogue e2;
         e2.bias = net->p(p + "node_mlp.2.bias");
         e2.act = ACT_SILU;
@@ -667,7 +667,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             e2.pre_act = tp.Ypre + (size_t)l * NH;
             e2.ld_pre = H;
         }
-        MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s));
+        MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s, &b->sk));
     }
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
@@ -678,10 +678,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
     }
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s));
+    MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s, &b->sk));
     GemmEpilogue et;
     et.bias = net->p("type_out.bias");
-    MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s));
+    MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
     hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (H + 9) * sizeof(float), s, b->hf, b->node_off,
                        net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
     MI_KERNEL_CHECK();
@@ -946,6 +946,10 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(pred_t, (size_t)N * MI_NUM_TYPES);
     A_(x_mid, (size_t)N * 3);
     A_(lp_corr, B);
+    if (N <= 2048) {  // small batches: node-level products are latency-bound, split-K partial sums live here
+        b->sk.floats = (size_t)N * 2 * H * 8;
+        A_(sk.buf, b->sk.floats);
+    }
 #undef A_
     if (rc != MI_OK) {
         mi_batch_destroy(b);

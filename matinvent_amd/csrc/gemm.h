@@ -16,6 +16,12 @@ namespace mi {
 
 enum { ACT_NONE = 0, ACT_SILU = 1 };
 
+// scratch for split-K partial sums (small-M products: more workgroups, shorter serial k-loops)
+struct SplitK {
+    float* buf = nullptr;
+    size_t floats = 0;
+};
+
 struct GemmEpilogue {
     const float* bias = nullptr;      // [N] added to every row
     const float* row_bias = nullptr;  // [G, ld_row_bias]; row r gets row_bias[row_group[r]]

@@ -54,7 +54,8 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) 
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                            float* __restrict__ C, int ldc, int M, int N, int K, GemmEpilogue ep) {
+                                                            float* __restrict__ C, int ldc, int M, int N, int K, GemmEpilogue ep, int kchunk,
+                                                            float* __restrict__ part) {
     constexpr int BK = 32, ROWB = 80;            // bytes per row per plane (64 + 16 pad: conflict-free b128 reads)
     constexpr int TM = BM / 64, TN = BN / 64;    // 32x32 tiles per wave along M / N
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
     const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    // split-K: slice z of the reduction; with more than one slice the raw partial sums go to part[z][M][N] and
+    // splitk_reduce_kernel adds them in a fixed order and applies the epilogue
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -82,14 +86,14 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
         for (int v = 0; v < A_V; ++v) {
             int f = tid + v * 256, r = f >> 3, c = (f & 7) * 4, gr = row0 + r, gk = k0 + c;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (gr < M && gk < K) val = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
+            if (gr < M && gk < kend) val = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
             qa[v] = val;
         }
 #pragma unroll
         for (int v = 0; v < W_V; ++v) {
             int f = tid + v * 256, r = f >> 3, c = (f & 7) * 4, gr = col0 + r, gk = k0 + c;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (gr < N && gk < K) val = *reinterpret_cast<const f32x4*>(W + (size_t)gr * ldw + gk);
+            if (gr < N && gk < kend) val = *reinterpret_cast<const f32x4*>(W + (size_t)gr * ldw + gk);
             qw[v] = val;
         }
     };
@@ -140,9 +144,9 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
         __syncthreads();
     };
 
-    load_tiles(0, ra[0], rw[0]);
-    load_tiles(BK, ra[1], rw[1]);
-    for (int k0 = 0; k0 < K; k0 += 2 * BK) {  // steps in pairs (an odd last step multiplies a zero tile)
+    load_tiles(kbeg, ra[0], rw[0]);
+    load_tiles(kbeg + BK, ra[1], rw[1]);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {  // steps in pairs (an odd last step multiplies a zero tile)
         step(k0, ra[0], rw[0]);
         step(k0 + BK, ra[1], rw[1]);
     }
@@ -158,6 +162,10 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) {
                 int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (row >= M) continue;
+                if (gridDim.z > 1) {
+                    part[((size_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bcol;
                 v = apply_epilogue(ep, v, row, col);
                 C[(size_t)row * ldc + col] = v;
@@ -165,18 +173,38 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
         }
 }
 
+static __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpilogue ep) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int row = (int)(idx / N), col = (int)(idx % N);
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += part[(size_t)z * M * N + idx];
+    v += ep.bias ? ep.bias[col] : 0.f;
+    C[(size_t)row * ldc + col] = apply_epilogue(ep, v, row, col);
+}
+
 inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-                         hipStream_t s) {
+                         hipStream_t s, const SplitK* sk = nullptr) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt_split: K/lda/ldw must be multiples of 4");
     if (M <= 0 || N <= 0) return MI_OK;
     if ((int64_t)cdiv(M, 128) * cdiv(N, 128) >= 256) {
         constexpr int BM = 128, BN = 128;
         hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C, ldc,
-                           M, N, K, ep);
+                           M, N, K, ep, K, (float*)nullptr);
     } else {
         constexpr int BM = 64, BN = 64;
-        hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C, ldc,
-                           M, N, K, ep);
+        // few output tiles and a long reduction: the serial k-loop is the latency -- cut it into slices
+        const int tiles = cdiv(M, BM) * cdiv(N, BN);
+        int S = 1;
+        if (sk && sk->buf && tiles <= 128 && K >= 256) {
+            S = std::min(8, K / 128);
+            while (S > 1 && (tiles * S > 512 || (size_t)S * M * N > sk->floats)) --S;
+        }
+        const int kchunk = S > 1 ? cdiv(cdiv(K, S), 64) * 64 : K;
+        S = cdiv(K, kchunk);
+        hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C,
+                           ldc, M, N, K, ep, kchunk, S > 1 ? sk->buf : (float*)nullptr);
+        if (S > 1) hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, s, sk->buf, S, M, N, C, ldc, ep);
     }
     MI_KERNEL_CHECK();
     return MI_OK;
@@ -190,8 +218,8 @@ extern int g_planes_variant;  // 0 = 128x128 tiles, 1 = 256x128 double-buffered 
 extern int g_planes_db_min_tiles;
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-                   hipStream_t s) {
-    return g_gemm_mode == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, ep, s) : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
+                   hipStream_t s, const SplitK* sk = nullptr) {
+    return g_gemm_mode == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, ep, s) : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, ep, s, sk);
 }
 
 }  // namespace mi

@@ -3,6 +3,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "gemm.h"
 
 struct ParamInfo {
     std::string name;
@@ -112,6 +113,7 @@ struct mi_batch {
     float* lp_corr = nullptr;  // [B]
     float* coef = nullptr;     // [T+1][MI_NCOEF]
     int coef_T = -1;
+    mi::SplitK sk;  // split-K scratch of the node-level products (small batches only)
     Tape tape;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // fork / join of work put on an auxiliary stream (mi_ft_micro_step)
     std::vector<void*> allocs;
