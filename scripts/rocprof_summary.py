@@ -28,7 +28,7 @@ def main():
     dur = {}
     cur = sqlite3.connect(trace).cursor()
     for name, calls, tot, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        dur[name.split("(")[0]] = (avg, calls)   # avg in ns
+        dur[name.split("(")[0]] = (avg, calls)   # avg in us
     per = {}
     for p in pmcs:
         cur = sqlite3.connect(p).cursor()
@@ -39,7 +39,7 @@ def main():
     for k, d in per.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d and k in dur:
             fetch, write = 2.0 * d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0
-            avg_us = dur[k][0] / 1e3
+            avg_us = dur[k][0]
             rows.append((dur[k][0] * dur[k][1], k, avg_us, fetch, write, (fetch + write) / (avg_us * 1e-6) / 1e9))
     if rows:
         lines += ["", "## HBM-side traffic per dispatch (FETCH_SIZE x2 correction, WRITE_SIZE as reported) and achieved bandwidth", "",
