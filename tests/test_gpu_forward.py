@@ -190,3 +190,26 @@ def test_full_size_paths_agree():
             set_gemm_mode("split")
     for a, b, w in zip(outs["split"], outs["f32"], ("pred_l", "pred_x", "pred_t")):
         _close(a, b, 2e-5, w + " split vs f32")
+
+
+def test_full_size_forward_vs_oracle():
+    """BASELINE config-2 shape (B=256, n=20, H=512, L=6, F=128, E=102 400): the default HIP path against the CPU oracle itself
+    (one evaluation; the oracle materialises the reference's [E, 1801] edge input, ~0.7 GB).  This is the direct parity check of
+    the kernels that only engage at full size: pair-mode Fourier GEMM, 256-row double-buffered GEMM, fused segmented sum."""
+    B, n, H, L, F = 256, 20, 512, 6, 128
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=4)
+    net = _net(H, L, F, P)
+    g = torch.Generator().manual_seed(17)
+    N = B * n
+    na = torch.full((B,), n, dtype=torch.long)
+    n2g = torch.repeat_interleave(torch.arange(B), na)
+    t_emb = O.time_embedding(torch.full((B,), 640), 256)
+    at = torch.randn(N, 100, generator=g)
+    fr = torch.rand(N, 3, generator=g)
+    lat = 4 * torch.eye(3) + torch.randn(B, 3, 3, generator=g)
+    with torch.no_grad():
+        ref = O.cspnet_forward(P, hp, t_emb, at, fr, lat, na, n2g)
+    out = net(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), None, batch=net.make_batch([n] * B))
+    for a, b, w in zip(out, ref, ("pred_l", "pred_x", "pred_t")):
+        _close(a, b, 2e-5, w + " full size vs oracle")

@@ -143,6 +143,35 @@ def test_gradients_vs_oracle_autograd_ragged():
     assert torch.allclose(m.decoder.theta.grad, 2 * g1, rtol=1e-5, atol=1e-6)
 
 
+def test_gradients_vs_oracle_autograd_mid_size():
+    """The same check at a size where the large-problem kernels run in the training forward and the backward (B=96 x 20 atoms,
+    E=38 400, H=512, L=2, F=128: pair-mode Fourier GEMM and its pair-mode weight gradient, 256-row double-buffered GEMM)."""
+    H, L, F = 512, 2, 128
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=6)
+    gen = torch.Generator().manual_seed(12)
+    m = make_module(H, L, F, 20, P)
+    B, n = 96, 20
+    na = torch.full((B,), n, dtype=torch.long)
+    N = B * n
+    n2g = torch.repeat_interleave(torch.arange(B), na)
+    t_emb = O.time_embedding(torch.full((B,), 7), 256)
+    at, fr = torch.randn(N, 100, generator=gen), torch.rand(N, 3, generator=gen)
+    lat = 4 * torch.eye(3) + torch.randn(B, 3, 3, generator=gen)
+    ul, ux, ut = torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ol, ox, ot = O.cspnet_forward(Pg, hp, t_emb, at, fr, lat, na, n2g)
+    ((ol * ul).sum() + (ox * ux).sum() + (ot * ut).sum()).backward()
+    pl, px, pt = m.decoder(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), na)
+    ((pl * ul.cuda()).sum() + (px * ux.cuda()).sum() + (pt * ut.cuda()).sum()).backward()
+    _rel(pl, ol.detach(), 2e-5, "pred_l")
+    _rel(px, ox.detach(), 2e-5, "pred_x")
+    _rel(pt, ot.detach(), 2e-5, "pred_t")
+    th = m.decoder.theta
+    for k, (o, cnt, shape) in m.decoder.layout.items():
+        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 1e-3, f"grad {k}")
+
+
 def test_fused_adam_matches_torch_adam():
     from matinvent_amd.optim import FusedAdam
     torch.manual_seed(0)
