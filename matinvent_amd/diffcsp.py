@@ -245,6 +245,10 @@ class DiffCSPModule(nn.Module):
 
         def merge(ds):
             m = {}
+            for d in ds:  # the parts were allocated on the group streams and are consumed on the caller's stream
+                for v in d.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
             for name in ds[0]:
                 if name == "batch_idx":
                     m[name] = torch.cat([d[name] + g0[k] for k, d in enumerate(ds)])
