@@ -195,7 +195,7 @@ class DiffCSPModule(nn.Module):
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
         na = [int(v) for v in batch.num_atoms.tolist()]
         if streams is None:
-            streams = 2 if sum(v * v for v in na) >= 65536 else 1
+            streams = 2 if sum(v * v for v in na) >= 16384 else 1  # measured: +8 % at E = 26k (192 mp_20-sized crystals), +6-11 % at 102k
         streams = max(1, min(int(streams), len(na)))
         if streams == 1:
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
