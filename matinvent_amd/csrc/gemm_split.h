@@ -545,8 +545,10 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
 // was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
 // Global -> register prefetch runs TWO k-tiles ahead (the A operand streams from HBM/MALL).
-// This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU), used when M is too small to fill
-// the chip with 256-row tiles; the double-buffered kernel below takes the large edge-level products.
+// This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU).  V = 0: plain products whose M is too
+// small to fill the chip with 256-row tiles (the double-buffered kernel below takes the large ones); V = 1: PAIR mode (see
+// PlanesEpilogue) at every size -- its epilogue is twice as heavy per row of MFMA work, and the second workgroup of the CU
+// hides it behind its own main loop.
 template <int V>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
                                                                                                          int rt_base) {
