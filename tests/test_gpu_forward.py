@@ -213,3 +213,29 @@ def test_full_size_forward_vs_oracle():
     out = net(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), None, batch=net.make_batch([n] * B))
     for a, b, w in zip(out, ref, ("pred_l", "pred_x", "pred_t")):
         _close(a, b, 2e-5, w + " full size vs oracle")
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_forward_random_ragged_batches_vs_oracle(seed):
+    """Randomly drawn ragged batches (1..30 atoms, empty crystals allowed, skewed cells) on the default path: pair tables,
+    segment runs crossing tile boundaries, crystals larger than a 32-row block."""
+    rng = np.random.RandomState(seed)
+    Bc = int(rng.randint(1, 13))
+    na = [int(x) for x in rng.randint(0, 31, size=Bc)]
+    if sum(na) == 0:
+        na[0] = 3
+    H, L, F = (64, 2, 8) if seed % 2 else (128, 1, 10)
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=seed)
+    net = _net(H, L, F, P)
+    g = torch.Generator().manual_seed(seed)
+    N = sum(na)
+    nat = torch.tensor(na)
+    n2g = torch.repeat_interleave(torch.arange(Bc), nat)
+    t_emb = O.time_embedding(torch.randint(1, 1000, (Bc,), generator=g), 256)
+    at, fr = torch.randn(N, 100, generator=g), torch.rand(N, 3, generator=g)
+    lat = 3 * torch.eye(3) + torch.randn(Bc, 3, 3, generator=g)
+    ref = O.cspnet_forward(P, hp, t_emb, at, fr, lat, nat, n2g)
+    out = net(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), None, batch=net.make_batch(na))
+    for a, b, w in zip(out, ref, ("pred_l", "pred_x", "pred_t")):
+        _close(a, b, 2e-5, f"{w} seed {seed} atoms {na}")
