@@ -533,7 +533,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(fourier_pack_kernel, dim3((unsigned)cdiv(nf4, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FFp, b->E, net->F,
                            net->KP);
         MI_KERNEL_CHECK();
-    } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn) {
+    } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0) {
         if (b->Np > 0) {  // pair mode: one operand row per unordered pair
             Planes ffp = make_planes(b->FFpl, 2 * net->Kh);
             const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 2);
@@ -611,7 +611,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 PlanesEpilogue pe1;
                 pe1.ep = g1e;
                 pe1.Cp = m1p;
-                if (g_edge_pairs && !b->knn) {
+                if (g_edge_pairs && !b->knn && H % 8 == 0) {  // (the pair epilogue moves 8 columns per lane)
                     // symmetric edge list: sin(2 pi k (1 - d)) = -sin(2 pi k d), cos unchanged, so one operand row per unordered
                     // pair yields both directed edges (half the MFMA work of this GEMM); self edges (d = 0) are a constant
                     const int Kp = 2 * net->Kh;
