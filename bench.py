@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ft-groups", type=int, default=None, help="--mode ft: crystal groups fine-tuned concurrently (default: automatic)")
-    ap.add_argument("--streams", type=int, default=2, help="crystal groups of the batch sampled concurrently on separate HIP "
+    ap.add_argument("--streams", type=int, default=4, help="crystal groups of the batch sampled concurrently on separate HIP "
                     "streams (same samples: the noise is indexed by global ids)")
     ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused"], default="split-gemm",
                     help="arithmetic path: split-gemm (default) = bf16 three-plane split GEMMs, fp32-class accuracy; "
@@ -274,7 +274,7 @@ def main():
         fp32_equiv = n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12   # TFLOP/s of fp32 multiply-adds the stage delivers
         if args.path == "split-gemm":
             # every fp32 product is issued as SIX bf16 MFMA products: price the matrix pipe with what it executes
-            kernel, issued, peak, dtype = "gemm_planes_kernel<pair> + gemm_planes_db_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
+            kernel, issued, peak, dtype = "gemm_planes_kernel<pair> + gemm_planes_kernel / gemm_planes_db_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges; the 256-row kernel takes the second GEMM from 512 tiles up)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
                 "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"

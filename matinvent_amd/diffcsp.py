@@ -189,13 +189,16 @@ class DiffCSPModule(nn.Module):
         `streams` > 1 splits the crystals into that many contiguous groups and runs their chains CONCURRENTLY on separate
         HIP streams (crystals never interact, and the counter-based noise is indexed by global atom / crystal id, so the
         samples are the same as those of the unsplit batch): the node-level kernels and the partial last round of one
-        group's edge GEMMs overlap the other group's edge GEMMs.  None = automatic (2 for large batches).
+        group's edge GEMMs overlap the other groups' edge GEMMs.  None = automatic (2-4 for large batches).
         """
         if isinstance(batch, CrystalBatch):
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
         na = [int(v) for v in batch.num_atoms.tolist()]
         if streams is None:
-            streams = 2 if sum(v * v for v in na) >= 16384 else 1  # measured: +8 % at E = 26k (192 mp_20-sized crystals), +6-11 % at 102k
+            e_total = sum(v * v for v in na)
+            # measured: 2 chains +8 % at E = 26k (192 mp_20-sized crystals); at E = 102k 1/2/3/4/5 chains give
+            # 24.3 / 25.8 / 26.7 / 27.4 / 22.8 structures/s (the runtime has four hardware queues)
+            streams = 4 if e_total >= 98304 else 3 if e_total >= 49152 else 2 if e_total >= 16384 else 1
         streams = max(1, min(int(streams), len(na)))
         if streams == 1:
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
