@@ -498,7 +498,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
 }
 
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
-                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train) {
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train, bool reuse_embedding) {
     MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_cspnet_forward before mi_net_set_params");
     const int H = net->H, L = net->L, N = b->N, B = b->B, TD = net->TD;
     if (N == 0 || B == 0) return MI_OK;
@@ -514,7 +514,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_HIP(hipMemcpyAsync(tp.frac, frac, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
     }
     // ---- embedding (cspnet.py:265-271) ----
-    {
+    // (reuse_embedding: same t_emb and atom_types as this batch's previous evaluation -- the sampler's predictor evaluation
+    // differs from its corrector evaluation only in the coordinates -- so b->h[0] is still valid)
+    if (!reuse_embedding) {
         GemmEpilogue ep;
         ep.bias = net->p("node_embedding.bias");
         MI_TRY(gemm_nt(atom_types, MI_NUM_TYPES, net->p("node_embedding.weight"), MI_NUM_TYPES, b->x1, H, N, H, MI_NUM_TYPES, ep, s, &b->sk));

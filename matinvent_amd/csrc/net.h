@@ -121,7 +121,8 @@ struct mi_batch {
 
 namespace mi {
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
-                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train = false);
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train = false,
+                bool reuse_embedding = false);
 int net_tape_prepare(mi_net* net, mi_batch* b);
 int net_pack_transposes(mi_net* net, hipStream_t s);
 int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s);

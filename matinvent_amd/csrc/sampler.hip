@@ -259,7 +259,8 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
                            (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr);
         MI_KERNEL_CHECK();
         // predictor
-        MI_TRY(net_forward(net, b, b->temb, atom_types, b->x_mid, lattices, b->pred_l, b->pred_x, b->pred_t, s));
+        // the corrector moved the coordinates only (diffusion.py:320-322): layer-0 node features are those of the evaluation above
+        MI_TRY(net_forward(net, b, b->temb, atom_types, b->x_mid, lattices, b->pred_l, b->pred_x, b->pred_t, s, false, true));
         PredictorArgs a;
         a.x_mid = b->x_mid;
         a.pred_x = b->pred_x;
