@@ -632,7 +632,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     };
 
     load_tiles(0, ra0, rw0);
-    if (KT > 1) load_tiles(1, ra1, rw1);
+    if (V == 0 && KT > 1) load_tiles(1, ra1, rw1);
     int kt = 0;
     // k-tiles kt .. kend-1 (kend - kt even), two per iteration so that the accumulators never cross a conditional; the register
     // prefetch keeps running across calls
@@ -663,20 +663,20 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         };
-        if ((half & 1) == 0) {
-            run_pairs(half);
-            swap_acc();
-            run_pairs(KT);
-        } else {  // odd half (tiny K): plain one-tile-per-iteration loop
-            for (int k2 = 0; k2 < KT; ++k2) {
-                if (k2 == half) swap_acc();
-                load_tiles(k2, ra0, rw0);
+        // one register set, prefetch one k-tile ahead: with two accumulator sets live the two-set loop above spills in its
+        // main loop (120 spilled registers); the second workgroup of the CU covers the shorter prefetch distance
+        auto run_single = [&](int kend) {
+            for (; kt < kend; ++kt) {
                 store_tiles(ra0, rw0);
                 __syncthreads();
+                load_tiles(kt + 1, ra0, rw0);  // past the last k-tile: outside the descriptor (zeros), never staged
                 compute();
                 __syncthreads();
             }
-        }
+        };
+        run_single(half);
+        swap_acc();
+        run_single(KT);
         planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
         return;
     }
