@@ -544,7 +544,7 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // Fragment reads (ds_read_b128, 16-lane groups of rows distinct mod 16, same chunk) and staging writes
 // (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
 // was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
-// Global -> register prefetch runs TWO k-tiles ahead (the A operand streams from HBM/MALL).
+// Global -> register prefetch runs one k-tile ahead (issued right after the staging barrier).
 // This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU).  V = 0: plain products whose M is too
 // small to fill the chip with 256-row tiles (the double-buffered kernel below takes the large ones); V = 1: PAIR mode (see
 // PlanesEpilogue) at every size -- its epilogue is twice as heavy per row of MFMA work, and the second workgroup of the CU
@@ -577,7 +577,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     // a plane tile = 128 rows x 64 B = 512 chunks of 16 B; two per thread per plane.  Buffer loads: the descriptor covers
     // this block's row tile (uniform), the per-thread offset is constant and every tile/plane offset is scalar, so the
     // loop carries no per-load vector address arithmetic.
-    u32x4 ra0[3][2], rw0[3][2], ra1[3][2], rw1[3][2];
+    u32x4 ra0[3][2], rw0[3][2];
     const int KT = (K + 31) / 32;
     const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(rt, 0), KT * 24576);
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(W.base + W.tile(ct, 0), KT * 24576);
@@ -632,61 +632,35 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     };
 
     load_tiles(0, ra0, rw0);
-    if (V == 0 && KT > 1) load_tiles(1, ra1, rw1);
     int kt = 0;
-    // k-tiles kt .. kend-1 (kend - kt even), two per iteration so that the accumulators never cross a conditional; the register
-    // prefetch keeps running across calls
-    auto run_pairs = [&](int kend) {
-        for (; kt + 2 <= kend; kt += 2) {
+    // k-tiles kt .. kend-1.  One register set, loads issued one k-tile ahead (right after the staging barrier, so they have the
+    // whole compute phase to land); the second workgroup of the CU covers what is left.  A two-set, two-tiles-ahead loop measured
+    // 2 % slower here -- and with the pair mode's second accumulator set live it spilled 120 registers inside the loop.
+    auto run = [&](int kend) {
+        for (; kt < kend; ++kt) {
             store_tiles(ra0, rw0);
             __syncthreads();
-            if (kt + 2 < KT) load_tiles(kt + 2, ra0, rw0);
-            compute();
-            __syncthreads();
-            store_tiles(ra1, rw1);
-            __syncthreads();
-            if (kt + 3 < KT) load_tiles(kt + 3, ra1, rw1);
+            load_tiles(kt + 1, ra0, rw0);  // past the last k-tile: outside the descriptor (zeros), never staged
             compute();
             __syncthreads();
         }
     };
     if constexpr (V == 1) {  // PAIR mode: sine half of K into one accumulator set, cosine half into the other (see PlanesEpilogue)
         f32x16 accS[TM][TN];
-        const int half = KT / 2;
-        auto swap_acc = [&]() {
+        run(KT / 2);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    accS[i][j] = acc[i][j];
+            for (int j = 0; j < TN; ++j) {
+                accS[i][j] = acc[i][j];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                }
-        };
-        // one register set, prefetch one k-tile ahead: with two accumulator sets live the two-set loop above spills in its
-        // main loop (120 spilled registers); the second workgroup of the CU covers the shorter prefetch distance
-        auto run_single = [&](int kend) {
-            for (; kt < kend; ++kt) {
-                store_tiles(ra0, rw0);
-                __syncthreads();
-                load_tiles(kt + 1, ra0, rw0);  // past the last k-tile: outside the descriptor (zeros), never staged
-                compute();
-                __syncthreads();
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
-        };
-        run_single(half);
-        swap_acc();
-        run_single(KT);
+        run(KT);
         planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
         return;
     }
-    run_pairs(KT);
-    if (kt < KT) {
-        store_tiles(ra0, rw0);
-        __syncthreads();
-        compute();
-        __syncthreads();
-    }
+    run(KT);
 
     if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
         __syncthreads();                   // the staging patches overlay the operand tiles
