@@ -274,7 +274,7 @@ def main():
         fp32_equiv = n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12   # TFLOP/s of fp32 multiply-adds the stage delivers
         if args.path == "split-gemm":
             # every fp32 product is issued as SIX bf16 MFMA products: price the matrix pipe with what it executes
-            kernel, issued, peak, dtype = "gemm_planes_kernel<pair> + gemm_planes_kernel / gemm_planes_db_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges; the 256-row kernel takes the second GEMM from 512 tiles up)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
+            kernel, issued, peak, dtype = "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
                 "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"

@@ -545,12 +545,12 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // (ds_write_b128, 8 consecutive lanes = 2 rows x 4 chunks) are both conflict-free; a padded-row layout
 // was 2-way on the writes (SQ_LDS_BANK_CONFLICT = 33 % of LDS cycles).
 // Global -> register prefetch runs one k-tile ahead (issued right after the staging barrier).
-// This is the 128x128-tile, two-barriers-per-k-step structure (two workgroups per CU).  V = 0: plain products whose M is too
-// small to fill the chip with 256-row tiles (the double-buffered kernel below takes the large ones); V = 1: PAIR mode (see
-// PlanesEpilogue) at every size -- its epilogue is twice as heavy per row of MFMA work, and the second workgroup of the CU
-// hides it behind its own main loop.
+// This is the 128x128-tile, two-barriers-per-k-step structure.  V = 0: plain products -- 135 registers, so THREE workgroups
+// share a CU (3 x 48 KiB LDS) and cover each other's staging, barriers and epilogues; in situ this beats the 256-row
+// double-buffered kernel below (one workgroup per CU), which is kept as an option.  V = 1: PAIR mode (see PlanesEpilogue) -- a
+// second accumulator set, 196 registers, two workgroups per CU.
 template <int V>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
                                                                                                          int rt_base) {
     constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
