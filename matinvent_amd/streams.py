@@ -12,14 +12,22 @@ import torch
 _CACHE = {}
 
 
-def _pair_is_concurrent(lib, a, b, cycles=400_000):
+def _pair_is_concurrent(lib, a, b, cycles=3_000_000):
+    """Device-side timing (events), and a busy-wait long enough (~1.5 ms) that the host's launch jitter cannot keep two
+    concurrent-capable streams from overlapping."""
     def run(streams):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record(streams[0])
+        ends = []
         for s in streams:
+            s.wait_event(t0)
             lib.mi_debug_spin(cycles, C.c_void_p(s.cuda_stream))
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(s)
+            ends.append(e)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return max(t0.elapsed_time(e) for e in ends)
     run([a])
     one = min(run([a]) for _ in range(2))
     two = min(run([a, b]) for _ in range(2))
