@@ -55,27 +55,24 @@ def test_writers_roundtrip(tmp_path):
     assert "_cell_length_a   5.64" in txt and "_chemical_formula_sum   'ClNa'" in txt and txt.count("\n  Na  Na") == 4
 
 
-def test_host_geometry_matches_oracle_and_filters():
+def test_invalid_filter_thresholds_and_missing_geometry():
+    """The filter thresholds the device-side quantities the sampler attached (here: the oracle's numbers stand in for them);
+    a record without them is an error, not a silent host-side recomputation."""
+    import pytest
     g = torch.Generator().manual_seed(3)
-    data, fr, lat, na = [], [], [], []
-    for n in (1, 4, 9):
-        lengths, angles = 3 + 4 * torch.rand(1, 3, generator=g), 75 + 30 * torch.rand(1, 3, generator=g)
-        f = torch.rand(n, 3, generator=g)
-        data.append(CrystalData(frac_coords=f, atom_types=torch.randint(1, 90, (n,), generator=g), lengths=lengths, angles=angles))
-        fr.append(f)
-        lat.append(torch.from_numpy(S.lattice_matrix(lengths[0].tolist(), angles[0].tolist())).float())
-        na.append(n)
-    chk = O.structure_check(torch.cat(fr), torch.stack(lat), torch.tensor(na))
-    from matinvent_amd.filters import _geometry_host
-    for i, d in enumerate(data):
-        gh = _geometry_host(d)
-        np.testing.assert_allclose([gh["max_cell_edge"], gh["min_distance"], gh["volume"]], chk[i, :3].numpy(), rtol=2e-5)
-    # thresholds: an overlapping pair and a 30 A cell are rejected
+    good = _nacl()
     bad1 = CrystalData(frac_coords=torch.tensor([[0., 0, 0], [0.01, 0, 0]]), atom_types=torch.tensor([1, 1]), lengths=torch.tensor([[5., 5, 5]]),
                        angles=torch.tensor([[90., 90, 90]]))
     bad2 = CrystalData(frac_coords=torch.tensor([[0., 0, 0]]), atom_types=torch.tensor([1]), lengths=torch.tensor([[30., 5, 5]]),
                        angles=torch.tensor([[90., 90, 90]]))
-    good = _nacl()
-    assert invalid_filter([bad1, good, bad2], return_mask=True).tolist() == [False, True, False]
-    kept, _ = invalid_filter([bad1, good, bad2], None)
+    recs = [bad1, good, bad2]
+    fr = torch.cat([d.frac_coords for d in recs])
+    lat = torch.stack([torch.from_numpy(S.lattice_matrix(d.lengths[0].tolist(), d.angles[0].tolist())).float() for d in recs])
+    chk = O.structure_check(fr, lat, torch.tensor([d.num_atoms for d in recs]))
+    for d, c in zip(recs, chk):
+        d.geometry = {"max_cell_edge": float(c[0]), "min_distance": float(c[1]), "volume": float(c[2])}
+    assert invalid_filter(recs, return_mask=True).tolist() == [False, True, False]
+    kept, _ = invalid_filter(recs, None)
     assert kept == [good]
+    with pytest.raises(ValueError, match="geometry"):
+        invalid_filter([_nacl()])
