@@ -275,6 +275,9 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
 int mi_debug_spin(long long cycles, void* stream);
 /* Tuning knob: smallest number of 256-row tiles for which the double-buffered plane GEMM is used (default 256). */
 int mi_debug_set_db_min_tiles(int n);
+/* Tuning knob: smallest node count for which the node-level products (P_i/P_j projections, node MLP) run on the plane-set
+ * GEMM kernel (pre-split weights, producer-written activation planes); smaller batches use the fp32-operand split-K kernel. */
+int mi_debug_set_node_planes_min_rows(int n);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 

@@ -16,6 +16,7 @@ int g_planes_variant = 0;  // 0: 128-row kernel everywhere (default: with three 
 int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
+int g_node_planes_min_rows = 512;  // node-level products: plane-set kernel from this many nodes up, fp32-operand split-K kernel below
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -231,14 +232,14 @@ __global__ void wff_cos_rowsum_kernel(const float* __restrict__ W1, int edge_in,
 //   Z1 = P_i[i] + P_j[i] + G[graph] + C0;  M1 = SiLU(Z1) written as planes at row e_diag[i]  (cspnet.py:59-79)
 __global__ void edge_diag_kernel(const float* __restrict__ PQ, const float* __restrict__ G, const float* __restrict__ C0,
                                  const int* __restrict__ node2graph, const int* __restrict__ e_diag, float* __restrict__ pre_act, Planes M1,
-                                 int N, int H) {
+                                 int N, int H, int ldpq) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * (H / 2)) return;
     const int i = (int)(idx / (H / 2)), f = (int)(idx % (H / 2)) * 2, e = e_diag[i], g = node2graph[i];
     float v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        v[u] = C0[f + u] + ((PQ[(size_t)i * 2 * H + f + u] + PQ[(size_t)i * 2 * H + H + f + u]) + G[(size_t)g * H + f + u]);
+        v[u] = C0[f + u] + ((PQ[(size_t)i * ldpq + f + u] + PQ[(size_t)i * ldpq + H + f + u]) + G[(size_t)g * H + f + u]);
     if (pre_act) {
         pre_act[(size_t)e * H + f] = v[0];
         pre_act[(size_t)e * H + f + 1] = v[1];
@@ -280,9 +281,10 @@ __global__ void pack_w2_kernel(const float* __restrict__ W2, int H, float* __res
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (one wave per row).  y has row stride ldy (writes into cat[:, :H]).
 // ------------------------------------------------------------------------------------------
+// ypl (optional): the same values as a bf16 plane set (the A operand of the node-level GEMMs).
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bsh, float* __restrict__ y, int ldy,
-                                                        float* __restrict__ stats, int N, int H) {
+                                                        float* __restrict__ stats, int N, int H, Planes ypl = Planes()) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const float* xr = x + (size_t)row * H;
@@ -303,18 +305,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float rstd = 1.0f / sqrtf(var + 1e-5f);
     float* yr = y + (size_t)row * ldy;
     cnt = 0;
-    for (int c = lane; c < H; c += 64) yr[c] = (v[cnt++] - mean) * rstd * w[c] + bsh[c];
+    for (int c = lane; c < H; c += 64) {
+        const float o = (v[cnt++] - mean) * rstd * w[c] + bsh[c];
+        yr[c] = o;
+        if (ypl.base) {
+            u16 p0, p1, p2;
+            split3(o, p0, p1, p2);
+            ypl.base[ypl.elem(row, c, 0)] = p0;
+            ypl.base[ypl.elem(row, c, 1)] = p1;
+            ypl.base[ypl.elem(row, c, 2)] = p2;
+        }
+    }
     if (stats && lane == 0) {
         stats[2 * row] = mean;
         stats[2 * row + 1] = rstd;
     }
 }
 
-__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy, int N, int H) {
+__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy, int N, int H, Planes ypl = Planes()) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * H) return;
     int r = (int)(idx / H), c = (int)(idx % H);
     y[(size_t)r * ldy + c] = x[idx];
+    if (ypl.base) {
+        u16 p0, p1, p2;
+        split3(x[idx], p0, p1, p2);
+        ypl.base[ypl.elem(r, c, 0)] = p0;
+        ypl.base[ypl.elem(r, c, 1)] = p1;
+        ypl.base[ypl.elem(r, c, 2)] = p2;
+    }
 }
 
 // G[b][f] = b1[f] + sum_m (L L^T)[b].flat[m] * W1[f][2H + m]      (cspnet.py:68-72)
@@ -338,8 +357,9 @@ __global__ void gram_term_kernel(const float* __restrict__ lattices, const float
 }
 
 // agg[i] = (sum of this node's slots) / degree  -> cat[i][H:2H]       (scatter mean, cspnet.py:79)
+// aggpl (optional): the same values as a bf16 plane set (N x H).
 __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* __restrict__ rowptr,
-                                    float* __restrict__ cat, int N, int H) {
+                                    float* __restrict__ cat, int N, int H, Planes aggpl = Planes()) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * H) return;
     int i = (int)(idx / H), f = (int)(idx % H);
@@ -351,6 +371,13 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
         s = s / (float)(e1 - e0);
     }
     cat[(size_t)i * (2 * H) + H + f] = s;
+    if (aggpl.base) {
+        u16 p0, p1, p2;
+        split3(s, p0, p1, p2);
+        aggpl.base[aggpl.elem(i, f, 0)] = p0;
+        aggpl.base[aggpl.elem(i, f, 1)] = p1;
+        aggpl.base[aggpl.elem(i, f, 2)] = p2;
+    }
 }
 
 // graph mean-pool + lattice head:  out[b] = reshape(Wl * mean_i hf_i, 3, 3) @ L_b  (cspnet.py:281-289)
@@ -560,25 +587,40 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
+    const bool node_planes = g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && H % 32 == 0 && N >= g_node_planes_min_rows;
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
         float* h_out = b->h + (l + 1) * NH;
         float* cat = train ? tp.cat + (size_t)l * N * 2 * H : b->cat;
+        // node-level products on the plane-set kernel too (weights pre-split once per parameter update, the activations' planes
+        // written by their producers; the fp32-operand kernel re-splits every operand tile in every workgroup).  Grouped by
+        // operand: everything LayerNorm(h) feeds -- P_i, P_j and its half of the node MLP's first product -- is ONE product
+        // before the edge stage, so only agg x W[:, H:] (K = H instead of 2H) is left on the path after it.
+        const Planes lnp = node_planes ? make_planes(b->lnpl, H) : Planes();
+        const Planes aggp = node_planes ? make_planes(b->aggpl, H) : Planes();
+        const int ldpq = node_planes ? 3 * H : 2 * H;
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_in, net->p(p + "layer_norm.weight"),
-                               net->p(p + "layer_norm.bias"), cat, 2 * H, train ? tp.lnstat + (size_t)l * N * 2 : (float*)nullptr, N, H);
+                               net->p(p + "layer_norm.bias"), cat, 2 * H, train ? tp.lnstat + (size_t)l * N * 2 : (float*)nullptr, N, H, lnp);
         } else {
-            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, cat, 2 * H, N, H);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, cat, 2 * H, N, H, lnp);
         }
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+        if (node_planes) {
+            PlanesEpilogue pq;
+            pq.C = b->PQ;
+            pq.ldc = ldpq;
+            MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, s));
+        } else {
+            MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+        }
         hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
                            net->p(p + "edge_mlp.0.bias"), b->G, H);
         MI_KERNEL_CHECK();
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
             MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
-            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         } else if (b->E > 0) {      // two tiled GEMMs over the edge list with gather / SiLU epilogues
             const int E = (int)b->E, F6 = 6 * net->F;
@@ -587,10 +629,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             GemmEpilogue g1e;       // Z1 = FF Wff^T + P_i[src] + P_j[dst] + G[graph];  M1 = SiLU(Z1)
             g1e.row_bias = b->PQ;
             g1e.row_group = b->src;
-            g1e.ld_row_bias = 2 * H;
+            g1e.ld_row_bias = ldpq;
             g1e.row_bias2 = b->PQ + H;
             g1e.row_group2 = b->dst;
-            g1e.ld_row_bias2 = 2 * H;
+            g1e.ld_row_bias2 = ldpq;
             g1e.row_bias3 = b->G;
             g1e.row_group3 = b->edge_graph;
             g1e.ld_row_bias3 = H;
@@ -627,7 +669,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
                     hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G,
-                                       net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H);
+                                       net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
                     MI_KERNEL_CHECK();
                 } else {
                     MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
@@ -640,7 +682,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_nodes = N;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
                 MI_TRY(prof_end(net, s, ps));
-                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
                 MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
@@ -650,7 +692,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 MI_KERNEL_CHECK();
             }
         } else {
-            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H);
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         }
         GemmEpilogue e1;
@@ -660,7 +702,16 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             e1.pre_act = tp.Xpre + (size_t)l * NH;
             e1.ld_pre = H;
         }
-        MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s, &b->sk));
+        if (node_planes) {
+            PlanesEpilogue p1;
+            p1.ep = e1;
+            p1.ep.pre_add = b->PQ + 2 * H;  // LayerNorm(h) x W[:, :H], computed with P_i / P_j
+            p1.ep.ld_pre_add = ldpq;
+            p1.Cp = make_planes(b->Xpl, H);
+            MI_TRY(gemm_planes(aggp, make_planes(net->Waggpl + (size_t)l * planes_elems(H, H), H), N, H, H, p1, s));
+        } else {
+            MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s, &b->sk));
+        }
         GemmEpilogue e2;
         e2.bias = net->p(p + "node_mlp.2.bias");
         e2.act = ACT_SILU;
@@ -670,7 +721,15 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             e2.pre_act = tp.Ypre + (size_t)l * NH;
             e2.ld_pre = H;
         }
-        MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s, &b->sk));
+        if (node_planes) {
+            PlanesEpilogue p2;
+            p2.ep = e2;
+            p2.C = h_out;
+            p2.ldc = H;
+            MI_TRY(gemm_planes(make_planes(b->Xpl, H), make_planes(net->Wn2pl + (size_t)l * planes_elems(H, H), H), N, H, H, p2, s));
+        } else {
+            MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s, &b->sk));
+        }
     }
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
@@ -768,6 +827,9 @@ void mi_net_destroy(mi_net* n) {
     if (n->Wffpl_pair) (void)hipFree(n->Wffpl_pair);
     if (n->C0) (void)hipFree(n->C0);
     if (n->W2pl) (void)hipFree(n->W2pl);
+    if (n->Wlnpl) (void)hipFree(n->Wlnpl);
+    if (n->Waggpl) (void)hipFree(n->Waggpl);
+    if (n->Wn2pl) (void)hipFree(n->Wn2pl);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
 }
@@ -799,6 +861,9 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Wff, (size_t)n->L * H * 6 * n->F * sizeof(float)));
         MI_HIP(hipMalloc((void**)&n->Wffpl, (size_t)n->L * planes_elems(H, 6 * n->F) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->W2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->Wlnpl, (size_t)n->L * planes_elems(3 * H, H) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->Waggpl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->Wn2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
@@ -830,6 +895,17 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             Planes wpp = make_planes(n->Wffpl_pair + (size_t)l * planes_elems(H, 2 * n->Kh), 2 * n->Kh);
             hipLaunchKernelGGL(pack_wff_pair_planes_kernel, dim3(cdiv((int64_t)Hp * n->Kh, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->Kh, wpp);
             hipLaunchKernelGGL(wff_cos_rowsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->C0 + (size_t)l * H);
+            // node-level weights, grouped by operand: [P_i; P_j; node_mlp.0[:, :H]] multiply LayerNorm(h), node_mlp.0[:, H:] the
+            // aggregated messages (that product then sits alone on the path after the edge stage)
+            const float* Wn0 = n->p(p + "node_mlp.0.weight");
+            const int H3p = (3 * H + 127) / 128 * 128;
+            Planes wlnp = make_planes(n->Wlnpl + (size_t)l * planes_elems(3 * H, H), H);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, n->Whh + l * n->whh_stride(), H, 2 * H, H, wlnp, 0);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, Wn0, 2 * H, H, H, wlnp, 2 * H);
+            Planes waggp = make_planes(n->Waggpl + (size_t)l * planes_elems(H, H), H);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
+            Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
         }
     }
     MI_KERNEL_CHECK();
@@ -923,7 +999,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(rowptr, N + 1);
     A_(h, (L + 1) * NH);
     A_(cat, 2 * NH);
-    A_(PQ, 2 * NH);
+    A_(PQ, 3 * NH);  // [N][2H] P_i | P_j, or [N][3H] with the LayerNorm(h) part of the node MLP's first product appended
     A_(G, (size_t)B * H);
     A_(part, nslots * NH);
     A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
@@ -938,6 +1014,9 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(pair_graph, (size_t)b->Np);
     A_(e_diag, knn ? 0 : N);
     A_(M1pl, planes_elems(E, H));
+    A_(lnpl, planes_elems(N, H));
+    A_(aggpl, planes_elems(N, H));
+    A_(Xpl, planes_elems(N, H));
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);
@@ -959,7 +1038,10 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
         return rc;
     }
     // M1 planes: the GEMM epilogue only writes rows < E; the row padding of the last tile must be finite
-    if (hipMemset(b->M1pl, 0, planes_elems(E, H) * sizeof(unsigned short)) != hipSuccess) {
+    if (hipMemset(b->M1pl, 0, planes_elems(E, H) * sizeof(unsigned short)) != hipSuccess ||
+        hipMemset(b->lnpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
+        hipMemset(b->aggpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
+        hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess) {
         mi_batch_destroy(b);
         set_error("hipMemset failed");
         return MI_EHIP;
@@ -1035,6 +1117,11 @@ int mi_set_gemm_mode(int mode) {
 int mi_debug_set_db_min_tiles(int n) {
     if (n < 0) g_pair_kernel = 1;  // negative: also let pair-mode GEMMs pick the kernel by size
     g_planes_db_min_tiles = n < 0 ? -n : n;
+    return MI_OK;
+}
+
+int mi_debug_set_node_planes_min_rows(int n) {
+    g_node_planes_min_rows = n;
     return MI_OK;
 }
 

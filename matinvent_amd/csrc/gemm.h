@@ -33,6 +33,8 @@ struct GemmEpilogue {
     const float* row_bias3 = nullptr;
     const int* row_group3 = nullptr;
     int ld_row_bias3 = 0;
+    const float* pre_add = nullptr;   // [M, ld_pre_add] added BEFORE the activation (a partial product computed earlier)
+    int ld_pre_add = 0;
     const float* residual = nullptr;  // [M, ld_res] added AFTER the activation
     int ld_res = 0;
     int act = ACT_NONE;
@@ -50,6 +52,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
         if (ep.row_bias3) g += ep.row_bias3[(size_t)ep.row_group3[row] * ep.ld_row_bias3 + col];
         v += g;
     }
+    if (ep.pre_add) v += ep.pre_add[(size_t)row * ep.ld_pre_add + col];
     if (ep.pre_act) ep.pre_act[(size_t)row * ep.ld_pre + col] = v;
     if (ep.act == ACT_SILU) v = FAST ? silu_fast(v) : silu(v);
     if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];

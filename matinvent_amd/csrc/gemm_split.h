@@ -251,10 +251,12 @@ static inline size_t planes_elems(int64_t rows, int cols) { return (size_t)((row
 static inline Planes make_planes(u16* base, int cols) { return Planes{base, (cols + 31) / 32}; }
 
 // fp32 [rows][cols] (row stride ld_src) -> plane set (pads written as zero); one thread per column pair
-static __global__ void split_planes_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, Planes dst) {
+// (row0: first destination row -- lets several matrices share one plane set; the zero row padding then runs to the next
+// multiple of 128 destination rows, so stack them in increasing row order)
+static __global__ void split_planes_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, Planes dst, int row0 = 0) {
     const int cp = dst.KT * 16;  // column pairs per padded row
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t rows_pad = (int64_t)(rows + 127) / 128 * 128;
+    const int64_t rows_pad = (int64_t)(row0 + rows + 127) / 128 * 128 - row0;
     if (idx >= rows_pad * cp) return;
     int r = (int)(idx / cp), c = (int)(idx % cp) * 2;
     float x = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
@@ -262,7 +264,7 @@ static __global__ void split_planes_kernel(const float* __restrict__ src, int ld
     unsigned p[3];
     split3_pair(x, y, p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(r, c, k)) = p[k];
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(row0 + r, c, k)) = p[k];
 }
 
 // buffer descriptor over [p, p + bytes) with every field forced into scalar registers (the compiler otherwise
@@ -408,6 +410,7 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] += g[k];
                     }
+                    if (ep.pre_add) add8(v, ep.pre_add + (size_t)row * ep.ld_pre_add + col);
                     if (ep.pre_act) {
                         float* d = ep.pre_act + (size_t)row * ep.ld_pre + col;
                         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
@@ -417,6 +420,7 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
                     }
+                    if (ep.residual) add8(v, ep.residual + (size_t)row * ep.ld_res + col);
                     if (pe.C) {
                         float* d = pe.C + (size_t)row * pe.ldc + col;
                         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
@@ -533,7 +537,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
 
 // whether the row-major epilogue applies (otherwise the result-layout one, which also carries the fused segmented sum)
 __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
-    return pe.Cp.base != nullptr && pe.seg_part == nullptr && pe.ep.residual == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 &&
+    return (pe.Cp.base != nullptr || pe.C != nullptr) && pe.seg_part == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 && (pe.ep.ld_res & 3) == 0 && (pe.ep.ld_pre_add & 3) == 0 &&
            (pe.ep.ld_pre & 3) == 0 && (pe.ep.ld_row_bias & 3) == 0 && (pe.ep.ld_row_bias2 & 3) == 0 && (pe.ep.ld_row_bias3 & 3) == 0;
 }
 
@@ -689,7 +693,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     if (rt2 * 256 >= Mlim) return;  // this launch covers rows [0, Mlim)
     const int row0 = rt2 * 256, col0 = ct * 128;
     const int KT = (K + 31) / 32, RT = (M + 127) / 128;
-    const int rowtile_bytes = (KT * 12288 + 2048) * 2;
+    const int rowtile_bytes = (A.KT * 12288 + 2048) * 2;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -812,7 +816,8 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
-    MI_CHECK(A.KT == (K + 31) / 32 && W.KT == A.KT, MI_EINVAL, "gemm_planes: operand plane sets do not match K");
+    // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
+    MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
     const bool pair = pe.pair_i != nullptr;
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,

@@ -28,6 +28,10 @@ struct mi_net {
     int edge_mode = 1;       // MI_EDGE_GEMM (default) or MI_EDGE_FUSED_F32
     unsigned short* Wffpl = nullptr;  // [L][3][H][ld(6F)] bf16 planes of Wff
     unsigned short* W2pl = nullptr;   // [L][3][H][H]      bf16 planes of edge_mlp.2.weight
+    // [L] plane sets of the node-level weights, grouped by the operand they multiply:
+    unsigned short* Wlnpl = nullptr;   // (3H x H): [P_i block; P_j block; node_mlp.0.weight[:, :H]] -- everything LayerNorm(h) feeds
+    unsigned short* Waggpl = nullptr;  // (H x H):  node_mlp.0.weight[:, H:]  (multiplies the aggregated messages)
+    unsigned short* Wn2pl = nullptr;   // (H x H):  node_mlp.2.weight
     // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],
     // Kh = 3F rounded up to 32, so that each block is a whole number of k-tiles
     int Kh = 0;
@@ -99,6 +103,9 @@ struct mi_batch {
     float* M2 = nullptr;     // [E][H]
     unsigned short* FFpl = nullptr;  // [3][E][ld(6F)] bf16 planes of the Fourier features
     unsigned short* M1pl = nullptr;  // [3][E][H]      bf16 planes of M1
+    unsigned short* lnpl = nullptr;  // plane sets of LayerNorm(h) and of the aggregated messages (N x H each)
+    unsigned short* aggpl = nullptr;
+    unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
