@@ -220,6 +220,8 @@ def main():
         lib.mi_debug_set_db_min_tiles(int(os.environ["MI_DB_MIN_TILES"]))
     if os.environ.get("MI_NODE_PLANES_MIN_ROWS"):
         lib.mi_debug_set_node_planes_min_rows(int(os.environ["MI_NODE_PLANES_MIN_ROWS"]))
+    if os.environ.get("MI_PLANES_SMALL_TILES"):
+        lib.mi_debug_set_planes_small_tiles(int(os.environ["MI_PLANES_SMALL_TILES"]))
     if os.environ.get("MI_EDGE_PAIRS"):
         lib.mi_set_edge_pairs(int(os.environ["MI_EDGE_PAIRS"]))
     from matinvent_amd.cspnet import set_gemm_mode

@@ -278,6 +278,8 @@ int mi_debug_set_db_min_tiles(int n);
 /* Tuning knob: smallest node count for which the node-level products (P_i/P_j projections, node MLP) run on the plane-set
  * GEMM kernel (pre-split weights, producer-written activation planes); smaller batches use the fp32-operand split-K kernel. */
 int mi_debug_set_node_planes_min_rows(int n);
+/* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
+int mi_debug_set_planes_small_tiles(int n);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 

@@ -15,6 +15,7 @@ int g_planes_variant = 0;  // 0: 128-row kernel everywhere (default: with three 
                            // kernel in situ: 26.8 vs 25.2 structures/s on one stream); 1: 256-row kernel from g_planes_db_min_tiles up
 int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
+int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 int g_node_planes_min_rows = 512;  // node-level products: plane-set kernel from this many nodes up, fp32-operand split-K kernel below
 
@@ -1117,6 +1118,11 @@ int mi_set_gemm_mode(int mode) {
 int mi_debug_set_db_min_tiles(int n) {
     if (n < 0) g_pair_kernel = 1;  // negative: also let pair-mode GEMMs pick the kernel by size
     g_planes_db_min_tiles = n < 0 ? -n : n;
+    return MI_OK;
+}
+
+int mi_debug_set_planes_small_tiles(int n) {
+    g_planes_small_tiles = n;
     return MI_OK;
 }
 

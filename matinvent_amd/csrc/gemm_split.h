@@ -216,6 +216,7 @@ inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float
 extern int g_gemm_mode;
 extern int g_planes_variant;  // 0 = 128x128 tiles, 1 = 256x128 double-buffered (large M)
 extern int g_planes_db_min_tiles;
+extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                    hipStream_t s, const SplitK* sk = nullptr) {
@@ -553,13 +554,13 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // share a CU (3 x 48 KiB LDS) and cover each other's staging, barriers and epilogues; in situ this beats the 256-row
 // double-buffered kernel below (one workgroup per CU), which is kept as an option.  V = 1: PAIR mode (see PlanesEpilogue) -- a
 // second accumulator set, 196 registers, two workgroups per CU.
-template <int V>
+template <int V, int TM = 2>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
                                                                                                          int rt_base) {
-    constexpr int BM = 128, BN = 128, BK = 32, TM = 2, TN = 2, PLB = 128 * 64;  // bytes per plane tile in LDS
+    constexpr int BM = 64 * TM, BN = 128, BK = 32, TN = 2, PLA = BM * 64, PLB = 128 * 64;  // bytes per plane tile in LDS (A, W)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Ws = smem + 3 * PLB;
+    unsigned char* Ws = smem + 3 * PLA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
     // XCD-aware tile mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all column tiles of one row tile run
@@ -581,26 +582,28 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     // a plane tile = 128 rows x 64 B = 512 chunks of 16 B; two per thread per plane.  Buffer loads: the descriptor covers
     // this block's row tile (uniform), the per-thread offset is constant and every tile/plane offset is scalar, so the
     // loop carries no per-load vector address arithmetic.
-    u32x4 ra0[3][2], rw0[3][2];
+    u32x4 ra0[3][TM], rw0[3][2];
     const int KT = (K + 31) / 32;
-    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(rt, 0), KT * 24576);
+    // (TM = 1: 64-row tiles, i.e. one half of a 128-row plane tile -- 4 KiB into each plane)
+    const int ahalf = TM == 1 ? (rt & 1) * 4096 : 0;
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(TM == 1 ? rt >> 1 : rt, 0), KT * 24576);
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(W.base + W.tile(ct, 0), KT * 24576);
-    auto load_tiles = [&](int kt, u32x4 (&ra)[3][2], u32x4 (&rw)[3][2]) {
+    auto load_tiles = [&](int kt, u32x4 (&ra)[3][TM], u32x4 (&rw)[3][2]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                ra[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, kt * 24576 + p * 8192 + v * 4096, 0);
+                if (v < TM) ra[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, kt * 24576 + p * 8192 + v * 4096 + ahalf, 0);
                 rw[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsw, tid * 16, kt * 24576 + p * 8192 + v * 4096, 0);
             }
     };
-    auto store_tiles = [&](const u32x4 (&ra)[3][2], const u32x4 (&rw)[3][2]) {
+    auto store_tiles = [&](const u32x4 (&ra)[3][TM], const u32x4 (&rw)[3][2]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 const int f = v * 256 + tid, r = f >> 2, c = (f & 3) ^ ((r >> 2) & 3);
-                *reinterpret_cast<u32x4*>(As + p * PLB + r * 64 + c * 16) = ra[p][v];
+                if (v < TM) *reinterpret_cast<u32x4*>(As + p * PLA + r * 64 + c * 16) = ra[p][v];
                 *reinterpret_cast<u32x4*>(Ws + p * PLB + r * 64 + c * 16) = rw[p][v];
             }
     };
@@ -612,7 +615,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
             for (int i = 0; i < TM; ++i) {
                 const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLB + r * 64 + c * 16);
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + r * 64 + c * 16);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -838,9 +841,12 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else if (pair) {
-        hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+    } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
+        // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
+        hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), 3 * 64 * 64 + 3 * 128 * 64, s, A, W, M, N, K, pe, 0);
     } else {
-        hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
     }
     MI_KERNEL_CHECK();
     return MI_OK;

@@ -46,3 +46,27 @@ def test_double_buffered_plane_gemm_vs_fp64(M, N, K):
         torch.cuda.synchronize()
         errs[kind] = (out.double() - ref).abs().max().item() / scale
         assert errs[kind] < 3e-6, (kind, errs)
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 1536, 512), (5120, 512, 512), (193, 512, 96), (64, 100, 100)])
+def test_plane_gemm_64_row_tiles_bit_identical(M, N, K):
+    """Few-tile products (the node-level ones) run on 64-row tiles; per output element the k order and the order of the six
+    product terms are those of the 128-row kernel, so the two must agree bit for bit (ragged M: odd number of 64-row tiles)."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    outs = []
+    try:
+        for small in (0, 1 << 30):
+            _lib.check(lib.mi_debug_set_planes_small_tiles(small))
+            out = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(lib.mi_debug_gemm(2, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.check(lib.mi_debug_set_planes_small_tiles(0))
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double() @ W.double().t()
+    assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
