@@ -119,6 +119,15 @@ def _oracle_steps(O, P, hp, sch, na, noise, t_from, t_to):
     return O.sample(P, hp, s, na, noise, step_lr=STEP_LR, t_stop=t_to, keep_traj=False)
 
 
+def _apply_env_knobs(lib):
+    """Experiment knobs (A/B runs of kernel choices); the defaults are what the library ships with."""
+    for env, fn in (("MI_DB_MIN_TILES", lib.mi_debug_set_db_min_tiles), ("MI_NODE_PLANES_MIN_ROWS", lib.mi_debug_set_node_planes_min_rows),
+                    ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128),
+                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs)):
+        if os.environ.get(env):
+            fn(int(os.environ[env]))
+
+
 def main_ft(args):
     """Secondary metric (BASELINE configs[2]/[3]): crystal-timesteps / second of the fine-tune loop
     (noise + agent fwd + frozen-prior fwd + agent bwd per timestep, fused Adam every 50), ft set =
@@ -141,6 +150,8 @@ def main_ft(args):
     torch.cuda.set_device(dev)
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import ft_step
+    from matinvent_amd import _lib
+    _apply_env_knobs(_lib.load())
     agent, prior = build_module(dev), build_module(dev)
     prior.requires_grad_(False)
     g = torch.Generator().manual_seed(7)
@@ -216,14 +227,7 @@ def main():
     from matinvent_amd import _lib, build as _build
     _build.build(verbose=False)
     lib = _lib.load()
-    if os.environ.get("MI_DB_MIN_TILES"):
-        lib.mi_debug_set_db_min_tiles(int(os.environ["MI_DB_MIN_TILES"]))
-    if os.environ.get("MI_NODE_PLANES_MIN_ROWS"):
-        lib.mi_debug_set_node_planes_min_rows(int(os.environ["MI_NODE_PLANES_MIN_ROWS"]))
-    if os.environ.get("MI_PLANES_SMALL_TILES"):
-        lib.mi_debug_set_planes_small_tiles(int(os.environ["MI_PLANES_SMALL_TILES"]))
-    if os.environ.get("MI_EDGE_PAIRS"):
-        lib.mi_set_edge_pairs(int(os.environ["MI_EDGE_PAIRS"]))
+    _apply_env_knobs(lib)
     from matinvent_amd.cspnet import set_gemm_mode
     set_gemm_mode("split" if args.path == "split-gemm" else "f32")
     m = build_module(dev)

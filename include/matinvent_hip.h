@@ -263,7 +263,9 @@ int mi_net_set_edge_mode(mi_net* net, int mode);
 int mi_set_edge_pairs(int on);
 
 /* Diagnostics: C[M,N] = A[M,K] W[N,K]^T through the node-level GEMM kernels.  kind 0 = f32-input MFMA,
- * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe. */
+ * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe; kinds 2 / 3 = the same on pre-split
+ * tile-blocked plane sets (128-row / 256-row double-buffered kernel); kind 4 = the weight-gradient form C[M,N] += A^T W with
+ * A [K,M] and W [K,N] (contraction over rows, f32 MFMA, deterministic split reduction). */
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M,
                   int N, int K, void* stream);
 /* bench.py's roofline hook: HIP events bracket the dominant stage (the per-edge MLP of one layer) on the stream it is
@@ -278,6 +280,8 @@ int mi_debug_set_db_min_tiles(int n);
 /* Tuning knob: smallest node count for which the node-level products (P_i/P_j projections, node MLP) run on the plane-set
  * GEMM kernel (pre-split weights, producer-written activation planes); smaller batches use the fp32-operand split-K kernel. */
 int mi_debug_set_node_planes_min_rows(int n);
+/* Tuning knob: weight-gradient products over long row lists on 128 x 128 tiles (default 1) or always 64 x 64 (0). */
+int mi_debug_set_tn128(int on);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
 int mi_profile_enable(mi_net* net, int on);

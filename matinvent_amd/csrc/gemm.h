@@ -14,6 +14,8 @@
 
 namespace mi {
 
+extern int g_tn128;  // weight-gradient products over long row lists on 128 x 128 tiles (1) or always 64 x 64 (0)
+
 enum { ACT_NONE = 0, ACT_SILU = 1 };
 
 // scratch for split-K partial sums (small-M products: more workgroups, shorter serial k-loops)
@@ -239,6 +241,92 @@ static __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __rest
     }
 }
 
+// The same product on 128 x 128 output tiles (each wave a 64 x 64 quadrant = four accumulator tiles): half the LDS reads and a
+// quarter of the operand re-reads per MFMA of the 64 x 64 kernel, next 32-row slab prefetched into registers during the MFMAs.
+// Used for the large weight-gradient products (contraction over the edge or pair list).
+static __global__ __launch_bounds__(256) void gemm_tn128_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
+                                                                float* __restrict__ P, int M, int Na, int Kx, int rows_per_split, int gx,
+                                                                int gy, int nsplit) {
+    constexpr int BM = 32, LD = 132;
+    // XCD-aware mapping (workgroup id % 8 = XCD, each with its own L2): all gx*gy output tiles of one row range run on the SAME
+    // XCD, so each operand slab comes from HBM once instead of once per XCD (measured: 3x the algorithmic fetch without it)
+    const int id_ = blockIdx.x, slot_ = id_ >> 3, tile_ = slot_ % (gx * gy), bz = (slot_ / (gx * gy)) * 8 + (id_ & 7);
+    if (bz >= nsplit) return;
+    const int bx = tile_ % gx, by = tile_ / gx;
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[BM * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int n0 = by * 128, k0 = bx * 128;
+    const int m_begin = bz * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool a_vec = (lda % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
+    const bool x_vec = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+    // a 32-row slab = 32 x 128 floats per operand = 1024 float4: four per thread and operand
+    f32x4 va[4], vx[4];
+    auto load_slab = [&](int m0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int f = tid + v * 256, r = f >> 5, c = (f & 31) * 4, gm = m0 + r;
+            va[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vx[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gm < m_end) {
+                const float* pa = A + (size_t)gm * lda + n0 + c;
+                const float* px = X + (size_t)gm * ldx + k0 + c;
+                if (a_vec && n0 + c + 3 < Na) va[v] = *reinterpret_cast<const f32x4*>(pa);
+                else
+                    for (int u = 0; u < 4; ++u) va[v][u] = (n0 + c + u < Na) ? pa[u] : 0.f;
+                if (x_vec && k0 + c + 3 < Kx) vx[v] = *reinterpret_cast<const f32x4*>(px);
+                else
+                    for (int u = 0; u < 4; ++u) vx[v][u] = (k0 + c + u < Kx) ? px[u] : 0.f;
+            }
+        }
+    };
+    load_slab(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += BM) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int f = tid + v * 256, r = f >> 5, c = (f & 31) * 4;
+            *reinterpret_cast<f32x4*>(&As[r * LD + c]) = va[v];
+            *reinterpret_cast<f32x4*>(&Xs[r * LD + c]) = vx[v];
+        }
+        __syncthreads();
+        if (m0 + BM < m_end) load_slab(m0 + BM);
+#pragma unroll
+        for (int s = 0; s < BM / 2; ++s) {
+            float av[2], xv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i] = As[(2 * s + hi) * LD + wn * 64 + i * 32 + l31];
+                xv[i] = Xs[(2 * s + hi) * LD + wk * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], xv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int PK = gx * 128;
+    float* Pt = P + (size_t)bz * (gy * 128) * PK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk * 64 + j * 32 + l31;
+                Pt[(size_t)n * PK + k] = acc[i][j][r];
+            }
+}
+
 static __global__ void tn_reduce_kernel(const float* __restrict__ P, int nsplit, int PN, int PK, float* __restrict__ C, int ldc, int Na,
                                  int Kx, float scale) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,6 +341,19 @@ static __global__ void tn_reduce_kernel(const float* __restrict__ P, int nsplit,
 inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
                        size_t scratch_floats, hipStream_t s) {
     if (M <= 0 || Na <= 0 || Kx <= 0) return MI_OK;
+    if (g_tn128 && Na >= 128 && Kx >= 128 && M >= 8192) {  // the edge / pair-list contractions
+        const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
+        while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
+        MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
+        const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
+        nsplit = cdiv(M, rows);
+        hipLaunchKernelGGL(gemm_tn128_kernel, dim3(gx * gy * ((nsplit + 7) / 8 * 8)), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc,
+                           Na, Kx, 1.0f);
+        MI_KERNEL_CHECK();
+        return MI_OK;
+    }
     const int gy = cdiv(Na, 64), gx = cdiv(Kx, 64);
     int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(1024, gx * gy)));
     while (nsplit > 1 && (size_t)nsplit * gy * 64 * gx * 64 > scratch_floats) --nsplit;

@@ -70,3 +70,26 @@ def test_plane_gemm_64_row_tiles_bit_identical(M, N, K):
     assert torch.equal(outs[0], outs[1])
     ref = A.double() @ W.double().t()
     assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 20000), (512, 384, 48640), (200, 130, 9000), (512, 1024, 5120), (100, 3, 700)])
+def test_weight_gradient_gemm_vs_fp64(M, N, K):
+    """C += A^T W over K rows (the dW products of the backward pass): the 128x128-tile kernel (long row lists) and the 64x64 one
+    must both accumulate into C and agree with fp64; ragged tile edges and unaligned leading dimensions included."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g).cuda()
+    W = torch.randn(K, N, generator=g).cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+    ref = C0.double() + A.double().t() @ W.double()
+    scale = ref.abs().max().item()
+    try:
+        for on in (0, 1):
+            _lib.check(lib.mi_debug_set_tn128(on))
+            out = C0.clone()
+            _lib.check(lib.mi_debug_gemm(4, C.c_void_p(A.data_ptr()), M, C.c_void_p(W.data_ptr()), N, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+            torch.cuda.synchronize()
+            assert (out.double() - ref).abs().max().item() / scale < 3e-6, on
+    finally:
+        _lib.check(lib.mi_debug_set_tn128(1))
