@@ -59,11 +59,11 @@ def main():
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         fetch = 2.0 * traffic["FETCH_SIZE"]["avg_reported_KiB"] * 1024.0
         write = traffic["WRITE_SIZE"]["avg_reported_KiB"] * 1024.0
-        rec = {"kernel": "gemm_planes_kernel<pair> + gemm_planes_db_kernel", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
+        rec = {"kernel": "gemm_planes_kernel<1> (pair mode) + gemm_planes_kernel<0> (edge stage; the FETCH/WRITE passes run with the node-level products on the fp32-operand kernel so that every plane-GEMM dispatch is an edge-stage one)", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
                "write_bytes_per_dispatch": write, "dispatches_per_bench_launch": 2, "counters": traffic,
                "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
         json.dump(rec, open(out.rsplit(".", 1)[0] + "_traffic.json", "w"), indent=1)
-        lines += ["", f"HBM-side traffic of `gemm_planes_db_kernel` per dispatch (corrected): fetch {fetch / 1e6:.1f} MB + write {write / 1e6:.1f} MB"]
+        lines += ["", f"HBM-side traffic of the edge-stage `gemm_planes_kernel` dispatches, per dispatch (corrected): fetch {fetch / 1e6:.1f} MB + write {write / 1e6:.1f} MB"]
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
