@@ -54,6 +54,25 @@ __global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __res
     Z2[idx] = (dcat[(size_t)i * (2 * H) + H + f] / deg) * silu_grad(Z2[idx]);
 }
 
+// The same with the bias gradient's column sums folded in (one pass over [E, H] less): a block owns 256 columns of a 256-row
+// chunk, writes dZ2 in place and its column sums of the chunk to part[chunk][H] (reduced by part_reduce_kernel).
+__global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __restrict__ dcat, const int* __restrict__ src,
+                                                              const int* __restrict__ rowptr, float* __restrict__ Z2, float* __restrict__ part,
+                                                              int64_t E, int H) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.y * 256, e1 = e0 + 256 < E ? e0 + 256 : E;
+    if (c >= H) return;
+    float sum = 0.f;
+    for (int64_t e = e0; e < e1; ++e) {
+        const int i = src[e];
+        const float deg = (float)(rowptr[i + 1] - rowptr[i]);
+        const float v = (dcat[(size_t)i * (2 * H) + H + c] / deg) * silu_grad(Z2[e * H + c]);
+        Z2[e * H + c] = v;
+        sum += v;
+    }
+    part[(size_t)blockIdx.y * H + c] = sum;
+}
+
 __global__ void fourier_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
                                const int* __restrict__ dst, float* __restrict__ FF, int64_t E, int F);
 
@@ -119,24 +138,38 @@ __global__ void graph_sum_kernel(const float* __restrict__ X, int ldx, const int
 }
 
 // gram term backward: gW1[f][2H+m] += sum_b dG[b][f] * gram_b[m];  gb1[f] += sum_b dG[b][f]
-__global__ void gram_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ lattices, float* __restrict__ gW1,
-                                int edge_in, float* __restrict__ gb1, int B, int H) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= H) return;
+// 32 features x 8 graph groups per block (graph sums combined through LDS in a fixed order): with one thread per feature looping
+// over all graphs the whole job was two workgroups and 96 us of latency.
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ lattices, float* __restrict__ gW1,
+                                                       int edge_in, float* __restrict__ gb1, int B, int H) {
+    __shared__ float red[8][10][32];
+    const int fl = threadIdx.x & 31, bg = threadIdx.x >> 5, f = blockIdx.x * 32 + fl;
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* Lm = lattices + (size_t)b * 9;
-        float d = dG[(size_t)b * H + f];
-        sb += d;
+    if (f < H)
+        for (int b = bg; b < B; b += 8) {
+            const float* Lm = lattices + (size_t)b * 9;
+            float d = dG[(size_t)b * H + f];
+            sb += d;
 #pragma unroll
-        for (int m = 0; m < 9; ++m) {
-            int r = m / 3, c = m % 3;
-            acc[m] += d * (Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2]);
+            for (int m = 0; m < 9; ++m) {
+                int r = m / 3, c = m % 3;
+                acc[m] += d * (Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2]);
+            }
         }
-    }
 #pragma unroll
-    for (int m = 0; m < 9; ++m) gW1[(size_t)f * edge_in + 2 * H + m] += acc[m];
-    gb1[f] += sb;
+    for (int m = 0; m < 9; ++m) red[bg][m][fl] = acc[m];
+    red[bg][9][fl] = sb;
+    __syncthreads();
+    // 10 outputs x 32 features per block, one thread each
+    for (int o = threadIdx.x; o < 320; o += 256) {
+        const int m = o >> 5, ff = o & 31, fo = blockIdx.x * 32 + ff;
+        if (fo >= H) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][m][ff];
+        if (m < 9) gW1[(size_t)fo * edge_in + 2 * H + m] += t;
+        else gb1[fo] += t;
+    }
 }
 
 // LayerNorm backward (one wave per row): dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w.
@@ -317,7 +350,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 8 * H * sizeof(float), s, dy, ld_dy, x, stats, net->p(wname + ".weight"),
                            dx, accumulate, sc, N, H, rows_per_block);
         // part[blk][0:H] -> dw, [H:2H] -> db ; weight and bias are adjacent in theta (weight first)
-        hipLaunchKernelGGL(tn_reduce_kernel, g1(2 * H), dim3(256), 0, s, sc, nblk, 1, 2 * H, G(wname + ".weight"), 2 * H, 1, 2 * H, 1.0f);
+        hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, s, sc, nblk, 2 * H, G(wname + ".weight"), 2 * H);
         MI_KERNEL_CHECK();
         return MI_OK;
     };
@@ -363,11 +396,18 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         // edge stage (cspnet.py:59-79)
         if (E > 0) {
-            hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);  // Z2 := dZ2
+            const int nchunk = (int)cdiv(E, 256);
+            const bool dz2_sums = (size_t)nchunk * H <= scf;  // Z2 := dZ2, with edge_mlp.2.bias's gradient (column sums) on the way
+            if (dz2_sums) {
+                hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(cdiv(H, 256), nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H);
+                hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, 64)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
+            } else {
+                hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
+            }
             hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
             MI_KERNEL_CHECK();
             MI_TRY(gemm_tn_acc(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
-            MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
+            if (!dz2_sums) MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
             MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
             hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
             MI_KERNEL_CHECK();
@@ -395,7 +435,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             MI_HIP(hipMemsetAsync(t.dPQ, 0, NH * 2 * 4, s));
         }
         hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dPQ, 2 * H, b->node_off, t.dG, B, H);
-        hipLaunchKernelGGL(gram_bwd_kernel, g1(H), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
+        hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
                            G(p + "edge_mlp.0.bias"), B, H);
         MI_KERNEL_CHECK();
         MI_TRY(gemm_tn_acc(t.dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));

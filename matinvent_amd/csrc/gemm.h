@@ -367,6 +367,26 @@ inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* 
     return MI_OK;
 }
 
+// out[c] += sum_z P[z][c]  (P row stride ldp): the second stage of the column-sum style reductions.  64 columns x 4 row groups
+// per block, combined through LDS in a fixed order (deterministic); tn_reduce_kernel's one-thread-per-output loop over a few
+// hundred partial rows in two to four workgroups was pure latency (77 us for the LayerNorm weight gradients).
+static __global__ __launch_bounds__(256) void part_reduce_kernel(const float* __restrict__ P, int nsplit, int ldp, float* __restrict__ out, int Nc) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < Nc) {
+        int z = rg;
+        for (; z + 4 < nsplit; z += 8) {  // two independent chains: more loads in flight
+            s0 += P[(size_t)z * ldp + c];
+            s1 += P[(size_t)(z + 4) * ldp + c];
+        }
+        if (z < nsplit) s0 += P[(size_t)z * ldp + c];
+    }
+    red[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < Nc) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // out[c] += sum_m A[m][c]   (bias gradients), two stages through `scratch` like gemm_tn_acc
 static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ P, int M, int Nc,
                                                      int rows_per_split, const int* __restrict__ row_idx = nullptr) {
@@ -390,7 +410,7 @@ inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float*
     int rows = cdiv(M, nsplit);
     nsplit = cdiv(M, rows);
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows, row_idx);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(Nc, 256)), dim3(256), 0, s, scratch, nsplit, 1, gx * 64, out, Nc, 1, Nc, 1.0f);
+    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(Nc, 64)), dim3(256), 0, s, scratch, nsplit, gx * 64, out, Nc);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
