@@ -280,7 +280,8 @@ int mi_debug_set_db_min_tiles(int n);
 /* Tuning knob: smallest node count for which the node-level products (P_i/P_j projections, node MLP) run on the plane-set
  * GEMM kernel (pre-split weights, producer-written activation planes); smaller batches use the fp32-operand split-K kernel. */
 int mi_debug_set_node_planes_min_rows(int n);
-/* Tuning knob: weight-gradient products over long row lists on 128 x 128 tiles (default 1) or always 64 x 64 (0). */
+/* Tuning knob for the weight-gradient products over long row lists (edge / pair list): 3 (default) = bf16 three-plane split on
+ * the matrix pipe (split arithmetic path only), 1 = f32 MFMA on 128 x 128 tiles, 0 = f32 MFMA on 64 x 64 tiles. */
 int mi_debug_set_tn128(int on);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);

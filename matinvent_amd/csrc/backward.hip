@@ -336,13 +336,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     // ---------------- heads ----------------
     hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.lattices, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_acc(t.dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
     hipLaunchKernelGGL(heads_bwd_kernel, g1(NH), dim3(256), 0, s, d_type, d_coord, t.dgf, net->p("type_out.weight"),
                        net->p("coord_out.weight"), b->node2graph, b->node_off, t.dY, N, H);  // dY = d hf
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_acc(d_type, MI_NUM_TYPES, b->hf, H, G("type_out.weight"), H, N, MI_NUM_TYPES, H, sc, scf, s));
+    MI_TRY(gemm_tn_auto(d_type, MI_NUM_TYPES, b->hf, H, G("type_out.weight"), H, N, MI_NUM_TYPES, H, sc, scf, s));
     MI_TRY(colsum_acc(d_type, MI_NUM_TYPES, G("type_out.bias"), N, MI_NUM_TYPES, sc, scf, s));
-    MI_TRY(gemm_tn_acc(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
+    MI_TRY(gemm_tn_auto(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
 
     auto ln_bwd = [&](const float* dy, int ld_dy, const float* x, const float* stats, const std::string& wname, float* dx, int accumulate) {
         const int rows_per_block = N >= 16384 ? 64 : (N >= 2048 ? 16 : 4), nblk = cdiv(N, rows_per_block);  // >= ~256 blocks when possible
@@ -384,14 +384,14 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, t.dY, (int64_t)NH);
         hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, t.Xa, (int64_t)NH);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_acc(t.dY, H, t.Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.dY, H, t.Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
         MI_TRY(colsum_acc(t.dY, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
         MI_TRY(gemm_nt(t.dY, H, net->Wn2T + l * (size_t)H * H, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
         // (silu' as this product's epilogue measured 2.5 % slower end to end than the separate vectorised pass: in the MFMA result
         // layout a lane owns one column of 16 rows, so the pre-activation comes in as 16 four-byte loads per tile)
         hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dXa, Xpre, t.dXa, (int64_t)NH);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_acc(t.dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
         MI_TRY(colsum_acc(t.dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
         MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         // edge stage (cspnet.py:59-79)
@@ -406,7 +406,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             }
             hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
             MI_KERNEL_CHECK();
-            MI_TRY(gemm_tn_acc(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
+            MI_TRY(gemm_tn_auto(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
             if (!dz2_sums) MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
             MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
             hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
@@ -417,8 +417,8 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                     float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
                     hipLaunchKernelGGL(pair_combine_kernel, g1(Np * (H / 4)), dim3(256), 0, s, t.dM1, b->pair_e1, b->pair_e2, Dm, Dp, Np, H);
                     MI_KERNEL_CHECK();
-                    MI_TRY(gemm_tn_acc(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
-                    MI_TRY(gemm_tn_acc(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
+                    MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
+                    MI_TRY(gemm_tn_auto(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
                 }
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
                 MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
@@ -426,7 +426,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
                 MI_KERNEL_CHECK();
             } else {
-                MI_TRY(gemm_tn_acc(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
+                MI_TRY(gemm_tn_auto(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
             }
             if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
             else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
@@ -438,8 +438,8 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
                            G(p + "edge_mlp.0.bias"), B, H);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_acc(t.dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
-        MI_TRY(gemm_tn_acc(t.dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
         // d hn = dcat[:, :H] + dPQ * Whh   -> dY (reuse)
         GemmEpilogue er;
         er.residual = t.dcat;
@@ -456,13 +456,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 
     // ---------------- embedding (cspnet.py:265-271) ----------------
     const int WA = H + TD;
-    MI_TRY(gemm_tn_acc(t.dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
     hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dh, H, b->node_off, t.dtproj, B, H);
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_acc(t.dtproj, H, t.t_emb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dtproj, H, t.t_emb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
     MI_TRY(colsum_acc(t.dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
     MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
-    MI_TRY(gemm_tn_acc(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
     return MI_OK;
 }
@@ -744,7 +744,7 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
         static float* sc = nullptr;
         const size_t scf = (size_t)1 << 24;
         if (!sc) MI_HIP(hipMalloc((void**)&sc, scf * sizeof(float)));
-        return gemm_tn_acc(A, lda, W, ldw, C, ldc, K, M, N, sc, scf, (hipStream_t)stream);
+        return gemm_tn_auto(A, lda, W, ldw, C, ldc, K, M, N, sc, scf, (hipStream_t)stream);
     }
     return kind == 0 ? gemm_nt_f32(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream)
                      : gemm_nt_split(A, lda, W, ldw, C, ldc, M, N, K, GemmEpilogue(), (hipStream_t)stream);

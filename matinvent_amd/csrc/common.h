@@ -39,6 +39,7 @@ void set_error(const char* fmt, ...);
 
 #define MI_KERNEL_CHECK() MI_HIP(hipGetLastError())
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

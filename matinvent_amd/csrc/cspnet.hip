@@ -17,6 +17,7 @@ int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 int g_tn128 = 1;
+int g_tn_split = 1;
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 int g_node_planes_min_rows = 512;  // node-level products: plane-set kernel from this many nodes up, fp32-operand split-K kernel below
 
@@ -1128,7 +1129,8 @@ int mi_debug_set_planes_small_tiles(int n) {
 }
 
 int mi_debug_set_tn128(int on) {
-    g_tn128 = on != 0;
+    g_tn128 = (on & 1) != 0;
+    g_tn_split = (on & 2) != 0;  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
     return MI_OK;
 }
 

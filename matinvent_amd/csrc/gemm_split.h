@@ -818,6 +818,140 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
+// Weight-gradient product  P[split][Na][Kx] = sum over the split's rows m of A[m][Na]^T X[m][Kx]  on the bf16 matrix pipe:
+// the fp32 operands are split into three planes ON THE WAY into LDS and transposed there, so that the contraction index m is
+// the contiguous one -- the LDS image of a 32-row slab is exactly the plane GEMM's ([plane][128 output rows][32 k] bf16, 64-byte
+// rows, 16-byte chunks XOR-swizzled), and the MFMA loop is the same six-term one (staging: see below).  Needs even leading
+// dimensions and 8-byte aligned operands.  128 x 128 output tile, next slab prefetched into registers during the MFMAs,
+// XCD-aware tile order as in gemm_tn128_kernel, partial tiles reduced in fixed order by tn_reduce_kernel.
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_tn_split_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx, float* __restrict__ P, int M, int Na, int Kx, int rows_per_split,
+    int gx, int gy, int nsplit) {
+    constexpr int PLB = 128 * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLB];
+    unsigned char* As = smem;
+    unsigned char* Xs = smem + 3 * PLB;
+    const int id_ = blockIdx.x, slot_ = id_ >> 3, tile_ = slot_ % (gx * gy), bz = (slot_ / (gx * gy)) * 8 + (id_ & 7);
+    if (bz >= nsplit) return;
+    const int bx = tile_ % gx, by = tile_ / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    const int n0 = by * 128, k0 = bx * 128;
+    const int m_begin = bz * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: a thread owns two adjacent operand columns (8-byte global loads; a wave covers 128 consecutive floats of a row)
+    // and 8 consecutive rows of the slab = ONE 16-byte chunk (8 k positions) of two LDS rows
+    const int nl = (tid & 63) * 2, mq = tid >> 6;
+    const bool a_ok = n0 + nl < Na, x_ok = k0 + nl < Kx;  // (Na, Kx even: a column pair is in range or not as a whole)
+    const float* pa = A + n0 + nl;
+    const float* px = X + k0 + nl;
+    f32x2 ra[8], rx[8];
+    auto load_slab = [&](int m0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int gm = m0 + mq * 8 + t;
+            ra[t] = (a_ok && gm < m_end) ? *reinterpret_cast<const f32x2*>(pa + (size_t)gm * lda) : f32x2{0.f, 0.f};
+            rx[t] = (x_ok && gm < m_end) ? *reinterpret_cast<const f32x2*>(px + (size_t)gm * ldx) : f32x2{0.f, 0.f};
+        }
+    };
+    auto store_slab = [&]() {
+        // (8 consecutive lanes = 8 even rows, same chunk index: conflict-free under the XOR swizzle)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 va[3], vx[3];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                unsigned p[3], q[3];
+                split3_pair(ra[2 * t2][u], ra[2 * t2 + 1][u], p);
+                split3_pair(rx[2 * t2][u], rx[2 * t2 + 1][u], q);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    va[pl][t2] = p[pl];
+                    vx[pl][t2] = q[pl];
+                }
+            }
+            const int row = nl + u, off = row * 64 + ((mq ^ ((row >> 2) & 3)) * 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<u32x4*>(As + pl * PLB + off) = va[pl];
+                *reinterpret_cast<u32x4*>(Xs + pl * PLB + off) = vx[pl];
+            }
+        }
+    };
+    load_slab(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        store_slab();
+        __syncthreads();
+        if (m0 + 32 < m_end) load_slab(m0 + 32);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (wm * 2 + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLB + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (wn * 2 + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(Xs + pl * PLB + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    const int PK = gx * 128;
+    float* Pt = P + (size_t)bz * (gy * 128) * PK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, k = k0 + wn * 64 + j * 32 + l31;
+                Pt[(size_t)n * PK + k] = acc[i][j][r];
+            }
+}
+
+extern int g_tn_split;  // long weight-gradient contractions on the bf16 matrix pipe (1, split path only) or the f32 MFMA (0)
+// C[Na,Kx] (ldc) += A^T X: picks the kernel by shape and arithmetic path (see gemm_tn_acc for the scratch contract)
+inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+                        size_t scratch_floats, hipStream_t s) {
+    if (g_gemm_mode != 0 && g_tn_split && M >= 8192 && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 && ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0) {
+        const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
+        while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
+        MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
+        const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
+        nsplit = cdiv(M, rows);
+        hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(gx * gy * ((nsplit + 7) / 8 * 8)), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy,
+                           nsplit);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx,
+                           1.0f);
+        MI_KERNEL_CHECK();
+        return MI_OK;
+    }
+    return gemm_tn_acc(A, lda, X, ldx, C, ldc, M, Na, Kx, scratch, scratch_floats, s);
+}
+
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");

@@ -74,8 +74,9 @@ def test_plane_gemm_64_row_tiles_bit_identical(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(512, 512, 20000), (512, 384, 48640), (200, 130, 9000), (512, 1024, 5120), (100, 3, 700)])
 def test_weight_gradient_gemm_vs_fp64(M, N, K):
-    """C += A^T W over K rows (the dW products of the backward pass): the 128x128-tile kernel (long row lists) and the 64x64 one
-    must both accumulate into C and agree with fp64; ragged tile edges and unaligned leading dimensions included."""
+    """C += A^T W over K rows (the dW products of the backward pass): the bf16 three-plane-split kernel (long row lists, default),
+    the 128x128-tile f32-MFMA kernel and the 64x64 one must all accumulate into C and agree with fp64; ragged tile edges and
+    unaligned leading dimensions included."""
     from matinvent_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + N + K)
@@ -85,11 +86,11 @@ def test_weight_gradient_gemm_vs_fp64(M, N, K):
     ref = C0.double() + A.double().t() @ W.double()
     scale = ref.abs().max().item()
     try:
-        for on in (0, 1):
+        for on in (0, 1, 3):
             _lib.check(lib.mi_debug_set_tn128(on))
             out = C0.clone()
             _lib.check(lib.mi_debug_gemm(4, C.c_void_p(A.data_ptr()), M, C.c_void_p(W.data_ptr()), N, C.c_void_p(out.data_ptr()), N, M, N, K, None))
             torch.cuda.synchronize()
             assert (out.double() - ref).abs().max().item() / scale < 3e-6, on
     finally:
-        _lib.check(lib.mi_debug_set_tn128(1))
+        _lib.check(lib.mi_debug_set_tn128(3))
