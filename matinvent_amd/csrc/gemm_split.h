@@ -536,6 +536,46 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
         }
 }
 
+// Pre-activation save of the result-layout epilogue (training forward of the second edge linear: Z2 = acc + bias is kept for the
+// backward pass while the activation and the fused segmented sum go on in registers).  Through the per-wave LDS patch so that the
+// stores are 16-byte row-major ones instead of 16 four-byte column stores per tile and lane.  No row-gathered addends here.
+template <int TM, int TN>
+__device__ __forceinline__ void planes_store_preact_rows(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N,
+                                                         int lane, float* stage) {
+    const GemmEpilogue& ep = pe.ep;
+    const int l31 = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = row_w + i * 32, cb = col_w + j * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = lane + 64 * u, rl = q >> 2, c8 = (q & 3) * 8;
+                const int row = rb + rl, col = cb + c8;
+                f32x4 z0 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8);
+                f32x4 z1 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8 + 4);
+                if (row < M && col < N) {
+                    if (ep.bias) {
+                        z0 += *reinterpret_cast<const f32x4*>(ep.bias + col);
+                        z1 += *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+                    }
+                    float* d = ep.pre_act + (size_t)row * ep.ld_pre + col;
+                    *reinterpret_cast<f32x4*>(d) = z0;
+                    *reinterpret_cast<f32x4*>(d + 4) = z1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+__device__ __forceinline__ bool planes_preact_rows_applies(const PlanesEpilogue& pe, int N) {
+    return pe.seg_part != nullptr && pe.ep.pre_act != nullptr && pe.ep.row_bias == nullptr && pe.ep.pre_add == nullptr && (N & 7) == 0 &&
+           (pe.ep.ld_pre & 3) == 0;
+}
+
 // whether the row-major epilogue applies (otherwise the result-layout one, which also carries the fused segmented sum)
 __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
     return (pe.Cp.base != nullptr || pe.C != nullptr) && pe.seg_part == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 && (pe.ep.ld_res & 3) == 0 && (pe.ep.ld_pre_add & 3) == 0 &&
@@ -672,6 +712,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
         __syncthreads();                   // the staging patches overlay the operand tiles
         planes_epilogue_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    } else if (planes_preact_rows_applies(pe, N)) {  // training forward: pre-activation rows through LDS, the rest in registers
+        __syncthreads();
+        planes_store_preact_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+        PlanesEpilogue pq = pe;
+        pq.ep.pre_act = nullptr;
+        planes_epilogue<TM, TN>(pq, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, l31, kg);
     } else {
         planes_epilogue<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, l31, kg);
     }
