@@ -339,10 +339,12 @@ __global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// G[b][f] = b1[f] + sum_m (L L^T)[b].flat[m] * W1[f][2H + m]      (cspnet.py:68-72)
-__global__ void gram_term_kernel(const float* __restrict__ lattices, const float* __restrict__ W1, int edge_in,
-                                 const float* __restrict__ b1, float* __restrict__ G, int H) {
-    int b = blockIdx.x;
+// G[l][b][f] = b1_l[f] + sum_m (L L^T)[b].flat[m] * W1_l[f][2H + m]      (cspnet.py:68-72), every layer in one launch (the lattices
+// do not change inside an evaluation); layer l's edge_mlp.0 weight / bias sit `layer_stride` floats after layer l-1's in the flat
+// parameter vector.
+__global__ void gram_term_all_kernel(const float* __restrict__ lattices, const float* __restrict__ W1_0, int64_t layer_stride, int edge_in,
+                                     const float* __restrict__ b1_0, float* __restrict__ G, int H, int B) {
+    const int b = blockIdx.x, l = blockIdx.y;
     __shared__ float gram[9];
     if (threadIdx.x < 9) {
         int r = threadIdx.x / 3, c = threadIdx.x % 3;
@@ -350,12 +352,14 @@ __global__ void gram_term_kernel(const float* __restrict__ lattices, const float
         gram[threadIdx.x] = Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2];
     }
     __syncthreads();
+    const float* W1 = W1_0 + l * layer_stride;
+    const float* b1 = b1_0 + l * layer_stride;
     for (int f = threadIdx.x; f < H; f += blockDim.x) {
         const float* w = W1 + (size_t)f * edge_in + 2 * H;
         float s = 0.f;
 #pragma unroll
         for (int m = 0; m < 9; ++m) s += gram[m] * w[m];
-        G[(size_t)b * H + f] = s + b1[f];
+        G[((size_t)l * B + b) * H + f] = s + b1[f];
     }
 }
 
@@ -462,7 +466,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     const std::string p = "csp_layer_" + std::to_string(layer) + ".";
     EdgeFwdArgs a;
     a.PQ = b->PQ;
-    a.G = b->G;
+    a.G = b->G + (size_t)layer * b->B * b->H;
     a.FFp = b->FFp;
     a.src = b->src;
     a.dst = b->dst;
@@ -589,6 +593,15 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)cdiv(b->E * 3 * net->F, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, b->FF, b->E, net->F);
         MI_KERNEL_CHECK();
     }
+    // gram-matrix term of every layer's first edge linear (cspnet.py:68-72), one launch
+    if (B > 0 && L > 0) {
+        const float* w0 = net->p("csp_layer_0.edge_mlp.0.weight");
+        const float* b0 = net->p("csp_layer_0.edge_mlp.0.bias");
+        const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
+        MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
+        hipLaunchKernelGGL(gram_term_all_kernel, dim3(B, L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B);
+        MI_KERNEL_CHECK();
+    }
     // ---- message-passing layers (cspnet.py:84-91) ----
     const bool node_planes = g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && H % 32 == 0 && N >= g_node_planes_min_rows;
     for (int l = 0; l < L; ++l) {
@@ -618,9 +631,6 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         } else {
             MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         }
-        hipLaunchKernelGGL(gram_term_kernel, dim3(B), dim3(256), 0, s, lattices, net->p(p + "edge_mlp.0.weight"), net->edge_in,
-                           net->p(p + "edge_mlp.0.bias"), b->G, H);
-        MI_KERNEL_CHECK();
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
             MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
             hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
@@ -636,7 +646,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             g1e.row_bias2 = b->PQ + H;
             g1e.row_group2 = b->dst;
             g1e.ld_row_bias2 = ldpq;
-            g1e.row_bias3 = b->G;
+            g1e.row_bias3 = b->G + (size_t)l * B * H;
             g1e.row_group3 = b->edge_graph;
             g1e.ld_row_bias3 = H;
             g1e.act = ACT_SILU;
@@ -671,7 +681,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                     if (b->Np > 0)
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
-                    hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G,
+                    hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G + (size_t)l * B * H,
                                        net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
                     MI_KERNEL_CHECK();
                 } else {
@@ -1003,7 +1013,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(h, (L + 1) * NH);
     A_(cat, 2 * NH);
     A_(PQ, 3 * NH);  // [N][2H] P_i | P_j, or [N][3H] with the LayerNorm(h) part of the node MLP's first product appended
-    A_(G, (size_t)B * H);
+    A_(G, (size_t)L * B * H);
     A_(part, nslots * NH);
     A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
     A_(FF, (size_t)E * 6 * net->F);
