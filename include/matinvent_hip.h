@@ -243,6 +243,22 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
                      int b_global, int accum_steps, float* grad_theta, float* stats, float* out_sample_loss,
                      float* out_kl, void* stream, void* aux_stream);
 
+/* `copies` consecutive timesteps of one gradient-accumulation window (mat_invent.py:146-167: the weights only change at the
+ * optimizer step, so the window's timesteps are independent) as ONE micro-step over a batch holding `copies` replicas of the
+ * fine-tune set: ab / pb are batch handles for the atom counts repeated `copies` times (same node / graph offsets as the
+ * unstacked handles), the input arrays and `reward` are the replicated ones, replica c is noised for diffusion time t_host[c]
+ * with the schedule values *_host[c] and noise call `noise_step + c`, its draws indexed by the ORIGINAL crystal / atom ids -- so
+ * the accumulated gradient and `stats` are those of `copies` successive mi_ft_micro_step calls (up to fp32 summation order).
+ * For small fine-tune sets (the reference's default is 18 crystals), where a single timestep is bound by the host's launch rate. */
+#define MI_MAX_STACK 16
+int mi_ft_micro_steps_stacked(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths,
+                              const float* angles, const float* frac0, const int* atom_types, const float* reward,
+                              const float* time_freqs, int copies, const int* t_host, const float* c0_host,
+                              const float* c1_host, const float* sigma_t_host, const float* sigma_norm_host, uint64_t seed,
+                              uint32_t noise_step, const float* rand_l, const float* rand_x, const float* rand_t,
+                              float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global,
+                              int accum_steps, float* grad_theta, float* stats, void* stream, void* aux_stream);
+
 /* ---------------------------------------------------------------------------------------
  * Arithmetic paths.  Both reproduce the reference to fp32 round-off (tests state the bounds).
  *   GEMM mode (process-wide): MI_GEMM_SPLIT (default) evaluates every fp32 product on the bf16 matrix

@@ -66,6 +66,8 @@ SIGNATURES = {
                           _P, _P, _P]),
     "mi_ft_micro_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, C.c_float, C.c_float, _U64, _U32, _P, _P, _P,
                               C.c_float, C.c_float, C.c_float, C.c_float, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "mi_ft_micro_steps_stacked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _U64, _U32, _P, _P, _P,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, _I, _I, _P, _P, _P, _P]),
     "mi_set_gemm_mode": (_I, [_I]),
     "mi_net_set_edge_mode": (_I, [_P, _I]),
     "mi_debug_gemm": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),

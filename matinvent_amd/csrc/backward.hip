@@ -597,33 +597,52 @@ struct NoiseArgs {
     uint64_t seed;
     uint32_t step;
     int64_t node_offset, graph_offset;
+    // stacked timesteps (mi_ft_micro_steps_stacked): the batch holds `copies` replicas of a set of stack_B0 crystals / stack_N0
+    // atoms, replica c noised for its own timestep -- schedule values sched[c], noise call `step + c`, and the counter-based draws
+    // indexed by the ORIGINAL crystal / atom ids, so every replica sees exactly the noise of its own unstacked micro-step
+    int stack_B0 = 0, stack_N0 = 0;
+    float sc0[MI_MAX_STACK], sc1[MI_MAX_STACK], ssig[MI_MAX_STACK], ssn[MI_MAX_STACK];
 };
 
 __global__ __launch_bounds__(256) void add_noise_kernel(NoiseArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int cp = a.stack_B0 ? b / a.stack_B0 : 0;  // replica (stacked timesteps), 0 otherwise
+    const float c0 = a.stack_B0 ? a.sc0[cp] : a.c0, c1 = a.stack_B0 ? a.sc1[cp] : a.c1;
+    const float sigma = a.stack_B0 ? a.ssig[cp] : a.sigma, sigma_norm = a.stack_B0 ? a.ssn[cp] : a.sigma_norm;
+    const uint32_t step = a.step + (uint32_t)cp;
+    const int64_t gsub = (int64_t)cp * a.stack_B0, nsub = (int64_t)cp * a.stack_N0;  // replica's first crystal / atom in the batch
     __shared__ float Lm[9];
     if (tid == 0) lattice_matrix(a.lengths + b * 3, a.angles + b * 3, Lm);
     __syncthreads();
     if (tid < 9) {
         int idx = b * 9 + tid;
-        float z = a.rand_l ? a.rand_l[idx] : philox_normal1(a.seed, a.step, DRAW_FT_L, (uint64_t)a.graph_offset * 9 + idx);
+        float z = a.rand_l ? a.rand_l[idx] : philox_normal1(a.seed, step, DRAW_FT_L, (uint64_t)(a.graph_offset - gsub) * 9 + idx);
         a.out_rand_l[idx] = z;
-        a.in_lat[idx] = a.c0 * Lm[tid] + a.c1 * z;
+        a.in_lat[idx] = c0 * Lm[tid] + c1 * z;
     }
     const int n0 = a.node_off[b], n1 = a.node_off[b + 1];
     for (int idx = n0 * 3 + tid; idx < n1 * 3; idx += 256) {
-        float z = a.rand_x ? a.rand_x[idx] : philox_normal1(a.seed, a.step, DRAW_FT_X, (uint64_t)a.node_offset * 3 + idx);
-        float sx = a.sigma * z;
+        float z = a.rand_x ? a.rand_x[idx] : philox_normal1(a.seed, step, DRAW_FT_X, (uint64_t)(a.node_offset - nsub) * 3 + idx);
+        float sx = sigma * z;
         a.in_frac[idx] = pymod1(a.frac0[idx] + sx);
-        a.tar_x[idx] = d_log_p_wn(sx, a.sigma) / sqrtf(a.sigma_norm);
+        a.tar_x[idx] = d_log_p_wn(sx, sigma) / sqrtf(sigma_norm);
     }
     for (int64_t idx = (int64_t)n0 * MI_NUM_TYPES + tid; idx < (int64_t)n1 * MI_NUM_TYPES; idx += 256) {
         int i = (int)(idx / MI_NUM_TYPES), k = (int)(idx % MI_NUM_TYPES);
-        float z = a.rand_t ? a.rand_t[idx] : philox_normal1(a.seed, a.step, DRAW_FT_T, (uint64_t)a.node_offset * MI_NUM_TYPES + idx);
+        float z = a.rand_t ? a.rand_t[idx] : philox_normal1(a.seed, step, DRAW_FT_T, (uint64_t)(a.node_offset - nsub) * MI_NUM_TYPES + idx);
         float onehot = (a.atom_types[i] - 1 == k) ? 1.f : 0.f;
         a.out_rand_t[idx] = z;
-        a.in_types[idx] = a.c0 * onehot + a.c1 * z;
+        a.in_types[idx] = c0 * onehot + c1 * z;
     }
+}
+
+// times[b] = t[b / B0]  (stacked timesteps)
+struct StackTimes {
+    int t[MI_MAX_STACK];
+};
+__global__ void fill_stack_times_kernel(int* __restrict__ times, StackTimes st, int B0, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) times[b] = st.t[b / B0];
 }
 
 }  // namespace mi
@@ -671,24 +690,47 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
     return MI_OK;
 }
 
-int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,
-                     const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int t, float c0, float c1,
-                     float sigma_t, float sigma_norm, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
-                     const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global, int accum_steps,
-                     float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream, void* aux_stream) {
+// One fine-tune micro-step; `copies` > 0: stacked timesteps (see mi_ft_micro_steps_stacked), the schedule arrays then hold one value
+// per replica and t / c0 / c1 / sigma_t / sigma_norm are ignored.
+static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,
+                         const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int t, float c0, float c1,
+                         float sigma_t, float sigma_norm, int copies, const int* ts, const float* c0s, const float* c1s, const float* sigmas,
+                         const float* sigma_norms, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
+                         const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global,
+                         int accum_steps, float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream,
+                         void* aux_stream) {
     MI_CHECK(agent && ab && prior && pb && lengths && angles && frac0 && atom_types && reward && time_freqs && grad_theta, MI_EINVAL,
              "null argument");
     MI_CHECK(ab != pb, MI_EINVAL, "agent and prior need separate batch handles (separate workspace)");
-    MI_CHECK(ab->B == pb->B && ab->N == pb->N && b_global >= ab->B && accum_steps >= 1, MI_EINVAL, "inconsistent batch arguments");
+    MI_CHECK(ab->B == pb->B && ab->N == pb->N && b_global >= ab->B / (copies > 0 ? copies : 1) && accum_steps >= 1, MI_EINVAL,
+             "inconsistent batch arguments");
     hipStream_t s = (hipStream_t)stream;
     const int B = ab->B, N = ab->N;
     if (B == 0 || N == 0) return MI_OK;
     MI_TRY(net_tape_prepare(agent, ab));
     Tape& tp = ab->tape;
-    hipLaunchKernelGGL(fill_int_kernel2, dim3(cdiv(B, 256)), dim3(256), 0, s, ab->times, t, B);
+    NoiseArgs na{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, ab->node_off, tp.nz_lat, tp.nz_frac, tp.nz_types, tp.tar_x,
+                 tp.rnd_l, tp.rnd_t, c0, c1, sigma_t, sigma_norm, seed, noise_step, ab->node_offset, ab->graph_offset};
+    if (copies > 0) {
+        MI_CHECK(copies <= MI_MAX_STACK && B % copies == 0 && N % copies == 0 && ts && c0s && c1s && sigmas && sigma_norms, MI_EINVAL,
+                 "stacked micro-step: %d replicas do not fit the batch (B = %d, N = %d) or the limit %d", copies, B, N, MI_MAX_STACK);
+        StackTimes st;
+        na.stack_B0 = B / copies;
+        na.stack_N0 = N / copies;
+        for (int c = 0; c < copies; ++c) {
+            st.t[c] = ts[c];
+            na.sc0[c] = c0s[c];
+            na.sc1[c] = c1s[c];
+            na.ssig[c] = sigmas[c];
+            na.ssn[c] = sigma_norms[c];
+        }
+        hipLaunchKernelGGL(fill_stack_times_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, ab->times, st, na.stack_B0, B);
+    } else {
+        hipLaunchKernelGGL(fill_int_kernel2, dim3(cdiv(B, 256)), dim3(256), 0, s, ab->times, t, B);
+    }
     MI_TRY(mi_time_embedding(ab->times, time_freqs, B, agent->TD, ab->temb, stream));
-    MI_TRY(mi_add_noise(ab, lengths, angles, frac0, atom_types, c0, c1, sigma_t, sigma_norm, seed, noise_step, rand_l, rand_x, rand_t,
-                        tp.nz_lat, tp.nz_frac, tp.nz_types, tp.tar_x, tp.rnd_l, tp.rnd_t, stream));
+    hipLaunchKernelGGL(add_noise_kernel, dim3(B), dim3(256), 0, s, na);
+    MI_KERNEL_CHECK();
     if (aux_stream && aux_stream != stream) {
         // the frozen prior's forward is independent of the agent's: fork it onto the auxiliary stream (small fine-tune sets leave
         // most of the chip idle, so the two forwards overlap), join before the loss kernel reads both predictions
@@ -716,6 +758,28 @@ int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, c
     if (out_sample_loss) MI_HIP(hipMemcpyAsync(out_sample_loss, tp.Lb, B * 4, hipMemcpyDeviceToDevice, s));
     if (out_kl) MI_HIP(hipMemcpyAsync(out_kl, tp.KLb, B * 4, hipMemcpyDeviceToDevice, s));
     return net_backward(agent, ab, tp.d_l, tp.d_x, tp.d_t, grad_theta, s);
+}
+
+int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,
+                     const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int t, float c0, float c1,
+                     float sigma_t, float sigma_norm, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
+                     const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global, int accum_steps,
+                     float* grad_theta, float* stats, float* out_sample_loss, float* out_kl, void* stream, void* aux_stream) {
+    return ft_micro_impl(agent, ab, prior, pb, lengths, angles, frac0, atom_types, reward, time_freqs, t, c0, c1, sigma_t, sigma_norm, 0, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, seed, noise_step, rand_l, rand_x, rand_t, cost_lattice, cost_coord, cost_type,
+                         kl_sigma, b_global, accum_steps, grad_theta, stats, out_sample_loss, out_kl, stream, aux_stream);
+}
+
+int mi_ft_micro_steps_stacked(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,
+                              const float* frac0, const int* atom_types, const float* reward, const float* time_freqs, int copies,
+                              const int* t_host, const float* c0_host, const float* c1_host, const float* sigma_t_host,
+                              const float* sigma_norm_host, uint64_t seed, uint32_t noise_step, const float* rand_l, const float* rand_x,
+                              const float* rand_t, float cost_lattice, float cost_coord, float cost_type, float kl_sigma, int b_global,
+                              int accum_steps, float* grad_theta, float* stats, void* stream, void* aux_stream) {
+    MI_CHECK(copies >= 1, MI_EINVAL, "copies must be positive");
+    return ft_micro_impl(agent, ab, prior, pb, lengths, angles, frac0, atom_types, reward, time_freqs, 0, 0.f, 0.f, 0.f, 0.f, copies, t_host,
+                         c0_host, c1_host, sigma_t_host, sigma_norm_host, seed, noise_step, rand_l, rand_x, rand_t, cost_lattice, cost_coord,
+                         cost_type, kl_sigma, b_global, accum_steps, grad_theta, stats, nullptr, nullptr, stream, aux_stream);
 }
 
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, void* stream) {

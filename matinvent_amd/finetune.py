@@ -52,7 +52,71 @@ def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, acc
                                     C.c_void_p(aux_stream.cuda_stream) if aux_stream is not None else None), "mi_ft_micro_step")
 
 
-def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, log=logging.info, fused=True, groups=None):
+def _stacked_micro_steps(agent, prior, batch, time_idxs, noises, sigma, n_global, accum_steps, grad, stats, aux_stream=None):
+    """`len(time_idxs)` consecutive timesteps of one accumulation window as ONE micro-step over a batch holding that many replicas
+    of the fine-tune set (mi_ft_micro_steps_stacked): the same gradient and statistics as calling _fused_micro_step once per
+    timestep, with a fraction of the kernel launches -- a single timestep of a small set is bound by the host's launch rate."""
+    import ctypes as C
+    from . import _lib
+    from .cspnet import _ptr, _stream
+    lib = _lib.load()
+    dev = agent.device
+    k = len(time_idxs)
+    T = agent.beta_scheduler.timesteps
+    ts = [T - int(i) for i in time_idxs]
+    num_atoms = batch.num_atoms.repeat(k)
+    ab, pb = agent._batch_for(num_atoms), prior._batch_for(num_atoms)
+    agent.decoder.sync()
+    prior.decoder.sync()
+    ac = [agent.beta_scheduler.alphas_cumprod[t] for t in ts]
+    arr = lambda ctype, vals: (ctype * k)(*vals)
+    c0 = arr(C.c_float, [float(torch.sqrt(a)) for a in ac])
+    c1 = arr(C.c_float, [float(torch.sqrt(1.0 - a)) for a in ac])
+    sig = arr(C.c_float, [float(agent.sigma_scheduler.sigmas[t]) for t in ts])
+    sn = arr(C.c_float, [float(agent.sigma_scheduler.sigmas_norm[t]) for t in ts])
+    cache = batch.__dict__.setdefault("_mi_dev_stacked", {})
+    if k not in cache:
+        f = lambda x: x.to(dev, torch.float32).contiguous()
+        rep = lambda x: x.repeat(k, *([1] * (x.dim() - 1))).contiguous()
+        cache[k] = dict(lengths=rep(f(batch.lengths)), angles=rep(f(batch.angles)), frac=rep(f(batch.frac_coords)),
+                        types=rep(batch.atom_types.to(dev, torch.int32)), reward=rep(f(batch.reward)))
+        while len(cache) > 3:
+            cache.pop(next(iter(cache)))
+    c = cache[k]
+    nz = (None, None, None)
+    if noises is not None:  # injected noise (parity tests): the replicas' arrays one after the other
+        nz = tuple(torch.cat([n[j].to(dev, torch.float32) for n in noises]).contiguous() for j in range(3))
+    call0 = getattr(agent, "_noise_calls", 0) + 1  # replica j uses the call id of its own timestep
+    agent._noise_calls = call0 + k - 1
+    _lib.check(lib.mi_ft_micro_steps_stacked(agent.decoder._h, ab._h, prior.decoder._h, pb._h, _ptr(c["lengths"]), _ptr(c["angles"]),
+                                             _ptr(c["frac"]), _ptr(c["types"]), _ptr(c["reward"]), _ptr(agent.time_embedding.freqs), k,
+                                             arr(C.c_int, ts), c0, c1, sig, sn, getattr(agent, "noise_seed", 0), call0 & 0xFFFFFFFF,
+                                             _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), agent.cost_lattice, agent.cost_coord, agent.cost_type,
+                                             sigma, n_global, accum_steps, _ptr(grad), _ptr(stats), _stream(),
+                                             C.c_void_p(aux_stream.cuda_stream) if aux_stream is not None else None),
+               "mi_ft_micro_steps_stacked")
+
+
+MAX_STACK = 16  # MI_MAX_STACK of the C ABI
+
+
+def _stack_plan(e_one, accum_steps, timesteps, stack):
+    """Chunk sizes of the timestep loop: every chunk lies inside one accumulation window.  stack=None: as many timesteps per
+    chunk as bring the stacked batch to ~32k edges (beyond that a micro-step is no longer launch-bound), evenly sized."""
+    if stack is None:
+        stack = max(1, min(MAX_STACK, 32768 // max(1, e_one)))
+    stack = max(1, min(int(stack), MAX_STACK))
+    plan, t = [], 0
+    while t < timesteps:
+        w = min(accum_steps - t % accum_steps, timesteps - t)  # timesteps left in this window
+        n = -(-w // stack)                                     # chunks for them, sized evenly
+        sizes = [w // n + (1 if j < w % n else 0) for j in range(n)]
+        plan += sizes
+        t += w
+    return plan
+
+
+def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, log=logging.info, fused=True, groups=None, stack=None):
     """cfg needs: lr, accum_steps, epochs, timesteps, sigma (attribute or key access).
     `noise_fn(epoch, t)` -> (rand_l, rand_x, rand_t) injects noise (parity tests); default Philox.
     fused=True (default) enqueues each timestep through mi_ft_micro_step (noise, both forwards, the fused
@@ -63,7 +127,10 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     enqueued on separate HIP streams and run concurrently, each accumulating into its own gradient buffer (summed before
     the optimizer step) -- the same arithmetic as data-parallel ranks, inside one GPU: one group's node-level and
     reduction kernels overlap the other's large GEMMs.  None = automatic (2-3 for large sets; measured at 256 x 20 atoms:
-    7.5k -> 9.0k / 9.3k / 8.9k crystal-timesteps/s with 2 / 3 / 4 groups)."""
+    7.5k -> 9.0k / 9.3k / 8.9k crystal-timesteps/s with 2 / 3 / 4 groups).
+    `stack` (fused path, single group): up to that many consecutive timesteps of an accumulation window run as ONE stacked
+    micro-step (the weights only change at the optimizer step, so they are independent; same noise, same gradient up to fp32
+    summation order).  None = automatic (small sets, which are bound by the host's launch rate); 1 = off."""
     get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
     lr, accum_steps, epochs, timesteps, sigma = get("lr"), int(get("accum_steps")), int(get("epochs")), int(get("timesteps")), get("sigma")
     device = device or agent.device
@@ -94,17 +161,26 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
         optimizer.zero_grad(set_to_none=False) if theta.grad is not None else None
         acc = torch.zeros(3, device=device)  # loss, loss_diff, loss_kl accumulators (device side)
         t = -1
-        for t in range(timesteps):
-            noise = None if noise_fn is None else noise_fn(epoch, t)
-            if fused:
-                if theta.grad is None:
-                    theta.grad = torch.zeros_like(theta)
-                _fused_micro_step(agent, prior, batch, t, noise, sigma, n_global, accum_steps, theta.grad, acc, aux_stream=aux)
+        if fused:
+            if theta.grad is None:
+                theta.grad = torch.zeros_like(theta)
+            t0 = 0
+            for k in _stack_plan(sum(d.num_atoms ** 2 for d in dataset.data_list[lo:hi]), accum_steps, timesteps, stack):
+                tidx = list(range(t0, t0 + k))
+                noises = None if noise_fn is None else [noise_fn(epoch, i) for i in tidx]
+                if k == 1:
+                    _fused_micro_step(agent, prior, batch, t0, None if noises is None else noises[0], sigma, n_global, accum_steps, theta.grad,
+                                      acc, aux_stream=aux)
+                else:
+                    _stacked_micro_steps(agent, prior, batch, tidx, noises, sigma, n_global, accum_steps, theta.grad, acc, aux_stream=aux)
+                t0 += k
+                t = t0 - 1
                 if (t + 1) % accum_steps == 0:
                     allreduce_flat_(theta.grad)
                     optimizer.step()
                     optimizer.zero_grad(set_to_none=False)
-                continue
+        for t in (() if fused else range(timesteps)):
+            noise = None if noise_fn is None else noise_fn(epoch, t)
             noised = agent.add_noise(batch, t, noise=noise)                       # :152
             sample_loss, agent_pred = agent.calc_sample_loss(noised)              # :153
             with torch.no_grad():

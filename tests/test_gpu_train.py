@@ -186,13 +186,16 @@ def test_fused_adam_matches_torch_adam():
     assert float((p1 - p2).detach().abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("fused,groups", [(True, 1), (True, 2), (True, 3), (False, 1)],
-                         ids=["fused-micro-step", "fused-2-concurrent-groups", "fused-3-concurrent-groups", "autograd-surface"])
-def test_ft_step_end_to_end_vs_oracle(fused, groups):
+@pytest.mark.parametrize("fused,groups,stack", [(True, 1, 1), (True, 1, None), (True, 1, 2), (True, 2, 1), (True, 3, 1), (False, 1, 1)],
+                         ids=["fused-micro-step", "fused-stacked-timesteps", "fused-stacked-2+1", "fused-2-concurrent-groups",
+                              "fused-3-concurrent-groups", "autograd-surface"])
+def test_ft_step_end_to_end_vs_oracle(fused, groups, stack):
     """matinvent_amd.finetune.ft_step (device-side loss accumulation, fused Adam, flat gradient) vs
     the oracle's literal restatement of pipeline/mat_invent.py:125-189: 2 epochs x 6 timesteps,
     accum 3 -> 4 optimizer steps, injected noise.  `groups` > 1: the set is cut into crystal groups whose
-    micro-steps run concurrently on separate streams with separate gradient buffers (ragged: 4 crystals in 3 groups)."""
+    micro-steps run concurrently on separate streams with separate gradient buffers (ragged: 4 crystals in 3 groups).  `stack`: the
+    timesteps of an accumulation window as one stacked micro-step over replicas of the set (None = automatic: all 3 of a window;
+    2: chunks of 2 + 1)."""
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import ft_step
     hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
@@ -211,7 +214,7 @@ def test_ft_step_end_to_end_vs_oracle(fused, groups):
     noises = {(e, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
               for e in range(2) for t in range(6)}
     cfg = dict(lr=1e-4, accum_steps=3, epochs=2, timesteps=6, sigma=0.025)
-    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=fused, groups=groups)
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=fused, groups=groups, stack=stack)
     # oracle side
     sch = O.Schedules.make(1000, sigmas_norm=sn)
     sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
@@ -234,3 +237,34 @@ def test_ft_step_end_to_end_vs_oracle(fused, groups):
     ref_kl0 = float(sum(((1.1 - rw) * k).sum() for k in rec["kl"][:6]) / 6 / len(na))
     assert abs(stats[0]["loss_diff"] - ref_diff0) <= 1e-4 * max(1.0, abs(ref_diff0))
     assert abs(stats[0]["loss_kl"] - ref_kl0) <= 2e-4 * max(1e-3, abs(ref_kl0))
+
+
+def test_stacked_timesteps_reproduce_the_sequential_update_with_device_noise():
+    """Counter-based (Philox) noise: replica c of a stacked micro-step must draw exactly what timestep c of the sequential loop
+    draws (call id + c, original crystal / atom ids), so both routes end at the same parameters up to fp32 summation order;
+    ragged set, 7 timesteps in windows of 5 (chunks 3+2 and 2)."""
+    from matinvent_amd.data import CrystalData
+    from matinvent_amd.finetune import ft_step
+    hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
+    gen = torch.Generator().manual_seed(21)
+    na = [5, 1, 7, 3, 4]
+    data = [CrystalData(torch.rand(n, 3, generator=gen), torch.randint(1, 95, (n,), generator=gen), 4 + 6 * torch.rand(1, 3, generator=gen),
+                        70 + 40 * torch.rand(1, 3, generator=gen)) for n in na]
+    rewards = torch.rand(len(na), generator=gen).numpy()
+    cfg = dict(lr=1e-4, accum_steps=5, epochs=1, timesteps=7, sigma=0.025)
+    out = []
+    for stack in (1, 3):
+        P0 = O.init_params(hp, seed=5)
+        agent, prior = make_module(64, 2, 8, 1000, P0), make_module(64, 2, 8, 1000, O.init_params(hp, seed=6))
+        prior.requires_grad_(False)
+        agent.noise_seed = 1234
+        st = ft_step(agent, prior, data, rewards, cfg, fused=True, groups=1, stack=stack)
+        out.append(({k: w.detach().cpu().clone() for k, w in agent.decoder.views().items()}, st, P0))
+    (wa, sa, P0), (wb, sb, _) = out
+    moved = 0.0
+    for k in wa:
+        assert float((wa[k] - wb[k]).abs().max()) <= 2e-6, k
+        moved = max(moved, float((wa[k] - P0["decoder." + k]).abs().max()))
+    assert moved > 5e-5  # two Adam steps really happened
+    for key in ("loss", "loss_diff", "loss_kl"):
+        assert abs(sa[0][key] - sb[0][key]) <= 1e-5 * max(1.0, abs(sa[0][key])), key
