@@ -19,6 +19,18 @@ from .dist import allreduce_flat_, rank_world, shard_range
 from .optim import FusedAdam
 
 
+def _sched_host(agent):
+    """Host copies of the noise schedules (made once per module): indexing the device tensors costs a device sync per scalar and
+    timestep, which the launch-bound small-set regime cannot afford."""
+    h = agent.__dict__.get("_mi_sched_host")
+    if h is None:
+        ac = agent.beta_scheduler.alphas_cumprod.detach().cpu()
+        h = agent.__dict__["_mi_sched_host"] = (torch.sqrt(ac).tolist(), torch.sqrt(1.0 - ac).tolist(),
+                                                agent.sigma_scheduler.sigmas.detach().cpu().tolist(),
+                                                agent.sigma_scheduler.sigmas_norm.detach().cpu().tolist())
+    return h
+
+
 def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats, call_id=None, aux_stream=None):
     """One timestep through mi_ft_micro_step on the current stream; accumulates into `grad` (+=) and `stats` (device, 3
     floats).  `call_id` = the noise-stream call counter (one value per timestep, shared by every crystal group)."""
@@ -29,12 +41,12 @@ def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, acc
     dev = agent.device
     T = agent.beta_scheduler.timesteps
     t = T - int(time_idx)
-    ab, pb = agent._batch_for(batch.num_atoms), prior._batch_for(batch.num_atoms)
+    na = batch.__dict__.setdefault("_mi_na", batch.num_atoms.cpu())  # host copy made once: no device sync per timestep
+    ab, pb = agent._batch_for(na), prior._batch_for(na)
     agent.decoder.sync()
     prior.decoder.sync()
-    ac = agent.beta_scheduler.alphas_cumprod[t]
-    c0, c1 = float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac))
-    sig, sn = float(agent.sigma_scheduler.sigmas[t]), float(agent.sigma_scheduler.sigmas_norm[t])
+    sc0, sc1, ssig, ssn = _sched_host(agent)
+    c0, c1, sig, sn = sc0[t], sc1[t], ssig[t], ssn[t]
     cache = batch.__dict__.setdefault("_mi_dev", {})
     if not cache:
         f = lambda x: x.to(dev, torch.float32).contiguous()
@@ -64,16 +76,14 @@ def _stacked_micro_steps(agent, prior, batch, time_idxs, noises, sigma, n_global
     k = len(time_idxs)
     T = agent.beta_scheduler.timesteps
     ts = [T - int(i) for i in time_idxs]
-    num_atoms = batch.num_atoms.repeat(k)
+    num_atoms = batch.__dict__.setdefault("_mi_na", batch.num_atoms.cpu()).repeat(k)
     ab, pb = agent._batch_for(num_atoms), prior._batch_for(num_atoms)
     agent.decoder.sync()
     prior.decoder.sync()
-    ac = [agent.beta_scheduler.alphas_cumprod[t] for t in ts]
+    sc0, sc1, ssig, ssn = _sched_host(agent)
     arr = lambda ctype, vals: (ctype * k)(*vals)
-    c0 = arr(C.c_float, [float(torch.sqrt(a)) for a in ac])
-    c1 = arr(C.c_float, [float(torch.sqrt(1.0 - a)) for a in ac])
-    sig = arr(C.c_float, [float(agent.sigma_scheduler.sigmas[t]) for t in ts])
-    sn = arr(C.c_float, [float(agent.sigma_scheduler.sigmas_norm[t]) for t in ts])
+    c0, c1 = arr(C.c_float, [sc0[t] for t in ts]), arr(C.c_float, [sc1[t] for t in ts])
+    sig, sn = arr(C.c_float, [ssig[t] for t in ts]), arr(C.c_float, [ssn[t] for t in ts])
     cache = batch.__dict__.setdefault("_mi_dev_stacked", {})
     if k not in cache:
         f = lambda x: x.to(dev, torch.float32).contiguous()
