@@ -13,6 +13,7 @@
 
 namespace mi {
 extern int g_edge_pairs;
+int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
 }
 
 namespace mi {
@@ -104,6 +105,60 @@ __global__ void pair_combine_kernel(const float* __restrict__ dZ1, const int* __
     *reinterpret_cast<f32x4*>(Dm + (size_t)p * H + f) = a - b;
     *reinterpret_cast<f32x4*>(Dp + (size_t)p * H + f) = a + b;
 }
+// Everything of the fc pair-mode backward that consumes dZ1 = dM1 * silu'(Z1), in ONE pass over a crystal's edge block (instead of
+// the silu' pass, pair_combine, the two-read dPQ sums, the self-edge column sum and the per-graph sum: 7 -> 3 passes over [E, H]):
+//   Dm[p] = dZ1[i->j] - dZ1[j->i],  Dp[p] = dZ1[i->j] + dZ1[j->i]                 (pair-mode weight gradient operands)
+//   dPQ[i][0:H] = sum_j dZ1[(i,j)],  dPQ[j][H:2H] = sum_i dZ1[(i,j)],  dG[g] = sum_i dPQ[i][0:H]
+//   dsum_part[g] = sum_i dZ1[(i,i)]                                               (self edges: cosine block's constant column)
+// One block per (crystal, 128-column slice), a thread per column; the per-node row / column sums live in LDS ([2][n][128] floats,
+// each thread only touches its own column: no atomics, fixed order).  Edge (a -> b) of the crystal sits at e0 + a*n + b.
+__global__ __launch_bounds__(128) void edge_bwd_pairs_kernel(const float* __restrict__ dM1, const float* __restrict__ Z1,
+                                                             const int* __restrict__ node_off, const int* __restrict__ rowptr,
+                                                             const int* __restrict__ pair_off, float* __restrict__ Dm, float* __restrict__ Dp,
+                                                             float* __restrict__ dPQ, float* __restrict__ dG, float* __restrict__ dsum_part,
+                                                             int H) {
+    extern __shared__ float accs[];  // row sums [n][128], then column sums [n][128]
+    const int g = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 128 + tid;
+    const int o = node_off[g], n = node_off[g + 1] - o;
+    if (n == 0 || c >= H) return;
+    const int64_t e0 = rowptr[o];
+    float* row = accs;
+    float* col = accs + (size_t)n * 128;
+    float ds = 0.f;
+    for (int i = 0; i < n; ++i) {  // self edges first: they initialise the accumulators
+        const size_t a = (size_t)(e0 + (int64_t)i * n + i) * H + c;
+        const float v = dM1[a] * silu_grad(Z1[a]);
+        row[i * 128 + tid] = v;
+        col[i * 128 + tid] = v;
+        ds += v;
+    }
+    int64_t p = pair_off[g];
+    for (int i = 0; i < n; ++i) {
+        float ri = row[i * 128 + tid], ci = col[i * 128 + tid];
+        for (int j = i + 1; j < n; ++j, ++p) {
+            const size_t a1 = (size_t)(e0 + (int64_t)i * n + j) * H + c, a2 = (size_t)(e0 + (int64_t)j * n + i) * H + c;
+            const float v1 = dM1[a1] * silu_grad(Z1[a1]), v2 = dM1[a2] * silu_grad(Z1[a2]);
+            Dm[(size_t)p * H + c] = v1 - v2;
+            Dp[(size_t)p * H + c] = v1 + v2;
+            ri += v1;                    // i -> j: row i, column j
+            ci += v2;                    // j -> i: row j, column i
+            row[j * 128 + tid] += v2;
+            col[j * 128 + tid] += v1;
+        }
+        row[i * 128 + tid] = ri;
+        col[i * 128 + tid] = ci;
+    }
+    float gs = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float r = row[i * 128 + tid];
+        dPQ[(size_t)(o + i) * (2 * H) + c] = r;
+        dPQ[(size_t)(o + i) * (2 * H) + H + c] = col[i * 128 + tid];
+        gs += r;
+    }
+    dG[(size_t)g * H + c] = gs;
+    dsum_part[(size_t)g * H + c] = ds;
+}
+
 // gW[f][c] += v[f] for c < ncols   (self edges: every cosine feature is 1)
 __global__ void row_broadcast_add_kernel(const float* __restrict__ v, float* __restrict__ gW, int ld, int H, int ncols) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -395,6 +450,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_TRY(colsum_acc(t.dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
         MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         // edge stage (cspnet.py:59-79)
+        bool edge_sums_done = false;  // dPQ and dG already produced by the fused pair-mode kernel
         if (E > 0) {
             const int nchunk = (int)cdiv(E, 256);
             const bool dz2_sums = (size_t)nchunk * H <= scf;  // Z2 := dZ2, with edge_mlp.2.bias's gradient (column sums) on the way
@@ -409,32 +465,48 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             MI_TRY(gemm_tn_auto(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
             if (!dz2_sums) MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
             MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
-            hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
-            MI_KERNEL_CHECK();
+            // fc pair mode: one pass over the crystal blocks of dM1 / Z1 yields every consumer of dZ1 (see edge_bwd_pairs_kernel)
+            const bool fused_pairs = pairs && g_bwd_pairs_fused && b->nmax_fc <= 64 && (size_t)B * H <= scf - H;
+            if (!fused_pairs) {
+                hipLaunchKernelGGL(silu_bwd_kernel, g1(E * H), dim3(256), 0, s, t.dM1, Z1, t.dM1, E * H);  // dM1 := dZ1
+                MI_KERNEL_CHECK();
+            }
             if (pairs) {  // t.M1 is free again (its weight gradient is done): Dm | Dp live there
                 float* gWff = G(p + "edge_mlp.0.weight") + 2 * H + 9;
-                if (Np > 0) {
-                    float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
-                    hipLaunchKernelGGL(pair_combine_kernel, g1(Np * (H / 4)), dim3(256), 0, s, t.dM1, b->pair_e1, b->pair_e2, Dm, Dp, Np, H);
-                    MI_KERNEL_CHECK();
-                    MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
-                    MI_TRY(gemm_tn_auto(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf, s));
-                }
+                float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
                 MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
-                MI_TRY(colsum_acc(t.dM1, H, dsum, N, H, sc, scf - H, s, b->e_diag));
+                if (fused_pairs) {
+                    hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
+                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, t.dPQ, t.dG, sc, H);
+                    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, 64)), dim3(256), 0, s, sc, B, H, dsum, H);
+                    MI_KERNEL_CHECK();
+                } else {
+                    if (Np > 0) {
+                        hipLaunchKernelGGL(pair_combine_kernel, g1(Np * (H / 4)), dim3(256), 0, s, t.dM1, b->pair_e1, b->pair_e2, Dm, Dp, Np, H);
+                        MI_KERNEL_CHECK();
+                    }
+                    MI_TRY(colsum_acc(t.dM1, H, dsum, N, H, sc, scf - H, s, b->e_diag));
+                }
                 hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
                 MI_KERNEL_CHECK();
+                if (Np > 0) {
+                    MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s));
+                    MI_TRY(gemm_tn_auto(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s));
+                }
             } else {
                 MI_TRY(gemm_tn_auto(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
             }
-            if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
-            else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
-            MI_KERNEL_CHECK();
+            if (!fused_pairs) {
+                if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
+                else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
+                MI_KERNEL_CHECK();
+            }
+            edge_sums_done = fused_pairs;
         } else {
             MI_HIP(hipMemsetAsync(t.dPQ, 0, NH * 2 * 4, s));
         }
-        hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dPQ, 2 * H, b->node_off, t.dG, B, H);
+        if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dPQ, 2 * H, b->node_off, t.dG, B, H);
         hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
                            G(p + "edge_mlp.0.bias"), B, H);
         MI_KERNEL_CHECK();

@@ -16,6 +16,7 @@ int g_planes_variant = 0;  // 0: 128-row kernel everywhere (default: with three 
 int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
+extern int g_bwd_pairs_fused;
 int g_tn128 = 1;
 int g_tn_split = 1;
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
@@ -966,7 +967,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     }
     // fully connected edges, row-major incl. self loops (cspnet.py:239-241)
     const size_t Efc = knn ? 0 : (size_t)E;
-    std::vector<int> n2g(N), src(Efc), dst(Efc), rowptr(N + 1, 0), egraph(Efc), pr_i, pr_j, pr_e1, pr_e2, pr_g, ediag(knn ? 0 : N);
+    std::vector<int> n2g(N), src(Efc), dst(Efc), rowptr(N + 1, 0), egraph(Efc), pr_i, pr_j, pr_e1, pr_e2, pr_g, ediag(knn ? 0 : N), pr_off(B + 1, 0);
     size_t e = 0;
     int nslots = knn ? b->deg_cap / 32 + 2 : 1;
     for (int g = 0; g < B; ++g) {
@@ -983,6 +984,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
             if (!knn) nslots = std::max(nslots, (int)((e - 1) >> 5) - (rowptr[o + i] >> 5) + 1);
         }
         if (!knn) {  // unordered pairs i < j and self edges of this crystal; edge (a -> b) sits at rowptr[a] + b_local
+            pr_off[g] = (int)pr_i.size();
+            b->nmax_fc = std::max(b->nmax_fc, n);
             for (int i = 0; i < n; ++i) {
                 ediag[o + i] = rowptr[o + i] + i;
                 for (int j = i + 1; j < n; ++j) {
@@ -996,6 +999,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
         }
     }
     b->Np = (int64_t)pr_i.size();
+    pr_off[B] = (int)pr_i.size();
     rowptr[N] = (int)e;
     b->nslots = nslots;
     const int H = net->H, L = net->L;
@@ -1025,6 +1029,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(pair_e1, (size_t)b->Np);
     A_(pair_e2, (size_t)b->Np);
     A_(pair_graph, (size_t)b->Np);
+    A_(pair_off, B + 1);
     A_(e_diag, knn ? 0 : N);
     A_(M1pl, planes_elems(E, H));
     A_(lnpl, planes_elems(N, H));
@@ -1074,6 +1079,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     if (he == hipSuccess) he = up(b->pair_e1, pr_e1);
     if (he == hipSuccess) he = up(b->pair_e2, pr_e2);
     if (he == hipSuccess) he = up(b->pair_graph, pr_g);
+    if (he == hipSuccess) he = up(b->pair_off, pr_off);
     if (he == hipSuccess) he = up(b->e_diag, ediag);
     if (he != hipSuccess) {
         set_error("index table upload failed: %s", hipGetErrorString(he));
@@ -1140,7 +1146,8 @@ int mi_debug_set_planes_small_tiles(int n) {
 
 int mi_debug_set_tn128(int on) {
     g_tn128 = (on & 1) != 0;
-    g_tn_split = (on & 2) != 0;  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
+    g_tn_split = (on & 2) != 0;
+    g_bwd_pairs_fused = (on & 8) == 0;  // +8: the separate dZ1 consumers instead of the fused pair-mode backward pass  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
     return MI_OK;
 }
 

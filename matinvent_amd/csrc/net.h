@@ -81,6 +81,8 @@ struct mi_batch {
     int64_t Np = 0;
     int *pair_i = nullptr, *pair_j = nullptr, *pair_e1 = nullptr /*edge i->j*/, *pair_e2 = nullptr /*edge j->i*/, *pair_graph = nullptr,
         *e_diag = nullptr /*[N] self edge of node i*/;
+    int* pair_off = nullptr;  // [B+1] first pair row of each crystal (fc list); nmax_fc = largest atom count
+    int nmax_fc = 0;
     float* fd = nullptr;    // [E][3] explicit frac_diff per edge (CSR order); nullptr = fc: (x_dst - x_src) % 1
     int* inedge = nullptr;  // [E] edge ids grouped by destination node, node v at rowptr[v]..rowptr[v+1] (degrees are symmetric)
     int *kn_ent = nullptr, *kn_acnt = nullptr, *kn_deg = nullptr, *kn_mcount = nullptr, *kn_eoff = nullptr, *kn_meta = nullptr,
