@@ -298,7 +298,8 @@ int mi_debug_set_db_min_tiles(int n);
 int mi_debug_set_node_planes_min_rows(int n);
 /* Tuning knob for the weight-gradient products over long row lists (edge / pair list): 3 (default) = bf16 three-plane split on
  * the matrix pipe (split arithmetic path only), 1 = f32 MFMA on 128 x 128 tiles, 0 = f32 MFMA on 64 x 64 tiles; +8 = the separate
- * dZ1-consumer kernels instead of the fused fc pair-mode backward pass (ablation). */
+ * dZ1-consumer kernels instead of the fused fc pair-mode backward pass, +16 = a separate silu(Z1) pass instead of forming M1 inside
+ * the weight-gradient product's operand load (ablations). */
 int mi_debug_set_tn128(int on);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);

@@ -13,6 +13,7 @@
 
 namespace mi {
 extern int g_edge_pairs;
+int g_tn_xsilu = 1;          // M1 = silu(Z1) inside the weight-gradient product's operand load (0: separate pass, ablation)
 int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
 }
 
@@ -460,9 +461,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             } else {
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
             }
-            hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
-            MI_KERNEL_CHECK();
-            MI_TRY(gemm_tn_auto(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
+            if (g_tn_xsilu && gemm_tn_is_split(Z2, H, Z1, H, (int)E, H, H)) {  // M1 = silu(Z1) formed inside the product's operand load
+                MI_TRY(gemm_tn_auto(Z2, H, Z1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s, true));
+            } else {
+                hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
+                MI_KERNEL_CHECK();
+                MI_TRY(gemm_tn_auto(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
+            }
             if (!dz2_sums) MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
             MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
             // fc pair mode: one pass over the crystal blocks of dM1 / Z1 yields every consumer of dZ1 (see edge_bwd_pairs_kernel)

@@ -16,7 +16,7 @@ int g_planes_variant = 0;  // 0: 128-row kernel everywhere (default: with three 
 int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
-extern int g_bwd_pairs_fused;
+extern int g_bwd_pairs_fused, g_tn_xsilu;
 int g_tn128 = 1;
 int g_tn_split = 1;
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
@@ -1147,6 +1147,7 @@ int mi_debug_set_planes_small_tiles(int n) {
 int mi_debug_set_tn128(int on) {
     g_tn128 = (on & 1) != 0;
     g_tn_split = (on & 2) != 0;
+    g_tn_xsilu = (on & 16) == 0;         // +16: separate silu(Z1) pass instead of forming M1 inside the weight-gradient product
     g_bwd_pairs_fused = (on & 8) == 0;  // +8: the separate dZ1 consumers instead of the fused pair-mode backward pass  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
     return MI_OK;
 }

@@ -870,6 +870,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 // rows, 16-byte chunks XOR-swizzled), and the MFMA loop is the same six-term one (staging: see below).  Needs even leading
 // dimensions and 8-byte aligned operands.  128 x 128 output tile, next slab prefetched into registers during the MFMAs,
 // XCD-aware tile order as in gemm_tn128_kernel, partial tiles reduced in fixed order by tn_reduce_kernel.
+// XSILU: the X operand is silu(X) of what is stored (the backward pass keeps the pre-activation Z1; M1 = silu(Z1) is formed here
+// instead of by a separate pass over [E, H]).
+template <bool XSILU>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_tn_split_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx, float* __restrict__ P, int M, int Na, int Kx, int rows_per_split,
     int gx, int gy, int nsplit) {
@@ -915,7 +918,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
             for (int t2 = 0; t2 < 4; ++t2) {
                 unsigned p[3], q[3];
                 split3_pair(ra[2 * t2][u], ra[2 * t2 + 1][u], p);
-                split3_pair(rx[2 * t2][u], rx[2 * t2 + 1][u], q);
+                if constexpr (XSILU) split3_pair(silu_fast(rx[2 * t2][u]), silu_fast(rx[2 * t2 + 1][u]), q);
+                else split3_pair(rx[2 * t2][u], rx[2 * t2 + 1][u], q);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     va[pl][t2] = p[pl];
@@ -979,22 +983,29 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
 
 extern int g_tn_split;  // long weight-gradient contractions on the bf16 matrix pipe (1, split path only) or the f32 MFMA (0)
 // C[Na,Kx] (ldc) += A^T X: picks the kernel by shape and arithmetic path (see gemm_tn_acc for the scratch contract)
+// whether gemm_tn_auto will take the bf16-pipe kernel for this shape (the only one that can apply silu to X on the fly)
+inline bool gemm_tn_is_split(const float* A, int lda, const float* X, int ldx, int M, int Na, int Kx) {
+    return g_gemm_mode != 0 && g_tn_split && M >= 8192 && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 &&
+           ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0;
+}
 inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
-                        size_t scratch_floats, hipStream_t s) {
-    if (g_gemm_mode != 0 && g_tn_split && M >= 8192 && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 && ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0) {
+                        size_t scratch_floats, hipStream_t s, bool x_silu = false) {
+    if (gemm_tn_is_split(A, lda, X, ldx, M, Na, Kx)) {
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
         int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
         while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
         MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
         nsplit = cdiv(M, rows);
-        hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(gx * gy * ((nsplit + 7) / 8 * 8)), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy,
-                           nsplit);
+        const dim3 grid(gx * gy * ((nsplit + 7) / 8 * 8));
+        if (x_silu) hipLaunchKernelGGL(gemm_tn_split_kernel<true>, grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
+        else hipLaunchKernelGGL(gemm_tn_split_kernel<false>, grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx,
                            1.0f);
         MI_KERNEL_CHECK();
         return MI_OK;
     }
+    MI_CHECK(!x_silu, MI_EINVAL, "gemm_tn_auto: silu on the X operand needs the bf16-pipe kernel (check gemm_tn_is_split first)");
     return gemm_tn_acc(A, lda, X, ldx, C, ldc, M, Na, Kx, scratch, scratch_floats, s);
 }
 
