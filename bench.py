@@ -122,7 +122,7 @@ def _oracle_steps(O, P, hp, sch, na, noise, t_from, t_to):
 def _apply_env_knobs(lib):
     """Experiment knobs (A/B runs of kernel choices); the defaults are what the library ships with."""
     for env, fn in (("MI_DB_MIN_TILES", lib.mi_debug_set_db_min_tiles), ("MI_NODE_PLANES_MIN_ROWS", lib.mi_debug_set_node_planes_min_rows),
-                    ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128),
+                    ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128), ("MI_TN_SPLIT_MIN_ROWS", lib.mi_debug_set_tn_split_min_rows),
                     ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs)):
         if os.environ.get(env):
             fn(int(os.environ[env]))

@@ -301,6 +301,8 @@ int mi_debug_set_node_planes_min_rows(int n);
  * dZ1-consumer kernels instead of the fused fc pair-mode backward pass, +16 = a separate silu(Z1) pass instead of forming M1 inside
  * the weight-gradient product's operand load (ablations). */
 int mi_debug_set_tn128(int on);
+/* Tuning knob: shortest row list (contraction length) for which the bf16-pipe weight-gradient kernel is used (default 4096). */
+int mi_debug_set_tn_split_min_rows(int n);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
 int mi_profile_enable(mi_net* net, int on);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mi_debug_set_db_min_tiles": (_I, [_I]),
     "mi_debug_set_node_planes_min_rows": (_I, [_I]),
     "mi_debug_set_tn128": (_I, [_I]),
+    "mi_debug_set_tn_split_min_rows": (_I, [_I]),
     "mi_debug_set_planes_small_tiles": (_I, [_I]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),

@@ -19,6 +19,7 @@ int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles 
 extern int g_bwd_pairs_fused, g_tn_xsilu;
 int g_tn128 = 1;
 int g_tn_split = 1;
+int g_tn_split_min_rows = 4096;  // (at 5120 rows: 43 -> 39 us for 512 x 512, 71 -> 56 us for 512 x 1024; no gain below)
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 int g_node_planes_min_rows = 512;  // node-level products: plane-set kernel from this many nodes up, fp32-operand split-K kernel below
 
@@ -1149,6 +1150,11 @@ int mi_debug_set_tn128(int on) {
     g_tn_split = (on & 2) != 0;
     g_tn_xsilu = (on & 16) == 0;         // +16: separate silu(Z1) pass instead of forming M1 inside the weight-gradient product
     g_bwd_pairs_fused = (on & 8) == 0;  // +8: the separate dZ1 consumers instead of the fused pair-mode backward pass  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
+    return MI_OK;
+}
+
+int mi_debug_set_tn_split_min_rows(int n) {
+    g_tn_split_min_rows = n;
     return MI_OK;
 }
 

@@ -981,11 +981,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
             }
 }
 
+extern int g_tn_split_min_rows;  // shortest row list for which the bf16-pipe weight-gradient kernel is used
 extern int g_tn_split;  // long weight-gradient contractions on the bf16 matrix pipe (1, split path only) or the f32 MFMA (0)
 // C[Na,Kx] (ldc) += A^T X: picks the kernel by shape and arithmetic path (see gemm_tn_acc for the scratch contract)
 // whether gemm_tn_auto will take the bf16-pipe kernel for this shape (the only one that can apply silu to X on the fly)
 inline bool gemm_tn_is_split(const float* A, int lda, const float* X, int ldx, int M, int Na, int Kx) {
-    return g_gemm_mode != 0 && g_tn_split && M >= 8192 && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 &&
+    return g_gemm_mode != 0 && g_tn_split && M >= g_tn_split_min_rows && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 &&
            ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0;
 }
 inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
