@@ -867,7 +867,7 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
         hipStream_t s = (hipStream_t)stream;
         if (planes_elems(M, K) > na) { if (pa) (void)hipFree(pa); na = planes_elems(M, K); MI_HIP(hipMalloc((void**)&pa, na * 2)); }
         if (planes_elems(N, K) > nw) { if (pw) (void)hipFree(pw); nw = planes_elems(N, K); MI_HIP(hipMalloc((void**)&pw, nw * 2)); }
-        Planes PA = make_planes(pa, K), PW = make_planes(pw, K);
+        Planes PA = make_planes(pa, K, PL_S_LN), PW = make_planes(pw, K, PL_SW);
         if (ldc >= 0) {
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((M + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, M, K, PA);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((N + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, N, K, PW);

@@ -122,7 +122,7 @@ __global__ void fourier_planes_kernel(const float* __restrict__ frac, const floa
     if (m >= np) {  // zero padding of the K direction
         const int col = 2 * F3 + 2 * (m - np);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, col, k)) = 0u;
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, col, k)) = 0u;
         return;
     }
     float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
@@ -136,12 +136,12 @@ __global__ void fourier_planes_kernel(const float* __restrict__ frac, const floa
         }
     }
     unsigned p[3];
-    split3_pair(sn[0], sn[1], p);
+    pl_split_pair(sn[0], sn[1], FF.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
-    split3_pair(cs[0], cs[1], p);
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
+    pl_split_pair(cs[0], cs[1], FF.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, F3 + 2 * m, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, F3 + 2 * m, k)) = p[k];
 }
 
 // per-column-pair form (any F)
@@ -169,9 +169,9 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
         }
     }
     unsigned p[3];
-    split3_pair(v[0], v[1], p);
+    pl_split_pair(v[0], v[1], FF.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, c0, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, c0, k)) = p[k];
 }
 
 // Pair-mode Fourier operand: rows = unordered pairs (i, j), columns = [sin(3F) | 0 .. Kh) | cos(3F) | 0 .. 2Kh) of
@@ -198,12 +198,12 @@ __global__ void fourier_pair_planes_kernel(const float* __restrict__ frac, const
         }
     }
     unsigned p[3];
-    split3_pair(sn[0], sn[1], p);
+    pl_split_pair(sn[0], sn[1], FF.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
-    split3_pair(cs[0], cs[1], p);
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
+    pl_split_pair(cs[0], cs[1], FF.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, Kh + 2 * m, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, Kh + 2 * m, k)) = p[k];
 }
 
 // plane set of the Fourier block of edge_mlp.0 in the pair-mode column layout; C0[f] = sum of its cosine block
@@ -220,9 +220,9 @@ __global__ void pack_wff_pair_planes_kernel(const float* __restrict__ W1, int ed
         if (f < H && cc < F3) v[u] = W1[(size_t)f * edge_in + 2 * H + 9 + blk * F3 + cc];
     }
     unsigned p[3];
-    split3_pair(v[0], v[1], p);
+    pl_split_pair(v[0], v[1], dst.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(f, col, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(f, col, k)) = p[k];
 }
 __global__ void wff_cos_rowsum_kernel(const float* __restrict__ W1, int edge_in, int H, int F, float* __restrict__ C0) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,9 +250,9 @@ __global__ void edge_diag_kernel(const float* __restrict__ PQ, const float* __re
         pre_act[(size_t)e * H + f + 1] = v[1];
     }
     unsigned p[3];
-    split3_pair(silu_fast(v[0]), silu_fast(v[1]), p);
+    pl_split_pair(silu_fast(v[0]), silu_fast(v[1]), M1.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(M1.base + M1.elem(e, f, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(M1.base + M1.elem(e, f, k)) = p[k];
 }
 
 // Wff[f][0:6F] = W1[f][2H+9 : 2H+9+6F]  (contiguous, 16-byte aligned rows for the GEMM path)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         yr[c] = o;
         if (ypl.base) {
             u16 p0, p1, p2;
-            split3(o, p0, p1, p2);
+            pl_split(o, ypl.s(), p0, p1, p2);
             ypl.base[ypl.elem(row, c, 0)] = p0;
             ypl.base[ypl.elem(row, c, 1)] = p1;
             ypl.base[ypl.elem(row, c, 2)] = p2;
@@ -334,7 +334,7 @@ __global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict_
     y[(size_t)r * ldy + c] = x[idx];
     if (ypl.base) {
         u16 p0, p1, p2;
-        split3(x[idx], p0, p1, p2);
+        pl_split(x[idx], ypl.s(), p0, p1, p2);
         ypl.base[ypl.elem(r, c, 0)] = p0;
         ypl.base[ypl.elem(r, c, 1)] = p1;
         ypl.base[ypl.elem(r, c, 2)] = p2;
@@ -345,7 +345,7 @@ __global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict_
 // do not change inside an evaluation); layer l's edge_mlp.0 weight / bias sit `layer_stride` floats after layer l-1's in the flat
 // parameter vector.
 __global__ void gram_term_all_kernel(const float* __restrict__ lattices, const float* __restrict__ W1_0, int64_t layer_stride, int edge_in,
-                                     const float* __restrict__ b1_0, float* __restrict__ G, int H, int B) {
+                                     const float* __restrict__ b1_0, float* __restrict__ G, int H, int B, unsigned* __restrict__ gmax) {
     const int b = blockIdx.x, l = blockIdx.y;
     __shared__ float gram[9];
     if (threadIdx.x < 9) {
@@ -356,14 +356,88 @@ __global__ void gram_term_all_kernel(const float* __restrict__ lattices, const f
     __syncthreads();
     const float* W1 = W1_0 + l * layer_stride;
     const float* b1 = b1_0 + l * layer_stride;
+    float gm = 0.f;
     for (int f = threadIdx.x; f < H; f += blockDim.x) {
         const float* w = W1 + (size_t)f * edge_in + 2 * H;
         float s = 0.f;
 #pragma unroll
         for (int m = 0; m < 9; ++m) s += gram[m] * w[m];
         G[((size_t)l * B + b) * H + f] = s + b1[f];
+        gm = fmaxf(gm, fabsf(s + b1[f]));
+    }
+    if (gmax) {  // max |G[l]| over the batch (order-independent): part of the bound that scales the M1 plane set
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(gmax + l, __float_as_uint(gm));
     }
 }
+
+// max |x| over n floats -> atomicMax of the bit pattern (non-negative floats order like unsigned integers)
+__global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// wb[l][0..4] = max_f sum_k |Wff[f][k]| (Fourier block of edge_mlp.0), max_f sum_k |W2[f][k]|, max |b2|,
+//               max_f sum_k |node_mlp.0.weight[f][H + k]|, max |node_mlp.0.bias|      (one block per layer, at parameter updates)
+__global__ __launch_bounds__(256) void weight_bounds_kernel(const float* __restrict__ W1_0, const float* __restrict__ W2_0,
+                                                            const float* __restrict__ b2_0, const float* __restrict__ Wn0_0,
+                                                            const float* __restrict__ bn0_0, int64_t layer_stride, int edge_in, int H, int F6,
+                                                            float* __restrict__ wb) {
+    const int l = blockIdx.x;
+    const float *W1 = W1_0 + l * layer_stride, *W2 = W2_0 + l * layer_stride, *b2 = b2_0 + l * layer_stride, *Wn0 = Wn0_0 + l * layer_stride,
+                *bn0 = bn0_0 + l * layer_stride;
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+        float a = 0.f, c = 0.f, d = 0.f;
+        for (int k = 0; k < F6; ++k) a += fabsf(W1[(size_t)f * edge_in + 2 * H + 9 + k]);
+        for (int k = 0; k < H; ++k) {
+            c += fabsf(W2[(size_t)f * H + k]);
+            d += fabsf(Wn0[(size_t)f * 2 * H + H + k]);
+        }
+        m[0] = fmaxf(m[0], a);
+        m[1] = fmaxf(m[1], c);
+        m[2] = fmaxf(m[2], fabsf(b2[f]));
+        m[3] = fmaxf(m[3], d);
+        m[4] = fmaxf(m[4], fabsf(bn0[f]));
+    }
+    __shared__ float red[5][4];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[q] = fmaxf(m[q], __shfl_xor(m[q], o, 64));
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = m[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) wb[l * 8 + threadIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+}
+
+// Per layer, after the LayerNorm(h) product: power-of-two scales of the three unbounded activation plane sets from RIGOROUS bounds
+//   |M1| <= |Z1| <= sum|Wff| + max|P_i| + max|P_j| + max|G|            (|Fourier features| <= 1, |silu(z)| <= |z|)
+//   |agg| <= max|Z2| <= max|b2| + rowsum|W2| * bound(M1)
+//   |X|   <= |pre|   <= max|b| + rowsum|W[:, H:]| * bound(agg) + max|X_part|
+// (pq = max over the whole [P_i | P_j | X_part] block).  scale = 2^floor(log2(16384 / bound)): the largest stored magnitude
+// stays below 32768, elements down to bound * 2^-18 keep all 22 bits.  Resets pq for the next layer.
+__global__ void act_scales_kernel(unsigned* __restrict__ pq, const unsigned* __restrict__ gmax, const float* __restrict__ wb, float* __restrict__ dsc) {
+    const float mpq = __uint_as_float(*pq), mg = __uint_as_float(*gmax);
+    float bound[3];
+    bound[0] = wb[0] + 2.f * mpq + mg;
+    bound[1] = wb[2] + wb[1] * bound[0];
+    bound[2] = wb[4] + wb[3] * bound[1] + mpq;
+    for (int c = 0; c < 3; ++c) {
+        float bnd = bound[c];
+        int e = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
+        if (!(bnd == bnd) || bnd > 3e38f) e = -100;  // NaN / inf upstream: everything saturates, nothing overflows
+        e = e > 14 ? 14 : (e < -100 ? -100 : e);
+        dsc[2 * c] = exp2f((float)e);
+        dsc[2 * c + 1] = exp2f(-(float)e);
+    }
+    *pq = 0u;
+}
+
 
 // agg[i] = (sum of this node's slots) / degree  -> cat[i][H:2H]       (scatter mean, cspnet.py:79)
 // aggpl (optional): the same values as a bf16 plane set (N x H).
@@ -382,7 +456,7 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
     cat[(size_t)i * (2 * H) + H + f] = s;
     if (aggpl.base) {
         u16 p0, p1, p2;
-        split3(s, p0, p1, p2);
+        pl_split(s, aggpl.s(), p0, p1, p2);
         aggpl.base[aggpl.elem(i, f, 0)] = p0;
         aggpl.base[aggpl.elem(i, f, 1)] = p1;
         aggpl.base[aggpl.elem(i, f, 2)] = p2;
@@ -574,14 +648,14 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_KERNEL_CHECK();
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0) {
         if (b->Np > 0) {  // pair mode: one operand row per unordered pair
-            Planes ffp = make_planes(b->FFpl, 2 * net->Kh);
+            Planes ffp = make_planes(b->FFpl, 2 * net->Kh, PL_S_UNIT);
             const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 2);
             hipLaunchKernelGGL(fourier_pair_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np,
                                net->F, net->Kh);
             MI_KERNEL_CHECK();
         }
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
-        Planes ffp = make_planes(b->FFpl, 6 * net->F);
+        Planes ffp = make_planes(b->FFpl, 6 * net->F, PL_S_UNIT);
         const int64_t rows_pad = (b->E + 127) / 128 * 128;
         if (net->F % 2 == 0) {
             const int64_t nthr = rows_pad * (int64_t)(ffp.KT * 16 - 3 * net->F / 2);
@@ -601,7 +675,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const float* b0 = net->p("csp_layer_0.edge_mlp.0.bias");
         const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
-        hipLaunchKernelGGL(gram_term_all_kernel, dim3(B, L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B);
+        MI_HIP(hipMemsetAsync(b->absmax, 0, (1 + L) * sizeof(unsigned), s));
+        hipLaunchKernelGGL(gram_term_all_kernel, dim3(B, L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
@@ -615,8 +690,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         // written by their producers; the fp32-operand kernel re-splits every operand tile in every workgroup).  Grouped by
         // operand: everything LayerNorm(h) feeds -- P_i, P_j and its half of the node MLP's first product -- is ONE product
         // before the edge stage, so only agg x W[:, H:] (K = H instead of 2H) is left on the path after it.
-        const Planes lnp = node_planes ? make_planes(b->lnpl, H) : Planes();
-        const Planes aggp = node_planes ? make_planes(b->aggpl, H) : Planes();
+        const Planes lnp = node_planes ? make_planes(b->lnpl, H, PL_S_LN) : Planes();
+        const Planes aggp = node_planes ? make_planes(b->aggpl, H, PL_S_ACT, b->dsc + 2) : Planes();
         const int ldpq = node_planes ? 3 * H : 2 * H;
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_in, net->p(p + "layer_norm.weight"),
@@ -629,9 +704,19 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             PlanesEpilogue pq;
             pq.C = b->PQ;
             pq.ldc = ldpq;
+            pq.absmax = MI_PLANES_FP16 ? b->absmax : nullptr;
             MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, s));
         } else {
             MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+            if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && b->E > 0) {
+                hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, s, b->PQ, (int64_t)N * 2 * H,
+                                   b->absmax);
+                MI_KERNEL_CHECK();
+            }
+        }
+        if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT) {  // scales of this layer's M1 / agg / X plane sets
+            hipLaunchKernelGGL(act_scales_kernel, dim3(1), dim3(1), 0, s, b->absmax, b->absmax + 1 + l, net->wbounds + (size_t)l * 8, b->dsc);
+            MI_KERNEL_CHECK();
         }
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
             MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
@@ -664,9 +749,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 g2e.ld_pre = H;
             }
             if (g_gemm_mode == MI_GEMM_SPLIT) {  // operands pre-split into bf16 planes: pure bf16 GEMMs
-                Planes ffp = make_planes(b->FFpl, F6);
+                Planes ffp = make_planes(b->FFpl, F6, PL_S_UNIT);
                 Planes wffp = make_planes(net->Wffpl + (size_t)l * planes_elems(H, F6), F6);
-                Planes m1p = make_planes(b->M1pl, H);
+                Planes m1p = make_planes(b->M1pl, H, PL_S_ACT, b->dsc);
                 Planes w2p = make_planes(net->W2pl + (size_t)l * planes_elems(H, H), H);
                 PlanesEpilogue pe1;
                 pe1.ep = g1e;
@@ -681,7 +766,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                     pe1.pair_e2 = b->pair_e2;
                     pe1.pair_graph = b->pair_graph;
                     if (b->Np > 0)
-                        MI_TRY(gemm_planes(make_planes(b->FFpl, Kp), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
+                        MI_TRY(gemm_planes(make_planes(b->FFpl, Kp, PL_S_UNIT), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
                     hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G + (size_t)l * B * H,
                                        net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
@@ -722,7 +807,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             p1.ep = e1;
             p1.ep.pre_add = b->PQ + 2 * H;  // LayerNorm(h) x W[:, :H], computed with P_i / P_j
             p1.ep.ld_pre_add = ldpq;
-            p1.Cp = make_planes(b->Xpl, H);
+            p1.Cp = make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4);
             MI_TRY(gemm_planes(aggp, make_planes(net->Waggpl + (size_t)l * planes_elems(H, H), H), N, H, H, p1, s));
         } else {
             MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s, &b->sk));
@@ -741,7 +826,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             p2.ep = e2;
             p2.C = h_out;
             p2.ldc = H;
-            MI_TRY(gemm_planes(make_planes(b->Xpl, H), make_planes(net->Wn2pl + (size_t)l * planes_elems(H, H), H), N, H, H, p2, s));
+            MI_TRY(gemm_planes(make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4), make_planes(net->Wn2pl + (size_t)l * planes_elems(H, H), H), N, H, H, p2, s));
         } else {
             MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s, &b->sk));
         }
@@ -845,6 +930,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->Wlnpl) (void)hipFree(n->Wlnpl);
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
+    if (n->wbounds) (void)hipFree(n->wbounds);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
 }
@@ -879,6 +965,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Wlnpl, (size_t)n->L * planes_elems(3 * H, H) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->Waggpl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->Wn2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&n->wbounds, (size_t)n->L * 8 * sizeof(float)));
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
@@ -922,6 +1009,13 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
         }
+    }
+    if (n->L > 0) {  // weight bounds behind the activation scales of the fp16 plane format (see act_scales_kernel)
+        const float* w0 = n->p("csp_layer_0.edge_mlp.0.weight");
+        const int64_t lstride = n->L > 1 ? n->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
+        hipLaunchKernelGGL(weight_bounds_kernel, dim3(n->L), dim3(256), 0, s, w0, n->p("csp_layer_0.edge_mlp.2.weight"),
+                           n->p("csp_layer_0.edge_mlp.2.bias"), n->p("csp_layer_0.node_mlp.0.weight"), n->p("csp_layer_0.node_mlp.0.bias"), lstride,
+                           n->edge_in, H, 6 * n->F, n->wbounds);
     }
     MI_KERNEL_CHECK();
     MI_TRY(net_pack_transposes(n, s));
@@ -1036,6 +1130,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(lnpl, planes_elems(N, H));
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
+    A_(dsc, 6);
+    A_(absmax, 1 + L);
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);
@@ -1060,7 +1156,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     if (hipMemset(b->M1pl, 0, planes_elems(E, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->lnpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->aggpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
-        hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess) {
+        hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
+        hipMemset(b->absmax, 0, (1 + L) * sizeof(unsigned)) != hipSuccess) {
         mi_batch_destroy(b);
         set_error("hipMemset failed");
         return MI_EHIP;

@@ -52,6 +52,61 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) 
     p[2] = cvt_pk_bf16(rx, ry);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Element format of the PRE-SPLIT plane sets (the operands of gemm_planes*).
+//   MI_PLANES_FP16 = 1:  two fp16 planes,  x * s = h0 + h1  with h0 = fp16(x s), h1 = fp16(x s - h0): 22 mantissa bits in two
+//     16-bit words, so a product needs THREE MFMA terms (h0 g0 + h0 g1 + h1 g0; the dropped h1 g1 is 2^-22 relative) instead
+//     of the six of the three-plane bf16 split -- half the matrix-pipe work, two thirds of the operand bytes.  fp16 has a
+//     narrow exponent range, so each operand class carries a fixed power-of-two scale (below) chosen for the magnitudes it can
+//     take; the accumulator is multiplied by 1 / (sA sW) before the epilogue (a power of two: exact).  Where the scaled value
+//     is small the residual plane goes subnormal and the representation error becomes ABSOLUTE (2^-25 / scale) instead of
+//     relative; values beyond 65504 / scale saturate (finite, wrong) -- use the three-plane build for such networks.
+//   MI_PLANES_FP16 = 0:  three bf16 planes, six terms, no range limits.
+// Plane 2 of the tile layout is unused in the fp16 format (neither written nor read).
+// ------------------------------------------------------------------------------------------------------------------------
+#ifndef MI_PLANES_FP16
+#define MI_PLANES_FP16 1
+#endif
+constexpr int NPL = MI_PLANES_FP16 ? 2 : 3;
+// scales by operand class (a plane set carries its scale in Planes::scale; the GEMM multiplies the accumulator by 1 / (sA sW)):
+constexpr float PL_SW = MI_PLANES_FP16 ? 64.f : 1.f;      // weights: exact up to |w| = 1023, residual plane normal down to |w| ~ 2e-3
+constexpr float PL_S_UNIT = MI_PLANES_FP16 ? 64.f : 1.f;  // Fourier features, |x| <= 1
+constexpr float PL_S_LN = MI_PLANES_FP16 ? 8.f : 1.f;     // LayerNorm outputs (|x| <= sqrt(H) |w_ln|): up to 8188
+constexpr float PL_S_ACT = MI_PLANES_FP16 ? 0.125f : 1.f;  // unbounded activations (SiLU outputs, aggregated messages): up to 5.2e5,
+                                                           // absolute error <= 2.4e-7 below |x| ~ 1 (the residual plane goes subnormal)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
+    f16x2 h = {(_Float16)lo, (_Float16)hi};  // round to nearest even
+    return __builtin_bit_cast(unsigned, h);
+}
+// plane words of the element pair (x, y): p[k] = plane k of x | plane k of y << 16; `scale` = the destination plane set's scale
+__device__ __forceinline__ void pl_split_pair(float x, float y, float scale, unsigned (&p)[3]) {
+#if MI_PLANES_FP16
+    // (saturate instead of overflowing to inf: inf x 0 in a padded column would poison the whole row)
+    const float xs = fminf(fmaxf(x * scale, -65504.f), 65504.f), ys = fminf(fmaxf(y * scale, -65504.f), 65504.f);
+    const f16x2 h0 = {(_Float16)xs, (_Float16)ys};
+    p[0] = __builtin_bit_cast(unsigned, h0);
+    p[1] = pack_f16(xs - (float)h0[0], ys - (float)h0[1]);
+    p[2] = 0u;
+#else
+    (void)scale;
+    split3_pair(x, y, p);
+#endif
+}
+__device__ __forceinline__ void pl_split(float x, float scale, u16& p0, u16& p1, u16& p2) {
+#if MI_PLANES_FP16
+    const float xs = fminf(fmaxf(x * scale, -65504.f), 65504.f);
+    const _Float16 h0 = (_Float16)xs, h1 = (_Float16)(xs - (float)h0);
+    p0 = __builtin_bit_cast(u16, h0);
+    p1 = __builtin_bit_cast(u16, h1);
+    p2 = 0;
+#else
+    (void)scale;
+    split3(x, p0, p1, p2);
+#endif
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                             float* __restrict__ C, int ldc, int M, int N, int K, GemmEpilogue ep, int kchunk,
@@ -242,6 +297,9 @@ namespace mi {
 struct Planes {
     u16* base = nullptr;
     int KT = 0;  // column tiles per row tile
+    float scale = 1.f;  // power-of-two scale of the stored values (fp16 two-plane format; 1 for the bf16 format)
+    const float* dscale = nullptr;  // optional DEVICE-side {scale, 1 / scale}: per-evaluation scale of an unbounded activation class
+    __device__ __forceinline__ float s() const { return dscale ? dscale[0] : scale; }
     // +2048 elements (4 KiB) per row tile: without the skew every row tile starts a multiple of 64 KiB apart,
     // i.e. on the same memory channel, and workgroups marching through k in lockstep hammer a few channels
     // (measured: 2x slower than the row-major form).
@@ -249,7 +307,9 @@ struct Planes {
     __host__ __device__ size_t elem(int r, int c, int p) const { return tile(r >> 7, c >> 5) + (size_t)p * 4096 + (r & 127) * 32 + (c & 31); }
 };
 static inline size_t planes_elems(int64_t rows, int cols) { return (size_t)((rows + 127) / 128) * ((size_t)((cols + 31) / 32) * 12288 + 2048); }
-static inline Planes make_planes(u16* base, int cols) { return Planes{base, (cols + 31) / 32}; }
+static inline Planes make_planes(u16* base, int cols, float scale = PL_SW, const float* dscale = nullptr) {
+    return Planes{base, (cols + 31) / 32, scale, MI_PLANES_FP16 ? dscale : nullptr};
+}
 
 // fp32 [rows][cols] (row stride ld_src) -> plane set (pads written as zero); one thread per column pair
 // (row0: first destination row -- lets several matrices share one plane set; the zero row padding then runs to the next
@@ -263,9 +323,9 @@ static __global__ void split_planes_kernel(const float* __restrict__ src, int ld
     float x = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
     float y = (r < rows && c + 1 < cols) ? src[(size_t)r * ld_src + c + 1] : 0.f;
     unsigned p[3];
-    split3_pair(x, y, p);
+    pl_split_pair(x, y, dst.s(), p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(row0 + r, c, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(row0 + r, c, k)) = p[k];
 }
 
 // buffer descriptor over [p, p + bytes) with every field forced into scalar registers (the compiler otherwise
@@ -278,6 +338,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
 
 struct PlanesEpilogue {
     GemmEpilogue ep;       // bias / gathers / pre_act / act / residual as for the fp32 kernels
+    float out_scale = 1.f; // 1 / (A.scale * W.scale), set by gemm_planes: applied to the accumulator first
+    const float* a_dinv = nullptr;  // device-side 1 / (dynamic scale of A), multiplied in as well (set by gemm_planes)
+    unsigned* absmax = nullptr;     // optional: atomicMax of the bit pattern of max |output| (row-major epilogue only)
+    __device__ __forceinline__ float oscale() const { return a_dinv ? out_scale * a_dinv[0] : out_scale; }
     float* C = nullptr;    // optional fp32 output [M][ldc]
     int ldc = 0;
     Planes Cp;             // optional plane-set output (the A operand of the next GEMM)
@@ -307,6 +371,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N, int l31,
                                                 int kg) {
     const GemmEpilogue& ep = pe.ep;
+    const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rb = row_w + i * 32;  // first row of this 32-row block
@@ -330,14 +395,14 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
                 const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 float v = 0.f;
                 if (row < M && col_ok) {
-                    v = apply_epilogue<true>(ep, acc[i][j][r] + bcol, row, col);
+                    v = apply_epilogue<true>(ep, acc[i][j][r] * os + bcol, row, col);
                     if (pe.C) pe.C[(size_t)row * pe.ldc + col] = v;
                     if (pe.Cp.base) {
                         u16 p0, p1, p2;
-                        split3(v, p0, p1, p2);
+                        pl_split(v, cps, p0, p1, p2);
                         pe.Cp.base[pe.Cp.elem(row, col, 0)] = p0;
                         pe.Cp.base[pe.Cp.elem(row, col, 1)] = p1;
-                        pe.Cp.base[pe.Cp.elem(row, col, 2)] = p2;
+                        if (NPL > 2) pe.Cp.base[pe.Cp.elem(row, col, 2)] = p2;
                     }
                 }
                 val[r] = v;
@@ -377,14 +442,16 @@ template <int TM, int TN>
 __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N,
                                                      int lane, float* stage) {
     const GemmEpilogue& ep = pe.ep;
+    const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
     const int l31 = lane & 31, kg = lane >> 5;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rb = row_w + i * 32, cb = col_w + j * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r] * os;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -422,6 +489,10 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                         for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
                     }
                     if (ep.residual) add8(v, ep.residual + (size_t)row * ep.ld_res + col);
+                    if (pe.absmax) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+                    }
                     if (pe.C) {
                         float* d = pe.C + (size_t)row * pe.ldc + col;
                         *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
@@ -432,18 +503,23 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned pr[3];
-                            split3_pair(v[2 * k], v[2 * k + 1], pr);
+                            pl_split_pair(v[2 * k], v[2 * k + 1], cps, pr);
                             o[0][k] = pr[0];
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
                         }
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(row, col, pl)) = o[pl];
+                        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(row, col, pl)) = o[pl];
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+    if (pe.absmax) {  // max |output| of this wave's block: order-independent, so the atomic keeps the result deterministic
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) atomicMax(pe.absmax, __float_as_uint(amax));
+    }
 }
 // PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major
 // through two per-wave LDS patches; each lane handles 8 consecutive columns of one pair and emits BOTH directed edges.
@@ -451,6 +527,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, f32x16 (&accS)[TM][TN], f32x16 (&accC)[TM][TN], int row_w,
                                                       int col_w, int M, int N, int lane, float* stage) {
     const GemmEpilogue& ep = pe.ep;
+    const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
     const int l31 = lane & 31, kg = lane >> 5;
     float* stS = stage;
     float* stC = stage + 1152;
@@ -462,8 +539,8 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31;
-                stS[o] = accS[i][j][r];
-                stC[o] = accC[i][j][r];
+                stS[o] = accS[i][j][r] * os;
+                stC[o] = accC[i][j][r] * os;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -522,13 +599,13 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned pr[3];
-                            split3_pair(v[2 * k], v[2 * k + 1], pr);
+                            pl_split_pair(v[2 * k], v[2 * k + 1], cps, pr);
                             o[0][k] = pr[0];
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
                         }
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
                     }
                 }
             }
@@ -543,6 +620,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void planes_store_preact_rows(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N,
                                                          int lane, float* stage) {
     const GemmEpilogue& ep = pe.ep;
+    const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
     const int l31 = lane & 31, kg = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -550,7 +628,7 @@ __device__ __forceinline__ void planes_store_preact_rows(const PlanesEpilogue& p
         for (int j = 0; j < TN; ++j) {
             const int rb = row_w + i * 32, cb = col_w + j * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r] * os;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -630,7 +708,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(W.base + W.tile(ct, 0), KT * 24576);
     auto load_tiles = [&](int kt, u32x4 (&ra)[3][TM], u32x4 (&rw)[3][2]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 if (v < TM) ra[p][v] = __builtin_amdgcn_raw_buffer_load_b128(rsa, tid * 16, kt * 24576 + p * 8192 + v * 4096 + ahalf, 0);
@@ -639,7 +717,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     };
     auto store_tiles = [&](const u32x4 (&ra)[3][TM], const u32x4 (&rw)[3][2]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 const int f = v * 256 + tid, r = f >> 2, c = (f & 3) ^ ((r >> 2) & 3);
@@ -650,6 +728,30 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
+#if MI_PLANES_FP16
+            f16x8 a[TM][2], b[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = (wm * TM + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[i][pl] = *reinterpret_cast<const f16x8*>(As + pl * PLA + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = (wn * TN + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const f16x8*>(Ws + pl * PLB + r * 64 + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // the two residual cross terms first, the leading term last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+#else
             bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -675,6 +777,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
+#endif
         }
     };
 
@@ -1010,17 +1113,21 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
     return gemm_tn_acc(A, lda, X, ldx, C, ldc, M, Na, Kx, scratch, scratch_floats, s);
 }
 
-inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe, hipStream_t s) {
+inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s) {
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
+    PlanesEpilogue pe = pe_in;
+    pe.out_scale = 1.f / ((A.dscale ? 1.f : A.scale) * W.scale);
+    pe.a_dinv = A.dscale ? A.dscale + 1 : nullptr;
     const bool pair = pe.pair_i != nullptr;
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);
     // pair mode has twice the epilogue per row of MFMA work: two workgroups per CU (128-row kernel) hide it behind each other's main
     // loop, which measured faster than the one-workgroup-per-CU kernel at every size tried
-    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= g_planes_db_min_tiles && !(pair && g_pair_kernel == 0)) {
+    // (the 256-row double-buffered kernel only exists for the three-plane bf16 format)
+    if (!MI_PLANES_FP16 && g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= g_planes_db_min_tiles && !(pair && g_pair_kernel == 0)) {
         static bool attr_set = false;
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));

@@ -32,6 +32,7 @@ struct mi_net {
     unsigned short* Wlnpl = nullptr;   // (3H x H): [P_i block; P_j block; node_mlp.0.weight[:, :H]] -- everything LayerNorm(h) feeds
     unsigned short* Waggpl = nullptr;  // (H x H):  node_mlp.0.weight[:, H:]  (multiplies the aggregated messages)
     unsigned short* Wn2pl = nullptr;   // (H x H):  node_mlp.2.weight
+    float* wbounds = nullptr;          // [L][8] row-sum / bias bounds of the layer's weights (fp16 plane format: activation scales)
     // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],
     // Kh = 3F rounded up to 32, so that each block is a whole number of k-tiles
     int Kh = 0;
@@ -108,6 +109,8 @@ struct mi_batch {
     unsigned short* lnpl = nullptr;  // plane sets of LayerNorm(h) and of the aggregated messages (N x H each)
     unsigned short* aggpl = nullptr;
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
+    float* dsc = nullptr;            // [3][2] {scale, 1/scale} of this layer's M1 / agg / X plane sets (fp16 plane format)
+    unsigned* absmax = nullptr;      // [1 + L] bit patterns of max |P_i, P_j, X_part| of the current layer and of max |G[l]|
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
