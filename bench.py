@@ -179,7 +179,9 @@ def main_ft(args):
         flops = 4 * 5.893e9 * nglob * K  # agent fwd + prior fwd + 2x for backward
         print(json.dumps({"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
                           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32 (forward products: 2-plane fp16 split, 3 MFMA terms; backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
+                          "data": "synthetic",
                           "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps, 256 crystals x 20 atoms per GPU, "
                                                  "synthetic reward, accum_steps=50, fused Adam, flat-gradient all-reduce when N>1"},
                           "end_to_end": {"tflops_section8d": flops / elapsed / 1e12}}), flush=True)
@@ -281,9 +283,11 @@ def main():
         busy_ms = union_ms.value if S > 1 else tot_ms.value
         fp32_equiv = n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12   # TFLOP/s of fp32 multiply-adds the stage delivers
         if args.path == "split-gemm":
-            # every fp32 product is issued as SIX bf16 MFMA products: price the matrix pipe with what it executes
-            kernel, issued, peak, dtype = "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", 6 * fp32_equiv, PEAK_BF16_MFMA_TFLOPS, \
-                "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
+            # every fp32 product is issued as THREE fp16 MFMA products (two-plane fp16 operands; six bf16 products in the three-plane
+            # bf16 build): price the matrix pipe with what it executes (fp16 and bf16 MFMA have the same dense peak)
+            terms = 3 if lib.mi_plane_format() == 2 else 6
+            kernel, issued, peak = "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
+            dtype = "f32 via 2-plane fp16 split (3 fp16 MFMA terms, f32 accumulate)" if terms == 3 else "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
             issued, peak, dtype = fp32_equiv, PEAK_F32_MFMA_TFLOPS, "f32"

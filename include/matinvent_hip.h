@@ -278,6 +278,10 @@ int mi_net_set_edge_mode(mi_net* net, int mode);
  * features are (-sin, +cos) of the same arguments, so one operand row yields both directed edges; off = one row per edge. */
 int mi_set_edge_pairs(int on);
 
+/* Element format of the pre-split plane sets this library was built with: 2 = two fp16 planes with per-class power-of-two scales
+ * (three MFMA terms per product; the default), 3 = three bf16 planes (six terms, no range limits; build with -DMI_PLANES_FP16=0). */
+int mi_plane_format(void);
+
 /* Diagnostics: C[M,N] = A[M,K] W[N,K]^T through the node-level GEMM kernels.  kind 0 = f32-input MFMA,
  * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe; kinds 2 / 3 = the same on pre-split
  * tile-blocked plane sets (128-row / 256-row double-buffered kernel); kind 4 = the weight-gradient form C[M,N] += A^T W with

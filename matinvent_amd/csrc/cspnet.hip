@@ -1242,6 +1242,8 @@ int mi_debug_set_planes_small_tiles(int n) {
     return MI_OK;
 }
 
+int mi_plane_format(void) { return NPL; }
+
 int mi_debug_set_tn128(int on) {
     g_tn128 = (on & 1) != 0;
     g_tn_split = (on & 2) != 0;
