@@ -672,13 +672,12 @@ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe
 // share a CU (3 x 48 KiB LDS) and cover each other's staging, barriers and epilogues; in situ this beats the 256-row
 // double-buffered kernel below (one workgroup per CU), which is kept as an option.  V = 1: PAIR mode (see PlanesEpilogue) -- a
 // second accumulator set, 196 registers, two workgroups per CU.
-template <int V, int TM = 2>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe,
-                                                                                                         int rt_base) {
+template <int V, int TM>
+__device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int N, int K, const PlanesEpilogue& pe, int rt_base) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32, TN = 2, PLA = BM * 64, PLB = 128 * 64;  // bytes per plane tile in LDS (A, W)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Ws = smem + 3 * PLA;
+    unsigned char* Ws = smem + NPL * PLA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
     // XCD-aware tile mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all column tiles of one row tile run
@@ -824,6 +823,26 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     } else {
         planes_epilogue<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, l31, kg);
     }
+}
+
+// Occupancy targets (registers per lane follow from them): the plain kernel at MI_PLANES_OCC0 workgroups per CU, the pair-mode kernel
+// (two accumulator sets) at MI_PLANES_OCC1.  Measured in the fp16 format, same box, structures/s: (3, 2) 46.5, (4, 2) 46.6 (10
+// registers spilled), (3, 3) 44.9 and (4, 3) 45.0 (29 spilled in the pair kernel).
+#ifndef MI_PLANES_OCC0
+#define MI_PLANES_OCC0 3
+#endif
+#ifndef MI_PLANES_OCC1
+#define MI_PLANES_OCC1 2
+#endif
+template <int V, int TM = 2>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0, V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0)))
+void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
+    gemm_planes_body<V, TM>(A, W, M, N, K, pe, rt_base);
+}
+// dynamic LDS of gemm_planes_kernel: the operand tiles, overlaid after the loop by the epilogue's per-wave staging patches
+constexpr int planes_lds_bytes(int V, int TM) {
+    const int tiles = NPL * (64 * TM + 128) * 64, stage = 4 * (V == 1 ? 2304 : 1152) * 4;
+    return tiles > stage ? tiles : stage;
 }
 
 // The same contraction on a 256 x 128 tile with 8 waves and DOUBLE-BUFFERED LDS (2 x 72 KiB): one barrier per k-tile instead
@@ -1140,12 +1159,12 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else if (pair) {
-        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
-        hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), 3 * 64 * 64 + 3 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
     } else {
-        hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), 6 * 128 * 64, s, A, W, M, N, K, pe, 0);
+        hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
     }
     MI_KERNEL_CHECK();
     return MI_OK;
