@@ -377,10 +377,13 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
         const int rb = row_w + i * 32;  // first row of this 32-row block
         // segment structure of the block (runs of equal seg_src), wave-uniform
         uint32_t starts = 0;
-        int srcv = 0, nvalid = 0;
+        int srcv = 0, rpv = 0, nvalid = 0;
         if (pe.seg_part) {
             nvalid = M - rb < 32 ? (M - rb > 0 ? M - rb : 0) : 32;
             srcv = nvalid > 0 ? pe.seg_src[rb + (l31 < nvalid ? l31 : nvalid - 1)] : 0;
+            // the run's first edge, per lane and up front: looked up inside the segment loop it was one dependent global load per
+            // segment and column tile (a serial chain of ~12 load latencies = a quarter of this kernel's time)
+            rpv = nvalid > 0 ? pe.seg_rowptr[srcv] : 0;
             const int prev = __shfl_up(srcv, 1, 64);
             starts = (uint32_t)__ballot(kg == 0 && l31 < nvalid && (l31 == 0 || srcv != prev));
         }
@@ -413,7 +416,7 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
                     const int sg = __builtin_ctz(rem);
                     rem &= rem - 1;
                     const int end = rem ? __builtin_ctz(rem) : nvalid;
-                    const int node = __builtin_amdgcn_readlane(srcv, sg);
+                    const int node = __builtin_amdgcn_readlane(srcv, sg), rp = __builtin_amdgcn_readlane(rpv, sg);
                     // rows this lane holds: c + 4*kg for the 16 compile-time offsets c; in-range test as one unsigned compare
                     const unsigned lo = (unsigned)(sg - 4 * kg), span = (unsigned)(end - sg);
                     float sum = 0.f;
@@ -424,7 +427,7 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
                     }
                     sum += __shfl_xor(sum, 32, 64);
                     if (kg == 0 && col_ok) {
-                        const int slot = (rb >> 5) - (pe.seg_rowptr[node] >> 5);
+                        const int slot = (rb >> 5) - (rp >> 5);
                         pe.seg_part[((size_t)slot * pe.seg_nodes + node) * N + col] = sum;
                     }
                 }
@@ -784,7 +787,8 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
     int kt = 0;
     // k-tiles kt .. kend-1.  One register set, loads issued one k-tile ahead (right after the staging barrier, so they have the
     // whole compute phase to land); the second workgroup of the CU covers what is left.  A two-set, two-tiles-ahead loop measured
-    // 2 % slower here -- and with the pair mode's second accumulator set live it spilled 120 registers inside the loop.
+    // 2 % slower here -- and with the pair mode's second accumulator set live it spilled 120 registers inside the loop; tried again with
+    // the three-term fp16 loop (whose compute phase is half as long): 46.7 vs 46.7 structures/s, so the loads are not what it waits for.
     auto run = [&](int kend) {
         for (; kt < kend; ++kt) {
             store_tiles(ra0, rw0);
