@@ -382,21 +382,29 @@ __global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* 
 }
 
 // wb[l][0..4] = max_f sum_k |Wff[f][k]| (Fourier block of edge_mlp.0), max_f sum_k |W2[f][k]|, max |b2|,
-//               max_f sum_k |node_mlp.0.weight[f][H + k]|, max |node_mlp.0.bias|      (one block per layer, at parameter updates)
+//               max_f sum_k |node_mlp.0.weight[f][H + k]|, max |node_mlp.0.bias|      (at parameter updates)
+// grid (L, ceil(H / 64)): a wave per output row group, four rows at a time; maxima merged with atomicMax on the bit patterns
+// (non-negative floats order like unsigned integers; wb is zeroed first).
 __global__ __launch_bounds__(256) void weight_bounds_kernel(const float* __restrict__ W1_0, const float* __restrict__ W2_0,
                                                             const float* __restrict__ b2_0, const float* __restrict__ Wn0_0,
                                                             const float* __restrict__ bn0_0, int64_t layer_stride, int edge_in, int H, int F6,
-                                                            float* __restrict__ wb) {
-    const int l = blockIdx.x;
+                                                            unsigned* __restrict__ wb) {
+    const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *W1 = W1_0 + l * layer_stride, *W2 = W2_0 + l * layer_stride, *b2 = b2_0 + l * layer_stride, *Wn0 = Wn0_0 + l * layer_stride,
                 *bn0 = bn0_0 + l * layer_stride;
     float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+    for (int f = blockIdx.y * 64 + wave; f < min(H, (int)blockIdx.y * 64 + 64); f += 4) {  // one row per wave, lanes over its columns
         float a = 0.f, c = 0.f, d = 0.f;
-        for (int k = 0; k < F6; ++k) a += fabsf(W1[(size_t)f * edge_in + 2 * H + 9 + k]);
-        for (int k = 0; k < H; ++k) {
+        for (int k = lane; k < F6; k += 64) a += fabsf(W1[(size_t)f * edge_in + 2 * H + 9 + k]);
+        for (int k = lane; k < H; k += 64) {
             c += fabsf(W2[(size_t)f * H + k]);
             d += fabsf(Wn0[(size_t)f * 2 * H + H + k]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            c += __shfl_xor(c, o, 64);
+            d += __shfl_xor(d, o, 64);
         }
         m[0] = fmaxf(m[0], a);
         m[1] = fmaxf(m[1], c);
@@ -404,15 +412,10 @@ __global__ __launch_bounds__(256) void weight_bounds_kernel(const float* __restr
         m[3] = fmaxf(m[3], d);
         m[4] = fmaxf(m[4], fabsf(bn0[f]));
     }
-    __shared__ float red[5][4];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m[q] = fmaxf(m[q], __shfl_xor(m[q], o, 64));
-        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = m[q];
+    if (lane < 5) {
+        float v = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : lane == 3 ? m[3] : m[4];
+        atomicMax(wb + l * 8 + lane, __float_as_uint(v * 1.0001f));  // (the row sums are rounded: a hair of slack keeps the bound a bound)
     }
-    __syncthreads();
-    if (threadIdx.x < 5) wb[l * 8 + threadIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
 }
 
 // Per layer, after the LayerNorm(h) product: power-of-two scales of the three unbounded activation plane sets from RIGOROUS bounds
@@ -1013,9 +1016,10 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
     if (n->L > 0) {  // weight bounds behind the activation scales of the fp16 plane format (see act_scales_kernel)
         const float* w0 = n->p("csp_layer_0.edge_mlp.0.weight");
         const int64_t lstride = n->L > 1 ? n->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
-        hipLaunchKernelGGL(weight_bounds_kernel, dim3(n->L), dim3(256), 0, s, w0, n->p("csp_layer_0.edge_mlp.2.weight"),
+        MI_HIP(hipMemsetAsync(n->wbounds, 0, (size_t)n->L * 8 * sizeof(float), s));
+        hipLaunchKernelGGL(weight_bounds_kernel, dim3(n->L, cdiv(H, 64)), dim3(256), 0, s, w0, n->p("csp_layer_0.edge_mlp.2.weight"),
                            n->p("csp_layer_0.edge_mlp.2.bias"), n->p("csp_layer_0.node_mlp.0.weight"), n->p("csp_layer_0.node_mlp.0.bias"), lstride,
-                           n->edge_in, H, 6 * n->F, n->wbounds);
+                           n->edge_in, H, 6 * n->F, reinterpret_cast<unsigned*>(n->wbounds));
     }
     MI_KERNEL_CHECK();
     MI_TRY(net_pack_transposes(n, s));
