@@ -175,35 +175,58 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
 }
 
 // Pair-mode Fourier operand: rows = unordered pairs (i, j), columns = [sin(3F) | 0 .. Kh) | cos(3F) | 0 .. 2Kh) of
-// d = (x_j - x_i) % 1.  One thread per (row, sine column pair); pad rows / pad columns are written as zero.
-__global__ void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi, const int* __restrict__ pj, Planes FF,
-                                           int64_t Np, int F, int Kh) {
-    const int F3 = 3 * F, per_row = Kh / 2;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// d = (x_j - x_i) % 1; pad rows / pad columns are written as zero.  A wave owns 16 consecutive rows of one 32-column k-tile
+// (lane = row * 4 + 16-byte chunk): in the tile-blocked layout that is 1 KiB of contiguous bytes per plane, so every store
+// instruction writes whole lines (four-byte stores of one row per wave ran at 2.2 TB/s).  Each lane evaluates eight sine /
+// cosine pairs and stores them into the sine tile and the matching cosine tile.
+__global__ __launch_bounds__(256) void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi,
+                                                                  const int* __restrict__ pj, Planes FF, int64_t Np, int F, int Kh) {
+    const int F3 = 3 * F, kts = Kh / 32, lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t rows_pad = (Np + 127) / 128 * 128;
-    if (idx >= rows_pad * per_row) return;
-    const int64_t e = idx / per_row;
-    const int m = (int)(idx % per_row);
-    float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
-    if (e < Np) {
-        const int i = pi[e], j = pj[e];
+    const int64_t rb = w / kts;
+    if (rb * 16 >= rows_pad) return;
+    const int kt = (int)(w - rb * kts);
+    const int64_t e = rb * 16 + (lane >> 2);
+    const int col0 = kt * 32 + (lane & 3) * 8;
+    float sn[8], cs[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ck = 2 * m + u;
+    for (int u = 0; u < 8; ++u) sn[u] = cs[u] = 0.f;
+    if (e < Np && col0 < F3) {
+        const int i = pi[e], j = pj[e];
+        int cprev = -1;
+        float d = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ck = col0 + u;
             if (ck < F3) {
                 const int c = ck / F, k = ck - c * F;
-                const float d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+                if (c != cprev) {
+                    d = pymod1(frac[j * 3 + c] - frac[i * 3 + c]);
+                    cprev = c;
+                }
                 sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn[u], &cs[u]);
             }
         }
     }
-    unsigned p[3];
-    pl_split_pair(sn[0], sn[1], FF.s(), p);
+    u32x4 os[3], oc[3];
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
-    pl_split_pair(cs[0], cs[1], FF.s(), p);
+    for (int u = 0; u < 4; ++u) {
+        unsigned p[3];
+        pl_split_pair(sn[2 * u], sn[2 * u + 1], FF.s(), p);
+        os[0][u] = p[0];
+        os[1][u] = p[1];
+        os[2][u] = p[2];
+        pl_split_pair(cs[2 * u], cs[2 * u + 1], FF.s(), p);
+        oc[0][u] = p[0];
+        oc[1][u] = p[1];
+        oc[2][u] = p[2];
+    }
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, Kh + 2 * m, k)) = p[k];
+    for (int k = 0; k < NPL; ++k) {
+        *reinterpret_cast<u32x4*>(FF.base + FF.elem((int)e, col0, k)) = os[k];
+        *reinterpret_cast<u32x4*>(FF.base + FF.elem((int)e, Kh + col0, k)) = oc[k];
+    }
 }
 
 // plane set of the Fourier block of edge_mlp.0 in the pair-mode column layout; C0[f] = sum of its cosine block
@@ -344,14 +367,19 @@ __global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict_
 // G[l][b][f] = b1_l[f] + sum_m (L L^T)[b].flat[m] * W1_l[f][2H + m]      (cspnet.py:68-72), every layer in one launch (the lattices
 // do not change inside an evaluation); layer l's edge_mlp.0 weight / bias sit `layer_stride` floats after layer l-1's in the flat
 // parameter vector.
-__global__ void gram_term_all_kernel(const float* __restrict__ lattices, const float* __restrict__ W1_0, int64_t layer_stride, int edge_in,
-                                     const float* __restrict__ b1_0, float* __restrict__ G, int H, int B, unsigned* __restrict__ gmax) {
-    const int b = blockIdx.x, l = blockIdx.y;
-    __shared__ float gram[9];
-    if (threadIdx.x < 9) {
-        int r = threadIdx.x / 3, c = threadIdx.x % 3;
-        const float* Lm = lattices + (size_t)b * 9;
-        gram[threadIdx.x] = Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2];
+constexpr int GRAM_GB = 8;  // crystals per workgroup of gram_term_all_kernel
+// grid (ceil(B / GRAM_GB), L), 256 threads over the features: a thread reads its nine weights once (rows of edge_mlp.0 are
+// edge_in floats apart, so this is a gather) and reuses them for GRAM_GB crystals; one atomicMax per workgroup.
+__global__ __launch_bounds__(256) void gram_term_all_kernel(const float* __restrict__ lattices, const float* __restrict__ W1_0, int64_t layer_stride,
+                                                            int edge_in, const float* __restrict__ b1_0, float* __restrict__ G, int H, int B,
+                                                            unsigned* __restrict__ gmax) {
+    const int b0 = blockIdx.x * GRAM_GB, l = blockIdx.y, nb = min(GRAM_GB, B - b0);
+    __shared__ float gram[GRAM_GB][9];
+    __shared__ float wmax[4];
+    if (threadIdx.x < 9 * nb) {
+        const int g = threadIdx.x / 9, m = threadIdx.x % 9, r = m / 3, c = m % 3;
+        const float* Lm = lattices + (size_t)(b0 + g) * 9;
+        gram[g][m] = Lm[r * 3] * Lm[c * 3] + Lm[r * 3 + 1] * Lm[c * 3 + 1] + Lm[r * 3 + 2] * Lm[c * 3 + 2];
     }
     __syncthreads();
     const float* W1 = W1_0 + l * layer_stride;
@@ -359,16 +387,24 @@ __global__ void gram_term_all_kernel(const float* __restrict__ lattices, const f
     float gm = 0.f;
     for (int f = threadIdx.x; f < H; f += blockDim.x) {
         const float* w = W1 + (size_t)f * edge_in + 2 * H;
-        float s = 0.f;
+        float wv[9];
 #pragma unroll
-        for (int m = 0; m < 9; ++m) s += gram[m] * w[m];
-        G[((size_t)l * B + b) * H + f] = s + b1[f];
-        gm = fmaxf(gm, fabsf(s + b1[f]));
+        for (int m = 0; m < 9; ++m) wv[m] = w[m];
+        const float bf = b1[f];
+        for (int g = 0; g < nb; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) s += gram[g][m] * wv[m];
+            G[((size_t)l * B + b0 + g) * H + f] = s + bf;
+            gm = fmaxf(gm, fabsf(s + bf));
+        }
     }
     if (gmax) {  // max |G[l]| over the batch (order-independent): part of the bound that scales the M1 plane set
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(gmax + l, __float_as_uint(gm));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(gmax + l, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
     }
 }
 
@@ -652,7 +688,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0) {
         if (b->Np > 0) {  // pair mode: one operand row per unordered pair
             Planes ffp = make_planes(b->FFpl, 2 * net->Kh, PL_S_UNIT);
-            const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 2);
+            const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 8);  // a lane per row and 8-column chunk
             hipLaunchKernelGGL(fourier_pair_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np,
                                net->F, net->Kh);
             MI_KERNEL_CHECK();
@@ -679,7 +715,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
         MI_HIP(hipMemsetAsync(b->absmax, 0, (1 + L) * sizeof(unsigned), s));
-        hipLaunchKernelGGL(gram_term_all_kernel, dim3(B, L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
+        hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
     }
     // ---- message-passing layers (cspnet.py:84-91) ----
