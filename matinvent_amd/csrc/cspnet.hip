@@ -15,6 +15,7 @@ int g_planes_variant = 0;  // 0: 128-row kernel everywhere (default: with three 
                            // kernel in situ: 26.8 vs 25.2 structures/s on one stream); 1: 256-row kernel from g_planes_db_min_tiles up
 int g_planes_db_min_tiles = 512;
 int g_pair_kernel = 0;
+int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 extern int g_bwd_pairs_fused, g_tn_xsilu;
 int g_tn128 = 1;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void gram_term_all_kernel(const float* __restr
         for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gm;
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(gmax + l, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+        if (threadIdx.x == 0) atomicMax(gmax + 2 * l, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
     }
 }
 
@@ -454,27 +455,12 @@ __global__ __launch_bounds__(256) void weight_bounds_kernel(const float* __restr
     }
 }
 
-// Per layer, after the LayerNorm(h) product: power-of-two scales of the three unbounded activation plane sets from RIGOROUS bounds
-//   |M1| <= |Z1| <= sum|Wff| + max|P_i| + max|P_j| + max|G|            (|Fourier features| <= 1, |silu(z)| <= |z|)
-//   |agg| <= max|Z2| <= max|b2| + rowsum|W2| * bound(M1)
-//   |X|   <= |pre|   <= max|b| + rowsum|W[:, H:]| * bound(agg) + max|X_part|
-// (pq = max over the whole [P_i | P_j | X_part] block).  scale = 2^floor(log2(16384 / bound)): the largest stored magnitude
-// stays below 32768, elements down to bound * 2^-18 keep all 22 bits.  Resets pq for the next layer.
-__global__ void act_scales_kernel(unsigned* __restrict__ pq, const unsigned* __restrict__ gmax, const float* __restrict__ wb, float* __restrict__ dsc) {
-    const float mpq = __uint_as_float(*pq), mg = __uint_as_float(*gmax);
-    float bound[3];
-    bound[0] = wb[0] + 2.f * mpq + mg;
-    bound[1] = wb[2] + wb[1] * bound[0];
-    bound[2] = wb[4] + wb[3] * bound[1] + mpq;
-    for (int c = 0; c < 3; ++c) {
-        float bnd = bound[c];
-        int e = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
-        if (!(bnd == bnd) || bnd > 3e38f) e = -100;  // NaN / inf upstream: everything saturates, nothing overflows
-        e = e > 14 ? 14 : (e < -100 ? -100 : e);
-        dsc[2 * c] = exp2f((float)e);
-        dsc[2 * c + 1] = exp2f(-(float)e);
-    }
-    *pq = 0u;
+// Per layer, after the LayerNorm(h) product: the scales of act_scales_eval (gemm_split.h) as a launch of its own -- the
+// paths that do not fold them into the pair-mode edge GEMM.  pq / gmax: this layer's slots of the absmax array.
+__global__ void act_scales_kernel(const unsigned* __restrict__ pq, const unsigned* __restrict__ gmax, const float* __restrict__ wb, float* __restrict__ dsc) {
+    float d[6];
+    act_scales_eval(__uint_as_float(*pq), __uint_as_float(*gmax), wb, d);
+    for (int c = 0; c < 6; ++c) dsc[c] = d[c];
 }
 
 
@@ -714,7 +700,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const float* b0 = net->p("csp_layer_0.edge_mlp.0.bias");
         const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
-        MI_HIP(hipMemsetAsync(b->absmax, 0, (1 + L) * sizeof(unsigned), s));
+        MI_HIP(hipMemsetAsync(b->absmax, 0, 2 * L * sizeof(unsigned), s));
         hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
     }
@@ -743,18 +729,21 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             PlanesEpilogue pq;
             pq.C = b->PQ;
             pq.ldc = ldpq;
-            pq.absmax = MI_PLANES_FP16 ? b->absmax : nullptr;
+            pq.absmax = MI_PLANES_FP16 ? b->absmax + 2 * l : nullptr;
             MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, s));
         } else {
             MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
             if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && b->E > 0) {
                 hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, s, b->PQ, (int64_t)N * 2 * H,
-                                   b->absmax);
+                                   b->absmax + 2 * l);
                 MI_KERNEL_CHECK();
             }
         }
-        if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT) {  // scales of this layer's M1 / agg / X plane sets
-            hipLaunchKernelGGL(act_scales_kernel, dim3(1), dim3(1), 0, s, b->absmax, b->absmax + 1 + l, net->wbounds + (size_t)l * 8, b->dsc);
+        // pair mode folds the activation scales and the self edges into the launch of its Fourier-block GEMM
+        const bool pair_path = net->edge_mode != 0 && b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0;
+        const bool fold = pair_path && g_fold_pair_extras && b->Np > 0;
+        if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && !fold) {  // scales of this layer's M1 / agg / X plane sets
+            hipLaunchKernelGGL(act_scales_kernel, dim3(1), dim3(1), 0, s, b->absmax + 2 * l, b->absmax + 2 * l + 1, net->wbounds + (size_t)l * 8, b->dsc);
             MI_KERNEL_CHECK();
         }
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
@@ -804,12 +793,26 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                     pe1.pair_e1 = b->pair_e1;
                     pe1.pair_e2 = b->pair_e2;
                     pe1.pair_graph = b->pair_graph;
+                    if (fold) {
+                        if (MI_PLANES_FP16) {
+                            pe1.sc_pq = b->absmax + 2 * l;
+                            pe1.sc_gmax = b->absmax + 2 * l + 1;
+                            pe1.sc_wb = net->wbounds + (size_t)l * 8;
+                            pe1.sc_dsc = b->dsc;
+                        }
+                        pe1.diag_C0 = net->C0 + (size_t)l * H;
+                        pe1.diag_node2graph = b->node2graph;
+                        pe1.diag_e = b->e_diag;
+                        pe1.diag_nodes = N;
+                    }
                     if (b->Np > 0)
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp, PL_S_UNIT), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
-                    hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G + (size_t)l * B * H,
-                                       net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
-                    MI_KERNEL_CHECK();
+                    if (!fold) {
+                        hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G + (size_t)l * B * H,
+                                           net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
+                        MI_KERNEL_CHECK();
+                    }
                 } else {
                     MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
                 }
@@ -1171,7 +1174,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
     A_(dsc, 6);
-    A_(absmax, 1 + L);
+    A_(absmax, 2 * L + 2);
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);
@@ -1197,7 +1200,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
         hipMemset(b->lnpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->aggpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
-        hipMemset(b->absmax, 0, (1 + L) * sizeof(unsigned)) != hipSuccess) {
+        hipMemset(b->absmax, 0, (2 * L + 2) * sizeof(unsigned)) != hipSuccess) {
         mi_batch_destroy(b);
         set_error("hipMemset failed");
         return MI_EHIP;

@@ -363,7 +363,44 @@ struct PlanesEpilogue {
     const int* pair_e1 = nullptr;
     const int* pair_e2 = nullptr;
     const int* pair_graph = nullptr;
+    // optional, PAIR mode only: work folded into the same launch (two kernel boundaries less per layer).
+    //  * the power-of-two scales of this layer's unbounded activation plane sets (see act_scales_eval): every workgroup derives
+    //    the scale of the output plane set from sc_pq / sc_gmax / sc_wb itself, workgroup 0 publishes all of them in sc_dsc for
+    //    the kernels that follow in the stream;
+    //  * the SELF edges (i, i): d = 0, so the Fourier term is the constant diag_C0 -- extra workgroups from diag_block0 on,
+    //    eight nodes each, write  M1[diag_e[i]] = SiLU(diag_C0 + P_i[i] + P_j[i] + G[graph])  (cspnet.py:59-79).
+    const unsigned* sc_pq = nullptr;
+    const unsigned* sc_gmax = nullptr;
+    const float* sc_wb = nullptr;
+    float* sc_dsc = nullptr;
+    const float* diag_C0 = nullptr;
+    const int* diag_node2graph = nullptr;
+    const int* diag_e = nullptr;
+    int diag_nodes = 0;
+    int diag_block0 = 0;
 };
+
+// Power-of-two scales of the three unbounded activation plane sets of a layer from RIGOROUS bounds (fp16 plane format):
+//   |M1| <= |Z1| <= sum|Wff| + max|P_i| + max|P_j| + max|G|            (|Fourier features| <= 1, |silu(z)| <= |z|)
+//   |agg| <= max|Z2| <= max|b2| + rowsum|W2| * bound(M1)
+//   |X|   <= |pre|   <= max|b| + rowsum|W[:, H:]| * bound(agg) + max|X_part|
+// (mpq = max over the whole [P_i | P_j | X_part] block).  scale = 2^floor(log2(16384 / bound)): the largest stored magnitude
+// stays below 32768, elements down to bound * 2^-18 keep all 22 bits.  dsc = {scale, 1 / scale} x 3.
+__device__ __forceinline__ void act_scales_eval(float mpq, float mg, const float* __restrict__ wb, float (&dsc)[6]) {
+    float bound[3];
+    bound[0] = wb[0] + 2.f * mpq + mg;
+    bound[1] = wb[2] + wb[1] * bound[0];
+    bound[2] = wb[4] + wb[3] * bound[1] + mpq;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float bnd = bound[c];
+        int e = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
+        if (!(bnd == bnd) || bnd > 3e38f) e = -100;  // NaN / inf upstream: everything saturates, nothing overflows
+        e = e > 14 ? 14 : (e < -100 ? -100 : e);
+        dsc[2 * c] = exp2f((float)e);
+        dsc[2 * c + 1] = exp2f(-(float)e);
+    }
+}
 
 // Epilogue of one wave's TM x TN block of 32x32 accumulator tiles whose first row / column are row_w / col_w:
 // bias, gathers, activation, optional fp32 / plane-set stores and the fused segmented row sum.
@@ -528,9 +565,9 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 // through two per-wave LDS patches; each lane handles 8 consecutive columns of one pair and emits BOTH directed edges.
 template <int TM, int TN>
 __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, f32x16 (&accS)[TM][TN], f32x16 (&accC)[TM][TN], int row_w,
-                                                      int col_w, int M, int N, int lane, float* stage) {
+                                                      int col_w, int M, int N, int lane, float* stage, float cps_in = 0.f) {
     const GemmEpilogue& ep = pe.ep;
-    const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
+    const float os = pe.oscale(), cps = cps_in != 0.f ? cps_in : pe.Cp.base ? pe.Cp.s() : 1.f;
     const int l31 = lane & 31, kg = lane >> 5;
     float* stS = stage;
     float* stC = stage + 1152;
@@ -687,6 +724,39 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
     // on the same XCD, so the streamed A operand crosses the fabric once (measured on the pair-mode GEMM: FETCH_SIZE 4x the
     // operand size without it)
     const int nct_ = (N + BN - 1) / BN, id_ = blockIdx.x, slot_ = id_ >> 3;
+    float cps_local = 0.f;  // PAIR mode with folded-in scales: this layer's M1 scale, derived here instead of read from Cp.dscale
+    if constexpr (V == 1) {
+        if (pe.sc_pq) {
+            float dsc[6];
+            act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
+            cps_local = dsc[0];
+            if (id_ == 0 && tid < 6) pe.sc_dsc[tid] = dsc[tid];
+        }
+        if (pe.diag_C0 && id_ >= pe.diag_block0) {  // self edges: eight nodes per workgroup, a thread per column pair
+            const float cps = cps_local != 0.f ? cps_local : pe.Cp.s();
+            const int n0 = (id_ - pe.diag_block0) * 8, n1 = n0 + 8 < pe.diag_nodes ? n0 + 8 : pe.diag_nodes;
+            const float* PQ = pe.ep.row_bias;
+            const int ldpq = pe.ep.ld_row_bias;
+            for (int f = 2 * tid; f < N; f += 512) {
+                const float c0 = pe.diag_C0[f], c1 = pe.diag_C0[f + 1];
+                for (int i = n0; i < n1; ++i) {
+                    const int e = pe.diag_e[i], g = pe.diag_node2graph[i];
+                    const float* G = pe.ep.row_bias3 + (size_t)g * pe.ep.ld_row_bias3;
+                    const float v0 = c0 + ((PQ[(size_t)i * ldpq + f] + PQ[(size_t)i * ldpq + N + f]) + G[f]);
+                    const float v1 = c1 + ((PQ[(size_t)i * ldpq + f + 1] + PQ[(size_t)i * ldpq + N + f + 1]) + G[f + 1]);
+                    if (pe.ep.pre_act) {
+                        pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f] = v0;
+                        pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f + 1] = v1;
+                    }
+                    unsigned p[3];
+                    pl_split_pair(silu_fast(v0), silu_fast(v1), cps, p);
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(pe.Cp.base + pe.Cp.elem(e, f, k)) = p[k];
+                }
+            }
+            return;
+        }
+    }
     const int ct = slot_ % nct_, rt = rt_base + (slot_ / nct_) * 8 + (id_ & 7);
     if (rt * BM >= M) return;
     const int row0 = rt * BM, col0 = ct * BN;
@@ -810,7 +880,8 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
         run(KT);
-        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
+        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+                                      cps_local);
         return;
     }
     run(KT);
@@ -1163,7 +1234,12 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else if (pair) {
-        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        int nblk = nct * ((cdiv(M, 128) + 7) / 8 * 8);
+        if (pe.diag_C0) {  // self edges ride along as extra workgroups behind the GEMM tiles
+            pe.diag_block0 = nblk;
+            nblk += cdiv(pe.diag_nodes, 8);
+        }
+        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);

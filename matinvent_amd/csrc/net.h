@@ -110,7 +110,7 @@ struct mi_batch {
     unsigned short* aggpl = nullptr;
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
     float* dsc = nullptr;            // [3][2] {scale, 1/scale} of this layer's M1 / agg / X plane sets (fp16 plane format)
-    unsigned* absmax = nullptr;      // [1 + L] bit patterns of max |P_i, P_j, X_part| of the current layer and of max |G[l]|
+    unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation)
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
