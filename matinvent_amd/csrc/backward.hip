@@ -8,6 +8,7 @@
 // as [E,H] / [E,6F] scratch and pushed through the generic MFMA GEMMs (dgrad = gemm_nt against
 // pre-transposed weights, wgrad = gemm_tn with a fixed-order split reduction).  Deterministic: no
 // float atomics anywhere.
+#include <cstdlib>
 #include "gemm_split.h"
 #include "net.h"
 
@@ -56,6 +57,21 @@ __global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __res
     Z2[idx] = (dcat[(size_t)i * (2 * H) + H + f] / deg) * silu_grad(Z2[idx]);
 }
 
+// max |x| over n floats (16-byte loads) -> atomicMax of the bit pattern (non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void absmax_bwd_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+int g_bwd_dz2_planes = std::getenv("MI_BWD_DZ2_PLANES") ? std::atoi(std::getenv("MI_BWD_DZ2_PLANES")) : 1;  // experiment switch
+
 // The same with the bias gradient's column sums folded in (one pass over [E, H] less): a block owns a chunk of `rows` rows, writes dZ2
 // in place and the chunk's column sums to part[chunk][H] (reduced by part_reduce_kernel).  A thread owns FOUR consecutive columns
 // (16-byte accesses: a wave moves 1 KiB of a row per instruction; one column per thread ran at 2.1 TB/s) and every second row of
@@ -63,8 +79,24 @@ __global__ void edge_dz2_kernel(const float* __restrict__ dcat, const int* __res
 // Needs H % 4 == 0.
 __global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __restrict__ dcat, const int* __restrict__ src,
                                                               const int* __restrict__ rowptr, float* __restrict__ Z2, float* __restrict__ part,
-                                                              int64_t E, int H, int rows) {
+                                                              int64_t E, int H, int rows, Planes dzp = Planes(),
+                                                              const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
     const int q = H / 4;                                     // column quads per row
+    // optional: dZ2 also as an fp16 plane set (the A operand of the dM1 data gradient on the pre-split plane GEMM).  Its
+    // power-of-two scale follows from a rigorous bound, |dZ2| <= max|d cat| * max|silu'| (degrees are >= 1, |silu'| < 1.1):
+    // every thread derives it, block 0 publishes {scale, 1 / scale} for the GEMM.
+    float ps = 1.f;
+    if (dzp.base) {
+        const float bnd = 1.1f * __uint_as_float(amax[0]);
+        int ex = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
+        if (!(bnd == bnd) || bnd > 3e38f) ex = -100;
+        ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+        ps = exp2f((float)ex);
+        if (blockIdx.y == 0 && threadIdx.x == 0) {
+            dsc_out[0] = ps;
+            dsc_out[1] = exp2f(-(float)ex);
+        }
+    }
     const int64_t e0 = (int64_t)blockIdx.y * rows, e1 = e0 + rows < E ? e0 + rows : E;
     __shared__ f32x4 comb[256];
     for (int cq0 = 0; cq0 < q; cq0 += 256) {                 // (H > 1024: several column passes)
@@ -84,6 +116,16 @@ __global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = (d[k] / deg) * silu_grad(z[k]);
                 *reinterpret_cast<f32x4*>(zp) = v;
+                if (dzp.base) {
+                    unsigned lo[3], hi[3];
+                    pl_split_pair(v[0], v[1], ps, lo);
+                    pl_split_pair(v[2], v[3], ps, hi);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        uint2 pk = {lo[pl], hi[pl]};
+                        *reinterpret_cast<uint2*>(dzp.base + dzp.elem((int)e, 4 * cq, pl)) = pk;
+                    }
+                }
                 sum += v;
             }
         }
@@ -479,8 +521,19 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             const int crows = (size_t)cdiv(E, 64) * H <= scf ? 64 : 256;
             const int nchunk = (int)cdiv(E, crows);
             const bool dz2_sums = (size_t)nchunk * H <= scf && H % 4 == 0;  // Z2 := dZ2, with edge_mlp.2.bias's gradient (column sums) on the way
+            // fp16 plane format: dZ2 is also written as a plane set (scale from max |d cat|), and its data gradient runs on the
+            // pre-split plane GEMM (three fp16 terms) instead of the on-the-fly three-plane bf16 split (six terms)
+            const bool dz2_planes = MI_PLANES_FP16 && g_bwd_dz2_planes && dz2_sums && g_gemm_mode == MI_GEMM_SPLIT && net->W2Tpl && b->M1pl && H % 32 == 0;
+            Planes dzp;
+            if (dz2_planes) {
+                dzp = make_planes(b->M1pl, H, 1.f, b->dsc + 6);
+                MI_HIP(hipMemsetAsync(b->absmax + 2 * L, 0, sizeof(unsigned), s));
+                hipLaunchKernelGGL(absmax_bwd_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 1024))), dim3(256), 0, s, t.dcat, (int64_t)N * 2 * H,
+                                   b->absmax + 2 * L);
+            }
             if (dz2_sums) {
-                hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(1, nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H, crows);
+                hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(1, nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H, crows, dzp,
+                                   b->absmax + 2 * L, b->dsc + 6);
                 hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
             } else {
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
@@ -493,7 +546,14 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 MI_TRY(gemm_tn_auto(Z2, H, t.M1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s));
             }
             if (!dz2_sums) MI_TRY(colsum_acc(Z2, H, G(p + "edge_mlp.2.bias"), (int)E, H, sc, scf, s));
-            MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
+            if (dz2_planes) {
+                PlanesEpilogue pd;
+                pd.C = t.dM1;
+                pd.ldc = H;
+                MI_TRY(gemm_planes(dzp, make_planes(net->W2Tpl + (size_t)l * planes_elems(H, H), H), (int)E, H, H, pd, s));
+            } else {
+                MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
+            }
             // fc pair mode: one pass over the crystal blocks of dM1 / Z1 yields every consumer of dZ1 (see edge_bwd_pairs_kernel)
             const bool fused_pairs = pairs && g_bwd_pairs_fused && b->nmax_fc <= 64 && (size_t)B * H <= scf - H;
             if (!fused_pairs) {
@@ -644,10 +704,16 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
         MI_HIP(hipMalloc((void**)&n->Wn1T, (size_t)L * 2 * H * H * 4));
         MI_HIP(hipMalloc((void**)&n->WhhT, (size_t)L * 2 * H * H * 4));
         MI_HIP(hipMalloc((void**)&n->WaT, (size_t)H * H * 4));
+        if (MI_PLANES_FP16 && H % 32 == 0) MI_HIP(hipMalloc((void**)&n->W2Tpl, (size_t)L * planes_elems(H, H) * sizeof(u16)));
     }
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "edge_mlp.2.weight"), H, H, H, n->W2T + (size_t)l * H * H);
+        if (n->W2Tpl) {
+            Planes wp = make_planes(n->W2Tpl + (size_t)l * planes_elems(H, H), H);
+            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((H + 127) / 128 * 128) * wp.KT * 16, 256)), dim3(256), 0, s,
+                               n->W2T + (size_t)l * H * H, H, H, H, wp, 0);
+        }
         hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, n->Wn2T + (size_t)l * H * H);
         hipLaunchKernelGGL(transpose_kernel, g1(2 * H * H), dim3(256), 0, s, n->p(p + "node_mlp.0.weight"), 2 * H, H, 2 * H,
                            n->Wn1T + (size_t)l * 2 * H * H);

@@ -969,6 +969,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->Wffpl_pair) (void)hipFree(n->Wffpl_pair);
     if (n->C0) (void)hipFree(n->C0);
     if (n->W2pl) (void)hipFree(n->W2pl);
+    if (n->W2Tpl) (void)hipFree(n->W2Tpl);
     if (n->Wlnpl) (void)hipFree(n->Wlnpl);
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
@@ -1173,7 +1174,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(lnpl, planes_elems(N, H));
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
-    A_(dsc, 6);
+    A_(dsc, 8);
     A_(absmax, 2 * L + 2);
     A_(X, NH);
     A_(x1, NH);

@@ -40,6 +40,7 @@ struct mi_net {
     float* C0 = nullptr;                   // [L][H] sum of the cosine-block weights = the Fourier term of a self edge (d = 0)
     // transposed copies for the data-gradient GEMMs (training), rebuilt with the packs
     float* W2T = nullptr;    // [L][H][H]
+    unsigned short* W2Tpl = nullptr;  // [L] plane sets of W2T (fp16 plane format): the W operand of the dM1 data gradient
     float* Wn2T = nullptr;   // [L][H][H]
     float* Wn1T = nullptr;   // [L][2H][H]
     float* WhhT = nullptr;   // [L][H][2H]
@@ -109,8 +110,8 @@ struct mi_batch {
     unsigned short* lnpl = nullptr;  // plane sets of LayerNorm(h) and of the aggregated messages (N x H each)
     unsigned short* aggpl = nullptr;
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
-    float* dsc = nullptr;            // [3][2] {scale, 1/scale} of this layer's M1 / agg / X plane sets (fp16 plane format)
-    unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation)
+    float* dsc = nullptr;            // [4][2] {scale, 1/scale} of this layer's M1 / agg / X plane sets and of the backward pass's dZ2 planes (fp16 plane format)
+    unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation); [2L] = max |d cat| of the layer the backward pass is in
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
