@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void absmax_bwd_kernel(const float* __restrict
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
+int g_bwd_wgrad_f16 = std::getenv("MI_BWD_WGRAD_F16") ? std::atoi(std::getenv("MI_BWD_WGRAD_F16")) : 1;  // experiment switch
 int g_bwd_dz2_planes = std::getenv("MI_BWD_DZ2_PLANES") ? std::atoi(std::getenv("MI_BWD_DZ2_PLANES")) : 1;  // experiment switch
 
 // The same with the bias gradient's column sums folded in (one pass over [E, H] less): a block owns a chunk of `rows` rows, writes dZ2
@@ -402,6 +403,7 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
     T_(Xpre, L * N * H);
     T_(Ypre, L * N * H);
     T_(lnstat, (L + 1) * N * 2);
+    T_(dsc_layers, L * 8);
     T_(gf, B * H);
     T_(atom_types, N * MI_NUM_TYPES);
     T_(t_emb, B * TD);
@@ -539,7 +541,10 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
             }
             if (g_tn_xsilu && gemm_tn_is_split(Z2, H, Z1, H, (int)E, H, H)) {  // M1 = silu(Z1) formed inside the product's operand load
-                MI_TRY(gemm_tn_auto(Z2, H, Z1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s, true));
+                // (fp16 plane format: dZ2's scale was published by the dZ2 kernel, M1's by this layer's training forward)
+                const bool w2_f16 = dz2_planes && t.dsc_layers_valid && g_bwd_wgrad_f16;
+                MI_TRY(gemm_tn_auto(Z2, H, Z1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s, true, w2_f16 ? b->dsc + 6 : nullptr,
+                                    w2_f16 ? t.dsc_layers + (size_t)l * 8 : nullptr));
             } else {
                 hipLaunchKernelGGL(silu_fwd_kernel, g1(E * H), dim3(256), 0, s, Z1, t.M1, E * H);
                 MI_KERNEL_CHECK();

@@ -742,6 +742,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         // pair mode folds the activation scales and the self edges into the launch of its Fourier-block GEMM
         const bool pair_path = net->edge_mode != 0 && b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0;
         const bool fold = pair_path && g_fold_pair_extras && b->Np > 0;
+        if (train) tp.dsc_layers_valid = fold && MI_PLANES_FP16;
         if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && !fold) {  // scales of this layer's M1 / agg / X plane sets
             hipLaunchKernelGGL(act_scales_kernel, dim3(1), dim3(1), 0, s, b->absmax + 2 * l, b->absmax + 2 * l + 1, net->wbounds + (size_t)l * 8, b->dsc);
             MI_KERNEL_CHECK();
@@ -799,6 +800,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                             pe1.sc_gmax = b->absmax + 2 * l + 1;
                             pe1.sc_wb = net->wbounds + (size_t)l * 8;
                             pe1.sc_dsc = b->dsc;
+                            if (train) pe1.sc_dsc2 = tp.dsc_layers + (size_t)l * 8;
                         }
                         pe1.diag_C0 = net->C0 + (size_t)l * H;
                         pe1.diag_node2graph = b->node2graph;

@@ -373,6 +373,7 @@ struct PlanesEpilogue {
     const unsigned* sc_gmax = nullptr;
     const float* sc_wb = nullptr;
     float* sc_dsc = nullptr;
+    float* sc_dsc2 = nullptr;  // optional second copy (the training tape keeps each layer's scales for the backward pass)
     const float* diag_C0 = nullptr;
     const int* diag_node2graph = nullptr;
     const int* diag_e = nullptr;
@@ -730,7 +731,10 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
             float dsc[6];
             act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
             cps_local = dsc[0];
-            if (id_ == 0 && tid < 6) pe.sc_dsc[tid] = dsc[tid];
+            if (id_ == 0 && tid < 6) {
+                pe.sc_dsc[tid] = dsc[tid];
+                if (pe.sc_dsc2) pe.sc_dsc2[tid] = dsc[tid];
+            }
         }
         if (pe.diag_C0 && id_ >= pe.diag_block0) {  // self edges: eight nodes per workgroup, a thread per column pair
             const float cps = cps_local != 0.f ? cps_local : pe.Cp.s();
@@ -1069,10 +1073,13 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 // XCD-aware tile order as in gemm_tn128_kernel, partial tiles reduced in fixed order by tn_reduce_kernel.
 // XSILU: the X operand is silu(X) of what is stored (the backward pass keeps the pre-activation Z1; M1 = silu(Z1) is formed here
 // instead of by a separate pass over [E, H]).
-template <bool XSILU>
+// F16 (fp16 plane format only): both operands carry a DEVICE-side power-of-two scale {s, 1 / s} from a rigorous bound of their
+// magnitude (sa, sx); they are split into TWO fp16 planes and multiplied with three terms, and the tile is scaled back by
+// 1 / (sa sx) (exact) before it is written -- half the matrix-pipe work of the six-term form.
+template <bool XSILU, bool F16 = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_tn_split_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx, float* __restrict__ P, int M, int Na, int Kx, int rows_per_split,
-    int gx, int gy, int nsplit) {
+    int gx, int gy, int nsplit, const float* __restrict__ sa = nullptr, const float* __restrict__ sx = nullptr) {
     constexpr int PLB = 128 * 64;
     __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLB];
     unsigned char* As = smem;
@@ -1094,6 +1101,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
     // staging: a thread owns two adjacent operand columns (8-byte global loads; a wave covers 128 consecutive floats of a row)
     // and 8 consecutive rows of the slab = ONE 16-byte chunk (8 k positions) of two LDS rows
     const int nl = (tid & 63) * 2, mq = tid >> 6;
+    const float sca = F16 ? sa[0] : 1.f, scx = F16 ? sx[0] : 1.f, sc_out = F16 ? sa[1] * sx[1] : 1.f;
     const bool a_ok = n0 + nl < Na, x_ok = k0 + nl < Kx;  // (Na, Kx even: a column pair is in range or not as a whole)
     const float* pa = A + n0 + nl;
     const float* px = X + k0 + nl;
@@ -1114,9 +1122,18 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
 #pragma unroll
             for (int t2 = 0; t2 < 4; ++t2) {
                 unsigned p[3], q[3];
-                split3_pair(ra[2 * t2][u], ra[2 * t2 + 1][u], p);
-                if constexpr (XSILU) split3_pair(silu_fast(rx[2 * t2][u]), silu_fast(rx[2 * t2 + 1][u]), q);
-                else split3_pair(rx[2 * t2][u], rx[2 * t2 + 1][u], q);
+                float x0 = rx[2 * t2][u], x1 = rx[2 * t2 + 1][u];
+                if constexpr (XSILU) {
+                    x0 = silu_fast(x0);
+                    x1 = silu_fast(x1);
+                }
+                if constexpr (F16) {
+                    pl_split_pair(ra[2 * t2][u], ra[2 * t2 + 1][u], sca, p);
+                    pl_split_pair(x0, x1, scx, q);
+                } else {
+                    split3_pair(ra[2 * t2][u], ra[2 * t2 + 1][u], p);
+                    split3_pair(x0, x1, q);
+                }
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     va[pl][t2] = p[pl];
@@ -1125,7 +1142,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
             }
             const int row = nl + u, off = row * 64 + ((mq ^ ((row >> 2) & 3)) * 16);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < (F16 ? 2 : 3); ++pl) {
                 *reinterpret_cast<u32x4*>(As + pl * PLB + off) = va[pl];
                 *reinterpret_cast<u32x4*>(Xs + pl * PLB + off) = vx[pl];
             }
@@ -1138,6 +1155,31 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
         if (m0 + 32 < m_end) load_slab(m0 + 32);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            if constexpr (F16) {
+#if MI_PLANES_FP16
+                f16x8 a[2][2], b[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = (wm * 2 + i) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) a[i][pl] = *reinterpret_cast<const f16x8*>(As + pl * PLB + r * 64 + c * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = (wn * 2 + j) * 32 + l31, c = (2 * s + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const f16x8*>(Xs + pl * PLB + r * 64 + c * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    }
+#endif
+            } else {
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1162,6 +1204,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
+            }
         }
         __syncthreads();
     }
@@ -1174,7 +1217,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, k = k0 + wn * 64 + j * 32 + l31;
-                Pt[(size_t)n * PK + k] = acc[i][j][r];
+                Pt[(size_t)n * PK + k] = F16 ? acc[i][j][r] * sc_out : acc[i][j][r];
             }
 }
 
@@ -1186,8 +1229,9 @@ inline bool gemm_tn_is_split(const float* A, int lda, const float* X, int ldx, i
     return g_gemm_mode != 0 && g_tn_split && M >= g_tn_split_min_rows && Na >= 128 && Kx >= 128 && ((lda | ldx | Na | Kx) & 1) == 0 &&
            ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0;
 }
+// sa / sx (fp16 plane format): optional device-side {scale, 1 / scale} of the two operands -> two-plane fp16 split, three terms
 inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
-                        size_t scratch_floats, hipStream_t s, bool x_silu = false) {
+                        size_t scratch_floats, hipStream_t s, bool x_silu = false, const float* sa = nullptr, const float* sx = nullptr) {
     if (gemm_tn_is_split(A, lda, X, ldx, M, Na, Kx)) {
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
         int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
@@ -1196,8 +1240,11 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
         nsplit = cdiv(M, rows);
         const dim3 grid(gx * gy * ((nsplit + 7) / 8 * 8));
-        if (x_silu) hipLaunchKernelGGL(gemm_tn_split_kernel<true>, grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
-        else hipLaunchKernelGGL(gemm_tn_split_kernel<false>, grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
+        const bool f16 = MI_PLANES_FP16 && sa && sx;
+        if (f16 && x_silu) hipLaunchKernelGGL((gemm_tn_split_kernel<true, true>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
+        else if (f16) hipLaunchKernelGGL((gemm_tn_split_kernel<false, true>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
+        else if (x_silu) hipLaunchKernelGGL((gemm_tn_split_kernel<true, false>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
+        else hipLaunchKernelGGL((gemm_tn_split_kernel<false, false>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx,
                            1.0f);
         MI_KERNEL_CHECK();

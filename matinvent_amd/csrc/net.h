@@ -69,6 +69,8 @@ struct Tape {
     // fused fine-tune micro-step: noised inputs, targets, gradient seeds, per-crystal losses
     float *nz_lat = nullptr, *nz_frac = nullptr, *nz_types = nullptr, *tar_x = nullptr, *rnd_l = nullptr, *rnd_t = nullptr, *d_l = nullptr,
           *d_x = nullptr, *d_t = nullptr, *Lb = nullptr, *KLb = nullptr;
+    float* dsc_layers = nullptr;  // [L][8] each layer's activation scales of the training forward (fp16 plane format, folded launch)
+    bool dsc_layers_valid = false;
     size_t scratch_floats = 0;
 };
 
