@@ -182,8 +182,20 @@ __global__ __launch_bounds__(128) void edge_bwd_pairs_kernel(const float* __rest
                                                              const int* __restrict__ node_off, const int* __restrict__ rowptr,
                                                              const int* __restrict__ pair_off, float* __restrict__ Dm, float* __restrict__ Dp,
                                                              float* __restrict__ dPQ, float* __restrict__ dG, float* __restrict__ dsum_part,
-                                                             int H) {
+                                                             int H, const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
     extern __shared__ float accs[];  // row sums [n][128], then column sums [n][128]
+    // fp16 plane format: publish the scales of the Fourier-block weight gradient's operands.  |Dm|, |Dp| <= 2 max|dZ1| and
+    // |dZ1| = |dM1 silu'(Z1)| <= 1.1 max|dM1| (amax: written by the dM1 product's epilogue); the Fourier features are <= 1.
+    if (dsc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const float bnd = 2.2f * __uint_as_float(amax[0]);
+        int ex = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
+        if (!(bnd == bnd) || bnd > 3e38f) ex = -100;
+        ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+        dsc_out[0] = exp2f((float)ex);
+        dsc_out[1] = exp2f(-(float)ex);
+        dsc_out[2] = 16384.f;
+        dsc_out[3] = 1.f / 16384.f;
+    }
     const int g = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 128 + tid;
     const int o = node_off[g], n = node_off[g + 1] - o;
     if (n == 0 || c >= H) return;
@@ -529,7 +541,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             Planes dzp;
             if (dz2_planes) {
                 dzp = make_planes(b->M1pl, H, 1.f, b->dsc + 6);
-                MI_HIP(hipMemsetAsync(b->absmax + 2 * L, 0, sizeof(unsigned), s));
+                MI_HIP(hipMemsetAsync(b->absmax + 2 * L, 0, 2 * sizeof(unsigned), s));
                 hipLaunchKernelGGL(absmax_bwd_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 1024))), dim3(256), 0, s, t.dcat, (int64_t)N * 2 * H,
                                    b->absmax + 2 * L);
             }
@@ -555,6 +567,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 PlanesEpilogue pd;
                 pd.C = t.dM1;
                 pd.ldc = H;
+                pd.absmax = b->absmax + 2 * L + 1;  // max |dM1|: bounds the pair-mode weight gradient's operands
                 MI_TRY(gemm_planes(dzp, make_planes(net->W2Tpl + (size_t)l * planes_elems(H, H), H), (int)E, H, H, pd, s));
             } else {
                 MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
@@ -570,9 +583,11 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
                 MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
+                const bool wff_f16 = dz2_planes && fused_pairs && g_bwd_wgrad_f16;  // two-plane fp16 operands for the Fourier-block weight gradient
                 if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
-                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, t.dPQ, t.dG, sc, H);
+                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, t.dPQ, t.dG, sc, H,
+                                       wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
                 } else {
@@ -585,8 +600,10 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
                 MI_KERNEL_CHECK();
                 if (Np > 0) {
-                    MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s));
-                    MI_TRY(gemm_tn_auto(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s));
+                    MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s, false, wff_f16 ? b->dsc + 8 : nullptr,
+                                        wff_f16 ? b->dsc + 10 : nullptr));
+                    MI_TRY(gemm_tn_auto(Dp, H, t.FF + 3 * F, 6 * F, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s, false,
+                                        wff_f16 ? b->dsc + 8 : nullptr, wff_f16 ? b->dsc + 10 : nullptr));
                 }
             } else {
                 MI_TRY(gemm_tn_auto(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));

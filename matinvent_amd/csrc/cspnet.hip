@@ -1176,7 +1176,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(lnpl, planes_elems(N, H));
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
-    A_(dsc, 8);
+    A_(dsc, 12);
     A_(absmax, 2 * L + 2);
     A_(X, NH);
     A_(x1, NH);

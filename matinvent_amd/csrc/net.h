@@ -112,8 +112,8 @@ struct mi_batch {
     unsigned short* lnpl = nullptr;  // plane sets of LayerNorm(h) and of the aggregated messages (N x H each)
     unsigned short* aggpl = nullptr;
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
-    float* dsc = nullptr;            // [4][2] {scale, 1/scale} of this layer's M1 / agg / X plane sets and of the backward pass's dZ2 planes (fp16 plane format)
-    unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation); [2L] = max |d cat| of the layer the backward pass is in
+    float* dsc = nullptr;            // [6][2] {scale, 1/scale}: this layer's M1 / agg / X plane sets; backward pass: dZ2, the pair differences, the Fourier features (fp16 plane format)
+    unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation); [2L], [2L + 1] = max |d cat|, max |dM1| of the layer the backward pass is in
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
