@@ -303,7 +303,9 @@ int mi_debug_set_node_planes_min_rows(int n);
 /* Tuning knob for the weight-gradient products over long row lists (edge / pair list): 3 (default) = bf16 three-plane split on
  * the matrix pipe (split arithmetic path only), 1 = f32 MFMA on 128 x 128 tiles, 0 = f32 MFMA on 64 x 64 tiles; +8 = the separate
  * dZ1-consumer kernels instead of the fused fc pair-mode backward pass, +16 = a separate silu(Z1) pass instead of forming M1 inside
- * the weight-gradient product's operand load (ablations). */
+ * the weight-gradient product's operand load, +32 = the dM1 data gradient on the on-the-fly three-plane bf16 split instead of the
+ * pre-split fp16 plane GEMM, +64 = the edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes /
+ * three (ablations). */
 int mi_debug_set_tn128(int on);
 /* Tuning knob: shortest row list (contraction length) for which the bf16-pipe weight-gradient kernel is used (default 4096). */
 int mi_debug_set_tn_split_min_rows(int n);

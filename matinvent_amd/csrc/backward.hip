@@ -8,7 +8,6 @@
 // as [E,H] / [E,6F] scratch and pushed through the generic MFMA GEMMs (dgrad = gemm_nt against
 // pre-transposed weights, wgrad = gemm_tn with a fixed-order split reduction).  Deterministic: no
 // float atomics anywhere.
-#include <cstdlib>
 #include "gemm_split.h"
 #include "net.h"
 
@@ -16,6 +15,8 @@ namespace mi {
 extern int g_edge_pairs;
 int g_tn_xsilu = 1;          // M1 = silu(Z1) inside the weight-gradient product's operand load (0: separate pass, ablation)
 int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
+int g_bwd_dz2_planes = 1;   // fp16 plane format: dZ2 also as a plane set, its data gradient on the pre-split plane GEMM (0: on-the-fly bf16 split)
+int g_bwd_wgrad_f16 = 1;    // fp16 plane format: edge-level weight gradients on two fp16 planes / three terms (0: three bf16 planes / six)
 }
 
 namespace mi {
@@ -70,8 +71,6 @@ __global__ __launch_bounds__(256) void absmax_bwd_kernel(const float* __restrict
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
-int g_bwd_wgrad_f16 = std::getenv("MI_BWD_WGRAD_F16") ? std::atoi(std::getenv("MI_BWD_WGRAD_F16")) : 1;  // experiment switch
-int g_bwd_dz2_planes = std::getenv("MI_BWD_DZ2_PLANES") ? std::atoi(std::getenv("MI_BWD_DZ2_PLANES")) : 1;  // experiment switch
 
 // The same with the bias gradient's column sums folded in (one pass over [E, H] less): a block owns a chunk of `rows` rows, writes dZ2
 // in place and the chunk's column sums to part[chunk][H] (reduced by part_reduce_kernel).  A thread owns FOUR consecutive columns
