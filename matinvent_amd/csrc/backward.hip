@@ -536,7 +536,10 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             const bool dz2_sums = (size_t)nchunk * H <= scf && H % 4 == 0;  // Z2 := dZ2, with edge_mlp.2.bias's gradient (column sums) on the way
             // fp16 plane format: dZ2 is also written as a plane set (scale from max |d cat|), and its data gradient runs on the
             // pre-split plane GEMM (three fp16 terms) instead of the on-the-fly three-plane bf16 split (six terms)
-            const bool dz2_planes = MI_PLANES_FP16 && g_bwd_dz2_planes && dz2_sums && g_gemm_mode == MI_GEMM_SPLIT && net->W2Tpl && b->M1pl && H % 32 == 0;
+            // (short edge lists are bound by the launch rate: the two extra launches cost more than the products save -- 18 crystals,
+            // 2.7k edges: 3.55 -> 3.75 ms per unstacked micro-step; the stacked form, 32k edges, gains 2 %)
+            const bool dz2_planes = MI_PLANES_FP16 && g_bwd_dz2_planes && dz2_sums && g_gemm_mode == MI_GEMM_SPLIT && net->W2Tpl && b->M1pl && H % 32 == 0 &&
+                                    E >= 8192;
             Planes dzp;
             if (dz2_planes) {
                 dzp = make_planes(b->M1pl, H, 1.f, b->dsc + 6);
