@@ -172,6 +172,37 @@ def test_gradients_vs_oracle_autograd_mid_size():
         _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 1e-3, f"grad {k}")
 
 
+def test_gradients_vs_oracle_autograd_ragged_large():
+    """Ragged crystals (1..20 atoms, single-atom cells included) at a size where the edge-level backward products take their
+    large-list forms: E > 8192 edges, so dZ2 is also written as an fp16 plane set, its data gradient runs on the plane GEMM and
+    both edge-level weight gradients split into two fp16 planes with device-side scales."""
+    H, L, F = 256, 2, 32
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=9)
+    gen = torch.Generator().manual_seed(21)
+    m = make_module(H, L, F, 20, P)
+    na = torch.randint(1, 21, (150,), generator=gen)
+    na[:3] = torch.tensor([1, 20, 1])
+    assert int((na * na).sum()) > 8192
+    B, N = len(na), int(na.sum())
+    n2g = torch.repeat_interleave(torch.arange(B), na)
+    t_emb = O.time_embedding(torch.randint(1, 20, (B,), generator=gen), 256)
+    at, fr = torch.randn(N, 100, generator=gen), torch.rand(N, 3, generator=gen)
+    lat = 4 * torch.eye(3) + torch.randn(B, 3, 3, generator=gen)
+    ul, ux, ut = torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ol, ox, ot = O.cspnet_forward(Pg, hp, t_emb, at, fr, lat, na, n2g)
+    ((ol * ul).sum() + (ox * ux).sum() + (ot * ut).sum()).backward()
+    pl, px, pt = m.decoder(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), na)
+    ((pl * ul.cuda()).sum() + (px * ux.cuda()).sum() + (pt * ut.cuda()).sum()).backward()
+    _rel(pl, ol.detach(), 2e-5, "pred_l")
+    _rel(px, ox.detach(), 2e-5, "pred_x")
+    _rel(pt, ot.detach(), 2e-5, "pred_t")
+    th = m.decoder.theta
+    for k, (o, cnt, shape) in m.decoder.layout.items():
+        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 1e-3, f"grad {k}")
+
+
 def test_fused_adam_matches_torch_adam():
     from matinvent_amd.optim import FusedAdam
     torch.manual_seed(0)
