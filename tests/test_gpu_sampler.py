@@ -191,3 +191,26 @@ def test_concurrent_streams_reproduce_the_single_stream_chain():
     g2, _ = m.sample(Box(na), step_lr=5e-6, seed=seed, init=init, streams=2)
     assert wrap_dist(g1["frac_coords"].cpu().numpy(), g2["frac_coords"].cpu().numpy()).max() < 2e-5
     np.testing.assert_allclose(g1["lattices"].cpu().numpy(), g2["lattices"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_benchmark_workload_first_steps_vs_oracle():
+    """The benchmark's own workload (bench.py: H=512, L=6, F=128, T=1000, 20-atom crystals, counter-based noise, heads x 1e-2) for
+    the first two denoising steps of the chain, one 64-crystal group sampled as two concurrent chains, against the oracle consuming
+    the same Philox stream.  (A full 1000-step chain is chaotic in fp32; its properties are checked above.)"""
+    import bench
+    T, seed = bench.T, bench.SEED_NOISE
+    hp = O.CSPNetHParams(hidden_dim=bench.H, num_layers=bench.L, num_freqs=bench.F)
+    P = O.init_params(hp, seed=bench.SEED_W, head_scale=bench.HEAD_SCALE)
+    m = bench.build_module(torch.device("cuda", 0))
+    m.decoder.load_state_dict({k[len("decoder."):]: v for k, v in P.items()})
+    na = torch.full((64,), bench.NATOM, dtype=torch.long)
+    final, _ = m.sample(Box(na), step_lr=bench.STEP_LR, seed=seed, t_start=T, t_stop=T - 2, streams=2)
+    torch.cuda.synchronize()
+    sch = O.Schedules.make(T, sigmas_norm=m.sigma_scheduler.sigmas_norm.cpu())
+    sch.beta = {k: getattr(m.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
+    noise = O.philox_sampler_noise(seed, na, T, t_stop=T - 2)
+    of, _ = O.sample(P, hp, sch, na, noise, step_lr=bench.STEP_LR, t_stop=T - 2, keep_traj=False)
+    assert wrap_dist(final["frac_coords"].cpu().numpy(), of["frac_coords"].numpy()).max() < 2e-5
+    for k in ("lattices", "atom_types"):
+        a, b = final[k].cpu().numpy(), of[k].numpy()
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), k
