@@ -248,13 +248,17 @@ __global__ void pack_wff_pair_planes_kernel(const float* __restrict__ W1, int ed
 #pragma unroll
     for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(dst.base + dst.elem(f, col, k)) = p[k];
 }
-__global__ void wff_cos_rowsum_kernel(const float* __restrict__ W1, int edge_in, int H, int F, float* __restrict__ C0) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// C0[f] = sum of the cosine block of row f of edge_mlp.0's Fourier columns: one wave per row, lanes over the 3F columns, fixed-order
+// shuffle reduction (a thread per row walking 3F floats a row stride apart took 100 us per layer at every parameter update).
+__global__ __launch_bounds__(256) void wff_cos_rowsum_kernel(const float* __restrict__ W1, int edge_in, int H, int F, float* __restrict__ C0) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= H) return;
     const float* w = W1 + (size_t)f * edge_in + 2 * H + 9 + 3 * F;
     float s = 0.f;
-    for (int k = 0; k < 3 * F; ++k) s += w[k];
-    C0[f] = s;
+    for (int k = lane; k < 3 * F; k += 64) s += w[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) C0[f] = s;
 }
 
 // Self edges (i, i) of the fc list in pair mode: d = 0, so the Fourier term is the constant C0:
@@ -1041,7 +1045,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * w2p.KT * 16, 256)), dim3(256), 0, s, W2, H, H, H, w2p);
             Planes wpp = make_planes(n->Wffpl_pair + (size_t)l * planes_elems(H, 2 * n->Kh), 2 * n->Kh);
             hipLaunchKernelGGL(pack_wff_pair_planes_kernel, dim3(cdiv((int64_t)Hp * n->Kh, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->Kh, wpp);
-            hipLaunchKernelGGL(wff_cos_rowsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->C0 + (size_t)l * H);
+            hipLaunchKernelGGL(wff_cos_rowsum_kernel, dim3(cdiv(H, 4)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->C0 + (size_t)l * H);
             // node-level weights, grouped by operand: [P_i; P_j; node_mlp.0[:, :H]] multiply LayerNorm(h), node_mlp.0[:, H:] the
             // aggregated messages (that product then sits alone on the path after the edge stage)
             const float* Wn0 = n->p(p + "node_mlp.0.weight");
