@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import diffcsp_oracle as O  # noqa: E402
 from tests.gpu_util import make_module  # noqa: E402
 

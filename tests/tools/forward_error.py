@@ -1,8 +1,8 @@
 """Deviation of the HIP forward from the CPU oracle (fp32) and from the oracle evaluated in fp64, at the benchmark shape
 (B = 256 x 20 atoms, H = 512, L = 6, F = 128): max |difference| / max(1, max |reference|) per output.  The fp64 column separates
-the arithmetic error of the plane-set GEMMs from the fp32 oracle's own rounding.  Usage (GPU box): PYTHONPATH=. python scripts/forward_error.py"""
+the arithmetic error of the plane-set GEMMs from the fp32 oracle's own rounding.  Usage (GPU box): python tests/tools/forward_error.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import diffcsp_oracle as O
 from tests.gpu_util import load_decoder
