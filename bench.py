@@ -180,7 +180,7 @@ def main_ft(args):
         print(json.dumps({"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
                           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32 (forward products: 2-plane fp16 split, 3 MFMA terms; backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
+                          "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
                           "data": "synthetic",
                           "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps, 256 crystals x 20 atoms per GPU, "
                                                  "synthetic reward, accum_steps=50, fused Adam, flat-gradient all-reduce when N>1"},
