@@ -23,15 +23,32 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile the library if it is missing or older than its sources.  Safe to call from several processes at once (one rank
+    per GPU): an exclusive file lock serialises them, the compiler writes to a temporary file that is renamed into place, and a
+    process that waited for the lock re-checks before compiling again."""
     if not force and not _stale():
         return LIB
+    import fcntl
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
-    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
+            tmp = f"{LIB}.tmp{os.getpid()}"
+            cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
