@@ -109,6 +109,35 @@ def cpu_baseline(budget_s=15.0):
                       f"denoising steps in {t_total:.1f} s, scaled linearly (per-step cost is t-independent)"}
 
 
+def cpu_baseline_ft(budget_s=15.0):
+    """The CPU oracle's ft_step (restatement of pipeline/mat_invent.py:150-177: noise, agent forward, frozen-prior forward,
+    autograd backward) on this host's cores: a bounded slice of the same workload (16 of the 256 crystals, a few timesteps)."""
+    from oracle import diffcsp_oracle as O
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    agent, prior = O.init_params(hp, seed=SEED_W, head_scale=HEAD_SCALE), O.init_params(hp, seed=SEED_W, head_scale=HEAD_SCALE)
+    sch = O.Schedules.make(T, sigmas_norm=torch.from_numpy(np.load(SIGMAS_NORM)))
+    Bc = 16
+    g = torch.Generator().manual_seed(7)
+    batch = dict(num_atoms=torch.full((Bc,), NATOM, dtype=torch.long), frac_coords=torch.rand(Bc * NATOM, 3, generator=g),
+                 atom_types=torch.randint(1, 95, (Bc * NATOM,), generator=g), lengths=4 + 6 * torch.rand(Bc, 3, generator=g),
+                 angles=70 + 40 * torch.rand(Bc, 3, generator=g))
+    rewards = torch.rand(Bc, generator=g)
+
+    def noise_fn(epoch, t):
+        return dict(rand_l=torch.randn(Bc, 3, 3, generator=g), rand_x=torch.randn(Bc * NATOM, 3, generator=g),
+                    rand_t=torch.randn(Bc * NATOM, 100, generator=g))
+    done, t_total, n = 0, 0.0, 1
+    while t_total < budget_s and done < 24:
+        t0 = time.perf_counter()
+        O.ft_step(agent, prior, hp, sch, O.Costs(), batch, rewards, noise_fn, lr=1e-4, timesteps=n, accum_steps=n, sigma=0.025)
+        t_total += time.perf_counter() - t0
+        done += n
+        n = max(1, min(24 - done, int((budget_s - t_total) / (t_total / done))))
+    return {"value": Bc * done / t_total, "unit": "crystal-timesteps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/diffcsp_oracle.py ft_step (plain torch fp32 CPU, autograd), {Bc} crystals x {NATOM} atoms, {done} timesteps "
+                      f"(+ one Adam step per call) in {t_total:.1f} s"}
+
+
 def _oracle_steps(O, P, hp, sch, na, noise, t_from, t_to):
     """Run oracle steps t_from .. t_to+1 starting from the state in noise[x_T,l_T,t_T]."""
     # O.sample always starts at sch.timesteps; emulate a mid-chain start by a shallow schedule view
@@ -167,26 +196,68 @@ def main_ft(args):
         if world > 1:
             dist.barrier() if share else dist.barrier(device_ids=[local_rank])
 
+    import ctypes as C
+    lib = _lib.load()
     run(max(W, 1))
+    _lib.check(lib.mi_profile_enable(agent.decoder._h, 1))
     t0 = time.perf_counter()
     run(K)
     elapsed = time.perf_counter() - t0
+    n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(lib.mi_profile_read(agent.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
+    _lib.check(lib.mi_profile_enable(agent.decoder._h, 0))
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
         flops = 4 * 5.893e9 * nglob * K  # agent fwd + prior fwd + 2x for backward
-        print(json.dumps({"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
-                          "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
-                          "data": "synthetic",
-                          "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps, 256 crystals x 20 atoms per GPU, "
-                                                 "synthetic reward, accum_steps=50, fused Adam, flat-gradient all-reduce when N>1"},
-                          "end_to_end": {"tflops_section8d": flops / elapsed / 1e12}}), flush=True)
+        # dominant kernel pair of the micro-step (profiles/*_finetune.md): the agent's forward edge stage -- the same two plane GEMMs
+        # as the sampler's, bracketed by HIP events on their launch stream; one launch = one layer over one crystal group
+        groups = max(1, n_launch.value // max(1, K * L))
+        E = B * NATOM * NATOM / groups
+        f_exec, f_alg = edge_flops_per_edge(pairs=True)
+        terms = 3 if lib.mi_plane_format() == 2 else 6
+        busy_ms = union_ms.value if groups > 1 else tot_ms.value
+        issued = terms * n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12
+        out = {"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
+               "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps (noise + agent fwd + frozen-prior fwd + agent bwd per "
+                                      "timestep), 256 crystals x 20 atoms per GPU, synthetic reward, accum_steps=50, fused Adam, one flat-gradient "
+                                      "all-reduce (RCCL) per optimizer step when N>1; a bench step = one timestep over the batch",
+                          "batch_per_gpu": B, "atoms_per_cell": NATOM, "accum_steps": 50, "concurrent_groups": groups,
+                          "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world},
+               "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (agent forward, edge MLP of one layer; the "
+                                                          "largest single kernel of the micro-step)",
+                            "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS,
+                            "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": tot_ms.value / max(1, n_launch.value),
+                            "concurrent_streams": groups, "stage_busy_ms": busy_ms,
+                            "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg},
+               "end_to_end": {"tflops_section8d": flops / elapsed / 1e12,
+                              "frac_of_f32_mfma_peak_section8d": flops / elapsed / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_ft()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): start the N ranks ourselves, one
+    process per GPU, through torch.distributed.run on the loopback address, and pass their output through -- rank 0 prints
+    the one JSON line.  Under an outer launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MI_BENCH_CHILD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -204,6 +275,8 @@ def main():
     ap.add_argument("--mode", choices=["sample", "ft"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
     if args.mode == "ft":
         return main_ft(args)
     K, W = args.steps, args.warmup
@@ -308,7 +381,7 @@ def main():
                                    "2 score-net evals/step (DiffCSP CSPNet H=512 L=6 F=128 fc edges; MatterGen arithmetic is "
                                    "un-vendored/parity-unpinned); a bench step = one denoising step over the batch",
                        "batch_per_gpu": B, "atoms_per_cell": NATOM, "T": T, "evals_per_step": 2, "path": args.path,
-                       "concurrent_chains": S,
+                       "concurrent_chains": S, "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
                        "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": issued, "peak": peak,
                          "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,

@@ -22,13 +22,14 @@ from .optim import FusedAdam
 def _sched_host(agent):
     """Host copies of the noise schedules (made once per module): indexing the device tensors costs a device sync per scalar and
     timestep, which the launch-bound small-set regime cannot afford."""
+    bufs = (agent.beta_scheduler.alphas_cumprod, agent.sigma_scheduler.sigmas, agent.sigma_scheduler.sigmas_norm)
+    key = tuple((b.data_ptr(), b._version) for b in bufs)  # a checkpoint load after the first ft_step changes the buffers
     h = agent.__dict__.get("_mi_sched_host")
-    if h is None:
-        ac = agent.beta_scheduler.alphas_cumprod.detach().cpu()
-        h = agent.__dict__["_mi_sched_host"] = (torch.sqrt(ac).tolist(), torch.sqrt(1.0 - ac).tolist(),
-                                                agent.sigma_scheduler.sigmas.detach().cpu().tolist(),
-                                                agent.sigma_scheduler.sigmas_norm.detach().cpu().tolist())
-    return h
+    if h is None or h[0] != key:
+        ac = bufs[0].detach().cpu()
+        h = agent.__dict__["_mi_sched_host"] = (key, (torch.sqrt(ac).tolist(), torch.sqrt(1.0 - ac).tolist(),
+                                                      bufs[1].detach().cpu().tolist(), bufs[2].detach().cpu().tolist()))
+    return h[1]
 
 
 def _fused_micro_step(agent, prior, batch, time_idx, noise, sigma, n_global, accum_steps, grad, stats, call_id=None, aux_stream=None):
@@ -148,6 +149,10 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     n_global = len(data_list)
     lo, hi = shard_range(n_global, rank, world)
     dataset = CrystalDataset(data_list, rewards)
+    if hi == lo:
+        # fewer crystals than ranks (the fine-tune set is top-k + replay and shrinks when the validity filter keeps few samples):
+        # this rank has nothing to differentiate, but must take part in every all-reduce and apply every optimizer step
+        return _ft_step_empty_shard(agent, n_global, lr, accum_steps, epochs, timesteps, log, rank)
     # one batch holding the whole (local shard of the) fine-tune set (:129-133); order is irrelevant to the update
     batch = CrystalBatchData([dataset[i] for i in range(lo, hi)]).to(device)
     node_lo = sum(d.num_atoms for d in dataset.data_list[:lo])
@@ -213,6 +218,30 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
             optimizer.zero_grad(set_to_none=False)
         allreduce_flat_(acc)
         a = acc.tolist()  # the only host sync of the epoch
+        d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
+        stats.append(d)
+        if rank == 0:
+            log(f"Epoch {epoch}: " + ", ".join(f"{k}: {v:.4f}" for k, v in d.items()))
+    return stats
+
+
+def _ft_step_empty_shard(agent, n_global, lr, accum_steps, epochs, timesteps, log, rank):
+    """ft_step of a rank whose shard is empty: zero gradient contribution, the same collectives and optimizer steps as its peers."""
+    theta = agent.decoder.theta
+    if theta.grad is None:
+        theta.grad = torch.zeros_like(theta)
+    optimizer = FusedAdam([theta], lr=lr)
+    stats = []
+    for epoch in range(epochs):
+        theta.grad.zero_()
+        n_steps = timesteps // accum_steps + (1 if timesteps % accum_steps else 0)
+        for _ in range(n_steps):
+            allreduce_flat_(theta.grad)
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=False)
+        acc = torch.zeros(3, device=theta.device)
+        allreduce_flat_(acc)
+        a = acc.tolist()
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:

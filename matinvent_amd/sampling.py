@@ -52,6 +52,11 @@ class DiffCSPSampler:
         rank, world = int(kwargs.get("rank", 0)), int(kwargs.get("world_size", 1))
         model.eval()
         dataset = SampleDataset(total_num=batch_size * num_batches, dataset=self.num_atoms_distribution)
+        if world > 1:
+            # the atom counts come from numpy's unseeded GLOBAL generator (sample.py:123): every rank would draw a different
+            # vector, while the shard ranges and the global noise offsets below assume ONE.  Rank 0's draw is the batch.
+            from .dist import broadcast_object
+            dataset.num_atoms = np.asarray(broadcast_object(dataset.num_atoms.tolist(), src=0))
         step_lr = DEFAULT_STEP_LR["gen"]["mp_20"]
         outputs = None
         for bi in range(num_batches):

@@ -90,7 +90,10 @@ class DiffCSPSuite(ModelSuite):
             ckpts = sorted(model_path.glob("*.ckpt"))
             if ckpts:
                 last = [c for c in ckpts if "last" in c.name]
-                ck = torch.load(str(last[0] if last else ckpts[-1]), map_location="cpu", weights_only=False)
+                if not last:  # models/suite/diffcsp.py:83-90: the numerically largest `epoch=N-...` name
+                    epochs = [int(c.name.split("-")[0].split("=")[1]) for c in ckpts]
+                    last = [ckpts[int(np.argsort(epochs)[-1])]]
+                ck = torch.load(str(last[-1]), map_location="cpu", weights_only=False)
                 model.load_state_dict(ck["state_dict"], strict=False)
         model.config = cfg
         return model

@@ -86,3 +86,126 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     # sampler shards: the post-fine-tune parameters differ by round-off between the runs, so compare at chain tolerance
     dx = np.abs(one["frac"] - two["frac"])
     assert np.minimum(dx, 1 - dx).max() < 2e-3
+
+
+WORKER2 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from oracle import diffcsp_oracle as O
+from tests.gpu_util import make_module
+from matinvent_amd.data import CrystalData
+from matinvent_amd.finetune import ft_step
+from matinvent_amd.sampling import DiffCSPSampler
+from matinvent_amd.dist import allreduce_flat_
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+backend = sys.argv[3]
+if world > 1:
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
+dev = torch.device("cuda", torch.cuda.current_device())
+hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
+P0 = O.init_params(hp, seed=3)
+gen = torch.Generator().manual_seed(9)
+T = 12
+sn = torch.cat([torch.ones(1), 0.5 + torch.rand(T, generator=gen)])
+agent, prior = make_module(64, 2, 8, T, P0, sigmas_norm=sn, device=dev), make_module(64, 2, 8, T, P0, sigmas_norm=sn, device=dev)
+prior.requires_grad_(False)
+# (1) flat all-reduce on the process group's backend
+buf = torch.full((1000,), float(rank + 1), device=dev)
+allreduce_flat_(buf)
+assert float(buf[0]) == world * (world + 1) / 2
+# (2) a fine-tune set SMALLER than the world: the last ranks' shards are empty, nobody may hang, every rank ends with the same parameters
+data = [CrystalData(torch.rand(5, 3, generator=gen), torch.randint(1, 95, (5,), generator=gen), 4 + 6 * torch.rand(1, 3, generator=gen),
+                    70 + 40 * torch.rand(1, 3, generator=gen))]
+agent.noise_seed = 5
+stats = ft_step(agent, prior, data, np.array([0.7]), dict(lr=1e-4, accum_steps=2, epochs=1, timesteps=5, sigma=0.025), log=lambda *_: None)
+theta = agent.decoder.theta.detach().cpu().numpy()
+# (3) DiffCSPSampler.generate: ranks seed numpy differently (the reference never seeds it); the atom counts must still be ONE vector
+np.random.seed(1234 + 17 * rank)
+sampler = DiffCSPSampler(batch_size=6, num_batches=1)
+recs, strucs = sampler.generate(model=agent, rank=rank, world_size=world)
+na = np.array([r.num_atoms for r in recs])
+frac = np.concatenate([r.frac_coords.numpy() for r in recs])
+if world > 1:
+    allt = [None] * world
+    dist.all_gather_object(allt, theta)
+    assert all(np.array_equal(allt[0], t) for t in allt), "ranks diverged"
+if rank == 0:
+    np.savez(sys.argv[2], theta=theta, na=na, frac=frac, loss=np.array([stats[0]["loss"]]))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def _run2(tmp_path, world, port, backend="gloo"):
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2)
+    out_file = tmp_path / f"out2_{world}.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    if world == 1:
+        cmd = [sys.executable, str(script), ROOT, str(out_file), backend]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script), ROOT, str(out_file), backend]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return np.load(out_file)
+
+
+def _check2(one, two):
+    d = np.abs(one["theta"] - two["theta"])
+    assert d.max() <= 1e-5, d.max()     # the same single crystal on rank 0, zero contributions elsewhere: round-off only
+    assert abs(float(one["loss"][0]) - float(two["loss"][0])) <= 1e-5 * max(1.0, abs(float(one["loss"][0])))
+    # rank 0's numpy stream decides the atom counts in both runs (seed 1234 on rank 0)
+    assert np.array_equal(one["na"], two["na"])
+    dx = np.abs(one["frac"] - two["frac"])
+    assert np.minimum(dx, 1 - dx).max() < 2e-3
+
+
+def test_empty_shard_and_sampler_generate_two_ranks(tmp_path):
+    _check2(_run2(tmp_path, 1, 29661), _run2(tmp_path, 2, 29662))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL ('nccl') backend with one process per GPU")
+def test_rccl_two_gpus(tmp_path):
+    _check2(_run2(tmp_path, 1, 29663), _run2(tmp_path, 2, 29664, backend="nccl"))
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it): bench.py starts the two ranks itself.
+    On the one-GPU test box the ranks share the device and talk over gloo (MI_BENCH_SHARE_GPU); with two GPUs the same command
+    runs one rank per GPU over RCCL (test below)."""
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"MI_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 256 * 3 / (1000 * d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    f = _bench(["--mode", "ft", "--gpus", "2", "--steps", "2", "--warmup", "1"], {"MI_BENCH_SHARE_GPU": "1"})
+    assert f["n_gpus"] == 2 and f["unit"] == "crystal-timesteps/s" and f["value"] > 0 and f["config"]["comm_backend"] == "gloo"
+    assert "roofline" in f and f["roofline"]["launches"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_two_gpus_over_rccl():
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {})
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    f = _bench(["--mode", "ft", "--gpus", "2", "--steps", "2", "--warmup", "1"], {})
+    assert f["n_gpus"] == 2 and f["config"]["comm_backend"] == "nccl"

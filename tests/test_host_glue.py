@@ -131,3 +131,31 @@ def test_data_parallel_gradient_equals_full_batch_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP_OK" in out.stdout
+
+
+def test_replay_buffer_follows_the_reference_semantics():
+    """memory/replay_buffer.py:33-105: merge, dedupe on the reduced formula keeping the best reward, top-K, THEN the strict
+    reward cutoff; sample size default 8; purge by formula."""
+    from types import SimpleNamespace as NS
+    from matinvent_amd.memory import ReplayBuffer
+    mk = lambda types: NS(atom_types=np.array(types))
+    rb = ReplayBuffer(buffer_size=3, reward_cutoff=0.2)
+    assert rb.sample_size == 8
+    fe2o3, fe4o6, nacl, sio2, h2 = mk([26, 26, 8, 8, 8]), mk([26] * 4 + [8] * 6), mk([11, 17]), mk([14, 8, 8]), mk([1, 1])
+    rb.extend([fe2o3, nacl, h2], None, [0.5, 0.2, 0.9])
+    # H2 0.9, Fe2O3 0.5 stay; NaCl sits exactly on the cutoff and is dropped (strict >)
+    assert [round(r[0], 3) for r in rb.rows] == [0.9, 0.5]
+    rb.extend([fe4o6, sio2], None, [0.7, 0.6])
+    # Fe4O6 has the same reduced formula as Fe2O3 and the higher reward: it replaces it; top-3 = H2, Fe4O6, SiO2
+    assert [round(r[0], 3) for r in rb.rows] == [0.9, 0.7, 0.6] and rb.rows[1][2] is fe4o6
+    data, rewards = rb.sample()
+    assert len(data) == 3 and sorted(np.round(rewards, 3).tolist()) == [0.6, 0.7, 0.9]
+    rb.memory_purge([NS(species=[8, 14, 8])])
+    assert [round(r[0], 3) for r in rb.rows] == [0.9, 0.7]
+
+
+def test_checkpoint_choice_is_numeric_on_the_epoch(tmp_path):
+    """models/suite/diffcsp.py:83-90: without a `last` file the numerically largest epoch wins (epoch=10 over epoch=9)."""
+    names = ["epoch=9-step=1.ckpt", "epoch=10-step=2.ckpt"]
+    epochs = [int(n.split("-")[0].split("=")[1]) for n in sorted(names)]
+    assert sorted(names)[int(np.argsort(epochs)[-1])] == "epoch=10-step=2.ckpt"
