@@ -340,6 +340,7 @@ def main():
     _lib.check(lib.mi_profile_read(m.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
     _lib.check(lib.mi_profile_enable(m.decoder._h, 0))
     finite = all(bool(torch.isfinite(v).all()) for v in (final["frac_coords"], final["lattices"], final["atom_types"]))
+    sat = _lib.saturation_events(reset=True)   # fp16-plane conversions that clamped during the run (0 = the format held)
 
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if os.environ.get("MI_BENCH_SHARE_GPU") else dev, dtype=torch.float64)
@@ -382,7 +383,8 @@ def main():
                                    "un-vendored/parity-unpinned); a bench step = one denoising step over the batch",
                        "batch_per_gpu": B, "atoms_per_cell": NATOM, "T": T, "evals_per_step": 2, "path": args.path,
                        "concurrent_chains": S, "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
-                       "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite},
+                       "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite,
+                       "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": issued, "peak": peak,
                          "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,
                          "launches": int(n_launch.value), "avg_launch_ms": avg_ms, "concurrent_streams": S,
@@ -402,6 +404,22 @@ def main():
                            "edge_stage_share_of_step": busy_ms * 1e-3 / elapsed},
         }
         if not args.no_cpu_baseline and world == 1:
+            if args.path == "split-gemm":
+                # the precision trade, visible in every record: the same workload on the exact-fp32 path (f32-input MFMA, register-
+                # chained edge stage, bit-for-bit an fp32 fma chain), a short run outside the timed region
+                set_gemm_mode("f32")
+                m.decoder.set_edge_mode("fused_f32")
+                m.sample(cb, seed=SEED_NOISE + 2, t_start=T, t_stop=T - 2, **dict(skw, streams=1))
+                torch.cuda.synchronize()
+                kx = min(K, 10)
+                tx = time.perf_counter()
+                m.sample(cb, seed=SEED_NOISE + 2, t_start=T, t_stop=T - kx, **dict(skw, streams=1))
+                torch.cuda.synchronize()
+                tx = time.perf_counter() - tx
+                out["extra"] = {"exact_fp32_path": {"value": B * kx / (T * tx), "unit": "structures/s", "steps": kx, "path": "f32-fused",
+                                                    "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
+                set_gemm_mode("split")
+                m.decoder.set_edge_mode("gemm")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -182,6 +182,11 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
                    const mi_sampler_record* rec, float* atom_types, float* frac, float* lattices,
                    void* stream);
 
+/* CSP mode of DiffCSPModule.sample (diffusion.py:78-79, 283-287, 308-312, 330, 348-349): with keep_lattice / keep_coords the
+ * lattice / the fractional coordinates handed to mi_sampler_run are the known ones and are never moved (the network is still
+ * evaluated on them and the per-step log-probabilities are those of the reference's formulas).  Sticky per batch handle. */
+int mi_sampler_set_keep(mi_batch* b, int keep_lattice, int keep_coords);
+
 /* Fill `out` with n standard normals (uniform = 1: U[0,1)) of draw (step, draw_id), elements
  * [elem_offset, elem_offset + n) -- exposes the noise contract for tests. */
 int mi_philox_fill(uint64_t seed, uint32_t step, uint32_t draw_id, int64_t elem_offset, int64_t n,
@@ -218,6 +223,14 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
                  uint32_t step, const float* rand_l, const float* rand_x, const float* rand_t,
                  float* in_lattice, float* in_frac, float* in_types, float* tar_x, float* out_rand_l,
                  float* out_rand_t, void* stream);
+
+/* mi_add_noise with one timestep PER CRYSTAL (DiffCSPModule.add_noise(batch) without `time`, diffusion.py:83-84, which draws
+ * the times with numpy on the host): sched [B][4] (device) = {sqrt(alphabar_t), sqrt(1-alphabar_t), sigma_t, sigmas_norm_t} of
+ * each crystal's time. */
+int mi_add_noise_per_crystal(mi_batch* b, const float* lengths, const float* angles, const float* frac0, const int* atom_types,
+                             const float* sched, uint64_t seed, uint32_t step, const float* rand_l, const float* rand_x,
+                             const float* rand_t, float* in_lattice, float* in_frac, float* in_types, float* tar_x,
+                             float* out_rand_l, float* out_rand_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Profiling hook used by bench.py: when enabled, the dominant kernel (edge-message MLP) is
@@ -311,6 +324,12 @@ int mi_debug_set_tn128(int on);
 int mi_debug_set_tn_split_min_rows(int n);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
+/* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
+ * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
+ * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results
+ * computed since the reset are NOT within the stated fp32-class tolerance (use the three-plane bf16 build, -DMI_PLANES_FP16=0, for
+ * networks whose weights exceed 1023 or whose LayerNorm outputs exceed 8188); zero means no conversion lost range. */
+int mi_saturation_events(int64_t* count, int reset);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mi_adam_step": (_I, [_P, _P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "mi_add_noise": (_I, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _U64, _U32, _P, _P, _P, _P, _P, _P, _P,
                           _P, _P, _P]),
+    "mi_add_noise_per_crystal": (_I, [_P, _P, _P, _P, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_sampler_set_keep": (_I, [_P, _I, _I]),
     "mi_ft_micro_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, C.c_float, C.c_float, _U64, _U32, _P, _P, _P,
                               C.c_float, C.c_float, C.c_float, C.c_float, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mi_ft_micro_steps_stacked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _U64, _U32, _P, _P, _P,
@@ -73,6 +75,7 @@ SIGNATURES = {
     "mi_set_gemm_mode": (_I, [_I]),
     "mi_net_set_edge_mode": (_I, [_P, _I]),
     "mi_debug_gemm": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "mi_saturation_events": (_I, [C.POINTER(_L), _I]),
     "mi_profile_enable": (_I, [_P, _I]),
     "mi_profile_read": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -105,3 +108,22 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().mi_last_error().decode(errors="replace")
         raise RuntimeError(f"matinvent_hip {what} failed (code {rc}): {msg}")
+
+
+def saturation_events(reset: bool = True) -> int:
+    """Number of fp32 -> fp16-plane conversions that had to clamp (or met NaN / inf) since the last reset, over every network and
+    stream of the current device (mi_saturation_events; synchronises the device)."""
+    n = C.c_int64()
+    check(load().mi_saturation_events(C.byref(n), 1 if reset else 0), "mi_saturation_events")
+    return int(n.value)
+
+
+def check_saturation(where: str):
+    """Raise if any operand left the range of the two-plane fp16 format since the last check: such results are finite but wrong,
+    and must never be handed on silently."""
+    n = saturation_events(reset=True)
+    if n:
+        raise FloatingPointError(
+            f"{where}: {n} operand conversions saturated the two-plane fp16 format (values beyond 65504 / scale, or NaN / inf "
+            "upstream): the results are outside the stated fp32-class tolerance.  Rebuild with MI_EXTRA_FLAGS=-DMI_PLANES_FP16=0 "
+            "(three bf16 planes, no range limit) or use --path f32-gemm")

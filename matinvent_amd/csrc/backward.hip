@@ -793,13 +793,16 @@ struct NoiseArgs {
     // indexed by the ORIGINAL crystal / atom ids, so every replica sees exactly the noise of its own unstacked micro-step
     int stack_B0 = 0, stack_N0 = 0;
     float sc0[MI_MAX_STACK], sc1[MI_MAX_STACK], ssig[MI_MAX_STACK], ssn[MI_MAX_STACK];
+    // per-crystal timesteps (add_noise without an explicit time, diffusion.py:83-84): sched[b] = {c0, c1, sigma, sigma_norm}
+    const float* sched = nullptr;
 };
 
 __global__ __launch_bounds__(256) void add_noise_kernel(NoiseArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int cp = a.stack_B0 ? b / a.stack_B0 : 0;  // replica (stacked timesteps), 0 otherwise
-    const float c0 = a.stack_B0 ? a.sc0[cp] : a.c0, c1 = a.stack_B0 ? a.sc1[cp] : a.c1;
-    const float sigma = a.stack_B0 ? a.ssig[cp] : a.sigma, sigma_norm = a.stack_B0 ? a.ssn[cp] : a.sigma_norm;
+    const float c0 = a.sched ? a.sched[b * 4] : a.stack_B0 ? a.sc0[cp] : a.c0, c1 = a.sched ? a.sched[b * 4 + 1] : a.stack_B0 ? a.sc1[cp] : a.c1;
+    const float sigma = a.sched ? a.sched[b * 4 + 2] : a.stack_B0 ? a.ssig[cp] : a.sigma;
+    const float sigma_norm = a.sched ? a.sched[b * 4 + 3] : a.stack_B0 ? a.ssn[cp] : a.sigma_norm;
     const uint32_t step = a.step + (uint32_t)cp;
     const int64_t gsub = (int64_t)cp * a.stack_B0, nsub = (int64_t)cp * a.stack_N0;  // replica's first crystal / atom in the batch
     __shared__ float Lm[9];
@@ -835,6 +838,8 @@ __global__ void fill_stack_times_kernel(int* __restrict__ times, StackTimes st, 
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) times[b] = st.t[b / B0];
 }
+
+int sat_fetch_backward(unsigned* out, bool reset) { return sat_fetch(out, reset); }
 
 }  // namespace mi
 
@@ -876,6 +881,21 @@ int mi_add_noise(mi_batch* b, const float* lengths, const float* angles, const f
     if (b->B == 0) return MI_OK;
     NoiseArgs a{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, b->node_off, in_lattice, in_frac, in_types, tar_x,
                 out_rand_l, out_rand_t, c0, c1, sigma, sigma_norm, seed, step, b->node_offset, b->graph_offset};
+    hipLaunchKernelGGL(add_noise_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_add_noise_per_crystal(mi_batch* b, const float* lengths, const float* angles, const float* frac0, const int* atom_types,
+                             const float* sched, uint64_t seed, uint32_t step, const float* rand_l, const float* rand_x, const float* rand_t,
+                             float* in_lattice, float* in_frac, float* in_types, float* tar_x, float* out_rand_l, float* out_rand_t,
+                             void* stream) {
+    MI_CHECK(b && lengths && angles && frac0 && atom_types && sched && in_lattice && in_frac && in_types && tar_x && out_rand_l && out_rand_t,
+             MI_EINVAL, "null argument");
+    if (b->B == 0) return MI_OK;
+    NoiseArgs a{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, b->node_off, in_lattice, in_frac, in_types, tar_x,
+                out_rand_l, out_rand_t, 0.f, 0.f, 0.f, 0.f, seed, step, b->node_offset, b->graph_offset};
+    a.sched = sched;
     hipLaunchKernelGGL(add_noise_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, a);
     MI_KERNEL_CHECK();
     return MI_OK;

@@ -1325,6 +1325,16 @@ int mi_net_set_edge_mode(mi_net* net, int mode) {
     return MI_OK;
 }
 
+int mi_saturation_events(int64_t* count, int reset) {
+    MI_CHECK(count, MI_EINVAL, "null argument");
+    MI_HIP(hipDeviceSynchronize());
+    unsigned a = 0, b = 0;
+    MI_TRY(mi::sat_fetch(&a, reset != 0));
+    MI_TRY(mi::sat_fetch_backward(&b, reset != 0));
+    *count = (int64_t)a + (int64_t)b;
+    return MI_OK;
+}
+
 int mi_profile_enable(mi_net* net, int on) {
     MI_CHECK(net, MI_EINVAL, "null handle");
     std::lock_guard<std::mutex> g(net->prof_mu);

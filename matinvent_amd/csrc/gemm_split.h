@@ -80,11 +80,27 @@ __device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
     f16x2 h = {(_Float16)lo, (_Float16)hi};  // round to nearest even
     return __builtin_bit_cast(unsigned, h);
 }
+// Saturation guard of the fp16 plane format: every conversion that had to clamp (or met a NaN) counts itself here, so finite
+// garbage can never be silent -- mi_saturation_events() reads the counters of all translation units (one copy per unit: the
+// library is built without relocatable device code).  The test is one compare on the hot path; the atomic runs only on a hit.
+static __device__ unsigned g_sat_events;
+__device__ __forceinline__ void sat_note(float a, float b = 0.f) {
+    if (!(fabsf(a) <= 65504.f) | !(fabsf(b) <= 65504.f)) atomicAdd(&g_sat_events, 1u);  // (NaN and inf count too)
+}
+static inline int sat_fetch(unsigned* out, bool reset) {
+    unsigned v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sat_events), sizeof(v)) != hipSuccess) return MI_EHIP;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_sat_events), &zero, sizeof(zero)) != hipSuccess) return MI_EHIP;
+    *out = v;
+    return MI_OK;
+}
 // plane words of the element pair (x, y): p[k] = plane k of x | plane k of y << 16; `scale` = the destination plane set's scale
 __device__ __forceinline__ void pl_split_pair(float x, float y, float scale, unsigned (&p)[3]) {
 #if MI_PLANES_FP16
-    // (saturate instead of overflowing to inf: inf x 0 in a padded column would poison the whole row)
-    const float xs = fminf(fmaxf(x * scale, -65504.f), 65504.f), ys = fminf(fmaxf(y * scale, -65504.f), 65504.f);
+    // (saturate instead of overflowing to inf: inf x 0 in a padded column would poison the whole row -- and say so)
+    const float xr = x * scale, yr = y * scale;
+    sat_note(xr, yr);
+    const float xs = fminf(fmaxf(xr, -65504.f), 65504.f), ys = fminf(fmaxf(yr, -65504.f), 65504.f);
     const f16x2 h0 = {(_Float16)xs, (_Float16)ys};
     p[0] = __builtin_bit_cast(unsigned, h0);
     p[1] = pack_f16(xs - (float)h0[0], ys - (float)h0[1]);
@@ -96,7 +112,9 @@ __device__ __forceinline__ void pl_split_pair(float x, float y, float scale, uns
 }
 __device__ __forceinline__ void pl_split(float x, float scale, u16& p0, u16& p1, u16& p2) {
 #if MI_PLANES_FP16
-    const float xs = fminf(fmaxf(x * scale, -65504.f), 65504.f);
+    const float xr = x * scale;
+    sat_note(xr);
+    const float xs = fminf(fmaxf(xr, -65504.f), 65504.f);
     const _Float16 h0 = (_Float16)xs, h1 = (_Float16)(xs - (float)h0);
     p0 = __builtin_bit_cast(u16, h0);
     p1 = __builtin_bit_cast(u16, h1);

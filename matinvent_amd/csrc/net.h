@@ -128,6 +128,8 @@ struct mi_batch {
     float* lp_corr = nullptr;  // [B]
     float* coef = nullptr;     // [T+1][MI_NCOEF]
     int coef_T = -1;
+    std::vector<float> coef_h;  // host copy of what `coef` holds (re-uploaded only when the caller's table differs)
+    int keep_lattice = 0, keep_coords = 0;  // CSP mode of the sampler (mi_sampler_set_keep)
     mi::SplitK sk;  // split-K scratch of the node-level products (small batches only)
     Tape tape;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // fork / join of work put on an auxiliary stream (mi_ft_micro_step)
@@ -145,4 +147,5 @@ template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
 int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
+int sat_fetch_backward(unsigned* out, bool reset);  // backward.hip's copy of the saturation counter (gemm_split.h)
 }  // namespace mi

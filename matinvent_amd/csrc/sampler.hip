@@ -6,6 +6,8 @@
 // contraction into FMAs is disabled for this translation unit.
 #pragma clang fp contract(off)
 
+#include <string.h>
+
 #include "net.h"
 
 namespace mi {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64) void corrector_kernel(const float* __restrict__
                                                        const float* __restrict__ noise_x, const float* __restrict__ coef, int t,
                                                        uint64_t seed, int64_t node_offset, const int* __restrict__ node_off,
                                                        float* __restrict__ x_mid, float* __restrict__ lp_corr,
-                                                       float* __restrict__ rec_mid) {
+                                                       float* __restrict__ rec_mid, int keep_coords) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const StepCoef c = load_coef(coef, t);
     const int n0 = node_off[b], n1 = node_off[b + 1];
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(64) void corrector_kernel(const float* __restrict__
         if (t > 1) z = noise_x ? noise_x[idx] : philox_normal1(seed, (uint32_t)t, DRAW_CORR_X, (uint64_t)node_offset * 3 + idx);
         float px = pred_x[idx] * c.sqrt_sn;
         float drift = x_t[idx] - c.step_corr * px;
-        float xm = drift + c.std_corr * z;
+        float xm = keep_coords ? x_t[idx] : drift + c.std_corr * z;  // CSP mode (:330): the coordinates are given and stay
         x_mid[idx] = xm;
         float xmw = pymod1(xm);
         if (rec_mid && t > 1) rec_mid[idx] = xmw;
@@ -116,6 +118,7 @@ struct PredictorArgs {
     uint64_t seed;
     int64_t node_offset, graph_offset;
     int t;
+    int keep_lattice, keep_coords;  // CSP mode (diffusion.py:283-287, 308-312, 348-349): that part of the state is never moved
 };
 
 __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
         float z = 0.f;
         if (t > 1) z = a.noise_l ? a.noise_l[idx] : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_L, (uint64_t)a.graph_offset * 9 + idx);
         float mu = c.c0 * (a.lattices[idx] - c.c1 * a.pred_l[idx]);
-        float v = mu + c.sigma * z;
+        float v = a.keep_lattice ? a.lattices[idx] : mu + c.sigma * z;
         a.lattices[idx] = v;
         if (a.rec_lat) a.rec_lat[idx] = v;
         if (t > 1) lp_l = normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
         if (t > 1) z = a.noise_x ? a.noise_x[idx] : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_X, (uint64_t)a.node_offset * 3 + idx);
         float px = a.pred_x[idx] * c.sqrt_sn;
         float drift = a.x_mid[idx] - c.step_pred * px;
-        float v = pymod1(drift + c.std_pred * z);
+        float v = pymod1(a.keep_coords ? a.x_mid[idx] : drift + c.std_pred * z);
         if (t > 1) lp_x += log_prob_wn(v, pymod1(drift), c.std_pred_sq);
         v = pymod1(v);  // traj[t-1]['frac_coords'] = x_{t-1} % 1  (:386)
         a.frac[idx] = v;
@@ -235,12 +238,19 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
     hipStream_t s = (hipStream_t)stream;
     const int N = b->N, B = b->B;
     if (N == 0 || B == 0) return MI_OK;
+    const size_t ncoef = (size_t)(T + 1) * MI_NCOEF;
     if (b->coef_T != T) {
-        MI_TRY(dev_alloc(b, &b->coef, (size_t)(T + 1) * MI_NCOEF));
+        MI_TRY(dev_alloc(b, &b->coef, ncoef));
         b->coef_T = T;
+        b->coef_h.clear();
     }
-    MI_HIP(hipMemcpyAsync(b->coef, coef_host, (size_t)(T + 1) * MI_NCOEF * sizeof(float), hipMemcpyHostToDevice, s));
-    MI_HIP(hipStreamSynchronize(s));  // coef_host may be transient
+    // the per-step scalars change only with the schedule buffers / step size: upload (and wait -- coef_host may be transient)
+    // when they differ from the copy this batch already holds, otherwise the chain is enqueued without any host synchronisation
+    if (b->coef_h.size() != ncoef || memcmp(b->coef_h.data(), coef_host, ncoef * sizeof(float)) != 0) {
+        b->coef_h.assign(coef_host, coef_host + ncoef);
+        MI_HIP(hipMemcpyAsync(b->coef, b->coef_h.data(), ncoef * sizeof(float), hipMemcpyHostToDevice, s));
+        MI_HIP(hipStreamSynchronize(s));
+    }
 
     const size_t n3 = (size_t)N * 3, nA = (size_t)N * MI_NUM_TYPES, b9 = (size_t)B * 9;
     if (rec) {  // traj[t_start] = current state (diffusion.py:287-293)
@@ -256,7 +266,7 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s));
         hipLaunchKernelGGL(corrector_kernel, dim3(B), dim3(64), 0, s, frac, b->pred_x, noise ? noise->corr_x + t * n3 : nullptr,
                            b->coef, t, seed, b->node_offset, b->node_off, b->x_mid, b->lp_corr,
-                           (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr);
+                           (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr, b->keep_coords);
         MI_KERNEL_CHECK();
         // predictor
         // the corrector moved the coordinates only (diffusion.py:320-322): layer-0 node features are those of the evaluation above
@@ -285,9 +295,18 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         a.node_offset = b->node_offset;
         a.graph_offset = b->graph_offset;
         a.t = t;
+        a.keep_lattice = b->keep_lattice;
+        a.keep_coords = b->keep_coords;
         hipLaunchKernelGGL(predictor_kernel, dim3(B), dim3(256), 0, s, a);
         MI_KERNEL_CHECK();
     }
+    return MI_OK;
+}
+
+int mi_sampler_set_keep(mi_batch* b, int keep_lattice, int keep_coords) {
+    MI_CHECK(b, MI_EINVAL, "null handle");
+    b->keep_lattice = keep_lattice != 0;
+    b->keep_coords = keep_coords != 0;
     return MI_OK;
 }
 

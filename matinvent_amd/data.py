@@ -82,6 +82,19 @@ class CrystalLoader:
             yield CrystalBatchData([self.dataset[i] for i in order[s:s + self.batch_size]])
 
 
+def lattice_params_to_matrix(lengths: torch.Tensor, angles: torch.Tensor) -> torch.Tensor:
+    """(a, b, c), (alpha, beta, gamma in degrees) -> 3x3 row-vector lattice; the formula of models/diffcsp/utils.py:68-96 (c along z, a in
+    the xz plane), used where the sampler is handed a known lattice (CSP mode, diffusion.py:286-287)."""
+    ar = torch.deg2rad(angles)
+    co, si = torch.cos(ar), torch.sin(ar)
+    gs = torch.arccos(torch.clamp((co[:, 0] * co[:, 1] - co[:, 2]) / (si[:, 0] * si[:, 1]), -1.0, 1.0))
+    z = torch.zeros_like(lengths[:, 0])
+    va = torch.stack([lengths[:, 0] * si[:, 1], z, lengths[:, 0] * co[:, 1]], dim=1)
+    vb = torch.stack([-lengths[:, 1] * si[:, 0] * torch.cos(gs), lengths[:, 1] * si[:, 0] * torch.sin(gs), lengths[:, 1] * co[:, 0]], dim=1)
+    vc = torch.stack([z, z, lengths[:, 2]], dim=1)
+    return torch.stack([va, vb, vc], dim=1)
+
+
 def lattices_to_params_shape(lattices: torch.Tensor):
     """3x3 lattice matrices -> (lengths, angles in degrees), models/diffcsp/sample.py:103-114."""
     lengths = torch.sqrt(torch.sum(lattices ** 2, dim=-1))

@@ -64,10 +64,8 @@ class DiffCSPModule(nn.Module):
         self.time_dim = time_dim
         self.time_embedding = SinusoidalTimeEmbeddings(time_dim)
         self.cost_lattice, self.cost_coord, self.cost_type = cost_lattice, cost_coord, cost_type
-        self.keep_lattice = cost_lattice < 1e-5
+        self.keep_lattice = cost_lattice < 1e-5   # diffusion.py:78-79: CSP mode, that part of the structure is given
         self.keep_coords = cost_coord < 1e-5
-        if self.keep_lattice or self.keep_coords:
-            raise NotImplementedError("keep_lattice / keep_coords (CSP mode) are not on the HIP path")
         self.to(dev)
 
     @property
@@ -109,19 +107,24 @@ class DiffCSPModule(nn.Module):
         (`time` in 0..T-1 -> diffusion time T - time, :86-87).  Returns the reference's triple
         (noised_input, noises, batch.batch).  Fresh Gaussian noise per call from the Philox
         stream (seed, running call counter) unless `noise` = (rand_l, rand_x, rand_t)."""
-        if time is None:
-            raise NotImplementedError("add_noise without an explicit timestep is not used by the pipeline and not built")
         lib = _lib.load()
         dev = self.device
         T = self.beta_scheduler.timesteps
-        t = T - int(time)
         cb = self._batch_for(batch.num_atoms)
         B, N = cb.num_graphs, cb.num_nodes
-        times = torch.full((B,), t, device=dev)
+        sched = None
+        if time is None:   # :83-84: one uniformly drawn time per crystal (numpy's global generator, like the reference)
+            times = self.beta_scheduler.uniform_sample_t(B, dev)
+            ac = self.beta_scheduler.alphas_cumprod[times]
+            sched = torch.stack([torch.sqrt(ac), torch.sqrt(1.0 - ac), self.sigma_scheduler.sigmas[times],
+                                 self.sigma_scheduler.sigmas_norm[times]], dim=1).to(torch.float32).contiguous()
+        else:
+            t = T - int(time)
+            times = torch.full((B,), t, device=dev)
+            ac = self.beta_scheduler.alphas_cumprod[t]
+            c0, c1 = float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac))
+            sig, sn = float(self.sigma_scheduler.sigmas[t]), float(self.sigma_scheduler.sigmas_norm[t])
         time_emb = self.time_embedding(times)
-        ac = self.beta_scheduler.alphas_cumprod[t]
-        c0, c1 = float(torch.sqrt(ac)), float(torch.sqrt(1.0 - ac))
-        sig, sn = float(self.sigma_scheduler.sigmas[t]), float(self.sigma_scheduler.sigmas_norm[t])
         f = lambda x: x.to(dev, torch.float32).contiguous()
         lengths, angles, frac0 = f(batch.lengths), f(batch.angles), f(batch.frac_coords)
         at = batch.atom_types.to(dev, torch.int32).contiguous()
@@ -131,9 +134,15 @@ class DiffCSPModule(nn.Module):
         nz = (None, None, None) if noise is None else tuple(f(x) for x in noise)
         self._noise_calls = getattr(self, "_noise_calls", 0) + 1
         seed = getattr(self, "noise_seed", 0) if seed is None else seed
-        _lib.check(lib.mi_add_noise(cb._h, _ptr(lengths), _ptr(angles), _ptr(frac0), _ptr(at), c0, c1, sig, sn, seed,
-                                    self._noise_calls & 0xFFFFFFFF, _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), _ptr(in_lat), _ptr(in_frac),
-                                    _ptr(in_types), _ptr(tar_x), _ptr(rand_l), _ptr(rand_t), _stream()), "mi_add_noise")
+        if sched is not None:
+            _lib.check(lib.mi_add_noise_per_crystal(cb._h, _ptr(lengths), _ptr(angles), _ptr(frac0), _ptr(at), _ptr(sched), seed,
+                                                    self._noise_calls & 0xFFFFFFFF, _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), _ptr(in_lat),
+                                                    _ptr(in_frac), _ptr(in_types), _ptr(tar_x), _ptr(rand_l), _ptr(rand_t), _stream()),
+                       "mi_add_noise_per_crystal")
+        else:
+            _lib.check(lib.mi_add_noise(cb._h, _ptr(lengths), _ptr(angles), _ptr(frac0), _ptr(at), c0, c1, sig, sn, seed,
+                                        self._noise_calls & 0xFFFFFFFF, _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), _ptr(in_lat), _ptr(in_frac),
+                                        _ptr(in_types), _ptr(tar_x), _ptr(rand_l), _ptr(rand_t), _stream()), "mi_add_noise")
         noised_input = (time_emb, in_types, in_frac, in_lat, cb.num_atoms, cb.batch)
         return noised_input, (rand_l, tar_x, rand_t), cb.batch
 
@@ -193,6 +202,19 @@ class DiffCSPModule(nn.Module):
         """
         if isinstance(batch, CrystalBatch):
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
+        if (self.keep_lattice or self.keep_coords) and init is None:
+            # CSP mode (diffusion.py:283-287): the known part of the structure replaces the drawn initial state and is never moved
+            cb0 = self.crystal_batch(batch, node_offset, graph_offset)
+            dev = self.device
+            x0, l0, a0 = (torch.empty(cb0.num_nodes, 3, device=dev), torch.empty(cb0.num_graphs, 3, 3, device=dev),
+                          torch.empty(cb0.num_nodes, MAX_ATOMIC_NUM, device=dev))
+            _lib.check(_lib.load().mi_sampler_init_state(cb0._h, seed, self.beta_scheduler.timesteps, _ptr(a0), _ptr(x0), _ptr(l0), _stream()))
+            if self.keep_coords:
+                x0 = batch.frac_coords.to(dev, torch.float32)
+            if self.keep_lattice:
+                from .data import lattice_params_to_matrix
+                l0 = lattice_params_to_matrix(batch.lengths.to(dev, torch.float32), batch.angles.to(dev, torch.float32))
+            init = (x0, l0, a0)
         na = [int(v) for v in batch.num_atoms.tolist()]
         if streams is None:
             e_total = sum(v * v for v in na)
@@ -286,6 +308,7 @@ class DiffCSPModule(nn.Module):
             x, l, a = (v.to(dev, torch.float32).contiguous().clone() for v in init)
         x = x % 1.0  # traj[T]['frac_coords'] = x_T % 1 (diffusion.py:289)
         coef = self._coefficients(step_lr)
+        _lib.check(lib.mi_sampler_set_keep(cb._h, int(self.keep_lattice), int(self.keep_coords)))
         nz = None
         if noise is not None:
             keep = {k: noise[k].to(dev, torch.float32).contiguous() for k in ("corr_x", "pred_l", "pred_t", "pred_x")}

@@ -67,6 +67,8 @@ class DiffCSPSampler:
             self.seed += 1
             counts = _AtomCounts(na[lo:hi])
             outputs, _ = model.sample(counts, step_lr=step_lr, seed=self.seed, node_offset=node_off, graph_offset=lo)
+        from . import _lib
+        _lib.check_saturation("DiffCSPSampler.generate")  # (the results are about to be copied to the host: the device is drained anyway)
         # geometric validity quantities of the final state, computed where it lives (K18); the filter step thresholds them
         from .structure import check_structures
         geom = check_structures(model.crystal_batch(counts, node_off, lo), outputs["frac_coords"], outputs["lattices"]).cpu()

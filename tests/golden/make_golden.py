@@ -92,7 +92,7 @@ class NoiseTape:
             assert self.i == len(self.items), (self.i, len(self.items))
 
 
-def make_module(H, L, F, T, seed, sigmas_norm_seed=1234, ln=True, edge_style="fc", head_scale=1.0):
+def make_module(H, L, F, T, seed, sigmas_norm_seed=1234, ln=True, edge_style="fc", head_scale=1.0, cost_lattice=1.0, cost_coord=1.0):
     hp = dict(
         decoder=dict(_target_="models.diffcsp.cspnet.CSPNet", hidden_dim=H, num_layers=L, max_atoms=100,
                      act_fn="silu", dis_emb="sin", num_freqs=F, edge_style=edge_style, ln=ln, ip=True,
@@ -100,7 +100,7 @@ def make_module(H, L, F, T, seed, sigmas_norm_seed=1234, ln=True, edge_style="fc
         beta_scheduler=dict(_target_="models.diffcsp.scheduler.BetaScheduler", timesteps=T, scheduler_mode="cosine"),
         sigma_scheduler=dict(_target_="models.diffcsp.scheduler.SigmaScheduler", timesteps=T, sigma_begin=0.005,
                              sigma_end=0.5),
-        latent_dim=0, time_dim=256, cost_lattice=1.0, cost_coord=1.0, cost_type=20.0)
+        latent_dim=0, time_dim=256, cost_lattice=cost_lattice, cost_coord=cost_coord, cost_type=20.0)
     # reference construction order: decoder (weights) first, then the schedulers
     # (SigmaScheduler draws 10000*T randn for sigmas_norm, scheduler.py:46-51,109)
     torch.manual_seed(seed)
@@ -431,7 +431,73 @@ def g9_host_glue():
         num_atoms_seed0_8=ds.num_atoms, num_atoms_seed0_64=ds64.num_atoms)
 
 
+def g10_csp_mode():
+    """DiffCSPModule.sample in CSP mode (diffusion.py:78-79, 283-287, 308-312, 330, 348-349): keep_coords (cost_coord = 0) and
+    keep_lattice (cost_lattice = 0), T = 10, injected noise."""
+    T = 10
+    out = {}
+    for tag, kw in (("kc", dict(cost_coord=0.0)), ("kl", dict(cost_lattice=0.0))):
+        m = make_module(H=64, L=2, F=8, T=T, seed=0, head_scale=0.5, **kw)
+        assert m.keep_coords == (tag == "kc") and m.keep_lattice == (tag == "kl")
+        g = torch.Generator().manual_seed(100)
+        b = ft_batch([4, 6], g)
+        B, N = b.num_graphs, b.num_nodes
+        noise = dict(x_T=torch.rand(N, 3, generator=g), l_T=torch.randn(B, 3, 3, generator=g),
+                     t_T=torch.randn(N, 100, generator=g), corr_x={}, pred_l={}, pred_t={}, pred_x={})
+        for t in range(T, 1, -1):
+            noise["corr_x"][t] = torch.randn(N, 3, generator=g)
+            noise["pred_l"][t] = torch.randn(B, 3, 3, generator=g)
+            noise["pred_t"][t] = torch.randn(N, 100, generator=g)
+            noise["pred_x"][t] = torch.randn(N, 3, generator=g)
+        with sampler_tape(noise, T, N, B):
+            final, traj = m.sample(b, step_lr=5e-6)
+        out.update({f"{tag}_num_atoms": b.num_atoms, f"{tag}_lengths": b.lengths, f"{tag}_angles": b.angles,
+                    f"{tag}_frac_coords": b.frac_coords, f"{tag}_x_T": noise["x_T"], f"{tag}_l_T": noise["l_T"], f"{tag}_t_T": noise["t_T"]})
+        for t in range(T, 1, -1):
+            for k in ("corr_x", "pred_l", "pred_t", "pred_x"):
+                out[f"{tag}_n_{k}_{t}"] = noise[k][t]
+        for t in range(T, -1, -1):
+            for k in ("atom_types", "frac_coords", "lattices"):
+                out[f"{tag}_traj_{t}_{k}"] = traj[t][k]
+            if t > 1:
+                for k in ("log_prob_l", "log_prob_t", "log_prob_x", "frac_coords_mid"):
+                    out[f"{tag}_traj_{t}_{k}"] = traj[t][k]
+        if tag == "kc":
+            out.update({"P__" + k: v for k, v in m.state_dict().items()})
+            out["T"] = np.array(T)
+            out["time_freqs"] = time_freqs(256)
+    npz("g10_csp_mode", **out)
+
+
+def g11_noise_sampled_times():
+    """DiffCSPModule.add_noise(batch) WITHOUT a time index (diffusion.py:83-84): one uniformly drawn time per crystal from numpy's
+    global generator; then calc_sample_loss."""
+    T = 1000
+    m = make_module(H=64, L=2, F=8, T=T, seed=0)
+    g = torch.Generator().manual_seed(110)
+    b = ft_batch([4, 2, 6, 5], g)
+    B, N = b.num_graphs, b.num_nodes
+    rl, rx, rt = torch.randn(B, 3, 3, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, 100, generator=g)
+    np.random.seed(11)
+    times = np.random.choice(np.arange(1, T + 1), B)
+    np.random.seed(11)
+    with NoiseTape([rl, rx, rt]):
+        noised = m.add_noise(b)
+    (t_emb, atp, ifr, ilat, na, bb), (rand_l, tar_x, rand_t), _ = noised
+    with torch.no_grad():
+        loss, pred = m.calc_sample_loss(noised)
+    sd = {"P__" + k: v for k, v in m.state_dict().items() if k.startswith("decoder.")}
+    npz("g11_noise_sampled_times", num_atoms=b.num_atoms, lengths=b.lengths, angles=b.angles, frac_coords=b.frac_coords,
+        atom_types=b.atom_types, sigmas_norm=m.sigma_scheduler.sigmas_norm, np_seed=np.array(11), times=times,
+        rand_l=rl, rand_x=rx, rand_t=rt, t_emb=t_emb, atom_type_probs=atp, input_frac=ifr, input_lattice=ilat, tar_x=tar_x,
+        loss=loss, pred_l=pred[0], pred_x=pred[1], pred_t=pred[2], time_freqs=time_freqs(256), **sd)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # only the named fixtures, e.g. `make_golden.py g10_csp_mode g11_noise_sampled_times`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_repeat_blocks()
     g2_schedulers()
     g3_lattice()
@@ -442,3 +508,5 @@ if __name__ == "__main__":
     g7_noise_loss()
     g8_ft_step()
     g9_host_glue()
+    g10_csp_mode()
+    g11_noise_sampled_times()

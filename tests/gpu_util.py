@@ -15,14 +15,14 @@ def load_decoder(net, P):
     return net
 
 
-def make_module(H, L, F, T, P=None, sigmas_norm=None, device="cuda"):
+def make_module(H, L, F, T, P=None, sigmas_norm=None, device="cuda", **kw):
     from matinvent_amd.diffcsp import DiffCSPModule
     if sigmas_norm is None:
         sigmas_norm = torch.ones(T + 1)
     m = DiffCSPModule(decoder=dict(hidden_dim=H, num_layers=L, num_freqs=F, ln=True, edge_style="fc"),
                       beta_scheduler=dict(timesteps=T, scheduler_mode="cosine"),
                       sigma_scheduler=dict(timesteps=T, sigma_begin=0.005, sigma_end=0.5, sigmas_norm=sigmas_norm),
-                      device=device)
+                      device=device, **kw)
     if P is not None:
         load_decoder(m.decoder, P)
     return m

@@ -214,3 +214,66 @@ def test_benchmark_workload_first_steps_vs_oracle():
     for k in ("lattices", "atom_types"):
         a, b = final[k].cpu().numpy(), of[k].numpy()
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), k
+
+
+def test_csp_mode_chains_golden(golden):
+    """CSP mode (diffusion.py:78-79, 283-287, 308-312, 330, 348-349): with cost_coord = 0 the coordinates, with cost_lattice = 0
+    the lattice of the batch are the given ones and never move; the rest of the chain and the log-probs follow the reference-
+    generated 10-step trajectories (g10)."""
+    g = golden("g10_csp_mode")
+    T = int(g["T"])
+    P = params_from_golden(g)
+    for tag, kw in (("kc", dict(cost_coord=0.0)), ("kl", dict(cost_lattice=0.0))):
+        m = make_module(64, 2, 8, T, P, sigmas_norm=P["sigma_scheduler.sigmas_norm"], **kw)
+        m.load_state_dict({k: v for k, v in P.items() if "scheduler" in k}, strict=False)
+        m.time_embedding.freqs.copy_(torch.from_numpy(g["time_freqs"]))
+        assert m.keep_coords == (tag == "kc") and m.keep_lattice == (tag == "kl")
+        na = g[f"{tag}_num_atoms"]
+        B, N = len(na), int(na.sum())
+        z = dict(corr_x=torch.zeros(T + 1, N, 3), pred_l=torch.zeros(T + 1, B, 3, 3), pred_t=torch.zeros(T + 1, N, 100), pred_x=torch.zeros(T + 1, N, 3))
+        for t in range(T, 1, -1):
+            for k in z:
+                z[k][t] = torch.from_numpy(g[f"{tag}_n_{k}_{t}"])
+        box = Box(na)
+        box.frac_coords, box.lengths, box.angles = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("frac_coords", "lengths", "angles"))
+        # the drawn part of the initial state comes from the fixture; the kept part from the batch, as in the reference
+        x_T = box.frac_coords if tag == "kc" else torch.from_numpy(g[f"{tag}_x_T"])
+        from matinvent_amd.data import lattice_params_to_matrix
+        l_T = lattice_params_to_matrix(box.lengths, box.angles) if tag == "kl" else torch.from_numpy(g[f"{tag}_l_T"])
+        final, traj = m.sample(box, step_lr=5e-6, noise=z, init=(x_T, l_T, torch.from_numpy(g[f"{tag}_t_T"])), record=True)
+        for t in range(T, -1, -1):
+            assert wrap_dist(traj[t]["frac_coords"].cpu().numpy(), g[f"{tag}_traj_{t}_frac_coords"]).max() < 3e-4, (tag, t)
+            np.testing.assert_allclose(traj[t]["lattices"].cpu().numpy(), g[f"{tag}_traj_{t}_lattices"], rtol=3e-4, atol=3e-4)
+            np.testing.assert_allclose(traj[t]["atom_types"].cpu().numpy(), g[f"{tag}_traj_{t}_atom_types"], rtol=3e-4, atol=3e-4)
+            if t > 1:
+                for k in ("log_prob_l", "log_prob_t", "log_prob_x"):
+                    np.testing.assert_allclose(traj[t][k].cpu().numpy(), g[f"{tag}_traj_{t}_{k}"], rtol=3e-3, atol=3e-3, err_msg=f"{tag} {t} {k}")
+        if tag == "kc":
+            assert wrap_dist(final["frac_coords"].cpu().numpy(), g["kc_frac_coords"] % 1.0).max() == 0
+        else:
+            np.testing.assert_allclose(final["lattices"].cpu().numpy(), g["kl_traj_0_lattices"], rtol=1e-6, atol=1e-6)
+        # without `init`, sample() takes the kept part from the batch itself (diffusion.py:283-287)
+        f2, _ = m.sample(box, step_lr=5e-6, seed=3)
+        if tag == "kc":
+            assert wrap_dist(f2["frac_coords"].cpu().numpy(), g["kc_frac_coords"] % 1.0).max() == 0
+        else:
+            np.testing.assert_allclose(f2["lattices"].cpu().numpy(), g["kl_traj_0_lattices"], rtol=1e-6, atol=1e-6)
+
+
+def test_chain_enqueue_does_not_synchronise_once_the_coefficients_are_resident():
+    """mi_sampler_run uploads its per-step scalar table only when it differs from the copy the batch holds: the second chain on the
+    same batch must be enqueued while a long-running kernel still occupies the stream (no hipStreamSynchronize inside)."""
+    import time
+    from matinvent_amd import _lib
+    m = make_module(64, 2, 8, 6, None)
+    box = Box([3, 4])
+    m.sample(box, step_lr=5e-6, seed=1)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    _lib.check(lib.mi_debug_spin(int(2.0e9), None))  # ~1 s of busy-wait on the null stream ahead of the chain
+    t0 = time.perf_counter()
+    m.sample(box, step_lr=5e-6, seed=2)
+    t_enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    assert t_total > 0.3 and t_enqueue < 0.5 * t_total, (t_enqueue, t_total)

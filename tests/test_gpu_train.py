@@ -1,6 +1,8 @@
 """GPU parity of the fine-tune path (noising, per-sample losses, anchor penalty, parameter
 gradients through the hand-written backward, fused Adam) against the reference-generated
 fixtures g7 / g8 and the oracle's autograd."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -28,6 +30,8 @@ def _rel(a, b, tol, what):
     b = np.asarray(b)
     scale = max(1e-12, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())
+    if os.environ.get("MI_TOL_REPORT"):   # calibration runs: print what was measured next to what is demanded
+        print(f"TOL {what}: measured {err / scale:.3e} of max|ref|, demanded {tol:.0e}")
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.0e} * max|ref| ({scale:.3g})"
 
 
@@ -97,8 +101,10 @@ def test_ft_gradients_and_adam_golden(golden):
             grads = {k: agent.decoder.theta.grad[o:o + n].view(shape) for k, (o, n, shape) in agent.decoder.layout.items()}
             for k, gr in grads.items():
                 ref = g[f"G{nstep}__decoder." + k]
-                # per-tensor: error relative to that tensor's largest gradient entry
-                _rel(gr, ref, 2e-3 if nstep == 0 else 2e-2, f"grad[{nstep}] {k}")
+                # per-tensor: error relative to that tensor's largest gradient entry.  Measured on MI355X: <= 6e-6 for every tensor
+                # (<= 1e-5 after the first optimizer step), except atom_latent_emb.weight, whose time-embedding columns see this
+                # host's libm-dependent frequency table (6e-5 in the embedding itself): 4.8e-5
+                _rel(gr, ref, 1e-4 if k == "atom_latent_emb.weight" else 2e-5, f"grad[{nstep}] {k}")
             opt.step()
             opt.zero_grad()
             for k, w in agent.decoder.views().items():
@@ -135,7 +141,7 @@ def test_gradients_vs_oracle_autograd_ragged():
     pl, px, pt = m.decoder(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), na)
     ((pl * ul.cuda()).sum() + (px * ux.cuda()).sum() + (pt * ut.cuda()).sum()).backward()
     for k, (o, n, shape) in m.decoder.layout.items():
-        _rel(m.decoder.theta.grad[o:o + n].view(shape), Pg["decoder." + k].grad.numpy(), 2e-4, f"grad {k}")
+        _rel(m.decoder.theta.grad[o:o + n].view(shape), Pg["decoder." + k].grad.numpy(), 2e-5, f"grad {k}")  # measured <= 4e-6
     # gradients accumulate (+=) across backward calls, like .grad
     g1 = m.decoder.theta.grad.clone()
     pl, px, pt = m.decoder(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), na)
@@ -169,7 +175,7 @@ def test_gradients_vs_oracle_autograd_mid_size():
     _rel(pt, ot.detach(), 2e-5, "pred_t")
     th = m.decoder.theta
     for k, (o, cnt, shape) in m.decoder.layout.items():
-        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 1e-3, f"grad {k}")
+        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 2e-5, f"grad {k}")  # measured <= 4e-6 of max|grad|
 
 
 def test_gradients_vs_oracle_autograd_ragged_large():
@@ -200,7 +206,7 @@ def test_gradients_vs_oracle_autograd_ragged_large():
     _rel(pt, ot.detach(), 2e-5, "pred_t")
     th = m.decoder.theta
     for k, (o, cnt, shape) in m.decoder.layout.items():
-        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 1e-3, f"grad {k}")
+        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 2e-5, f"grad {k}")  # measured <= 4e-6 of max|grad|
 
 
 def test_fused_adam_matches_torch_adam():
@@ -351,3 +357,77 @@ def test_stacked_timesteps_reproduce_the_sequential_update_with_device_noise():
     assert moved > 5e-5  # two Adam steps really happened
     for key in ("loss", "loss_diff", "loss_kl"):
         assert abs(sa[0][key] - sb[0][key]) <= 1e-5 * max(1.0, abs(sa[0][key])), key
+
+
+def test_ft_step_benchmark_hparams_three_concurrent_groups_vs_oracle():
+    """The route `bench.py --mode ft` takes at B = 256 (three concurrent crystal groups on separate streams with separate gradient
+    buffers, summed before the optimizer step) at the BENCHMARK network H=512, L=6, F=128: 192 crystals x 20 atoms = 76 800 edges in
+    three groups of 64 (each group's kernels are the large-list ones), one accumulation window of two timesteps with injected noise,
+    against the oracle's restatement of pipeline/mat_invent.py:125-189."""
+    from matinvent_amd.data import CrystalData
+    from matinvent_amd.finetune import auto_groups, ft_step
+    assert auto_groups(256 * 400) == 3 and auto_groups(192 * 400) == 2 and auto_groups(18 * 150) == 1  # what the bench's B = 256 gets
+    H, L, F = 512, 6, 128
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P0, Q0 = O.init_params(hp, seed=3, head_scale=0.1), O.init_params(hp, seed=3, head_scale=0.1)
+    gen = torch.Generator().manual_seed(23)
+    for k in P0:
+        P0[k] = P0[k] + 0.002 * torch.randn(P0[k].shape, generator=gen)
+    sn = torch.cat([torch.ones(1), 0.5 + torch.rand(1000, generator=gen)])
+    agent, prior = make_module(H, L, F, 1000, P0, sigmas_norm=sn), make_module(H, L, F, 1000, Q0, sigmas_norm=sn)
+    prior.requires_grad_(False)
+    na = [20] * 192
+    data = [CrystalData(torch.rand(n, 3, generator=gen), torch.randint(1, 95, (n,), generator=gen), 4 + 6 * torch.rand(1, 3, generator=gen),
+                        70 + 40 * torch.rand(1, 3, generator=gen)) for n in na]
+    rewards = torch.rand(len(na), generator=gen).numpy()
+    B, N, TS = len(na), sum(na), 2
+    noises = {(0, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
+              for t in range(TS)}
+    cfg = dict(lr=1e-4, accum_steps=TS, epochs=1, timesteps=TS, sigma=0.025)
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=True, groups=3)
+    sch = O.Schedules.make(1000, sigmas_norm=sn)
+    sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
+    batch = dict(num_atoms=torch.tensor(na), lengths=torch.cat([d.lengths for d in data]), angles=torch.cat([d.angles for d in data]),
+                 frac_coords=torch.cat([d.frac_coords for d in data]), atom_types=torch.cat([d.atom_types for d in data]))
+    A = {k: v.clone() for k, v in P0.items()}
+    rec = {}
+    O.ft_step(A, Q0, hp, sch, O.Costs(), batch, torch.from_numpy(rewards).float(),
+              lambda e, t: dict(zip(("rand_l", "rand_x", "rand_t"), noises[(e, t)])), lr=1e-4, timesteps=TS, accum_steps=TS, sigma=0.025,
+              epochs=1, record=rec)
+    ref_loss = float(torch.stack(rec["loss"][:TS]).sum())
+    assert abs(stats[0]["loss"] - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (stats[0]["loss"], ref_loss)
+    rw = torch.from_numpy(rewards).float()
+    ref_diff = float(sum((rw * l).sum() for l in rec["sample_loss"][:TS]) / TS / len(na))
+    assert abs(stats[0]["loss_diff"] - ref_diff) <= 1e-4 * max(1.0, abs(ref_diff))
+    # the accumulated gradient itself, through the oracle's recorded window (before the Adam step mixes in sign flips)
+    bad = tot = 0
+    for k, w in agent.decoder.views().items():
+        d = (w.detach().cpu() - A["decoder." + k]).abs()
+        assert float(d.max()) <= 2.1e-4, f"{k}: {float(d.max())}"
+        bad += int((d > 1e-5).sum())
+        tot += d.numel()
+    print(f"benchmark-network ft step, 3 concurrent groups: {bad} of {tot} parameters differ by more than 1e-5 after the Adam step")
+    assert bad <= 0.02 * tot
+
+
+def test_add_noise_sampled_times_golden(golden):
+    """add_noise(batch) without a time index (diffusion.py:83-84): per-crystal times from numpy's global generator, then the
+    per-sample loss, against the reference-generated fixture g11."""
+    g = golden("g11_noise_sampled_times")
+    P = params_from_golden(g)
+    agent = make_module(64, 2, 8, 1000, P, sigmas_norm=T(g["sigmas_norm"]))
+    batch = FtBatch(g)
+    np.random.seed(int(g["np_seed"]))
+    with torch.no_grad():
+        noised = agent.add_noise(batch, noise=tuple(T(g[k]) for k in ("rand_l", "rand_x", "rand_t")))
+        (t_emb, atp, ifr, ilat, na, n2g), (rl, tar_x, rt), _ = noised
+        _rel(t_emb, g["t_emb"], 7e-5, "t_emb (this host's libm-dependent table)")
+        _rel(atp, g["atom_type_probs"], 1e-6, "atom_type_probs")
+        d = np.abs(ifr.cpu().numpy() - g["input_frac"])
+        assert np.minimum(d, 1 - d).max() < 1e-6
+        _rel(ilat, g["input_lattice"], 2e-6, "input_lattice")
+        _rel(tar_x, g["tar_x"], 2e-5, "tar_x")
+        noised = ((T(g["t_emb"]).cuda(),) + noised[0][1:], noised[1], noised[2])
+        loss, pred = agent.calc_sample_loss(noised)
+    _rel(pred[1], g["pred_x"], 3e-5, "pred_x")
+    _rel(loss, g["loss"], 3e-5, "sample loss")

@@ -238,3 +238,67 @@ def test_philox_known_answer():
     np.testing.assert_array_equal(O.philox_normal(1234, 7, 3, 100, elem_offset=37), z[37:137])
     u = O.philox_uniform(1234, 7, 0, 10001)
     assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def _csp_noise(g, tag, Tn):
+    noise = dict(x_T=T(g[f"{tag}_x_T"]), l_T=T(g[f"{tag}_l_T"]), t_T=T(g[f"{tag}_t_T"]), corr_x={}, pred_l={}, pred_t={}, pred_x={})
+    for t in range(Tn, 1, -1):
+        for k in ("corr_x", "pred_l", "pred_t", "pred_x"):
+            noise[k][t] = T(g[f"{tag}_n_{k}_{t}"])
+    return noise
+
+
+def test_sample_chain_csp_mode(golden):
+    """keep_coords / keep_lattice (diffusion.py:283-287, 308-312, 330, 348-349) against the reference-generated chain."""
+    g = golden("g10_csp_mode")
+    Tn = int(g["T"])
+    P = params(g)
+    sch = _sched_from(g, Tn)
+    for tag in ("kc", "kl"):
+        na = T(g[f"{tag}_num_atoms"])
+        noise = _csp_noise(g, tag, Tn)
+        if tag == "kc":
+            noise["x_T"] = T(g["kc_frac_coords"])
+        else:
+            noise["l_T"] = O.lattice_params_to_matrix(T(g["kl_lengths"]), T(g["kl_angles"]))
+        final, traj = O.sample(P, TINY, sch, na, noise, step_lr=5e-6, keep_coords=tag == "kc", keep_lattice=tag == "kl")
+        for t in range(Tn, -1, -1):
+            for k in ("atom_types", "frac_coords", "lattices"):
+                a, b = traj[t][k].numpy(), g[f"{tag}_traj_{t}_{k}"]
+                if k == "frac_coords":
+                    d = np.abs(a - b); d = np.minimum(d, 1 - d)
+                    assert d.max() < 2e-4, (tag, t, k, d.max())
+                else:
+                    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4, err_msg=f"{tag} {t} {k}")
+            if t > 1:
+                for k in ("log_prob_l", "log_prob_t", "log_prob_x"):
+                    np.testing.assert_allclose(traj[t][k].numpy(), g[f"{tag}_traj_{t}_{k}"], rtol=2e-3, atol=2e-3, err_msg=f"{tag} {t} {k}")
+        # the kept part really is the given one at the end of the chain
+        if tag == "kc":
+            d = np.abs(final["frac_coords"].numpy() - g["kc_frac_coords"] % 1.0)
+            assert np.minimum(d, 1 - d).max() == 0
+        else:
+            assert np.array_equal(final["lattices"].numpy(), noise["l_T"].numpy())
+
+
+def test_add_noise_with_sampled_times(golden):
+    """add_noise(batch) without a time index (diffusion.py:83-84): per-crystal times from numpy's global generator."""
+    g = golden("g11_noise_sampled_times")
+    P = params(g)
+    sch = _sched_from(g, 1000, "sigmas_norm")
+    batch = dict(num_atoms=T(g["num_atoms"]), lengths=T(g["lengths"]), angles=T(g["angles"]), frac_coords=T(g["frac_coords"]),
+                 atom_types=T(g["atom_types"]))
+    noise = dict(rand_l=T(g["rand_l"]), rand_x=T(g["rand_x"]), rand_t=T(g["rand_t"]))
+    np.random.seed(int(g["np_seed"]))
+    noised = O.add_noise(TINY, sch, batch, None, noise)
+    (t_emb, atp, ifr, ilat, na, n2g), (rl, tar_x, rt), _ = noised
+    close(t_emb, g["t_emb"], rtol=0, atol=0)
+    close(atp, g["atom_type_probs"], rtol=0, atol=0)
+    close(ifr, g["input_frac"], rtol=0, atol=0)
+    close(ilat, g["input_lattice"], rtol=0, atol=0)
+    close(tar_x, g["tar_x"], rtol=1e-6, atol=1e-6)
+    loss, pred = O.calc_sample_loss(P, TINY, O.Costs(), noised)
+    close(loss, g["loss"], rtol=2e-5, atol=2e-5)
+    # the explicit-times form the HIP tests use gives the same result
+    n2 = O.add_noise(TINY, sch, batch, None, noise, times=g["times"])
+    close(n2[0][2], g["input_frac"], rtol=0, atol=0)
