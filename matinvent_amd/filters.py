@@ -6,12 +6,22 @@ element database: not reproduced, every composition passes) and `max(lattice.abc
 from the device kernel K18 (`matinvent_amd.structure.check_structures`), attached to each record by the sampler
 (`CrystalData.geometry`); a record without them is an error -- there is no host-side re-computation.
 """
+import logging
+
 import numpy as np
 
 MAX_CELL_EDGE, MIN_DISTANCE, MIN_VOLUME = 25.0, 0.5, 0.1
 
 
+_warned = []
+
+
 def invalid_filter(sample_data, sample_struc=None, return_mask=False):
+    if not _warned:  # once per process: the reference's filter is stricter than this one
+        _warned.append(True)
+        logging.warning("invalid_filter: SMACT charge-neutrality test is BYPASSED (its element database is not available); only the "
+                        "geometric tests (cell edge < 25 A, shortest distance > 0.5 A, volume > 0.1 A^3) are applied, so compositions the "
+                        "reference would reject pass")
     mask = []
     for d in sample_data:
         g = getattr(d, "geometry", None)

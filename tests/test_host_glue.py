@@ -159,3 +159,28 @@ def test_checkpoint_choice_is_numeric_on_the_epoch(tmp_path):
     names = ["epoch=9-step=1.ckpt", "epoch=10-step=2.ckpt"]
     epochs = [int(n.split("-")[0].split("=")[1]) for n in sorted(names)]
     assert sorted(names)[int(np.argsort(epochs)[-1])] == "epoch=10-step=2.ckpt"
+
+
+def test_reward_scaling_modes_follow_the_reference(tmp_path):
+    """rewards/reward.py:8-115: ascending / descending / float-target scaling, mean / min / weight reduction, NaN -> failed."""
+    from types import SimpleNamespace as NS
+    from matinvent_amd.rewards import PyMatGen, Reward, linear_scaling
+    assert np.allclose(linear_scaling(np.array([-1.0, 3.0, 9.0])), [0.0, 0.5, 1.0])
+    calc = lambda vals: NS(calc=lambda samples, label: np.array(vals, dtype=float))
+    cfg = [dict(name="a", calculator=calc([750.0, 2000.0, 3250.0, np.nan]), target="descending", minv=750, maxv=3250, weight=0.25),
+           dict(name="b", calculator=calc([0.0, 1.0, 2.5, 1.0]), target=2.5, minv=0.0, maxv=2.0, weight=0.75),
+           dict(name="c", calculator=calc([2.0, 6.0, 12.0, 3.0]), target="ascending", minv=2.0, maxv=10.0, weight=1.0)]
+    strucs = ([None] * 4, None)
+    r, props, failed = Reward(str(tmp_path / "r"), cfg, 0.8, reduce="mean").scoring(strucs)
+    # a: hhi-style descending -> [1, .5, 0]; b: |v - 2.5| = [2.5, 1.5, 0, 1.5] -> scale(-d, -2, 0) = [0, .25, 1, .25]; c: [0, .5, 1, .125]
+    assert np.allclose(r, [(1 + 0 + 0) / 3, (0.5 + 0.25 + 0.5) / 3, (0 + 1 + 1) / 3, 0.0]) and failed.tolist() == [False, False, False, True]
+    assert props["a"][3] == 0.0
+    r, _, _ = Reward(str(tmp_path / "r"), cfg, 0.8, reduce="min").scoring(strucs)
+    assert np.allclose(r, [0.0, 0.25, 0.0, 0.0])
+    r, _, _ = Reward(str(tmp_path / "r"), cfg, 0.8, reduce="weight").scoring(strucs)
+    assert np.allclose(r[:3], [0.25 * 1 + 0 + 0, 0.25 * 0.5 + 0.75 * 0.25 + 0.5, 0 + 0.75 + 1.0])
+    # density calculator on a record: cubic 4 A cell with one Fe and one O
+    s = NS(species=[26, 8], lengths=[4.0, 4.0, 4.0], angles=[90.0, 90.0, 90.0])
+    d = PyMatGen(task="density").calc(([s], None))
+    assert abs(d[0] - (55.845 + 15.999) * 1.66053906660 / 64.0) < 1e-6
+    assert np.isnan(PyMatGen(task="hhi").calc(([s], None))[0])  # no table offline -> failed sample, like the reference's except branch
