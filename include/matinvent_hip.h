@@ -333,6 +333,87 @@ int mi_saturation_events(int64_t* count, int reset);
 int mi_profile_enable(mi_net* net, int on);
 int mi_profile_read(mi_net* net, int64_t* launches, double* total_ms, double* union_ms);
 
+
+/* =======================================================================================
+ * MatterGen-shaped path  --  what the files under models/mattergen/ adapt from the un-vendored package
+ * `mattergen @ 5bb2b397` (PARITY UNPINNED; the arithmetic below follows the published
+ * GemNet-T / MatterGen description as restated, definition by definition, in oracle/mattergen_oracle.py).
+ * Replaces, behind MatterGenModule (models/mattergen/pl_module.py:17-125):
+ *   `self.diffusion_module.model(noisy_batch, t)`          (pl_module.py:42,73)   -> mi_gemnet_forward
+ *   autograd through it (pipeline/mat_invent.py:164)                               -> mi_gemnet_backward
+ *   `self.diffusion_module.corruption.sample_marginal`     (pl_module.py:68)      -> mi_mg_sample_marginal
+ *   `PredictorCorrector.sample` as driven by draw_samples_from_sampler (models/mattergen/sample.py:27-64) -> mi_mg_sampler_run
+ * Shapes: B crystals, N atoms, E directed edges of the periodic radius graph (rebuilt by every forward), fractional
+ * positions pos [N,3], cell [B,3,3] (rows = lattice vectors), atomic numbers [N] int32 in 1..100 or 101 = the D3PM mask
+ * state, diffusion time t [B] in (0, 1].  Outputs: pos score x std [N,3] (fractional), cell score x std [B,3,3]
+ * (symmetric), type logits [N,101].
+ * ======================================================================================= */
+#define MI_MG_CLASSES 101
+#define MI_MG_MASK 101
+typedef struct mi_gemnet mi_gemnet;
+typedef struct mi_gbatch mi_gbatch;
+typedef struct mi_gemnet_config {
+    int emb_atom, emb_edge, emb_trip, emb_rbf, emb_cbf, emb_bil;   /* 512 / 512 / 64 / 16 / 16 / 64                     */
+    int num_radial, num_spherical, num_blocks;                     /* 128 / 7 / 4                                       */
+    int num_before_skip, num_after_skip, num_concat, num_atom;     /* 1 / 2 / 1 / 3 residual layers                     */
+    int max_neighbors, max_images;                                 /* 50 nearest per target atom; <= 5 images per side  */
+    float cutoff;                                                  /* 7.0 A                                             */
+} mi_gemnet_config;
+int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out);
+void mi_gemnet_destroy(mi_gemnet* net);
+int64_t mi_gemnet_num_params(const mi_gemnet* net);
+int mi_gemnet_num_tensors(const mi_gemnet* net);
+/* i-th tensor of the flat parameter vector (the order of oracle/mattergen_oracle.py::param_list): name, offset, numel, rows, cols */
+int mi_gemnet_param_info(const mi_gemnet* net, int index, const char** name, int64_t* offset, int64_t* numel, int* rows, int* cols);
+/* bind the flat parameter vector (device); call again after every optimizer step (transposed copies for the backward) */
+int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream);
+int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
+                     mi_gbatch** out);
+void mi_gbatch_destroy(mi_gbatch* b);
+/* Periodic radius graph of (pos, cell): cutoff, the max_neighbors nearest per target atom, symmetrised; one host
+ * synchronisation (the edge count sizes the later launches).  *num_edges = E. */
+int mi_gemnet_graph(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, void* stream, int64_t* num_edges);
+/* copy out the current graph (any pointer may be NULL): src/dst [E], img [E][3], swap [E] (index of the reverse edge),
+ * rowptr [N+1] (edges are sorted by dst), D [E], V [E][3] (unit vector from dst to the periodic image of src) */
+int mi_gemnet_graph_read(const mi_gbatch* b, int* src, int* dst, int* img, int* swap, int* rowptr, float* D, float* V, void* stream);
+/* The denoiser.  train != 0 keeps the activations for mi_gemnet_backward (one pending backward per batch handle). */
+int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* atomic_numbers,
+                      const float* t, float* out_pos, float* out_cell, float* out_logits, int train, void* stream);
+/* grad_theta += dLoss/dtheta given dLoss/d(out_pos, out_cell, out_logits) (any may be NULL = zero) */
+int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const float* d_cell, const float* d_logits,
+                       float* grad_theta, void* stream);
+/* parity taps of the most recent forward: "h<i>" [N,emb_atom], "m<i>" [E,emb_edge] after block i (0 = embedding), "rbf" [E,num_radial] */
+int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream);
+
+/* Corruption constants (oracle/mattergen_oracle.py::Corruption): wrapped VE-SDE on positions (std = sigma_min^(1-t) sigma_max^t
+ * n^(-1/3)), VP-SDE on the cell towards (n / limit_density)^(1/3) I with std sqrt(limit_var_scale) n^(1/3), D3PM absorbing
+ * state on the types (d3pm_steps discrete steps). */
+typedef struct mi_mg_corruption {
+    float sigma_min, sigma_max, beta_min, beta_max, limit_density, limit_var_scale;
+    int d3pm_steps;
+} mi_mg_corruption;
+/* corruption.sample_marginal (pl_module.py:68) for per-crystal times t [B].  noise_* = injected draws (pos [N,3] normal,
+ * cell [B,9] normal, types [N] uniform) or NULL for the Philox stream (draw ids 10 / 11 / 12, counter step = `step`).
+ * Outputs: noisy pos / cell / types, and what the loss needs: delta [N,3] (= std z), eps [B,9] (symmetric noise),
+ * masked [N] (0/1). */
+int mi_mg_sample_marginal(mi_gbatch* b, const mi_mg_corruption* c, const float* pos0, const float* cell0, const int* types0,
+                          const float* t, uint64_t seed, uint32_t step, const float* noise_pos, const float* noise_cell,
+                          const float* noise_types, float* pos, float* cell, int* types, float* delta, float* eps, int* masked,
+                          void* stream);
+typedef struct mi_mg_sampler_noise {   /* device pointers, [n_steps][...] each; NULL struct = Philox stream */
+    const float *corr_pos, *corr_cell, *pred_pos, *pred_cell, *pred_u1, *pred_u2;
+} mi_mg_sampler_noise;
+/* initial state of the reverse chain: pos ~ U[0,1), cell = limit mean + limit std x symmetric noise, types = mask */
+int mi_mg_sampler_init(mi_gbatch* b, const mi_mg_corruption* c, uint64_t seed, const float* init_pos, const float* init_cell,
+                       float* pos, float* cell, int* types, void* stream);
+/* predictor-corrector steps i_start .. i_stop-1 of the time grid ts_host [n_steps] (= linspace(1, eps_t, n_steps) built by the host
+ * mirror with the same fp32 ops as the oracle): Langevin corrector
+ * (positions snr 0.4, cell snr 0.2), ancestral predictor, two denoiser evaluations per step; state updated in place,
+ * mean_pos / mean_cell receive the last predictor mean (what MatterGenSampler returns, sample.py:49-50). */
+int mi_mg_sampler_run(mi_gemnet* net, mi_gbatch* b, const mi_mg_corruption* c, int n_steps, int i_start, int i_stop, const float* ts_host,
+                      uint64_t seed, const mi_mg_sampler_noise* noise, float* pos, float* cell, int* types, float* mean_pos,
+                      float* mean_cell, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

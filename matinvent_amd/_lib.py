@@ -25,6 +25,20 @@ class SamplerRecord(C.Structure):
                 ("log_prob_x", C.c_void_p)]
 
 
+class GemNetConfig(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("emb_atom", "emb_edge", "emb_trip", "emb_rbf", "emb_cbf", "emb_bil", "num_radial", "num_spherical",
+                                       "num_blocks", "num_before_skip", "num_after_skip", "num_concat", "num_atom", "max_neighbors",
+                                       "max_images")] + [("cutoff", C.c_float)]
+
+
+class MGCorruption(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("sigma_min", "sigma_max", "beta_min", "beta_max", "limit_density", "limit_var_scale")] + [("d3pm_steps", C.c_int)]
+
+
+class MGSamplerNoise(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("corr_pos", "corr_cell", "pred_pos", "pred_cell", "pred_u1", "pred_u2")]
+
+
 _P, _I, _L, _U64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
 
 # name -> (restype, argtypes); mirrors include/matinvent_hip.h one to one
@@ -72,6 +86,23 @@ SIGNATURES = {
                               C.c_float, C.c_float, C.c_float, C.c_float, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mi_ft_micro_steps_stacked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _U64, _U32, _P, _P, _P,
                                        C.c_float, C.c_float, C.c_float, C.c_float, _I, _I, _P, _P, _P, _P]),
+    "mi_gemnet_create": (_I, [C.POINTER(GemNetConfig), C.POINTER(_P)]),
+    "mi_gemnet_destroy": (None, [_P]),
+    "mi_gemnet_num_params": (_L, [_P]),
+    "mi_gemnet_num_tensors": (_I, [_P]),
+    "mi_gemnet_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I), C.POINTER(_I)]),
+    "mi_gemnet_set_params": (_I, [_P, _P, _P]),
+    "mi_gbatch_create": (_I, [_P, C.POINTER(_I), _I, _L, _L, C.POINTER(_P)]),
+    "mi_gbatch_destroy": (None, [_P]),
+    "mi_gemnet_graph": (_I, [_P, _P, _P, _P, _P, C.POINTER(_L)]),
+    "mi_gemnet_graph_read": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_gemnet_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "mi_gemnet_backward": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "mi_gemnet_tap": (_I, [_P, C.c_char_p, _P, _L, C.POINTER(_L), _P]),
+    "mi_mg_sample_marginal": (_I, [_P, C.POINTER(MGCorruption), _P, _P, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_mg_sampler_init": (_I, [_P, C.POINTER(MGCorruption), _U64, _P, _P, _P, _P, _P, _P]),
+    "mi_mg_sampler_run": (_I, [_P, _P, C.POINTER(MGCorruption), _I, _I, _I, C.POINTER(C.c_float), _U64, C.POINTER(MGSamplerNoise), _P, _P, _P,
+                               _P, _P, _P]),
     "mi_set_gemm_mode": (_I, [_I]),
     "mi_net_set_edge_mode": (_I, [_P, _I]),
     "mi_debug_gemm": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmatinvent_hip.so")
-SOURCES = ["cspnet.hip", "sampler.hip", "backward.hip", "graph.hip"]
+SOURCES = ["cspnet.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

@@ -16,7 +16,7 @@ namespace mi {
 
 extern int g_tn128;  // weight-gradient products over long row lists on 128 x 128 tiles (1) or always 64 x 64 (0)
 
-enum { ACT_NONE = 0, ACT_SILU = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SSILU = 2 };  // ACT_SSILU: ScaledSiLU = silu(x) / 0.6 (GemNet's activation)
 
 // scratch for split-K partial sums (small-M products: more workgroups, shorter serial k-loops)
 struct SplitK {
@@ -57,6 +57,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     if (ep.pre_add) v += ep.pre_add[(size_t)row * ep.ld_pre_add + col];
     if (ep.pre_act) ep.pre_act[(size_t)row * ep.ld_pre + col] = v;
     if (ep.act == ACT_SILU) v = FAST ? silu_fast(v) : silu(v);
+    else if (ep.act == ACT_SSILU) v = (FAST ? silu_fast(v) : silu(v)) * 1.66666666666666667f;
     if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];
     return v;
 }

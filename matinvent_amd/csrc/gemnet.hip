@@ -1,0 +1,1804 @@
+// MatterGen-shaped path on gfx950: a GemNet-T-shaped denoiser (periodic radius graph, Gaussian radial basis x polynomial
+// envelope, spherical-harmonic triplet basis with the efficient bilinear contraction, 4 interaction blocks, per-edge force /
+// stress heads, type logits), its parameter-gradient backward, the three corruptions and the predictor-corrector sampler.
+//
+// PARITY UNPINNED: the reference adapts these from the un-vendored package `mattergen @ 5bb2b397` (models/mattergen/*.py);
+// the arithmetic here is the one restated definition by definition in oracle/mattergen_oracle.py, which the GPU tests
+// compare against.
+//
+// Structure: the network is written ONCE as a program over eight tensor ops (dense, multiply, scaled add with optional row
+// permutation, segmented sum, triplet contraction, weighted row dot, embedding lookup, heads).  Running the program
+// executes the forward kernels and -- in training mode -- records a tape; the backward walks the tape in reverse with each
+// op's gradient kernels.  All intermediates live in one arena per batch handle (a dry run of the program sizes it), the
+// gradient arena mirrors it.  Dense layers run on the fp32-operand split GEMM (gemm_nt: three bf16 planes, six MFMA terms,
+// fp32-class accuracy), weight gradients on gemm_tn_auto, data gradients on gemm_nt against transposed weight copies.
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm_split.h"
+
+namespace mi {
+
+constexpr int GN_NMAX = 64;    // atoms per crystal (LDS-resident coordinates)
+constexpr int GN_CAND = 512;   // candidates within the cutoff kept per target atom (more: the radius is bisected down)
+constexpr int GN_DEG = 128;    // in-degree capacity after symmetrisation
+constexpr int GN_CODE_BITS = 11;  // image code < (2 * 5 + 1)^3 = 1331
+constexpr float GN_ACT = 1.66666666666666667f;
+constexpr float GN_ISQ2 = 0.70710678118654752440f;
+constexpr int LOGIT_LD = 104;  // row stride of the logits buffer (101 padded to a multiple of 4: GEMM operand alignment)
+
+enum : uint32_t {  // Philox draw ids of this path (DESIGN.md "RNG"; mirrored by oracle-side helpers in the tests)
+    DRAW_MG_POS = 10, DRAW_MG_CELL = 11, DRAW_MG_TYPES = 12, DRAW_MG_CORR_POS = 13, DRAW_MG_CORR_CELL = 14, DRAW_MG_PRED_POS = 15,
+    DRAW_MG_PRED_CELL = 16, DRAW_MG_PRED_U1 = 17, DRAW_MG_PRED_U2 = 18, DRAW_MG_INIT_POS = 19, DRAW_MG_INIT_CELL = 20,
+};
+
+// ================================================================================================================================
+// graph
+// ================================================================================================================================
+struct GraphArgs {
+    const float *pos, *cell;
+    const int* node_off;
+    float cutoff;
+    int maxnb, R, cap;
+    int *ent, *acnt, *deg, *mcount, *meta;
+};
+
+// entries of target a: key = (c << 11) | code for each selected neighbour whose pair is represented by (a, c, code)
+__global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
+#pragma clang fp contract(off)
+    __shared__ float cart[GN_NMAX * 3];
+    __shared__ float Ls[9];
+    __shared__ int degl[GN_NMAX], cntl[GN_NMAX], reps[3];
+    __shared__ float dl_all[4][GN_CAND];
+    __shared__ unsigned kl_all[4][GN_CAND];
+    const int b = blockIdx.x, n0 = g.node_off[b], n = g.node_off[b + 1] - n0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* dl = dl_all[wave];
+    unsigned* kl = kl_all[wave];
+    const float* Lm = g.cell + (size_t)b * 9;
+    if (tid < 9) Ls[tid] = Lm[tid];
+    for (int i = tid; i < n; i += 256) {
+        const float* f = g.pos + (size_t)(n0 + i) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cart[i * 3 + c] = __builtin_fmaf(f[2], Lm[6 + c], __builtin_fmaf(f[1], Lm[3 + c], f[0] * Lm[c]));
+        degl[i] = 0;
+        cntl[i] = 0;
+    }
+    if (tid == 0) {  // images per dimension: ceil(cutoff / inter-plane spacing), at most R
+        const double a0 = Lm[0], a1 = Lm[1], a2 = Lm[2], b0 = Lm[3], b1 = Lm[4], b2 = Lm[5], c0 = Lm[6], c1 = Lm[7], c2 = Lm[8];
+        const double x23[3] = {b1 * c2 - b2 * c1, b2 * c0 - b0 * c2, b0 * c1 - b1 * c0};
+        const double x31[3] = {c1 * a2 - c2 * a1, c2 * a0 - c0 * a2, c0 * a1 - c1 * a0};
+        const double x12[3] = {a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0};
+        const double vol = fabs(a0 * x23[0] + a1 * x23[1] + a2 * x23[2]);
+        const double* xs[3] = {x23, x31, x12};
+        for (int k = 0; k < 3; ++k) {
+            const double nrm = sqrt(xs[k][0] * xs[k][0] + xs[k][1] * xs[k][1] + xs[k][2] * xs[k][2]);
+            const double spacing = vol / fmax(nrm, 1e-30);
+            double r = ceil((double)g.cutoff / fmax(spacing, 1e-30) - 1e-9);
+            if (!(r >= 1.0)) r = 1.0;
+            if (!(r <= (double)g.R)) r = (double)g.R;
+            reps[k] = (int)r;
+        }
+    }
+    __syncthreads();
+    const int ra = reps[0], rb = reps[1], rc = reps[2], wb = 2 * rb + 1, wc = 2 * rc + 1, W = 2 * g.R + 1;
+    const int nimg = (2 * ra + 1) * wb * wc, nq = nimg * n;
+    const float r2 = g.cutoff * g.cutoff;
+    const int zero_code = (g.R * W + g.R) * W + g.R;
+    for (int a = wave; a < n; a += 4) {
+        const float cx = cart[a * 3], cy = cart[a * 3 + 1], cz = cart[a * 3 + 2];
+        // d^2 and key of candidate q = (image, source), or d^2 = -1 outside (1e-6, limit]
+        auto cand = [&](int q, float limit, unsigned* key) -> float {
+            const int ii = q / n, c = q - ii * n;
+            const int ia = ii / (wb * wc) - ra, ib = (ii / wc) % wb - rb, ic = ii % wc - rc;
+            const float fa = (float)ia, fb = (float)ib, fc = (float)ic;
+            const float ox = (fa * Ls[0] + fb * Ls[3]) + fc * Ls[6], oy = (fa * Ls[1] + fb * Ls[4]) + fc * Ls[7],
+                        oz = (fa * Ls[2] + fb * Ls[5]) + fc * Ls[8];
+            const float dx = (cart[c * 3] + ox) - cx, dy = (cart[c * 3 + 1] + oy) - cy, dz = (cart[c * 3 + 2] + oz) - cz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            *key = ((unsigned)c << GN_CODE_BITS) | (unsigned)(((ia + g.R) * W + (ib + g.R)) * W + (ic + g.R));
+            return (d <= limit && d > 1e-6f) ? d : -1.f;
+        };
+        auto collect = [&](float limit) -> int {
+            int m = 0;
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int q = q0 + lane;
+                unsigned key = 0;
+                const float d = q < nq ? cand(q, limit, &key) : -1.f;
+                const bool pass = d >= 0.f;
+                const uint64_t mk = __ballot(pass);
+                if (pass) {
+                    const int p = m + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (p < GN_CAND) {
+                        dl[p] = d;
+                        kl[p] = key;
+                    }
+                }
+                m += __popcll(mk);
+            }
+            return m;
+        };
+        int m = collect(r2);
+        if (m > GN_CAND) {  // a very dense cell: shrink the radius until the list fits but still holds the maxnb nearest
+            float lo = 0.f, hi = r2, mid = r2;
+            bool ok = false;
+            for (int it = 0; it < 24 && !ok; ++it) {
+                mid = 0.5f * (lo + hi);
+                m = collect(mid);
+                if (m > GN_CAND) hi = mid;
+                else if (m < g.maxnb) lo = mid;
+                else ok = true;
+            }
+            if (!ok && lane == 0) atomicOr(&g.meta[2], 2);
+            if (m > GN_CAND) m = GN_CAND;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int cnt = 0;
+        for (int p0 = 0; p0 < m; p0 += 64) {
+            const int p = p0 + lane;
+            bool sel = false;
+            unsigned key = 0;
+            if (p < m) {
+                const float v = dl[p];
+                key = kl[p];
+                int rank = 0;
+                for (int k = 0; k < m; ++k) {
+                    const float x = dl[k];
+                    rank += (x < v) || (x == v && kl[k] < key);
+                }
+                const int c = (int)(key >> GN_CODE_BITS), code = (int)(key & ((1u << GN_CODE_BITS) - 1u));
+                sel = rank < g.maxnb && (c < a || (c == a && code < zero_code));
+            }
+            const uint64_t mk = __ballot(sel);
+            if (sel) {
+                const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                if (pos < g.cap) g.ent[(size_t)(n0 + a) * g.cap + pos] = (int)key;
+                atomicAdd(&degl[(int)(key >> GN_CODE_BITS)], 1);
+            }
+            cnt += __popcll(mk);
+        }
+        if (lane == 0) {
+            cntl[a] = cnt;
+            atomicAdd(&degl[a], cnt);
+            if (cnt > g.cap) atomicOr(&g.meta[2], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        g.acnt[n0 + i] = cntl[i];
+        g.deg[n0 + i] = degl[i];
+        if (degl[i] > GN_DEG) atomicOr(&g.meta[2], 4);
+    }
+}
+
+// rowptr = exclusive scan of deg; meta = {E, max degree, flags}
+__global__ __launch_bounds__(1024) void gg_scan_kernel(const int* __restrict__ deg, int N, int* __restrict__ rowptr, int* __restrict__ meta) {
+    __shared__ int part[1024], pmax[1024];
+    const int tid = threadIdx.x, chunk = (N + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < N ? lo + chunk : N;
+    int s = 0, mx = 0;
+    for (int k = lo; k < hi; ++k) {
+        s += deg[k];
+        mx = deg[k] > mx ? deg[k] : mx;
+    }
+    part[tid] = s;
+    pmax[tid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, m2 = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const int v = part[k];
+            part[k] = run;
+            run += v;
+            m2 = pmax[k] > m2 ? pmax[k] : m2;
+        }
+        rowptr[N] = run;
+        meta[0] = run;
+        meta[1] = m2;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = lo; k < hi; ++k) {
+        rowptr[k] = run;
+        run += deg[k];
+    }
+}
+
+struct EmitArgs {
+    const int *node_off, *ent, *acnt, *rowptr, *meta;
+    int cap, R;
+    int64_t E_cap;
+    int *src, *dst, *code, *ekey, *swap, *edge_graph;
+};
+
+// rows sorted by (source, image code); both directions of every kept pair; then the index of each edge's reverse
+__global__ __launch_bounds__(256) void gg_emit_kernel(EmitArgs g) {
+    extern __shared__ int el[];  // [n * cap] entries (a << 17 | key)
+    __shared__ int aoff[GN_NMAX + 1];
+    __shared__ unsigned rowbuf[4][GN_DEG];
+    if (g.meta[2] != 0 || (int64_t)g.meta[0] > g.E_cap) return;
+    const int b = blockIdx.x, n0 = g.node_off[b], n = g.node_off[b + 1] - n0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = 2 * g.R + 1;
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < n; ++i) {
+            aoff[i] = s;
+            s += g.acnt[n0 + i];
+        }
+        aoff[n] = s;
+    }
+    __syncthreads();
+    const int M = aoff[n];
+    for (int i = 0; i < n; ++i)
+        for (int k = tid; k < aoff[i + 1] - aoff[i]; k += 256) el[aoff[i] + k] = (i << 17) | g.ent[(size_t)(n0 + i) * g.cap + k];
+    __syncthreads();
+    const unsigned cmask = (1u << GN_CODE_BITS) - 1u;
+    for (int v = wave; v < n; v += 4) {
+        unsigned* rb = rowbuf[wave];
+        int cnt = 0;
+        for (int t0 = 0; t0 < M; t0 += 64) {
+            const int t = t0 + lane;
+            bool hit = false;
+            unsigned key = 0;
+            if (t < M) {
+                const int w = el[t], a = w >> 17, c = (w >> GN_CODE_BITS) & 63;
+                const unsigned code = (unsigned)w & cmask;
+                if (a == v) {  // c -> v with this image
+                    hit = true;
+                    key = ((unsigned)c << GN_CODE_BITS) | code;
+                } else if (c == v) {  // the reverse: a -> v with the negated image
+                    const int ia = (int)(code / (W * W)) - g.R, ib = (int)((code / W) % W) - g.R, ic = (int)(code % W) - g.R;
+                    hit = true;
+                    key = ((unsigned)a << GN_CODE_BITS) | (unsigned)(((-ia + g.R) * W + (-ib + g.R)) * W + (-ic + g.R));
+                }
+            }
+            const uint64_t mk = __ballot(hit);
+            if (hit) {
+                const int p = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                if (p < GN_DEG) rb[p] = key;
+            }
+            cnt += __popcll(mk);
+            // second direction of self pairs
+            bool hit2 = false;
+            unsigned key2 = 0;
+            if (t < M) {
+                const int w = el[t], a = w >> 17, c = (w >> GN_CODE_BITS) & 63;
+                if (a == v && c == v) {
+                    const unsigned code = (unsigned)w & cmask;
+                    const int ia = (int)(code / (W * W)) - g.R, ib = (int)((code / W) % W) - g.R, ic = (int)(code % W) - g.R;
+                    hit2 = true;
+                    key2 = ((unsigned)a << GN_CODE_BITS) | (unsigned)(((-ia + g.R) * W + (-ib + g.R)) * W + (-ic + g.R));
+                }
+            }
+            const uint64_t mk2 = __ballot(hit2);
+            if (hit2) {
+                const int p = cnt + __popcll(mk2 & ((1ull << lane) - 1ull));
+                if (p < GN_DEG) rb[p] = key2;
+            }
+            cnt += __popcll(mk2);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int r0 = g.rowptr[n0 + v];
+        for (int p = lane; p < cnt && p < GN_DEG; p += 64) {
+            const unsigned key = rb[p];
+            int rank = 0;
+            for (int k = 0; k < cnt; ++k) rank += rb[k] < key;
+            const int e = r0 + rank;
+            g.src[e] = n0 + (int)(key >> GN_CODE_BITS);
+            g.dst[e] = n0 + v;
+            g.code[e] = (int)(key & cmask);
+            g.ekey[e] = (int)key;
+            g.edge_graph[e] = b;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence();
+    __syncthreads();
+    // swap[e]: in row src(e), the edge coming from dst(e) with the negated image (rows are sorted by key: binary search)
+    const int e0 = g.rowptr[n0], e1 = g.rowptr[n0 + n];
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int s = g.src[e] - n0, v = g.dst[e] - n0;
+        const unsigned code = (unsigned)g.code[e];
+        const int ia = (int)(code / (W * W)) - g.R, ib = (int)((code / W) % W) - g.R, ic = (int)(code % W) - g.R;
+        const int want = (int)(((unsigned)v << GN_CODE_BITS) | (unsigned)(((-ia + g.R) * W + (-ib + g.R)) * W + (-ic + g.R)));
+        int lo = g.rowptr[n0 + s], hi = g.rowptr[n0 + s + 1] - 1, found = -1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1, k = g.ekey[mid];
+            if (k == want) {
+                found = mid;
+                break;
+            }
+            if (k < want) lo = mid + 1;
+            else hi = mid - 1;
+        }
+        g.swap[e] = found;
+    }
+}
+
+// D, V and the radial basis (polynomial envelope p = 5 x Gaussian smearing on d = D / cutoff): one thread per (edge, radial index)
+__global__ void edge_geom_rbf_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int* __restrict__ src,
+                                     const int* __restrict__ dst, const int* __restrict__ code, const int* __restrict__ edge_graph, int R_img,
+                                     float cutoff, int NR, int64_t E, float* __restrict__ D, float* __restrict__ V, float* __restrict__ rbf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * NR) return;
+    const int e = (int)(idx / NR), r = (int)(idx % NR);
+    const float* L = cell + (size_t)edge_graph[e] * 9;
+    const int W = 2 * R_img + 1, cd = code[e];
+    const float fa = (float)(cd / (W * W) - R_img), fb = (float)((cd / W) % W - R_img), fc = (float)(cd % W - R_img);
+    const float *ps = pos + (size_t)src[e] * 3, *pd = pos + (size_t)dst[e] * 3;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float cs = fmaf(ps[2], L[6 + c], fmaf(ps[1], L[3 + c], ps[0] * L[c]));
+        const float cdn = fmaf(pd[2], L[6 + c], fmaf(pd[1], L[3 + c], pd[0] * L[c]));
+        const float o = (fa * L[c] + fb * L[3 + c]) + fc * L[6 + c];
+        v[c] = (cs + o) - cdn;
+    }
+    const float dd = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (r == 0) {
+        D[e] = dd;
+        V[(size_t)e * 3] = v[0] / dd;
+        V[(size_t)e * 3 + 1] = v[1] / dd;
+        V[(size_t)e * 3 + 2] = v[2] / dd;
+    }
+    const float d = dd / cutoff;
+    const float d2 = d * d, d5 = d2 * d2 * d;
+    const float env = d < 1.f ? 1.f + d5 * (-21.f + d * (35.f - 15.f * d)) : 0.f;
+    const float step = 1.f / (float)(NR - 1), off = (float)r * step, coeff = -0.5f / (step * step);
+    rbf[idx] = env * expf(coeff * (d - off) * (d - off));
+}
+
+// noise-level encoding of t in (0, 1]: [sin(1000 t div_k) | cos(1000 t div_k)], div_k = exp(-k ln(1e4) / half)
+__global__ void nle_kernel(const float* __restrict__ t, float* __restrict__ z, int B, int A) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * A) return;
+    const int b = idx / A, k = idx % A, half = A / 2, kk = k < half ? k : k - half;
+    const float div = expf((float)kk * (-9.21034037197618273607f / (float)half));
+    const float arg = (t[b] * 1000.0f) * div;
+    z[idx] = k < half ? sinf(arg) : cosf(arg);
+}
+
+// ================================================================================================================================
+// op kernels
+// ================================================================================================================================
+__global__ void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ types, float* __restrict__ Y, int N, int A) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * A) return;
+    Y[idx] = table[(size_t)(types[idx / A] - 1) * A + idx % A];
+}
+// one block per table row: rows are added in atom order (deterministic)
+__global__ void embed_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ types, float* __restrict__ dT, int N, int A) {
+    const int r = blockIdx.x;
+    for (int k = threadIdx.x; k < A; k += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < N; ++i)
+            if (types[i] - 1 == r) s += dY[(size_t)i * A + k];
+        dT[(size_t)r * A + k] += s;
+    }
+}
+__global__ void mul_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] * b[i];
+}
+__global__ void mul_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dy, float* __restrict__ da,
+                               float* __restrict__ db, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = dy[i];
+    if (da) da[i] += g * b[i];
+    if (db) db[i] += g * a[i];
+}
+// y = (a + b[perm]) * s   (perm: row permutation of b, or NULL)
+__global__ void axpby_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ perm, float s, float* __restrict__ y,
+                                 int64_t rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i % cols);
+    y[i] = (a[i] + b[(perm ? (int64_t)perm[r] : r) * cols + c]) * s;
+}
+// da += s dy;  db[r] += s dy[perm[r]]  (perm is an involution)
+__global__ void axpby_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ perm, float s, float* __restrict__ da, float* __restrict__ db,
+                                 int64_t rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i % cols);
+    if (da) da[i] += s * dy[i];
+    if (db) db[i] += s * dy[(perm ? (int64_t)perm[r] : r) * cols + c];
+}
+__device__ __forceinline__ float ssilu_grad(float z) { return silu_grad(z) * GN_ACT; }
+// dZ = dY * act'(Z)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ z, float* __restrict__ dz, int64_t rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i % cols);
+    dz[i] = dy[r * ldy + c] * ssilu_grad(z[i]);
+}
+// Y[v] (+)= sum over the rows of segment v of X[perm ? perm[e] : e]
+__global__ void segsum_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ segptr, const int* __restrict__ perm, float* __restrict__ Y,
+                              int nseg, int cols, int acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nseg * cols) return;
+    const int v = (int)(i / cols), c = (int)(i % cols);
+    float s = 0.f;
+    for (int e = segptr[v]; e < segptr[v + 1]; ++e) s += X[(size_t)(perm ? perm[e] : e) * ldx + c];
+    Y[i] = acc ? Y[i] + s : s;
+}
+// dX[e] += dY[seg_of[e]]
+__global__ void gather_add_kernel(const float* __restrict__ dY, const int* __restrict__ seg_of, float* __restrict__ dX, int64_t rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    dX[i] += dY[(size_t)seg_of[i / cols] * cols + i % cols];
+}
+
+// ---- triplet contraction ---------------------------------------------------------------------------------------------------
+// One block per target atom a; its in-edges e (rows lo..hi) see each other as triplets (e, k), k != e, with angle cos = V_e . V_k.
+//   Tm[e][i][j] = sum_l cbfW[e][l][i] * sum_{k != e} Y_l(cos_ek) xd[k][j],   Y_l = sqrt((2l+1)/(4 pi)) P_l
+// Lane j holds feature j (TR <= 64 features), a wave walks the edges of the atom.
+template <int S>
+__device__ __forceinline__ void sph_l(float c, float (&y)[S]) {
+    float pm2 = 1.f, pm1 = c;
+    y[0] = 0.28209479177387814f;
+    if (S > 1) y[1] = 0.48860251190291992f * c;
+#pragma unroll
+    for (int l = 2; l < S; ++l) {
+        const float p = ((float)(2 * l - 1) * c * pm1 - (float)(l - 1) * pm2) / (float)l;
+        y[l] = sqrtf((float)(2 * l + 1) * 0.07957747154594767f) * p;
+        pm2 = pm1;
+        pm1 = p;
+    }
+}
+template <int S>
+__global__ __launch_bounds__(256) void triplet_fwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
+                                                          const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB) {
+    extern __shared__ float sm[];  // V [GN_DEG][3] | xd [GN_DEG][TR]
+    float* Vs = sm;
+    float* xs = sm + GN_DEG * 3;
+    const int a = blockIdx.x, lo = rowptr[a], deg = rowptr[a + 1] - lo, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < deg * 3; i += 256) Vs[i] = V[(size_t)lo * 3 + i];
+    for (int i = tid; i < deg * TR; i += 256) xs[i] = xd[(size_t)lo * TR + i];
+    __syncthreads();
+    for (int e = wave; e < deg; e += 4) {
+        const float vx = Vs[e * 3], vy = Vs[e * 3 + 1], vz = Vs[e * 3 + 2];
+        float acc[S];
+#pragma unroll
+        for (int l = 0; l < S; ++l) acc[l] = 0.f;
+        for (int k = 0; k < deg; ++k) {
+            if (k == e) continue;
+            float c = vx * Vs[k * 3] + vy * Vs[k * 3 + 1] + vz * Vs[k * 3 + 2];
+            c = fminf(fmaxf(c, -1.f), 1.f);
+            float y[S];
+            sph_l<S>(c, y);
+            const float x = lane < TR ? xs[k * TR + lane] : 0.f;
+#pragma unroll
+            for (int l = 0; l < S; ++l) acc[l] += y[l] * x;
+        }
+        const float* w = cbfW + (size_t)(lo + e) * S * CB;
+        if (lane < TR)
+            for (int i = 0; i < CB; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int l = 0; l < S; ++l) s += w[l * CB + i] * acc[l];
+                Tm[((size_t)(lo + e) * CB + i) * TR + lane] = s;
+            }
+    }
+}
+// backward: dxd[k][j] += sum_{e != k} sum_l Y_l(cos_ek) dacc_e[l][j],  dacc_e[l][j] = sum_i cbfW[e][l][i] dTm[e][i][j];
+//           dcbfW[e][l][i] += sum_j acc_e[l][j] dTm[e][i][j]   (acc recomputed).
+// Edges are processed in chunks of TCH whose dacc sits in LDS; each wave then owns target rows k and adds the chunk in a fixed order.
+constexpr int TCH = 16;
+template <int S>
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
+                                                          const int* __restrict__ rowptr, const float* __restrict__ dTm, float* __restrict__ dxd,
+                                                          float* __restrict__ dcbfW, int TR, int CB) {
+    extern __shared__ float sm[];  // V [GN_DEG][3] | xd [GN_DEG][TR] | dacc [TCH][S][64]
+    float* Vs = sm;
+    float* xs = sm + GN_DEG * 3;
+    float* da = xs + GN_DEG * TR;
+    const int a = blockIdx.x, lo = rowptr[a], deg = rowptr[a + 1] - lo, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < deg * 3; i += 256) Vs[i] = V[(size_t)lo * 3 + i];
+    for (int i = tid; i < deg * TR; i += 256) xs[i] = xd[(size_t)lo * TR + i];
+    __syncthreads();
+    float gk[GN_DEG / 4];  // this wave's rows k = wave, wave + 4, ...: accumulated gradient of feature `lane`
+#pragma unroll
+    for (int q = 0; q < GN_DEG / 4; ++q) gk[q] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += TCH) {
+        // phase A: dacc (and the cbfW gradient) of the chunk's edges
+        for (int ee = wave; ee < TCH; ee += 4) {
+            const int e = c0 + ee;
+            if (e >= deg) {
+#pragma unroll
+                for (int l = 0; l < S; ++l) da[(ee * S + l) * 64 + lane] = 0.f;
+                continue;
+            }
+            const float vx = Vs[e * 3], vy = Vs[e * 3 + 1], vz = Vs[e * 3 + 2];
+            float acc[S], dacc[S];
+#pragma unroll
+            for (int l = 0; l < S; ++l) acc[l] = dacc[l] = 0.f;
+            for (int k = 0; k < deg; ++k) {
+                if (k == e) continue;
+                float c = vx * Vs[k * 3] + vy * Vs[k * 3 + 1] + vz * Vs[k * 3 + 2];
+                c = fminf(fmaxf(c, -1.f), 1.f);
+                float y[S];
+                sph_l<S>(c, y);
+                const float x = lane < TR ? xs[k * TR + lane] : 0.f;
+#pragma unroll
+                for (int l = 0; l < S; ++l) acc[l] += y[l] * x;
+            }
+            const float* w = cbfW + (size_t)(lo + e) * S * CB;
+            for (int i = 0; i < CB; ++i) {
+                const float g = lane < TR ? dTm[((size_t)(lo + e) * CB + i) * TR + lane] : 0.f;
+#pragma unroll
+                for (int l = 0; l < S; ++l) {
+                    dacc[l] += w[l * CB + i] * g;
+                    const float r = wave_sum(acc[l] * g);
+                    if (lane == 0) dcbfW[(size_t)(lo + e) * S * CB + l * CB + i] += r;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < S; ++l) da[(ee * S + l) * 64 + lane] = dacc[l];
+        }
+        __syncthreads();
+        // phase B: every row k collects the chunk's contributions
+        int q = 0;
+        for (int k = wave; k < deg; k += 4, ++q) {
+            const float vx = Vs[k * 3], vy = Vs[k * 3 + 1], vz = Vs[k * 3 + 2];
+            float s = 0.f;
+            for (int ee = 0; ee < TCH && c0 + ee < deg; ++ee) {
+                const int e = c0 + ee;
+                if (e == k) continue;
+                float c = vx * Vs[e * 3] + vy * Vs[e * 3 + 1] + vz * Vs[e * 3 + 2];
+                c = fminf(fmaxf(c, -1.f), 1.f);
+                float y[S];
+                sph_l<S>(c, y);
+#pragma unroll
+                for (int l = 0; l < S; ++l) s += y[l] * da[(ee * S + l) * 64 + lane];
+            }
+            gk[q] += s;
+        }
+        __syncthreads();
+    }
+    int q = 0;
+    for (int k = wave; k < deg; k += 4, ++q)
+        if (lane < TR) dxd[(size_t)(lo + k) * TR + lane] += gk[q];
+}
+
+// ---- weighted row dot: y[e] (+)= sum_k A[e][k] B[e][k] w[k]  (the per-edge scalar heads) -----------------------------------------
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ w,
+                                                         float* __restrict__ y, int64_t rows, int K, int acc) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += A[r * K + k] * Bm[r * K + k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0) y[r] = acc ? y[r] + s : s;
+}
+__global__ void rowdot_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ w, const float* __restrict__ dy,
+                                  float* __restrict__ dA, float* __restrict__ dB, int64_t rows, int K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const float g = dy[i / K] * w[i % K];
+    dA[i] += g * Bm[i];
+    dB[i] += g * A[i];
+}
+// P[chunk][k] = sum over the chunk's rows of dy[e] A[e][k] B[e][k]   (then part_reduce_kernel adds the chunks into dw)
+__global__ __launch_bounds__(256) void rowdot_dw_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ dy,
+                                                        float* __restrict__ P, int64_t rows, int K, int rows_per) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += dy[r] * A[r * K + k] * Bm[r * K + k];
+    P[(size_t)blockIdx.y * K + k] = s;
+}
+
+// ---- heads -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3(const float* L, float* I) {
+    const float a = L[0], b = L[1], c = L[2], d = L[3], e = L[4], f = L[5], g = L[6], h = L[7], i = L[8];
+    const float A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+    const float det = a * A + b * Bc + c * C, id = 1.0f / det;
+    I[0] = A * id;
+    I[1] = -(b * i - c * h) * id;
+    I[2] = (b * f - c * e) * id;
+    I[3] = Bc * id;
+    I[4] = (a * i - c * g) * id;
+    I[5] = -(a * f - c * d) * id;
+    I[6] = C * id;
+    I[7] = -(a * h - b * g) * id;
+    I[8] = (a * e - b * d) * id;
+}
+// pos[a] = (sum_{e into a} F[e] V[e]) @ inv(L)
+__global__ void force_fwd_kernel(const float* __restrict__ F, const float* __restrict__ V, const int* __restrict__ rowptr, const int* __restrict__ n2g,
+                                 const float* __restrict__ cell, float* __restrict__ pos, int N) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N) return;
+    float f[3] = {0.f, 0.f, 0.f};
+    for (int e = rowptr[a]; e < rowptr[a + 1]; ++e) {
+        const float s = F[e];
+        f[0] += s * V[(size_t)e * 3];
+        f[1] += s * V[(size_t)e * 3 + 1];
+        f[2] += s * V[(size_t)e * 3 + 2];
+    }
+    float I[9];
+    inv3(cell + (size_t)n2g[a] * 9, I);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pos[(size_t)a * 3 + c] = f[0] * I[c] + f[1] * I[3 + c] + f[2] * I[6 + c];
+}
+// dF[e] += (dpos[dst] @ inv(L)^T) . V[e]
+__global__ void force_bwd_kernel(const float* __restrict__ dpos, const float* __restrict__ V, const int* __restrict__ dst, const int* __restrict__ n2g,
+                                 const float* __restrict__ cell, float* __restrict__ dF, int64_t E) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int a = dst[e];
+    float I[9];
+    inv3(cell + (size_t)n2g[a] * 9, I);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float df = dpos[(size_t)a * 3] * I[c * 3] + dpos[(size_t)a * 3 + 1] * I[c * 3 + 1] + dpos[(size_t)a * 3 + 2] * I[c * 3 + 2];
+        s += df * V[(size_t)e * 3 + c];
+    }
+    dF[e] += s;
+}
+// stress[b] = (1 / max(E_b, 1)) sum_{e in crystal b} Sc[e] V[e] (x) V[e]
+__global__ __launch_bounds__(256) void stress_fwd_kernel(const float* __restrict__ Sc, const float* __restrict__ V, const int* __restrict__ rowptr,
+                                                         const int* __restrict__ node_off, float* __restrict__ out) {
+    __shared__ float red[4][9];
+    const int b = blockIdx.x, e0 = rowptr[node_off[b]], e1 = rowptr[node_off[b + 1]], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = 0.f;
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const float w = Sc[e], x = V[(size_t)e * 3], y = V[(size_t)e * 3 + 1], z = V[(size_t)e * 3 + 2];
+        const float v[3] = {x, y, z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s[i * 3 + j] += w * v[i] * v[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const float r = wave_sum(s[q]);
+        if (lane == 0) red[wave][q] = r;
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const float cnt = (float)(e1 - e0 > 0 ? e1 - e0 : 1);
+        out[(size_t)b * 9 + tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / cnt;
+    }
+}
+__global__ void stress_bwd_kernel(const float* __restrict__ dS, const float* __restrict__ V, const int* __restrict__ edge_graph,
+                                  const int* __restrict__ rowptr, const int* __restrict__ node_off, float* __restrict__ dSc, int64_t E) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int b = edge_graph[e];
+    const int cnt = rowptr[node_off[b + 1]] - rowptr[node_off[b]];
+    const float v[3] = {V[(size_t)e * 3], V[(size_t)e * 3 + 1], V[(size_t)e * 3 + 2]};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s += dS[(size_t)b * 9 + i * 3 + j] * v[i] * v[j];
+    dSc[e] += s / (float)(cnt > 0 ? cnt : 1);
+}
+// W [rows][cols] (row stride cols) -> WT [cols][ldt]
+__global__ void gn_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int rows, int cols, int ldt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    WT[(size_t)c * ldt + r] = W[i];
+}
+__global__ void copy_ld_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int64_t rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    Y[(i / cols) * ldy + i % cols] = X[(i / cols) * ldx + i % cols];
+}
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace mi
+
+// ================================================================================================================================
+// host objects
+// ================================================================================================================================
+struct GParam {
+    std::string name;
+    int64_t off, numel, toff;  // toff: offset of the transposed copy
+    int rows, cols, ldt;
+};
+
+struct mi_gemnet {
+    mi_gemnet_config cfg;
+    std::vector<GParam> params;
+    std::map<std::string, int> index;
+    int64_t nparams = 0, ntrans = 0;
+    const float* theta = nullptr;
+    float* thetaT = nullptr;
+    const GParam& P(const std::string& n) const {
+        auto it = index.find(n);
+        if (it == index.end()) {
+            fprintf(stderr, "matinvent_hip: unknown gemnet parameter %s\n", n.c_str());
+            abort();
+        }
+        return params[it->second];
+    }
+};
+
+enum { OP_DENSE = 1, OP_MUL, OP_AXPBY, OP_SEGSUM, OP_TRIPLET, OP_ROWDOT, OP_EMBED, OP_FORCE, OP_STRESS };
+enum { GK_NONE = 0, GK_SRC = 1, GK_DST = 2, GK_NODE = 3 };
+
+struct GOp {
+    int type = 0;
+    const float *X = nullptr, *X2 = nullptr;  // inputs (arena or constant)
+    float *Y = nullptr, *Z = nullptr;         // output, saved pre-activation
+    int64_t M = 0;
+    int N = 0, K = 0, ldy = 0;
+    // dense
+    int pidx = -1, wcol0 = 0, bidx = -1, act = 0;
+    bool x_grad = true;
+    const float *G1 = nullptr, *G2 = nullptr;
+    int gk1 = 0, gk2 = 0;
+    // axpby / rowdot
+    float s = 1.f;
+    bool perm = false;
+    int widx = -1;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, top = 0;
+    float* take(size_t nfloats) {
+        const size_t bytes = (nfloats * sizeof(float) + 255) / 256 * 256;
+        float* p = reinterpret_cast<float*>(base + top);
+        top += bytes;
+        return p;
+    }
+};
+
+struct mi_gbatch {
+    int B = 0, N = 0;
+    int64_t E = 0, E_cap = 0;
+    int64_t node_offset = 0, graph_offset = 0;
+    std::vector<int> num_atoms_h, node_off_h;
+    int *num_atoms = nullptr, *node_off = nullptr, *node2graph = nullptr;
+    // graph
+    int cap = 0, R_img = 0;
+    int *ent = nullptr, *acnt = nullptr, *deg = nullptr, *mcount = nullptr, *meta = nullptr, *rowptr = nullptr, *src = nullptr, *dst = nullptr,
+        *code = nullptr, *ekey = nullptr, *swap = nullptr, *edge_graph = nullptr;
+    float *D = nullptr, *V = nullptr;
+    // runtime
+    Arena fwd, grad;
+    float* scratch = nullptr;  // dZ buffer [E][max N] + reduction scratch
+    size_t scratch_floats = 0, dz_floats = 0;
+    std::vector<GOp> tape;
+    bool tape_valid = false;
+    std::map<std::string, std::pair<const float*, int64_t>> taps;
+    float *out_pos = nullptr, *out_cell = nullptr, *out_logits = nullptr, *Fe = nullptr, *Se = nullptr;  // arena pointers of the last forward
+    const int* types_in = nullptr;   // inputs of the last training forward (device copies)
+    int* types_copy = nullptr;
+    float *pos_copy = nullptr, *cell_copy = nullptr, *t_buf = nullptr;
+    // sampler scratch
+    float *sp_pos = nullptr, *sp_cell = nullptr, *sp_logits = nullptr, *ts_dev = nullptr;
+    std::vector<float> ts_h;
+    std::vector<void*> allocs;
+};
+
+namespace mi {
+
+template <typename T>
+static int galloc(mi_gbatch* b, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return MI_ENOMEM;
+    }
+    b->allocs.push_back(q);
+    *p = (T*)q;
+    return MI_OK;
+}
+
+static int arena_ensure(Arena& a, size_t bytes) {
+    if (a.cap >= bytes) return MI_OK;
+    if (a.base) (void)hipFree(a.base);
+    a.base = nullptr;
+    a.cap = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for the activation arena failed: %s", want, hipGetErrorString(e));
+        return MI_ENOMEM;
+    }
+    a.base = (char*)q;
+    a.cap = want;
+    return MI_OK;
+}
+
+// ---- the program ---------------------------------------------------------------------------------------------------------------
+struct Ctx {
+    mi_gemnet* net;
+    mi_gbatch* b;
+    hipStream_t s;
+    bool dry, train;
+    int rc = MI_OK;
+    float* take(size_t n) { return b->fwd.take(n); }
+    const int* gidx(int kind) const { return kind == GK_SRC ? b->src : kind == GK_DST ? b->dst : b->node2graph; }
+};
+
+#define CTX_OK(c) ((c).rc == MI_OK)
+#define MI_HIP_VOID(call)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            mi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            c.rc = MI_EHIP;                                                                 \
+        }                                                                                   \
+    } while (0)
+#define CTX_TRY(c, expr)                      \
+    do {                                      \
+        if ((c).rc == MI_OK) (c).rc = (expr); \
+    } while (0)
+
+static inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+// Y[M,N] = act( X[M,K] W[:, wcol0 : wcol0+K]^T + bias + G1[idx1] + G2[idx2] )
+static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::string& wname, int wcol0 = 0, int act = ACT_NONE, bool x_grad = true,
+                       const std::string& bname = "", const float* G1 = nullptr, int gk1 = GK_NONE, const float* G2 = nullptr, int gk2 = GK_NONE,
+                       int ldy = 0) {
+    const GParam& w = c.net->P(wname);
+    const int N = w.rows;
+    if (ldy == 0) ldy = N;
+    float* Y = c.take((size_t)M * ldy);
+    float* Z = (act != ACT_NONE && c.train) ? c.take((size_t)M * N) : nullptr;
+    if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    GemmEpilogue ep;
+    if (!bname.empty()) ep.bias = c.net->theta + c.net->P(bname).off;
+    if (G1) {
+        ep.row_bias = G1;
+        ep.row_group = c.gidx(gk1);
+        ep.ld_row_bias = N;
+    }
+    if (G2) {
+        ep.row_bias2 = G2;
+        ep.row_group2 = c.gidx(gk2);
+        ep.ld_row_bias2 = N;
+    }
+    ep.act = act;
+    if (Z) {
+        ep.pre_act = Z;
+        ep.ld_pre = N;
+    }
+    if (ldy != N) MI_HIP_VOID(hipMemsetAsync(Y, 0, (size_t)M * ldy * sizeof(float), c.s));
+    CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
+    if (c.train) {
+        GOp o;
+        o.type = OP_DENSE;
+        o.X = X;
+        o.Y = Y;
+        o.Z = Z;
+        o.M = M;
+        o.N = N;
+        o.K = K;
+        o.ldy = ldy;
+        o.pidx = c.net->index.at(wname);
+        o.wcol0 = wcol0;
+        o.bidx = bname.empty() ? -1 : c.net->index.at(bname);
+        o.act = act;
+        o.x_grad = x_grad;
+        o.G1 = G1;
+        o.G2 = G2;
+        o.gk1 = gk1;
+        o.gk2 = gk2;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
+static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N) {
+    float* Y = c.take((size_t)M * N);
+    if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    hipLaunchKernelGGL(mul_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, Y, M * N);
+    if (c.train) {
+        GOp o;
+        o.type = OP_MUL;
+        o.X = A;
+        o.X2 = Bm;
+        o.Y = Y;
+        o.M = M;
+        o.N = N;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
+static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool perm = false) {
+    float* Y = c.take((size_t)M * N);
+    if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y, M, N);
+    if (c.train) {
+        GOp o;
+        o.type = OP_AXPBY;
+        o.X = A;
+        o.X2 = Bm;
+        o.Y = Y;
+        o.M = M;
+        o.N = N;
+        o.s = GN_ISQ2;
+        o.perm = perm;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
+static float* op_segsum(Ctx& c, const float* X, int cols) {  // edges -> atoms by target
+    float* Y = c.take((size_t)c.b->N * cols);
+    if (c.dry || !CTX_OK(c)) return Y;
+    hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)c.b->N * cols)), dim3(256), 0, c.s, X, cols, c.b->rowptr, (const int*)nullptr, Y, c.b->N, cols, 0);
+    if (c.train) {
+        GOp o;
+        o.type = OP_SEGSUM;
+        o.X = X;
+        o.Y = Y;
+        o.M = c.b->E;
+        o.N = cols;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
+static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
+    const mi_gemnet_config& g = c.net->cfg;
+    const int64_t E = c.b->E;
+    float* Y = c.take((size_t)E * g.emb_cbf * g.emb_trip);
+    if (c.dry || !CTX_OK(c) || E == 0) return Y;
+    const size_t sh = (size_t)(GN_DEG * 3 + GN_DEG * g.emb_trip) * sizeof(float);
+#define TRIP_FWD(SS)                                                                                                                       \
+    case SS:                                                                                                                               \
+        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(256), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, Y, g.emb_trip, g.emb_cbf); \
+        break;
+    switch (g.num_spherical) {
+        TRIP_FWD(1) TRIP_FWD(2) TRIP_FWD(3) TRIP_FWD(4) TRIP_FWD(5) TRIP_FWD(6) TRIP_FWD(7) TRIP_FWD(8)
+        default: c.rc = MI_EINVAL;
+    }
+#undef TRIP_FWD
+    if (c.train) {
+        GOp o;
+        o.type = OP_TRIPLET;
+        o.X = xd;
+        o.X2 = cbfW;
+        o.Y = Y;
+        o.M = E;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
+static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string& wname, float* y, int K, bool acc) {
+    if (c.dry || !CTX_OK(c) || c.b->E == 0) return;
+    const GParam& w = c.net->P(wname);
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(nblk(c.b->E, 4)), dim3(256), 0, c.s, A, Bm, c.net->theta + w.off, y, c.b->E, K, acc ? 1 : 0);
+    if (c.train) {
+        GOp o;
+        o.type = OP_ROWDOT;
+        o.X = A;
+        o.X2 = Bm;
+        o.Y = y;
+        o.M = c.b->E;
+        o.K = K;
+        o.widx = c.net->index.at(wname);
+        c.b->tape.push_back(o);
+    }
+}
+
+static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W) {
+    for (int k = 0; k < n; ++k) {
+        const std::string p = prefix + "." + std::to_string(k);
+        float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU);
+        float* y2 = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU);
+        x = op_axpby(c, x, y2, M, W);
+    }
+    return x;
+}
+
+static void out_block(Ctx& c, int i, const float* m, const float* rbf_out, bool first) {
+    const mi_gemnet_config& g = c.net->cfg;
+    const int64_t E = c.b->E;
+    const int Ed = g.emb_edge;
+    const std::string p = "out_blocks." + std::to_string(i);
+    float* t1 = op_dense(c, m, E, Ed, p + ".dense_F.weight", 0, ACT_SSILU);
+    float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed);
+    float* rF = op_dense(c, rbf_out, E, g.emb_rbf, p + ".rbf_F.weight");
+    op_rowdot(c, xF, rF, p + ".out_F.weight", c.b->Fe, Ed, !first);
+    float* xS = op_dense(c, m, E, Ed, p + ".dense_S.weight", 0, ACT_SSILU);
+    float* rS = op_dense(c, rbf_out, E, g.emb_rbf, p + ".rbf_S.weight");
+    op_rowdot(c, xS, rS, p + ".out_S.weight", c.b->Se, Ed, !first);
+}
+
+// the whole denoiser; pos / cell / types / t are the (device) inputs
+static void run_program(Ctx& c, const float* pos, const float* cell, const int* types, const float* t) {
+    const mi_gemnet_config& g = c.net->cfg;
+    mi_gbatch* b = c.b;
+    const int A = g.emb_atom, Ed = g.emb_edge, R = g.num_radial, Rb = g.emb_rbf, S = g.num_spherical, Cb = g.emb_cbf, Tr = g.emb_trip;
+    const int64_t E = b->E;
+    const int N = b->N, B = b->B;
+    b->fwd.top = 0;
+    b->tape.clear();
+    b->taps.clear();
+    float* rbf = c.take((size_t)E * R);
+    float* z = c.take((size_t)B * A);
+    float* H0 = c.take((size_t)N * A);
+    b->Fe = c.take((size_t)E);
+    b->Se = c.take((size_t)E);
+    b->out_pos = c.take((size_t)N * 3);
+    b->out_cell = c.take((size_t)B * 9);
+    if (!c.dry && CTX_OK(c)) {
+        if (E > 0)
+            hipLaunchKernelGGL(edge_geom_rbf_kernel, dim3(nblk(E * R)), dim3(256), 0, c.s, pos, cell, b->src, b->dst, b->code, b->edge_graph, g.max_images,
+                               g.cutoff, R, E, b->D, b->V, rbf);
+        hipLaunchKernelGGL(nle_kernel, dim3(nblk((int64_t)B * A)), dim3(256), 0, c.s, t, z, B, A);
+        hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk((int64_t)N * A)), dim3(256), 0, c.s, c.net->theta + c.net->P("atom_emb.weight").off, types, H0, N, A);
+        if (c.train) {
+            GOp o;
+            o.type = OP_EMBED;
+            o.Y = H0;
+            o.M = N;
+            o.N = A;
+            b->tape.push_back(o);
+        }
+    }
+    float* ZP = op_dense(c, z, B, A, "atom_latent_emb.weight", A, ACT_NONE, false);
+    float* h = op_dense(c, H0, N, A, "atom_latent_emb.weight", 0, ACT_NONE, true, "atom_latent_emb.bias", ZP, GK_NODE);
+    float* HS = op_dense(c, h, N, A, "edge_emb.weight", 0);
+    float* HT = op_dense(c, h, N, A, "edge_emb.weight", A);
+    float* m = op_dense(c, rbf, E, R, "edge_emb.weight", 2 * A, ACT_SSILU, false, "", HS, GK_SRC, HT, GK_DST);
+    float* rbf3 = op_dense(c, rbf, E, R, "mlp_rbf3.weight", 0, ACT_NONE, false);
+    float* cbfW = op_dense(c, rbf, E, R, "mlp_cbf3.weight", 0, ACT_NONE, false);
+    float* rbf_h = op_dense(c, rbf, E, R, "mlp_rbf_h.weight", 0, ACT_NONE, false);
+    float* rbf_out = op_dense(c, rbf, E, R, "mlp_rbf_out.weight", 0, ACT_NONE, false);
+    b->taps["rbf"] = {rbf, E * R};
+    b->taps["h0"] = {h, (int64_t)N * A};
+    b->taps["m0"] = {m, E * Ed};
+    out_block(c, 0, m, rbf_out, true);
+    for (int i = 0; i < g.num_blocks; ++i) {
+        const std::string p = "int_blocks." + std::to_string(i);
+        float* x_ca = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU);
+        float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
+        float* rr = op_dense(c, rbf3, E, Rb, p + ".mlp_rbf.weight");
+        float* x_ba = op_mul(c, tb, rr, E, Ed);
+        float* xd = op_dense(c, x_ba, E, Ed, p + ".down_projection.weight");
+        float* Tm = op_triplet(c, xd, cbfW);
+        float* x3 = op_dense(c, Tm, E, Cb * Tr, p + ".bilinear.weight");
+        b->taps["x3_" + std::to_string(i)] = {x3, E * g.emb_bil};
+        float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU);
+        float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU);
+        float* x3b = op_axpby(c, u1, u2, E, Ed, true);
+        float* x = op_axpby(c, x_ca, x3b, E, Ed);
+        x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
+        m = op_axpby(c, m, x, E, Ed);
+        m = res_stack(c, p + ".after_skip", g.num_after_skip, m, E, Ed);
+        float* ru = op_dense(c, rbf_h, E, Rb, p + ".atom_update.rbf.weight");
+        float* mm = op_mul(c, m, ru, E, Ed);
+        float* h2 = op_segsum(c, mm, Ed);
+        h2 = op_dense(c, h2, N, Ed, p + ".atom_update.dense.weight", 0, ACT_SSILU);
+        h2 = res_stack(c, p + ".atom_update.res", g.num_atom, h2, N, A);
+        h = op_axpby(c, h, h2, N, A);
+        HS = op_dense(c, h, N, A, p + ".concat.weight", 0);
+        HT = op_dense(c, h, N, A, p + ".concat.weight", A);
+        float* m2 = op_dense(c, m, E, Ed, p + ".concat.weight", 2 * A, ACT_SSILU, true, "", HS, GK_SRC, HT, GK_DST);
+        m2 = res_stack(c, p + ".residual_m", g.num_concat, m2, E, Ed);
+        m = op_axpby(c, m, m2, E, Ed);
+        b->taps["h" + std::to_string(i + 1)] = {h, (int64_t)N * A};
+        b->taps["m" + std::to_string(i + 1)] = {m, E * Ed};
+        out_block(c, i + 1, m, rbf_out, false);
+    }
+    b->out_logits = op_dense(c, h, N, A, "fc_atom.weight", 0, ACT_NONE, true, "fc_atom.bias", nullptr, GK_NONE, nullptr, GK_NONE, LOGIT_LD);
+    if (!c.dry && CTX_OK(c)) {
+        if (E == 0) {
+            MI_HIP_VOID(hipMemsetAsync(b->Fe, 0, sizeof(float), c.s));
+        }
+        hipLaunchKernelGGL(force_fwd_kernel, dim3(nblk(N)), dim3(256), 0, c.s, b->Fe, b->V, b->rowptr, b->node2graph, cell, b->out_pos, N);
+        hipLaunchKernelGGL(stress_fwd_kernel, dim3(B), dim3(256), 0, c.s, b->Se, b->V, b->rowptr, b->node_off, b->out_cell);
+    }
+}
+
+static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, hipStream_t s) {
+    const mi_gemnet_config& g = net->cfg;
+    MI_HIP(hipMemsetAsync(b->meta, 0, 4 * sizeof(int), s));
+    GraphArgs ga{pos, cell, b->node_off, g.cutoff, g.max_neighbors, g.max_images, b->cap, b->ent, b->acnt, b->deg, b->mcount, b->meta};
+    hipLaunchKernelGGL(gg_select_kernel, dim3(b->B), dim3(256), 0, s, ga);
+    hipLaunchKernelGGL(gg_scan_kernel, dim3(1), dim3(1024), 0, s, b->deg, b->N, b->rowptr, b->meta);
+    EmitArgs ea{b->node_off, b->ent, b->acnt, b->rowptr, b->meta, b->cap, g.max_images, b->E_cap, b->src, b->dst, b->code, b->ekey, b->swap, b->edge_graph};
+    int nmax = 1;
+    for (int v : b->num_atoms_h) nmax = std::max(nmax, v);
+    hipLaunchKernelGGL(gg_emit_kernel, dim3(b->B), dim3(256), (size_t)nmax * b->cap * sizeof(int), s, ea);
+    MI_KERNEL_CHECK();
+    int meta[4];
+    MI_HIP(hipMemcpyAsync(meta, b->meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    MI_CHECK(meta[2] == 0, MI_ENOMEM, "periodic graph: capacity exceeded (flags %d: 1 = more than max_neighbors kept pairs of one atom, 2 = more than %d atoms "
+             "inside the cutoff even after shrinking it, 4 = in-degree above %d)", meta[2], GN_CAND, GN_DEG);
+    MI_CHECK((int64_t)meta[0] <= b->E_cap, MI_ENOMEM, "periodic graph: %d edges exceed the capacity %lld", meta[0], (long long)b->E_cap);
+    b->E = meta[0];
+    return MI_OK;
+}
+
+static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* types, const float* t, bool train, hipStream_t s) {
+    MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_gemnet_forward before mi_gemnet_set_params");
+    b->tape_valid = false;
+    MI_TRY(graph_build(net, b, pos, cell, s));
+    Ctx dry{net, b, s, true, train};
+    run_program(dry, pos, cell, types, t);
+    const size_t need = b->fwd.top;
+    MI_TRY(arena_ensure(b->fwd, need));
+    const mi_gemnet_config& g = net->cfg;
+    const size_t dz = (size_t)std::max<int64_t>(b->E, b->N) * std::max(std::max(g.emb_edge, g.emb_atom), LOGIT_LD);
+    const size_t red = (size_t)1 << 24;
+    if (b->scratch_floats < dz + red) {
+        if (b->scratch) (void)hipFree(b->scratch);
+        b->scratch = nullptr;
+        MI_HIP(hipMalloc((void**)&b->scratch, (dz + dz / 8 + red) * sizeof(float)));
+        b->scratch_floats = dz + dz / 8 + red;
+        b->dz_floats = dz + dz / 8;
+    }
+    if (train) {  // the backward re-reads the inputs the forward saw
+        MI_HIP(hipMemcpyAsync(b->types_copy, types, (size_t)b->N * sizeof(int), hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(b->cell_copy, cell, (size_t)b->B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        types = b->types_copy;
+    }
+    Ctx run{net, b, s, false, train};
+    run_program(run, pos, train ? b->cell_copy : cell, types, t);
+    MI_TRY(run.rc);
+    MI_KERNEL_CHECK();
+    b->tape_valid = train;
+    return MI_OK;
+}
+
+static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const float* d_cell, const float* d_logits, float* grad, hipStream_t s) {
+    MI_CHECK(b->tape_valid, MI_ESTATE, "mi_gemnet_backward without a pending training forward on this batch");
+    MI_CHECK(net->thetaT != nullptr, MI_ESTATE, "mi_gemnet_set_params must run before backward");
+    b->tape_valid = false;
+    MI_TRY(arena_ensure(b->grad, b->fwd.top));
+    MI_HIP(hipMemsetAsync(b->grad.base, 0, b->fwd.top, s));
+    auto G = [&](const float* p) -> float* {
+        if (!p) return nullptr;
+        const char* q = reinterpret_cast<const char*>(p);
+        if (q < b->fwd.base || q >= b->fwd.base + b->fwd.top) return nullptr;
+        return reinterpret_cast<float*>(b->grad.base + (q - b->fwd.base));
+    };
+    const mi_gemnet_config& g = net->cfg;
+    const int64_t E = b->E;
+    const int N = b->N, B = b->B;
+    float* dz = b->scratch;
+    float* red = b->scratch + b->dz_floats;
+    const size_t red_floats = b->scratch_floats - b->dz_floats;
+    // seeds: heads
+    if (d_pos && E > 0) hipLaunchKernelGGL(force_bwd_kernel, dim3(nblk(E)), dim3(256), 0, s, d_pos, b->V, b->dst, b->node2graph, b->cell_copy, G(b->Fe), E);
+    if (d_cell && E > 0)
+        hipLaunchKernelGGL(stress_bwd_kernel, dim3(nblk(E)), dim3(256), 0, s, d_cell, b->V, b->edge_graph, b->rowptr, b->node_off, G(b->Se), E);
+    if (d_logits)
+        hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)N * MI_MG_CLASSES)), dim3(256), 0, s, d_logits, MI_MG_CLASSES, G(b->out_logits), LOGIT_LD, (int64_t)N,
+                           MI_MG_CLASSES);
+    MI_KERNEL_CHECK();
+    for (int k = (int)b->tape.size() - 1; k >= 0; --k) {
+        const GOp& o = b->tape[k];
+        float* dY = G(o.Y);
+        switch (o.type) {
+            case OP_DENSE: {
+                if (o.M == 0) break;
+                const GParam& w = net->params[o.pidx];
+                const float* dZ = dY;
+                int ldz = o.ldy;
+                if (o.act != ACT_NONE) {
+                    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.ldy, o.Z, dz, o.M, o.N);
+                    dZ = dz;
+                    ldz = o.N;
+                }
+                if (o.bidx >= 0) MI_TRY(colsum_acc(dZ, ldz, grad + net->params[o.bidx].off, (int)o.M, o.N, red, red_floats, s));
+                for (int q = 0; q < 2; ++q) {
+                    const float* Gq = q == 0 ? o.G1 : o.G2;
+                    const int gk = q == 0 ? o.gk1 : o.gk2;
+                    if (!Gq) continue;
+                    float* dG = G(Gq);
+                    MI_CHECK(dG && ldz == o.N, MI_ESTATE, "gathered addend outside the arena");
+                    if (gk == GK_DST) hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)N * o.N)), dim3(256), 0, s, dZ, ldz, b->rowptr, (const int*)nullptr, dG, N, o.N, 1);
+                    else if (gk == GK_SRC) hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)N * o.N)), dim3(256), 0, s, dZ, ldz, b->rowptr, b->swap, dG, N, o.N, 1);
+                    else hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)B * o.N)), dim3(256), 0, s, dZ, ldz, b->node_off, (const int*)nullptr, dG, B, o.N, 1);
+                }
+                // dW[:, wcol0 : wcol0 + K] += dZ^T X
+                MI_TRY(gemm_tn_auto(dZ, ldz, o.X, o.K, grad + w.off + o.wcol0, w.cols, (int)o.M, o.N, o.K, red, red_floats, s));
+                float* dX = o.x_grad ? G(o.X) : nullptr;
+                if (dX) {  // dX += dZ W[:, wcol0 : wcol0 + K]  = dZ (W^T rows wcol0..)^T
+                    GemmEpilogue ep;
+                    ep.residual = dX;
+                    ep.ld_res = o.K;
+                    const int kk = (ldz == o.N) ? o.N : ldz;   // logits: the padded columns are zero on both sides
+                    MI_TRY(gemm_nt(dZ, ldz, net->thetaT + w.toff + (size_t)o.wcol0 * w.ldt, w.ldt, dX, o.K, (int)o.M, o.K, kk, ep, s));
+                }
+                break;
+            }
+            case OP_MUL:
+                hipLaunchKernelGGL(mul_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, o.X, o.X2, dY, G(o.X), G(o.X2), o.M * o.N);
+                break;
+            case OP_AXPBY:
+                hipLaunchKernelGGL(axpby_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.perm ? b->swap : (const int*)nullptr, o.s, G(o.X), G(o.X2), o.M, o.N);
+                break;
+            case OP_SEGSUM:
+                if (o.M > 0) hipLaunchKernelGGL(gather_add_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, b->dst, G(o.X), o.M, o.N);
+                break;
+            case OP_TRIPLET: {
+                if (o.M == 0) break;
+                const size_t sh = (size_t)(GN_DEG * 3 + GN_DEG * g.emb_trip + TCH * g.num_spherical * 64) * sizeof(float);
+#define TRIP_BWD(SS)                                                                                                                              \
+    case SS:                                                                                                                                      \
+        hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(256), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf); \
+        break;
+                switch (g.num_spherical) {
+                    TRIP_BWD(1) TRIP_BWD(2) TRIP_BWD(3) TRIP_BWD(4) TRIP_BWD(5) TRIP_BWD(6) TRIP_BWD(7) TRIP_BWD(8)
+                }
+#undef TRIP_BWD
+                break;
+            }
+            case OP_ROWDOT: {
+                if (o.M == 0) break;
+                const GParam& w = net->params[o.widx];
+                hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk(o.M * o.K)), dim3(256), 0, s, o.X, o.X2, net->theta + w.off, dY, G(o.X), G(o.X2), o.M, o.K);
+                int chunks = (int)std::min<int64_t>(512, (o.M + 255) / 256);
+                while ((size_t)chunks * o.K > red_floats) --chunks;
+                const int rows_per = (int)((o.M + chunks - 1) / chunks);
+                chunks = (int)((o.M + rows_per - 1) / rows_per);
+                hipLaunchKernelGGL(rowdot_dw_kernel, dim3(nblk(o.K), chunks), dim3(256), 0, s, o.X, o.X2, dY, red, o.M, o.K, rows_per);
+                hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(o.K, PART_REDUCE_COLS)), dim3(256), 0, s, red, chunks, o.K, grad + w.off, o.K);
+                break;
+            }
+            case OP_EMBED:
+                hipLaunchKernelGGL(embed_bwd_kernel, dim3(MI_MG_CLASSES), dim3(256), 0, s, dY, b->types_copy, grad + net->P("atom_emb.weight").off, N, (int)o.N);
+                break;
+            default: break;
+        }
+        MI_KERNEL_CHECK();
+    }
+    return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out) {
+    MI_CHECK(cfg && out, MI_EINVAL, "null argument");
+    const mi_gemnet_config& g = *cfg;
+    MI_CHECK(g.emb_atom % 4 == 0 && g.emb_edge % 4 == 0 && g.emb_trip % 4 == 0 && g.emb_rbf % 4 == 0 && g.emb_cbf >= 1 && g.emb_bil % 4 == 0 &&
+                 g.num_radial % 4 == 0 && g.num_radial >= 4,
+             MI_EINVAL, "embedding sizes and num_radial must be multiples of 4");
+    MI_CHECK(g.emb_trip <= 64 && g.num_spherical >= 1 && g.num_spherical <= 8 && g.emb_atom % 2 == 0, MI_EINVAL, "emb_trip <= 64, 1 <= num_spherical <= 8");
+    MI_CHECK((g.num_spherical * g.emb_cbf) % 4 == 0 && (g.emb_cbf * g.emb_trip) % 4 == 0, MI_EINVAL, "num_spherical * emb_cbf must be a multiple of 4");
+    MI_CHECK(g.max_images >= 1 && g.max_images <= 5 && g.max_neighbors >= 1 && g.max_neighbors <= 64 && g.cutoff > 0, MI_EINVAL,
+             "1 <= max_images <= 5, 1 <= max_neighbors <= 64, cutoff > 0");
+    MI_CHECK(g.emb_atom == g.emb_edge, MI_EINVAL, "emb_atom must equal emb_edge (the atom update maps edge sums to atom features at equal width)");
+    mi_gemnet* n = new mi_gemnet();
+    n->cfg = g;
+    int64_t off = 0, toff = 0;
+    auto add = [&](const std::string& name, int rows, int cols) {
+        GParam p;
+        p.name = name;
+        p.off = off;
+        p.numel = (int64_t)rows * cols;
+        p.rows = rows;
+        p.cols = cols;
+        p.ldt = (rows + 3) / 4 * 4;
+        p.toff = toff;
+        n->index[name] = (int)n->params.size();
+        n->params.push_back(p);
+        off += ((int64_t)rows * cols + 3) / 4 * 4;
+        toff += (int64_t)cols * p.ldt;
+    };
+    const int A = g.emb_atom, Ed = g.emb_edge, Tr = g.emb_trip, Rb = g.emb_rbf, Cb = g.emb_cbf, Bl = g.emb_bil, R = g.num_radial, S = g.num_spherical;
+    add("atom_emb.weight", MI_MG_CLASSES, A);
+    add("atom_latent_emb.weight", A, 2 * A);
+    add("atom_latent_emb.bias", 1, A);
+    add("edge_emb.weight", Ed, 2 * A + R);
+    add("mlp_rbf3.weight", Rb, R);
+    add("mlp_cbf3.weight", S * Cb, R);
+    add("mlp_rbf_h.weight", Rb, R);
+    add("mlp_rbf_out.weight", Rb, R);
+    auto res = [&](const std::string& prefix, int cnt, int width) {
+        for (int k = 0; k < cnt; ++k) {
+            add(prefix + "." + std::to_string(k) + ".0.weight", width, width);
+            add(prefix + "." + std::to_string(k) + ".1.weight", width, width);
+        }
+    };
+    auto outb = [&](int i) {
+        const std::string p = "out_blocks." + std::to_string(i);
+        add(p + ".dense_F.weight", Ed, Ed);
+        res(p + ".res_F", 1, Ed);
+        add(p + ".rbf_F.weight", Ed, Rb);
+        add(p + ".out_F.weight", 1, Ed);
+        add(p + ".dense_S.weight", Ed, Ed);
+        add(p + ".rbf_S.weight", Ed, Rb);
+        add(p + ".out_S.weight", 1, Ed);
+    };
+    outb(0);
+    for (int i = 0; i < g.num_blocks; ++i) {
+        const std::string p = "int_blocks." + std::to_string(i);
+        add(p + ".dense_ca.weight", Ed, Ed);
+        add(p + ".dense_ba.weight", Ed, Ed);
+        add(p + ".mlp_rbf.weight", Ed, Rb);
+        add(p + ".down_projection.weight", Tr, Ed);
+        add(p + ".bilinear.weight", Bl, Cb * Tr);
+        add(p + ".up_projection_ca.weight", Ed, Bl);
+        add(p + ".up_projection_ac.weight", Ed, Bl);
+        res(p + ".before_skip", g.num_before_skip, Ed);
+        res(p + ".after_skip", g.num_after_skip, Ed);
+        add(p + ".atom_update.rbf.weight", Ed, Rb);
+        add(p + ".atom_update.dense.weight", A, Ed);
+        res(p + ".atom_update.res", g.num_atom, A);
+        add(p + ".concat.weight", Ed, 2 * A + Ed);
+        res(p + ".residual_m", g.num_concat, Ed);
+        outb(i + 1);
+    }
+    add("fc_atom.weight", MI_MG_CLASSES, A);
+    add("fc_atom.bias", 1, MI_MG_CLASSES);
+    n->nparams = off;
+    n->ntrans = toff;
+    *out = n;
+    return MI_OK;
+}
+
+void mi_gemnet_destroy(mi_gemnet* net) {
+    if (!net) return;
+    if (net->thetaT) (void)hipFree(net->thetaT);
+    delete net;
+}
+int64_t mi_gemnet_num_params(const mi_gemnet* net) { return net ? net->nparams : 0; }
+int mi_gemnet_num_tensors(const mi_gemnet* net) { return net ? (int)net->params.size() : 0; }
+int mi_gemnet_param_info(const mi_gemnet* net, int index, const char** name, int64_t* offset, int64_t* numel, int* rows, int* cols) {
+    MI_CHECK(net && index >= 0 && index < (int)net->params.size(), MI_EINVAL, "parameter index out of range");
+    const GParam& p = net->params[index];
+    if (name) *name = p.name.c_str();
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (rows) *rows = p.rows;
+    if (cols) *cols = p.cols;
+    return MI_OK;
+}
+int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
+    MI_CHECK(net && theta, MI_EINVAL, "null argument");
+    MI_CHECK((((uintptr_t)theta) & 15) == 0, MI_EINVAL, "theta must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    net->theta = theta;
+    if (!net->thetaT) {
+        MI_HIP(hipMalloc((void**)&net->thetaT, (size_t)net->ntrans * sizeof(float)));
+        MI_HIP(hipMemsetAsync(net->thetaT, 0, (size_t)net->ntrans * sizeof(float), s));
+    }
+    for (const GParam& p : net->params) {
+        if (p.rows == 1) continue;  // biases and the row-dot weights are never a data-gradient operand
+        hipLaunchKernelGGL(gn_transpose_kernel, dim3(nblk(p.numel)), dim3(256), 0, s, theta + p.off, net->thetaT + p.toff, p.rows, p.cols, p.ldt);
+    }
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset, mi_gbatch** out) {
+    MI_CHECK(net && num_atoms_host && out && B >= 0, MI_EINVAL, "bad argument");
+    mi_gbatch* b = new mi_gbatch();
+    b->B = B;
+    b->node_offset = node_offset;
+    b->graph_offset = graph_offset;
+    b->num_atoms_h.assign(num_atoms_host, num_atoms_host + B);
+    b->node_off_h.assign(B + 1, 0);
+    for (int i = 0; i < B; ++i) {
+        if (num_atoms_host[i] < 0 || num_atoms_host[i] > GN_NMAX) {
+            set_error("mi_gbatch_create: %d atoms in crystal %d (supported: 0..%d)", num_atoms_host[i], i, GN_NMAX);
+            delete b;
+            return MI_EINVAL;
+        }
+        b->node_off_h[i + 1] = b->node_off_h[i] + num_atoms_host[i];
+    }
+    const int N = b->N = b->node_off_h[B];
+    b->cap = net->cfg.max_neighbors;
+    b->R_img = net->cfg.max_images;
+    b->E_cap = (int64_t)N * std::min(2 * net->cfg.max_neighbors, GN_DEG);
+    std::vector<int> n2g(N);
+    for (int i = 0; i < B; ++i)
+        for (int k = b->node_off_h[i]; k < b->node_off_h[i + 1]; ++k) n2g[k] = i;
+    int rc = MI_OK;
+#define GA(ptr, n)                                  \
+    if (rc == MI_OK) rc = galloc(b, &b->ptr, (size_t)(n))
+    GA(num_atoms, B);
+    GA(node_off, B + 1);
+    GA(node2graph, N);
+    GA(ent, (size_t)N * b->cap);
+    GA(acnt, N);
+    GA(deg, N);
+    GA(mcount, B);
+    GA(meta, 4);
+    GA(rowptr, N + 1);
+    GA(src, b->E_cap);
+    GA(dst, b->E_cap);
+    GA(code, b->E_cap);
+    GA(ekey, b->E_cap);
+    GA(swap, b->E_cap);
+    GA(edge_graph, b->E_cap);
+    GA(D, b->E_cap);
+    GA(V, b->E_cap * 3);
+    GA(types_copy, N);
+    GA(cell_copy, (size_t)B * 9);
+    GA(t_buf, B);
+    GA(sp_pos, (size_t)N * 3);
+    GA(sp_cell, (size_t)B * 9);
+    GA(sp_logits, (size_t)N * MI_MG_CLASSES);
+#undef GA
+    if (rc != MI_OK) {
+        mi_gbatch_destroy(b);
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    if (B > 0) e = hipMemcpy(b->num_atoms, num_atoms_host, B * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->node_off, b->node_off_h.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && N > 0) e = hipMemcpy(b->node2graph, n2g.data(), N * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(b->rowptr, 0, (N + 1) * sizeof(int));
+    if (e != hipSuccess) {
+        set_error("mi_gbatch_create: %s", hipGetErrorString(e));
+        mi_gbatch_destroy(b);
+        return MI_EHIP;
+    }
+    *out = b;
+    return MI_OK;
+}
+
+void mi_gbatch_destroy(mi_gbatch* b) {
+    if (!b) return;
+    for (void* p : b->allocs) (void)hipFree(p);
+    if (b->fwd.base) (void)hipFree(b->fwd.base);
+    if (b->grad.base) (void)hipFree(b->grad.base);
+    if (b->scratch) (void)hipFree(b->scratch);
+    if (b->ts_dev) (void)hipFree(b->ts_dev);
+    delete b;
+}
+
+int mi_gemnet_graph(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, void* stream, int64_t* num_edges) {
+    MI_CHECK(net && b && pos && cell, MI_EINVAL, "null argument");
+    if (b->N == 0) {
+        b->E = 0;
+        if (num_edges) *num_edges = 0;
+        return MI_OK;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    MI_TRY(graph_build(net, b, pos, cell, s));
+    if (b->E > 0) {  // D / V without the basis: reuse the geometry kernel with a one-column basis into scratch
+        float* tmp = nullptr;
+        MI_HIP(hipMalloc((void**)&tmp, (size_t)b->E * 4 * sizeof(float)));
+        hipLaunchKernelGGL(edge_geom_rbf_kernel, dim3(nblk(b->E * 4)), dim3(256), 0, s, pos, cell, b->src, b->dst, b->code, b->edge_graph, net->cfg.max_images,
+                           net->cfg.cutoff, 4, b->E, b->D, b->V, tmp);
+        MI_HIP(hipStreamSynchronize(s));
+        (void)hipFree(tmp);
+    }
+    if (num_edges) *num_edges = b->E;
+    return MI_OK;
+}
+
+__global__ void code_to_img_kernel(const int* __restrict__ code, int* __restrict__ img, int64_t E, int R) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int W = 2 * R + 1, c = code[e];
+    img[e * 3] = c / (W * W) - R;
+    img[e * 3 + 1] = (c / W) % W - R;
+    img[e * 3 + 2] = c % W - R;
+}
+
+int mi_gemnet_graph_read(const mi_gbatch* b, int* src, int* dst, int* img, int* swap, int* rowptr, float* D, float* V, void* stream) {
+    MI_CHECK(b, MI_EINVAL, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t E = (size_t)b->E;
+    if (src) MI_HIP(hipMemcpyAsync(src, b->src, E * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (dst) MI_HIP(hipMemcpyAsync(dst, b->dst, E * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (swap) MI_HIP(hipMemcpyAsync(swap, b->swap, E * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (rowptr) MI_HIP(hipMemcpyAsync(rowptr, b->rowptr, (size_t)(b->N + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (D) MI_HIP(hipMemcpyAsync(D, b->D, E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (V) MI_HIP(hipMemcpyAsync(V, b->V, E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (img && E > 0) {
+        hipLaunchKernelGGL(code_to_img_kernel, dim3(nblk((int64_t)E)), dim3(256), 0, s, b->code, img, (int64_t)E, b->R_img);
+    }
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* atomic_numbers, const float* t, float* out_pos,
+                      float* out_cell, float* out_logits, int train, void* stream) {
+    MI_CHECK(net && b && pos && cell && atomic_numbers && t, MI_EINVAL, "null argument");
+    if (b->N == 0 || b->B == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MI_TRY(forward_impl(net, b, pos, cell, atomic_numbers, t, train != 0, s));
+    if (out_pos) MI_HIP(hipMemcpyAsync(out_pos, b->out_pos, (size_t)b->N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_cell) MI_HIP(hipMemcpyAsync(out_cell, b->out_cell, (size_t)b->B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_logits)
+        hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)b->N * MI_MG_CLASSES)), dim3(256), 0, s, b->out_logits, LOGIT_LD, out_logits, MI_MG_CLASSES,
+                           (int64_t)b->N, MI_MG_CLASSES);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const float* d_cell, const float* d_logits, float* grad_theta, void* stream) {
+    MI_CHECK(net && b && grad_theta, MI_EINVAL, "null argument");
+    if (b->N == 0 || b->B == 0) return MI_OK;
+    return backward_impl(net, b, d_pos, d_cell, d_logits, grad_theta, (hipStream_t)stream);
+}
+
+int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream) {
+    MI_CHECK(b && name, MI_EINVAL, "null argument");
+    auto it = b->taps.find(name);
+    MI_CHECK(it != b->taps.end(), MI_EINVAL, "unknown tap %s", name);
+    if (numel) *numel = it->second.second;
+    if (out) {
+        MI_CHECK(capacity >= it->second.second, MI_EINVAL, "tap %s needs %lld floats", name, (long long)it->second.second);
+        MI_HIP(hipMemcpyAsync(out, it->second.first, (size_t)it->second.second * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return MI_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================================================
+// corruptions and the predictor-corrector sampler (oracle/mattergen_oracle.py: sample_marginal, pc_sample)
+// ================================================================================================================================
+namespace mi {
+
+__device__ __forceinline__ float mg_pos_std(const mi_mg_corruption& c, float t, int n) {
+    return powf(c.sigma_min, 1.0f - t) * powf(c.sigma_max, t) * powf((float)n, -1.0f / 3.0f);
+}
+__device__ __forceinline__ float mg_alpha(const mi_mg_corruption& c, float t) {
+    return expf(-0.5f * (t * c.beta_min + 0.5f * t * t * (c.beta_max - c.beta_min)));
+}
+__device__ __forceinline__ float mg_tau(const mi_mg_corruption& c, float t) {
+    return fminf(fmaxf(ceilf(t * (float)c.d3pm_steps - 1e-6f), 1.0f), (float)c.d3pm_steps);
+}
+// entry q = 3 i + j of the symmetric noise made of the 9 normals G: diagonal kept, off-diagonal (G_ij + G_ji) / sqrt(2)
+__device__ __forceinline__ float sym_entry(const float* G, int q) {
+    const int i = q / 3, j = q % 3;
+    return i == j ? G[q] : (G[i * 3 + j] + G[j * 3 + i]) * GN_ISQ2;
+}
+
+struct MargArgs {
+    const float *pos0, *cell0;
+    const int* types0;
+    const float* t;
+    const int* node_off;
+    mi_mg_corruption c;
+    uint64_t seed;
+    uint32_t step;
+    int64_t node_offset, graph_offset;
+    const float *npos, *ncell, *ntypes;
+    float *pos, *cell;
+    int* types;
+    float *delta, *eps;
+    int* masked;
+};
+__global__ __launch_bounds__(64) void mg_marginal_kernel(MargArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x, n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    const float t = a.t[b];
+    const float std = mg_pos_std(a.c, t, n > 0 ? n : 1);
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64) {
+        const float z = a.npos ? a.npos[idx] : philox_normal1(a.seed, a.step, DRAW_MG_POS, (uint64_t)a.node_offset * 3 + idx);
+        const float d = std * z;
+        a.delta[idx] = d;
+        a.pos[idx] = pymod1(a.pos0[idx] + d);
+    }
+    __shared__ float G[9];
+    if (lane < 9) G[lane] = a.ncell ? a.ncell[b * 9 + lane] : philox_normal1(a.seed, a.step, DRAW_MG_CELL, (uint64_t)a.graph_offset * 9 + b * 9 + lane);
+    __syncthreads();
+    if (lane < 9) {
+        const float alpha = mg_alpha(a.c, t), nf = (float)(n > 0 ? n : 1);
+        const float mu = powf(nf / a.c.limit_density, 1.0f / 3.0f), kap = sqrtf(a.c.limit_var_scale) * powf(nf, 1.0f / 3.0f);
+        const float e = sym_entry(G, lane);
+        a.eps[b * 9 + lane] = e;
+        a.cell[b * 9 + lane] = alpha * a.cell0[b * 9 + lane] + (1.0f - alpha) * mu * (lane % 4 == 0 ? 1.f : 0.f) + sqrtf(1.0f - alpha * alpha) * kap * e;
+    }
+    const float frac = mg_tau(a.c, t) / (float)a.c.d3pm_steps;
+    for (int i = n0 + lane; i < n1; i += 64) {
+        const float u = a.ntypes ? a.ntypes[i] : philox_uniform1(a.seed, a.step, DRAW_MG_TYPES, (uint64_t)a.node_offset + i);
+        const int mk = u < frac;
+        a.masked[i] = mk;
+        a.types[i] = mk ? MI_MG_MASK : a.types0[i];
+    }
+}
+
+struct InitArgs {
+    const int* node_off;
+    mi_mg_corruption c;
+    uint64_t seed;
+    int64_t node_offset, graph_offset;
+    const float *ipos, *icell;
+    float *pos, *cell;
+    int* types;
+};
+__global__ __launch_bounds__(64) void mg_init_kernel(InitArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x, n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64)
+        a.pos[idx] = pymod1(a.ipos ? a.ipos[idx] : philox_uniform1(a.seed, 0u, DRAW_MG_INIT_POS, (uint64_t)a.node_offset * 3 + idx));
+    __shared__ float G[9];
+    if (lane < 9) G[lane] = a.icell ? a.icell[b * 9 + lane] : philox_normal1(a.seed, 0u, DRAW_MG_INIT_CELL, (uint64_t)a.graph_offset * 9 + b * 9 + lane);
+    __syncthreads();
+    if (lane < 9) {
+        const float nf = (float)(n > 0 ? n : 1);
+        const float mu = powf(nf / a.c.limit_density, 1.0f / 3.0f), kap = sqrtf(a.c.limit_var_scale) * powf(nf, 1.0f / 3.0f);
+        a.cell[b * 9 + lane] = mu * (lane % 4 == 0 ? 1.f : 0.f) + kap * sym_entry(G, lane);
+    }
+    for (int i = n0 + lane; i < n1; i += 64) a.types[i] = MI_MG_MASK;
+}
+
+struct StepArgs {
+    const int* node_off;
+    mi_mg_corruption c;
+    uint64_t seed;
+    uint32_t step;         // Philox counter step = i + 1
+    int64_t node_offset, graph_offset;
+    float t, dt;
+    int last;              // 1 on the final grid point: the next std is zero
+    const float *out_pos, *out_cell, *out_logits;   // denoiser outputs (logits row stride MI_MG_CLASSES)
+    const float *n_pos, *n_cell, *n_u1, *n_u2;      // injected noise slices or NULL
+    float *pos, *cell;
+    int* types;
+    float *mean_pos, *mean_cell;
+};
+// Langevin corrector with a per-crystal signal-to-noise step size: step = 2 (snr |z| / |score|)^2, x += step score + sqrt(2 step) z
+__global__ __launch_bounds__(64) void mg_corrector_kernel(StepArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x, n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    const float stdp = mg_pos_std(a.c, a.t, n > 0 ? n : 1);
+    float zz = 0.f, ss = 0.f, zv[3], sv[3];
+    int cnt = 0;
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64, ++cnt) {
+        const float z = a.n_pos ? a.n_pos[idx] : philox_normal1(a.seed, a.step, DRAW_MG_CORR_POS, (uint64_t)a.node_offset * 3 + idx);
+        const float sc = a.out_pos[idx] / stdp;
+        zv[cnt] = z;
+        sv[cnt] = sc;
+        zz += z * z;
+        ss += sc * sc;
+    }
+    zz = wave_sum(zz);
+    ss = wave_sum(ss);
+    float r = 0.4f * sqrtf(zz) / fmaxf(sqrtf(ss), 1e-12f);
+    float step = fminf(2.0f * r * r, 1e6f);
+    cnt = 0;
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64, ++cnt) a.pos[idx] = pymod1(a.pos[idx] + step * sv[cnt] + sqrtf(2.0f * step) * zv[cnt]);
+    __shared__ float G[9];
+    if (lane < 9) G[lane] = a.n_cell ? a.n_cell[b * 9 + lane] : philox_normal1(a.seed, a.step, DRAW_MG_CORR_CELL, (uint64_t)a.graph_offset * 9 + b * 9 + lane);
+    __syncthreads();
+    const float alpha = mg_alpha(a.c, a.t), nf = (float)(n > 0 ? n : 1);
+    const float kap = sqrtf(a.c.limit_var_scale) * powf(nf, 1.0f / 3.0f), stdc = sqrtf(1.0f - alpha * alpha) * kap;
+    float zc = 0.f, sc = 0.f;
+    if (lane < 9) {
+        zc = sym_entry(G, lane);
+        sc = a.out_cell[b * 9 + lane] / stdc;
+    }
+    const float zn = wave_sum(zc * zc), sn = wave_sum(sc * sc);
+    r = 0.2f * sqrtf(zn) / fmaxf(sqrtf(sn), 1e-12f);
+    step = fminf(2.0f * r * r, 1e6f);
+    if (lane < 9) a.cell[b * 9 + lane] = a.cell[b * 9 + lane] + step * sc + sqrtf(2.0f * step) * zc;
+}
+// ancestral predictor: positions (wrapped VE), cell (VP towards the limit mean), types (D3PM absorbing: a masked atom is revealed
+// with probability 1 / tau, drawing its element from the softmax over the 100 element logits)
+__global__ __launch_bounds__(64) void mg_predictor_kernel(StepArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x, n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
+    const int nn = n > 0 ? n : 1;
+    const float stdp = mg_pos_std(a.c, a.t, nn), tn = fmaxf(a.t - a.dt, 0.f), stdn = a.last ? 0.f : mg_pos_std(a.c, tn, nn);
+    const float var_d = stdp * stdp - stdn * stdn, nstd = sqrtf(stdn * stdn * var_d / (stdp * stdp));
+    for (int idx = n0 * 3 + lane; idx < n1 * 3; idx += 64) {
+        const float z = a.n_pos ? a.n_pos[idx] : philox_normal1(a.seed, a.step, DRAW_MG_PRED_POS, (uint64_t)a.node_offset * 3 + idx);
+        const float mean = a.pos[idx] + var_d * (a.out_pos[idx] / stdp);
+        a.mean_pos[idx] = pymod1(mean);
+        a.pos[idx] = pymod1(mean + nstd * z);
+    }
+    __shared__ float G[9];
+    if (lane < 9) G[lane] = a.n_cell ? a.n_cell[b * 9 + lane] : philox_normal1(a.seed, a.step, DRAW_MG_PRED_CELL, (uint64_t)a.graph_offset * 9 + b * 9 + lane);
+    __syncthreads();
+    if (lane < 9) {
+        const float alpha = mg_alpha(a.c, a.t), nf = (float)nn;
+        const float mu = powf(nf / a.c.limit_density, 1.0f / 3.0f), kap = sqrtf(a.c.limit_var_scale) * powf(nf, 1.0f / 3.0f);
+        const float stdc = sqrtf(1.0f - alpha * alpha) * kap;
+        const float bd = (a.c.beta_min + a.t * (a.c.beta_max - a.c.beta_min)) * a.dt;
+        const float L = a.cell[b * 9 + lane], sc = a.out_cell[b * 9 + lane] / stdc;
+        const float mean = L + 0.5f * bd * (L - mu * (lane % 4 == 0 ? 1.f : 0.f)) + bd * (kap * kap) * sc;
+        a.mean_cell[b * 9 + lane] = mean;
+        a.cell[b * 9 + lane] = mean + sqrtf(bd) * kap * sym_entry(G, lane);
+    }
+    const float inv_tau = 1.0f / mg_tau(a.c, a.t);
+    for (int i = n0 + lane; i < n1; i += 64) {
+        if (a.types[i] != MI_MG_MASK) continue;
+        const float u1 = a.n_u1 ? a.n_u1[i] : philox_uniform1(a.seed, a.step, DRAW_MG_PRED_U1, (uint64_t)a.node_offset + i);
+        if (!(u1 < inv_tau)) continue;
+        const float u2 = a.n_u2 ? a.n_u2[i] : philox_uniform1(a.seed, a.step, DRAW_MG_PRED_U2, (uint64_t)a.node_offset + i);
+        const float* lg = a.out_logits + (size_t)i * MI_MG_CLASSES;
+        float mx = lg[0];
+        for (int k = 1; k < MI_MG_CLASSES - 1; ++k) mx = fmaxf(mx, lg[k]);
+        float den = 0.f;
+        for (int k = 0; k < MI_MG_CLASSES - 1; ++k) den += expf(lg[k] - mx);
+        float cdf = 0.f;
+        int draw = 0;
+        for (int k = 0; k < MI_MG_CLASSES - 1; ++k) {
+            cdf += expf(lg[k] - mx) / den;
+            draw += u2 >= cdf;
+        }
+        a.types[i] = (draw > MI_MG_CLASSES - 2 ? MI_MG_CLASSES - 2 : draw) + 1;
+    }
+}
+
+}  // namespace mi
+
+extern "C" {
+
+int mi_mg_sample_marginal(mi_gbatch* b, const mi_mg_corruption* c, const float* pos0, const float* cell0, const int* types0, const float* t, uint64_t seed,
+                          uint32_t step, const float* noise_pos, const float* noise_cell, const float* noise_types, float* pos, float* cell, int* types,
+                          float* delta, float* eps, int* masked, void* stream) {
+    MI_CHECK(b && c && pos0 && cell0 && types0 && t && pos && cell && types && delta && eps && masked, MI_EINVAL, "null argument");
+    if (b->B == 0) return MI_OK;
+    MargArgs a{pos0, cell0, types0, t, b->node_off, *c, seed, step, b->node_offset, b->graph_offset, noise_pos, noise_cell, noise_types, pos, cell, types,
+               delta, eps, masked};
+    hipLaunchKernelGGL(mg_marginal_kernel, dim3(b->B), dim3(64), 0, (hipStream_t)stream, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_mg_sampler_init(mi_gbatch* b, const mi_mg_corruption* c, uint64_t seed, const float* init_pos, const float* init_cell, float* pos, float* cell,
+                       int* types, void* stream) {
+    MI_CHECK(b && c && pos && cell && types, MI_EINVAL, "null argument");
+    if (b->B == 0) return MI_OK;
+    InitArgs a{b->node_off, *c, seed, b->node_offset, b->graph_offset, init_pos, init_cell, pos, cell, types};
+    hipLaunchKernelGGL(mg_init_kernel, dim3(b->B), dim3(64), 0, (hipStream_t)stream, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+int mi_mg_sampler_run(mi_gemnet* net, mi_gbatch* b, const mi_mg_corruption* c, int n_steps, int i_start, int i_stop, const float* ts_host, uint64_t seed,
+                      const mi_mg_sampler_noise* noise, float* pos, float* cell, int* types, float* mean_pos, float* mean_cell, void* stream) {
+    MI_CHECK(net && b && c && ts_host && pos && cell && types && mean_pos && mean_cell, MI_EINVAL, "null argument");
+    MI_CHECK(n_steps >= 1 && i_start >= 0 && i_stop <= n_steps && i_start <= i_stop, MI_EINVAL, "bad step range");
+    if (b->B == 0 || b->N == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = b->N, B = b->B;
+    const float dt = n_steps > 1 ? ts_host[0] - ts_host[1] : ts_host[0];
+    for (int i = i_start; i < i_stop; ++i) {
+        const float t = ts_host[i];
+        hipLaunchKernelGGL(fill_kernel, dim3(nblk(B)), dim3(256), 0, s, b->t_buf, t, (int64_t)B);
+        StepArgs a;
+        a.node_off = b->node_off;
+        a.c = *c;
+        a.seed = seed;
+        a.step = (uint32_t)(i + 1);
+        a.node_offset = b->node_offset;
+        a.graph_offset = b->graph_offset;
+        a.t = t;
+        a.dt = dt;
+        a.last = i + 1 >= n_steps;
+        a.out_pos = b->sp_pos;
+        a.out_cell = b->sp_cell;
+        a.out_logits = b->sp_logits;
+        a.pos = pos;
+        a.cell = cell;
+        a.types = types;
+        a.mean_pos = mean_pos;
+        a.mean_cell = mean_cell;
+        // corrector
+        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, nullptr, 0, stream));
+        a.n_pos = noise && noise->corr_pos ? noise->corr_pos + (size_t)i * N * 3 : nullptr;
+        a.n_cell = noise && noise->corr_cell ? noise->corr_cell + (size_t)i * B * 9 : nullptr;
+        a.n_u1 = a.n_u2 = nullptr;
+        hipLaunchKernelGGL(mg_corrector_kernel, dim3(B), dim3(64), 0, s, a);
+        // predictor
+        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, b->sp_logits, 0, stream));
+        a.n_pos = noise && noise->pred_pos ? noise->pred_pos + (size_t)i * N * 3 : nullptr;
+        a.n_cell = noise && noise->pred_cell ? noise->pred_cell + (size_t)i * B * 9 : nullptr;
+        a.n_u1 = noise && noise->pred_u1 ? noise->pred_u1 + (size_t)i * N : nullptr;
+        a.n_u2 = noise && noise->pred_u2 ? noise->pred_u2 + (size_t)i * N : nullptr;
+        hipLaunchKernelGGL(mg_predictor_kernel, dim3(B), dim3(64), 0, s, a);
+        MI_KERNEL_CHECK();
+    }
+    return MI_OK;
+}
+
+}  // extern "C"

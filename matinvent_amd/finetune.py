@@ -154,6 +154,9 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     rank, world = rank_world()
     n_global = len(data_list)
     lo, hi = shard_range(n_global, rank, world)
+    if hasattr(agent, "collate"):   # MatterGen-shaped module: its own records / collate, the reference's loop over the module surface
+        return _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, lr, accum_steps, epochs, timesteps, sigma, device, noise_fn,
+                                       log, rank)
     dataset = CrystalDataset(data_list, rewards)
     if hi == lo:
         # fewer crystals than ranks (the fine-tune set is top-k + replay and shrinks when the validity filter keeps few samples):
@@ -225,6 +228,53 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
         a = acc.tolist()  # the only host sync of the epoch
         from . import _lib
         _lib.check_saturation("ft_step")
+        d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
+        stats.append(d)
+        if rank == 0:
+            log(f"Epoch {epoch}: " + ", ".join(f"{k}: {v:.4f}" for k, v in d.items()))
+    return stats
+
+
+def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, lr, accum_steps, epochs, timesteps, sigma, device, noise_fn, log, rank):
+    """pipeline/mat_invent.py:136-189 literally, over the module surface (add_noise / calc_sample_loss / calc_kl_reg; the network is
+    one differentiable op with a hand-written backward), with the fused Adam on the flat parameter vector, device-side loss
+    accumulators and the data-parallel scaling / all-reduce of ft_step."""
+    theta = agent.decoder.theta
+    if hi == lo:
+        return _ft_step_empty_shard(agent, n_global, lr, accum_steps, epochs, timesteps, log, rank)
+    batch = agent.collate(data_list[lo:hi], None if rewards is None else list(rewards[lo:hi])).to(device)
+    node_lo = sum(d.num_atoms for d in data_list[:lo])
+    agent.shard_offsets = prior.shard_offsets = (node_lo, lo)
+    optimizer = FusedAdam([theta], lr=lr)
+    stats = []
+    for epoch in range(epochs):
+        agent.train()
+        if theta.grad is not None:
+            optimizer.zero_grad(set_to_none=False)
+        acc = torch.zeros(3, device=device)
+        t = -1
+        for t in range(timesteps):
+            noise = None if noise_fn is None else noise_fn(epoch, t)
+            noised = agent.add_noise(batch, t, noise=noise)                       # :152
+            sample_loss, agent_pred = agent.calc_sample_loss(noised)              # :153
+            with torch.no_grad():
+                _, prior_pred = prior.calc_sample_loss(noised)                    # :154
+            loss_diff = batch.reward * sample_loss                                # :158
+            loss_kl = agent.calc_kl_reg(agent_pred, prior_pred, batch) * (1.1 - batch.reward)   # :160-161
+            loss = (loss_diff + loss_kl * sigma).sum() / (n_global * accum_steps)  # == .mean() / accum_steps (:163)
+            loss.backward()
+            with torch.no_grad():
+                acc += torch.stack([loss.detach() * accum_steps, loss_diff.detach().sum(), loss_kl.detach().sum()])
+            if (t + 1) % accum_steps == 0:                                        # :165-167
+                allreduce_flat_(theta.grad)
+                optimizer.step()
+                optimizer.zero_grad(set_to_none=False)
+        if (t + 1) % accum_steps != 0:                                            # :176-177
+            allreduce_flat_(theta.grad)
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=False)
+        allreduce_flat_(acc)
+        a = acc.tolist()
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:

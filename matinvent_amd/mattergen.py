@@ -1,0 +1,492 @@
+"""MatterGen-shaped model on the HIP path: the surface of models/mattergen/{pl_module,loss,sample,dataset}.py.
+
+PARITY UNPINNED.  The reference adapts the un-vendored package `mattergen @ 5bb2b397` (env.yml:31); its denoiser, corruptions,
+loss and sampler cannot be inspected or imported here.  The arithmetic behind this module is the published GemNet-T / MatterGen
+description as restated in oracle/mattergen_oracle.py (the GPU tests compare the two); what follows the reference's OWN files:
+  * MatterGenModule.add_noise / calc_sample_loss / calc_kl_reg   (pl_module.py:55-102): the time grid
+    linspace(T_max, 1/1000, 1000)[timestep], per-sample loss, anchor penalty on pos / cell / atomic_numbers;
+  * SampleLoss weights {atomic_numbers 1, cell 1, pos 0.1}       (loss.py:22-26, 71-73);
+  * MatterGenSampler.generate returning the `mean` batch          (sample.py:49-50, 270-303);
+  * MatterGenDataset.from_samples fields                          (dataset.py:42-65).
+There is no CPU fallback: everything numeric runs in libmatinvent_hip.so (csrc/gemnet.hip).
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .cspnet import _ptr, _stream
+from .data import SimpleStructure, lattices_to_params_shape
+
+NUM_CLASSES, MASK = 101, 101
+WEIGHTS = dict(atomic_numbers=1.0, cell=1.0, pos=0.1)  # loss.py:22-26
+D3PM_LAMBDA = 0.01                                     # loss.py:15
+
+DEFAULT_GEMNET = dict(emb_atom=512, emb_edge=512, emb_trip=64, emb_rbf=16, emb_cbf=16, emb_bil=64, num_radial=128, num_spherical=7,
+                      num_blocks=4, num_before_skip=1, num_after_skip=2, num_concat=1, num_atom=3, max_neighbors=50, max_images=5, cutoff=7.0)
+DEFAULT_CORRUPTION = dict(sigma_min=0.005, sigma_max=5.0, beta_min=0.1, beta_max=20.0, limit_density=0.05771451654022283, limit_var_scale=0.25,
+                          d3pm_steps=1000)
+
+
+# ---- records ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class ChemGraph:
+    """One crystal as the MatterGen side passes it around (mattergen.common.data.chemgraph.ChemGraph): fractional positions,
+    3x3 cell, atomic numbers."""
+    pos: torch.Tensor              # [n, 3] fractional
+    cell: torch.Tensor             # [1, 3, 3]
+    atomic_numbers: torch.Tensor   # [n] long
+    num_atoms: int = 0
+    reward: Optional[torch.Tensor] = None
+
+    def __post_init__(self):
+        self.num_atoms = int(self.num_atoms) if self.num_atoms else int(self.pos.shape[0])
+        self.cell = self.cell.reshape(1, 3, 3)
+
+
+class ChemGraphBatch:
+    """collate() of ChemGraphs: contiguous atoms, `get_batch_idx` = atom -> crystal (the two methods the reference calls,
+    pl_module.py:64,94; loss.py:48,58)."""
+
+    def __init__(self, items: List[ChemGraph]):
+        self.num_graphs = len(items)
+        self.num_atoms = torch.tensor([d.num_atoms for d in items], dtype=torch.long)
+        self.batch = torch.repeat_interleave(torch.arange(self.num_graphs), self.num_atoms)
+        self.pos = torch.cat([d.pos.float() for d in items]) if items else torch.zeros(0, 3)
+        self.cell = torch.cat([d.cell.float().reshape(1, 3, 3) for d in items]) if items else torch.zeros(0, 3, 3)
+        self.atomic_numbers = torch.cat([d.atomic_numbers.long() for d in items]) if items else torch.zeros(0, dtype=torch.long)
+        if items and all(d.reward is not None for d in items):
+            self.reward = torch.cat([torch.as_tensor(d.reward).float().view(1) for d in items])
+
+    def get_batch_idx(self, field=None):
+        return self.batch
+
+    def get_batch_size(self):
+        return self.num_graphs
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
+    def to_data_list(self):
+        off = [0] + torch.cumsum(self.num_atoms, 0).tolist()
+        return [ChemGraph(self.pos[off[i]:off[i + 1]].cpu(), self.cell[i:i + 1].cpu(), self.atomic_numbers[off[i]:off[i + 1]].cpu(), int(self.num_atoms[i]))
+                for i in range(self.num_graphs)]
+
+
+def symmetrize_lattice(cell: torch.Tensor) -> torch.Tensor:
+    """The per-item transform MatterGenDataset applies before noising (dataset.py:14-16, [UPSTREAM-UNVERIFIED]): replace the cell
+    by the symmetric matrix with the same metric, S = sqrtm(L L^T) (same lengths and angles, a rotated frame).  Host glue."""
+    L = cell.double().reshape(-1, 3, 3)
+    w, U = torch.linalg.eigh(L @ L.transpose(1, 2))
+    S = U @ torch.diag_embed(torch.sqrt(w.clamp(min=0))) @ U.transpose(1, 2)
+    return S.float().reshape(cell.shape)
+
+
+class MatterGenDataset:
+    """dataset.py:19-65: `from_samples(samples, rewards)` keeps pos / cell / atomic_numbers / num_atoms per crystal, attaches
+    `reward`, and applies the transform list (symmetrize_lattice; the chemical-system string is not used on this path)."""
+
+    def __init__(self, items: List[ChemGraph]):
+        self.items = items
+
+    @classmethod
+    def from_samples(cls, samples, rewards=None, transforms=(symmetrize_lattice,)):
+        if isinstance(samples, ChemGraphBatch):
+            samples = samples.to_data_list()
+        items = []
+        for i, s in enumerate(samples):
+            cell = s.cell
+            for tf in transforms or ():
+                cell = tf(cell)
+            r = None if rewards is None else torch.tensor([float(np.asarray(rewards)[i])])
+            items.append(ChemGraph(s.pos.clone(), cell, s.atomic_numbers.clone(), s.num_atoms, r))
+        return cls(items)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+class ChemGraphLoader:
+    def __init__(self, dataset, batch_size, shuffle=True):
+        self.dataset, self.batch_size, self.shuffle = dataset, max(1, int(batch_size)), shuffle
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        for s in range(0, n, self.batch_size):
+            yield ChemGraphBatch([self.dataset[i] for i in order[s:s + self.batch_size]])
+
+
+# ---- denoiser ---------------------------------------------------------------------------------------------------------------------
+class GBatch:
+    """Graph buffers + activation arena of one batch of crystals (mi_gbatch)."""
+
+    def __init__(self, net: "GemNetTDenoiser", num_atoms, node_offset=0, graph_offset=0):
+        lib = _lib.load()
+        na = [int(x) for x in (num_atoms.tolist() if torch.is_tensor(num_atoms) else num_atoms)]
+        self.num_atoms_list, self.num_graphs, self.num_nodes = na, len(na), sum(na)
+        h = C.c_void_p()
+        _lib.check(lib.mi_gbatch_create(net._h, (C.c_int * max(len(na), 1))(*na), len(na), node_offset, graph_offset, C.byref(h)), "mi_gbatch_create")
+        self._h, self._lib, self._dev, self._net = h, lib, net.theta.device, net
+        self.num_atoms = torch.tensor(na, dtype=torch.long, device=self._dev)
+        self.batch = torch.repeat_interleave(torch.arange(len(na), device=self._dev), self.num_atoms)
+
+    def graph(self, pos, cell):
+        """Build the periodic graph for (pos, cell) and return it: dict(src, dst, img, swap, rowptr, D, V)."""
+        f = lambda x: x.detach().to(self._dev, torch.float32).contiguous()
+        pos, cell = f(pos), f(cell)
+        n = C.c_int64()
+        self._net.sync()
+        _lib.check(self._lib.mi_gemnet_graph(self._net._h, self._h, _ptr(pos), _ptr(cell), _stream(), C.byref(n)), "mi_gemnet_graph")
+        E = int(n.value)
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=self._dev)
+        out = dict(src=i32(E), dst=i32(E), img=i32(E, 3), swap=i32(E), rowptr=i32(self.num_nodes + 1), D=torch.empty(E, device=self._dev),
+                   V=torch.empty(E, 3, device=self._dev))
+        _lib.check(self._lib.mi_gemnet_graph_read(self._h, *(_ptr(out[k]) for k in ("src", "dst", "img", "swap", "rowptr", "D", "V")), _stream()),
+                   "mi_gemnet_graph_read")
+        return {k: (v.long() if v.dtype == torch.int32 else v) for k, v in out.items()}
+
+    def tap(self, name):
+        n = C.c_int64()
+        _lib.check(self._lib.mi_gemnet_tap(self._h, name.encode(), None, 0, C.byref(n), _stream()), "mi_gemnet_tap")
+        out = torch.empty(int(n.value), device=self._dev)
+        _lib.check(self._lib.mi_gemnet_tap(self._h, name.encode(), _ptr(out), out.numel(), None, _stream()), "mi_gemnet_tap")
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and getattr(self, "_lib", None) is not None:
+            self._lib.mi_gbatch_destroy(h)
+
+
+class GemNetFunction(torch.autograd.Function):
+    """The denoiser as ONE differentiable op (gradient w.r.t. the flat parameter vector only: the fine-tune step never needs input
+    gradients, pipeline/mat_invent.py:164)."""
+
+    @staticmethod
+    def forward(ctx, theta, net, gb, pos, cell, types, t):
+        lib = _lib.load()
+        net.sync()
+        dev = theta.device
+        B, N = gb.num_graphs, gb.num_nodes
+        o_pos, o_cell, o_log = torch.empty(N, 3, device=dev), torch.empty(B, 3, 3, device=dev), torch.empty(N, NUM_CLASSES, device=dev)
+        _lib.check(lib.mi_gemnet_forward(net._h, gb._h, _ptr(pos), _ptr(cell), _ptr(types), _ptr(t), _ptr(o_pos), _ptr(o_cell), _ptr(o_log), 1, _stream()),
+                   "mi_gemnet_forward")
+        ctx.net, ctx.gb, ctx.n = net, gb, theta.numel()
+        return o_pos, o_cell, o_log
+
+    @staticmethod
+    def backward(ctx, d_pos, d_cell, d_log):
+        lib = _lib.load()
+        net, gb = ctx.net, ctx.gb
+        dev = net.theta.device
+        c = lambda g: None if g is None else g.contiguous().float()
+        d_pos, d_cell, d_log = c(d_pos), c(d_cell), c(d_log)
+        grad = torch.zeros(ctx.n, device=dev)
+        _lib.check(lib.mi_gemnet_backward(net._h, gb._h, _ptr(d_pos), _ptr(d_cell), _ptr(d_log), _ptr(grad), _stream()), "mi_gemnet_backward")
+        return grad, None, None, None, None, None, None
+
+
+class GemNetTDenoiser(nn.Module):
+    """GemNet-T-shaped denoiser (oracle/mattergen_oracle.py::gemnet_forward): ONE flat fp32 parameter vector in the order of
+    mi_gemnet_param_info; `views()` / `state_dict()` expose the named tensors."""
+
+    def __init__(self, device=None, **hp):
+        super().__init__()
+        cfgd = dict(DEFAULT_GEMNET, **hp)
+        self.hp = cfgd
+        lib = _lib.load()
+        self._lib = lib
+        cfg = _lib.GemNetConfig(*[int(cfgd[k]) for k, _ in _lib.GemNetConfig._fields_[:-1]], float(cfgd["cutoff"]))
+        h = C.c_void_p()
+        _lib.check(lib.mi_gemnet_create(C.byref(cfg), C.byref(h)), "mi_gemnet_create")
+        self._h = h
+        self.layout = OrderedDict()
+        for i in range(lib.mi_gemnet_num_tensors(h)):
+            name, off, numel, rows, cols = C.c_char_p(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+            _lib.check(lib.mi_gemnet_param_info(h, i, C.byref(name), C.byref(off), C.byref(numel), C.byref(rows), C.byref(cols)))
+            nm = name.value.decode()
+            self.layout[nm] = (off.value, numel.value, (cols.value,) if nm.endswith(".bias") else (rows.value, cols.value))
+        device = torch.device(device if device is not None else "cuda")
+        self.theta = nn.Parameter(torch.zeros(int(lib.mi_gemnet_num_params(h)), dtype=torch.float32, device=device))
+        self.theta._mi_owner = self
+        self._dirty, self._packed_version = True, -1
+        self.reset_parameters()
+
+    def views(self):
+        return OrderedDict((k, self.theta.data[o:o + n].view(shape)) for k, (o, n, shape) in self.layout.items())
+
+    @torch.no_grad()
+    def reset_parameters(self, head_scale=1.0):
+        """Variance-preserving normal init (std 1/sqrt(fan_in)), zero biases -- random-init runs only (the upstream checkpoints are
+        unreachable offline)."""
+        for name, w in self.views().items():
+            if name.endswith(".bias"):
+                w.zero_()
+            elif name == "atom_emb.weight":
+                w.copy_(torch.randn(w.shape))
+            else:
+                w.copy_(torch.randn(w.shape) / math.sqrt(w.shape[1]))
+                if ".out_F." in name or ".out_S." in name or name == "fc_atom.weight":
+                    w.mul_(head_scale)
+        self._dirty = True
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = destination if destination is not None else OrderedDict()
+        for k, w in self.views().items():
+            out[prefix + k] = w.detach().clone()
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        with torch.no_grad():
+            for k, w in self.views().items():
+                if prefix + k in state_dict:
+                    w.copy_(state_dict[prefix + k].reshape(w.shape))
+                elif strict:
+                    missing_keys.append(prefix + k)
+        self._dirty = True
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def sync(self):
+        if self._dirty or self._packed_version != self.theta._version:
+            _lib.check(self._lib.mi_gemnet_set_params(self._h, _ptr(self.theta.data), _stream()), "mi_gemnet_set_params")
+            self._dirty, self._packed_version = False, self.theta._version
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.theta._mi_owner = self
+        self._dirty = True
+        return r
+
+    def make_batch(self, num_atoms, node_offset=0, graph_offset=0) -> GBatch:
+        return GBatch(self, num_atoms, node_offset, graph_offset)
+
+    def forward(self, pos, cell, atomic_numbers, t, batch: GBatch):
+        """-> dict(pos [N,3], cell [B,3,3], atomic_numbers [N,101])."""
+        dev = self.theta.device
+        f = lambda x: x.detach().to(dev, torch.float32).contiguous()
+        pos, cell, t = f(pos), f(cell), f(t)
+        types = atomic_numbers.detach().to(dev, torch.int32).contiguous()
+        B, N = batch.num_graphs, batch.num_nodes
+        assert pos.shape == (N, 3) and cell.shape == (B, 3, 3) and t.shape == (B,) and types.shape == (N,)
+        if torch.is_grad_enabled() and self.theta.requires_grad:
+            o = GemNetFunction.apply(self.theta, self, batch, pos, cell, types, t)
+        else:
+            self.sync()
+            o = (torch.empty(N, 3, device=dev), torch.empty(B, 3, 3, device=dev), torch.empty(N, NUM_CLASSES, device=dev))
+            _lib.check(self._lib.mi_gemnet_forward(self._h, batch._h, _ptr(pos), _ptr(cell), _ptr(types), _ptr(t), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 0,
+                                                   _stream()), "mi_gemnet_forward")
+        return dict(pos=o[0], cell=o[1], atomic_numbers=o[2])
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and getattr(self, "_lib", None) is not None:
+            self._lib.mi_gemnet_destroy(h)
+
+
+def _scatter_mean(src, index, dim_size):
+    out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
+    return out / cnt.clamp(min=1)
+
+
+def _d_log_p_wn(x, sigma, N=10):
+    num, den = torch.zeros_like(x), torch.zeros_like(x)
+    for i in range(-N, N + 1):
+        e = torch.exp(-(x + i) ** 2 / 2 / sigma ** 2)
+        num = num + (x + i) / sigma ** 2 * e
+        den = den + e
+    return -num / den
+
+
+# ---- the module the pipeline talks to ----------------------------------------------------------------------------------------------
+class MatterGenModule(nn.Module):
+    """Mirror of models/mattergen/pl_module.py::MatterGenModule: add_noise / calc_sample_loss / calc_kl_reg (+ `sample`, which the
+    reference reaches through mattergen's PredictorCorrector)."""
+
+    def __init__(self, gemnet=None, corruption=None, device=None, **kwargs):
+        super().__init__()
+        dev = torch.device(device if device is not None else "cuda")
+        self.decoder = GemNetTDenoiser(device=dev, **dict(gemnet or {}))   # (named like the DiffCSP module's network: one ft_step serves both)
+        self.corruption = dict(DEFAULT_CORRUPTION, **dict(corruption or {}))
+        self.hparams = dict(gemnet=dict(self.decoder.hp), corruption=dict(self.corruption), **kwargs)
+        self.T = 1.0
+        self.to(dev)
+
+    @property
+    def device(self):
+        return self.decoder.theta.device
+
+    def _corr(self):
+        c = self.corruption
+        return _lib.MGCorruption(c["sigma_min"], c["sigma_max"], c["beta_min"], c["beta_max"], c["limit_density"], c["limit_var_scale"], int(c["d3pm_steps"]))
+
+    def collate(self, items, rewards=None):
+        """What MatterGenSuite.get_dataloader + MatterGenDataset.from_samples produce for ONE batch holding the whole set
+        (pipeline/mat_invent.py:129-133): symmetrised cells, rewards attached."""
+        ds = MatterGenDataset.from_samples(items, rewards)
+        return ChemGraphBatch([ds[i] for i in range(len(ds))])
+
+    def _batch_for(self, num_atoms):
+        off = getattr(self, "shard_offsets", (0, 0))
+        key = (tuple(int(x) for x in num_atoms.tolist()), off)
+        cache = self.__dict__.setdefault("_gb_cache", {})
+        gb = cache.get(key)
+        if gb is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            gb = cache[key] = self.decoder.make_batch(list(key[0]), off[0], off[1])
+        return gb
+
+    def add_noise(self, batch, timestep: int, noise=None, seed=None):
+        """pl_module.py:55-69: t = linspace(T_max, 1/N, N)[timestep] for every crystal, noisy = corruption.sample_marginal(batch, t).
+        Returns the reference's triple (noisy_batch, batch, t); the noisy batch carries what the loss needs (`aux`).
+        `noise` = (pos [N,3] normal, cell [B,3,3] normal, types [N] uniform) injects the draws (parity tests); default Philox."""
+        lib = _lib.load()
+        dev = self.device
+        N_grid = 1000
+        t_val = torch.linspace(self.T, 1.0 / N_grid, N_grid)[int(timestep)]
+        gb = self._batch_for(batch.num_atoms)
+        B, N = gb.num_graphs, gb.num_nodes
+        t = torch.full((B,), float(t_val), device=dev)
+        f = lambda x: x.to(dev, torch.float32).contiguous()
+        pos0, cell0 = f(batch.pos), f(batch.cell)
+        types0 = batch.atomic_numbers.to(dev, torch.int32).contiguous()
+        nz = (None, None, None) if noise is None else tuple(f(x) for x in noise)
+        pos, cell, types = torch.empty(N, 3, device=dev), torch.empty(B, 3, 3, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+        delta, eps, masked = torch.empty(N, 3, device=dev), torch.empty(B, 3, 3, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+        self._noise_calls = getattr(self, "_noise_calls", 0) + 1
+        seed = getattr(self, "noise_seed", 0) if seed is None else seed
+        corr = self._corr()
+        _lib.check(lib.mi_mg_sample_marginal(gb._h, C.byref(corr), _ptr(pos0), _ptr(cell0), _ptr(types0), _ptr(t), seed, self._noise_calls & 0xFFFFFFFF,
+                                             _ptr(nz[0]), _ptr(nz[1]), _ptr(nz[2]), _ptr(pos), _ptr(cell), _ptr(types), _ptr(delta), _ptr(eps), _ptr(masked),
+                                             _stream()), "mi_mg_sample_marginal")
+        na = gb.num_atoms
+        std = (self.corruption["sigma_min"] ** (1 - t) * self.corruption["sigma_max"] ** t * na.float() ** (-1.0 / 3.0))[gb.batch][:, None]
+        tau = torch.clamp(torch.ceil(t * self.corruption["d3pm_steps"] - 1e-6), 1, self.corruption["d3pm_steps"])[gb.batch]
+        noisy = dict(pos=pos, cell=cell, atomic_numbers=types.long(), num_atoms=na, aux=dict(delta=delta, std=std, eps=eps, tau=tau, masked=masked.bool()),
+                     counts=torch.tensor(gb.num_atoms_list))
+        return noisy, batch, t
+
+    def calc_sample_loss(self, noised_input):
+        """pl_module.py:71-81 + SampleLoss (loss.py:36-78): per-crystal sum_field w_field * loss_field, and the model output."""
+        noisy, batch, t = noised_input
+        gb, aux = self._batch_for(noisy["counts"]), noisy["aux"]   # THIS module's workspace (agent and prior must not share one)
+        pred = self.decoder(noisy["pos"], noisy["cell"], noisy["atomic_numbers"], t, gb)
+        B, n2g = gb.num_graphs, gb.batch
+        target = aux["std"] * _d_log_p_wn(aux["delta"], aux["std"])
+        l_pos = _scatter_mean(((pred["pos"] - target) ** 2).mean(1), n2g, B)
+        l_cell = ((pred["cell"] + aux["eps"]) ** 2).mean(dim=(1, 2))
+        logp = torch.log_softmax(pred["atomic_numbers"][:, :NUM_CLASSES - 1], dim=1)
+        x0 = batch.atomic_numbers.to(logp.device).long()
+        nll = -logp.gather(1, (x0 - 1)[:, None])[:, 0]
+        l_types = _scatter_mean(aux["masked"].to(nll.dtype) * nll / aux["tau"] + D3PM_LAMBDA * nll, n2g, B)
+        loss = WEIGHTS["atomic_numbers"] * l_types + WEIGHTS["cell"] * l_cell + WEIGHTS["pos"] * l_pos
+        return loss, pred
+
+    def calc_kl_reg(self, agent_pred, prior_pred, batch):
+        """pl_module.py:83-102."""
+        n2g = batch.get_batch_idx("pos").to(agent_pred["pos"].device)
+        B = agent_pred["cell"].shape[0]
+        k0 = torch.pow(agent_pred["cell"] - prior_pred["cell"].detach(), 2).mean(dim=(1, 2))
+        k1 = _scatter_mean(torch.pow(agent_pred["pos"] - prior_pred["pos"].detach(), 2).mean(dim=1), n2g, B)
+        k2 = _scatter_mean(torch.pow(agent_pred["atomic_numbers"] - prior_pred["atomic_numbers"].detach(), 2).mean(dim=1), n2g, B)
+        return k0 + k1 + k2
+
+    @torch.no_grad()
+    def sample(self, num_atoms, n_steps=1000, eps_t=1e-3, seed=0, noise=None, i_stop=None, node_offset=0, graph_offset=0, i_start=0, state=None):
+        """Predictor-corrector reverse chain (what draw_samples_from_sampler drives, sample.py:27-64): returns (sample, mean) dicts
+        with pos / cell / atomic_numbers / num_atoms.  `noise` (dict of [n_steps, ...] tensors + init_pos / init_cell) injects the draws."""
+        lib = _lib.load()
+        dev = self.device
+        self.shard_offsets = (node_offset, graph_offset)
+        gb = self._batch_for(torch.as_tensor(num_atoms))
+        B, N = gb.num_graphs, gb.num_nodes
+        self.decoder.sync()
+        corr = self._corr()
+        f = lambda x: x.to(dev, torch.float32).contiguous()
+        pos, cell, types = torch.empty(N, 3, device=dev), torch.empty(B, 3, 3, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+        ip = ic = None
+        if noise is not None:
+            ip, ic = f(noise["init_pos"]), f(noise["init_cell"])
+        if state is None:
+            _lib.check(lib.mi_mg_sampler_init(gb._h, C.byref(corr), seed, _ptr(ip), _ptr(ic), _ptr(pos), _ptr(cell), _ptr(types), _stream()), "mi_mg_sampler_init")
+        else:   # resume at grid point i_start from a given state (noise arrays are then indexed from i_start on)
+            pos, cell, types = f(state["pos"]) % 1.0, f(state["cell"]).clone(), state["atomic_numbers"].to(dev, torch.int32).contiguous().clone()
+        ts = torch.linspace(self.T, eps_t, n_steps).float().contiguous()
+        nzs, keep = None, None
+        if noise is not None:
+            keep = {k: f(torch.stack(list(noise[k]))) for k in ("corr_pos", "corr_cell", "pred_pos", "pred_cell", "pred_u1", "pred_u2")}
+            nzs = _lib.MGSamplerNoise(*(keep[k].data_ptr() for k in ("corr_pos", "corr_cell", "pred_pos", "pred_cell", "pred_u1", "pred_u2")))
+        mean_pos, mean_cell = pos.clone(), cell.clone()
+        stop = n_steps if i_stop is None else i_stop
+        _lib.check(lib.mi_mg_sampler_run(self.decoder._h, gb._h, C.byref(corr), n_steps, i_start, stop, ts.numpy().ctypes.data_as(C.POINTER(C.c_float)), seed,
+                                         C.byref(nzs) if nzs is not None else None, _ptr(pos), _ptr(cell), _ptr(types), _ptr(mean_pos), _ptr(mean_cell),
+                                         _stream()), "mi_mg_sampler_run")
+        del keep
+        sample = dict(pos=pos, cell=cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
+        mean = dict(pos=mean_pos, cell=mean_cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
+        return sample, mean
+
+
+# ---- sampler ------------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MatterGenSampler:
+    """models/mattergen/sample.py:127-303: `generate(model, batch_size, num_batches, **kwargs)` -> (list[ChemGraph], list[structure]);
+    1000 predictor-corrector steps, the MEAN batch of the last step is what is returned (sample.py:49-50).  Atom counts: the upstream
+    ALEX_MP_20 table is not available offline; the mp_20 prior of the DiffCSP side stands in ([UPSTREAM-UNVERIFIED])."""
+    batch_size: Optional[int] = None
+    num_batches: Optional[int] = None
+    num_atoms_distribution: str = "ALEX_MP_20"
+    n_steps: int = 1000
+    eps_t: float = 1e-3
+    seed: int = 0
+
+    def generate(self, model: MatterGenModule, batch_size=None, num_batches=None, **kwargs):
+        from .dist import all_gather_objects, broadcast_object, shard_range
+        from .sampling import ATOM_DIST
+        batch_size, num_batches = batch_size or self.batch_size, num_batches or self.num_batches
+        assert batch_size is not None and num_batches is not None
+        rank, world = int(kwargs.get("rank", 0)), int(kwargs.get("world_size", 1))
+        model.eval()
+        p = ATOM_DIST["mp_20"]
+        counts = np.random.choice(len(p), batch_size * num_batches, p=p)
+        if world > 1:
+            counts = np.asarray(broadcast_object(counts.tolist(), src=0))
+        graphs, strucs = [], []
+        for bi in range(num_batches):   # unlike the DiffCSP sampler, every batch's samples are kept (sample.py:41-50)
+            na = counts[bi * batch_size:(bi + 1) * batch_size]
+            lo, hi = shard_range(len(na), rank, world)
+            self.seed += 1
+            _, mean = model.sample(na[lo:hi], n_steps=self.n_steps, eps_t=self.eps_t, seed=self.seed, node_offset=int(np.sum(na[:lo])), graph_offset=lo)
+            _lib.check_saturation("MatterGenSampler.generate")
+            pos, cell, types, nat = (mean[k].detach().cpu() for k in ("pos", "cell", "atomic_numbers", "num_atoms"))
+            lengths, angles = lattices_to_params_shape(cell)
+            off = [0] + torch.cumsum(nat, 0).tolist()
+            for i in range(len(nat)):
+                g = ChemGraph(pos[off[i]:off[i + 1]], cell[i:i + 1], types[off[i]:off[i + 1]], int(nat[i]))
+                graphs.append(g)
+                strucs.append(SimpleStructure(lengths=lengths[i].tolist(), angles=angles[i].tolist(), species=g.atomic_numbers.tolist(),
+                                              frac_coords=g.pos.numpy()))
+        if world > 1:
+            parts = all_gather_objects((graphs, strucs))
+            graphs = [g for pp in parts for g in pp[0]]
+            strucs = [s for pp in parts for s in pp[1]]
+        return graphs, strucs
