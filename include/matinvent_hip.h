@@ -106,6 +106,8 @@ int mi_knn_graph_read(const mi_batch* b, int* edges, float* edge_vec, int order,
  * shortest interatomic distance over all pairs and 27 periodic images (A); cell volume |det L| (A^3); atom count }.
  * The thresholds of the external `structure_validity` check (distance / volume) are applied by the caller. */
 int mi_structure_check(const mi_batch* b, const float* frac, const float* lattices, float* out, void* stream);
+/* the same for any contiguous crystal layout: node_off [B+1] (device) = first atom of each crystal (MatterGen-side records) */
+int mi_structure_check_offsets(const int* node_off, int B, const float* frac, const float* lattices, float* out, void* stream);
 void mi_batch_destroy(mi_batch* b);
 int mi_batch_num_nodes(const mi_batch* b);
 int64_t mi_batch_num_edges(const mi_batch* b);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mi_knn_graph": (_I, [_P, _P, _P, _P, C.POINTER(_L)]),
     "mi_knn_graph_read": (_I, [_P, _P, _P, _I, _P]),
     "mi_structure_check": (_I, [_P, _P, _P, _P, _P]),
+    "mi_structure_check_offsets": (_I, [_P, _I, _P, _P, _P, _P]),
     "mi_debug_spin": (_I, [C.c_longlong, _P]),
     "mi_set_edge_pairs": (_I, [_I]),
     "mi_plane_format": (_I, []),

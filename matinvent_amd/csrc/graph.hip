@@ -393,6 +393,14 @@ int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* st
     return MI_OK;
 }
 
+int mi_structure_check_offsets(const int* node_off, int B, const float* frac, const float* lattices, float* out, void* stream) {
+    MI_CHECK(node_off && frac && lattices && out && B >= 0, MI_EINVAL, "bad argument");
+    if (B == 0) return MI_OK;
+    hipLaunchKernelGGL(structure_check_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, frac, lattices, node_off, out);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
 int mi_structure_check(const mi_batch* b, const float* frac, const float* lattices, float* out, void* stream) {
     MI_CHECK(b && frac && lattices && out, MI_EINVAL, "null argument");
     if (b->B == 0) return MI_OK;

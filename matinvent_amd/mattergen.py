@@ -49,6 +49,10 @@ class ChemGraph:
         self.num_atoms = int(self.num_atoms) if self.num_atoms else int(self.pos.shape[0])
         self.cell = self.cell.reshape(1, 3, 3)
 
+    @property
+    def atom_types(self):   # the name the DiffCSP-side records use (replay buffer / composition keys)
+        return self.atomic_numbers
+
 
 class ChemGraphBatch:
     """collate() of ChemGraphs: contiguous atoms, `get_batch_idx` = atom -> crystal (the two methods the reference calls,
@@ -477,11 +481,14 @@ class MatterGenSampler:
             self.seed += 1
             _, mean = model.sample(na[lo:hi], n_steps=self.n_steps, eps_t=self.eps_t, seed=self.seed, node_offset=int(np.sum(na[:lo])), graph_offset=lo)
             _lib.check_saturation("MatterGenSampler.generate")
+            from .structure import check_structures_counts   # geometric validity quantities where the final state lives (K18)
+            geom = check_structures_counts(mean["num_atoms"], mean["pos"], mean["cell"]).cpu()
             pos, cell, types, nat = (mean[k].detach().cpu() for k in ("pos", "cell", "atomic_numbers", "num_atoms"))
             lengths, angles = lattices_to_params_shape(cell)
             off = [0] + torch.cumsum(nat, 0).tolist()
             for i in range(len(nat)):
                 g = ChemGraph(pos[off[i]:off[i + 1]], cell[i:i + 1], types[off[i]:off[i + 1]], int(nat[i]))
+                g.geometry = {"max_cell_edge": float(geom[i, 0]), "min_distance": float(geom[i, 1]), "volume": float(geom[i, 2])}
                 graphs.append(g)
                 strucs.append(SimpleStructure(lengths=lengths[i].tolist(), angles=angles[i].tolist(), species=g.atomic_numbers.tolist(),
                                               frac_coords=g.pos.numpy()))

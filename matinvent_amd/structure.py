@@ -126,6 +126,20 @@ def check_structures(batch, frac_coords: torch.Tensor, lattices: torch.Tensor) -
     return out
 
 
+def check_structures_counts(num_atoms: torch.Tensor, frac_coords: torch.Tensor, lattices: torch.Tensor) -> torch.Tensor:
+    """check_structures for a batch described by its atom counts only (device tensors)."""
+    from . import _lib
+    lib = _lib.load()
+    fr, lat = frac_coords.detach().float().contiguous(), lattices.detach().float().contiguous()
+    off = torch.zeros(len(num_atoms) + 1, dtype=torch.int32, device=fr.device)
+    off[1:] = torch.cumsum(num_atoms.to(fr.device), 0)
+    out = torch.empty(len(num_atoms), 4, device=fr.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.mi_structure_check_offsets(p(off), len(num_atoms), p(fr), p(lat), p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "mi_structure_check_offsets")
+    return out
+
+
 def geometric_mask(check: torch.Tensor, max_cell: float = 25.0, min_dist: float = 0.5, min_volume: float = 0.1) -> torch.Tensor:
     """max(abc) < 25 (opt_filter.py:53-55) and the distance / volume thresholds of `structure_validity`."""
     return (check[:, 0] < max_cell) & (check[:, 1] > min_dist) & (check[:, 2] > min_volume)

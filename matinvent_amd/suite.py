@@ -116,10 +116,54 @@ class DiffCSPSuite(ModelSuite):
 
 
 class MatterGenSuite(ModelSuite):
-    """models/suite/mattergen.py: the GemNet-T denoiser, corruptions and sampler live in the un-vendored
-    pip package `mattergen @ 5bb2b397` (parity unpinned) -- not built."""
+    """models/suite/mattergen.py:32-131.  The reference loads `mattergen_base` from the HF hub through MatterGenCheckpointInfo
+    (:54-92); offline that is impossible, and the upstream checkpoint's parameter names belong to the un-vendored package, so:
+      * `model_path` = a directory written by `save_model` of THIS build (last.ckpt = {"state_dict", "config"} + config.yaml);
+      * `random_init: true` (+ optional `gemnet` / `corruption` / `head_scale` / `seed`) for synthetic runs.
+    The arithmetic is the MatterGen-shaped restatement (matinvent_amd.mattergen; parity-unpinned vs upstream)."""
 
     def load_model(self):
-        raise NotImplementedError("MatterGenSuite: the MatterGen arithmetic is an un-vendored dependency of the reference and is "
-                                  "not part of this build; use model=diffcsp")
-    get_sampler = get_dataloader = save_model = load_model
+        from .mattergen import MatterGenModule
+        if self.model_path is None:
+            if not self.cfg.get("random_init", False):
+                raise RuntimeError("MatterGenSuite.load_model: no model_path and no network access to the MatterGen checkpoints; give "
+                                   "model_path=<dir written by save_model> or random_init=true")
+            hp = dict(gemnet=C.to_container(self.cfg.get("gemnet")) if self.cfg.get("gemnet") is not None else {},
+                      corruption=C.to_container(self.cfg.get("corruption")) if self.cfg.get("corruption") is not None else {})
+            torch.manual_seed(int(self.cfg.get("seed", 0)))
+            model = MatterGenModule(**hp, device=self.device)
+            model.decoder.reset_parameters(head_scale=float(self.cfg.get("head_scale", 1.0)))
+            cfg = C.create({"lightning_module": hp})
+        else:
+            model_path = Path(os.path.abspath(self.model_path))
+            cfg = C.load(str(model_path / "config.yaml"))
+            hp = C.to_container(cfg["lightning_module"], resolve=True)
+            model = MatterGenModule(gemnet=hp.get("gemnet"), corruption=hp.get("corruption"), device=self.device)
+            ck = torch.load(str(model_path / "last.ckpt"), map_location="cpu", weights_only=False)
+            missing, unexpected = model.load_state_dict(ck["state_dict"], strict=False)
+            if unexpected:   # :86-89
+                raise ValueError(f"Unexpected keys in checkpoint: {unexpected}.")
+            if missing:
+                raise ValueError(f"Missing keys in checkpoint: {missing}.")
+        model.config = cfg["lightning_module"] if "lightning_module" in cfg else cfg
+        model.all_cfg = cfg
+        return model
+
+    def get_sampler(self):
+        from .mattergen import MatterGenSampler
+        return MatterGenSampler(batch_size=self.sample_cfg.batch_size, num_batches=self.sample_cfg.num_batches,
+                                n_steps=int(self.cfg.get("sampling_steps", 1000)))
+
+    def get_dataloader(self, samples, rewards, batch_size=None, shuffle=True):
+        """:101-118: MatterGenDataset.from_samples (cells symmetrised, rewards attached) behind a shuffling loader."""
+        from .mattergen import ChemGraphLoader, MatterGenDataset
+        if batch_size is None:
+            batch_size = self.finetune_cfg.batch_size
+        return ChemGraphLoader(MatterGenDataset.from_samples(samples, rewards), batch_size=batch_size, shuffle=shuffle)
+
+    def save_model(self, model, save_dir):
+        """:120-131: last.ckpt = {"state_dict", "config"} + config.yaml (all_cfg)."""
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "config": C.to_container(model.config, resolve=True)},
+                   os.path.join(save_dir, "last.ckpt"))
+        C.save(model.all_cfg, os.path.join(save_dir, "config.yaml"))

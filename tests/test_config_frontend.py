@@ -67,7 +67,9 @@ def test_dropin_import_paths_resolve():
         for t in ("models.suite.DiffCSPSuite", "models.suite.MatterGenSuite", "pipeline.mat_invent.MatInvent", "pipeline.baseline.Baseline",
                   "pipeline.utils.logger.CSVLogger", "pipeline.filters.opt_filter.OptFilter", "models.diffcsp.diffusion.DiffCSPModule",
                   "models.diffcsp.cspnet.CSPNet", "models.diffcsp.scheduler.BetaScheduler", "models.diffcsp.sample.DiffCSPSampler",
-                  "models.diffcsp.finetune.DiffCSPDataset", "rewards.synthetic.SyntheticReward"):
+                  "models.diffcsp.finetune.DiffCSPDataset", "rewards.synthetic.SyntheticReward", "rewards.reward.Reward",
+                  "rewards.calculators.PyMatGen", "models.mattergen.pl_module.MatterGenModule", "models.mattergen.sample.MatterGenSampler",
+                  "models.mattergen.dataset.MatterGenDataset"):
             assert C._locate(t) is not None, t
     finally:
         sys.path.remove(os.path.join(ROOT, "dropin"))

@@ -50,6 +50,45 @@ def test_main_runs_rl_loops_and_saves_reference_style_checkpoint(tmp_path):
         sys.path.remove(os.path.join(ROOT, "dropin"))
 
 
+def test_main_with_the_mattergen_model_runs_the_rl_loop(tmp_path):
+    """The reference's DEFAULT command line selects model=mattergen (configs/base.yaml:34): compose it through dropin/main.py, sample
+    with the predictor-corrector chain (a short grid), score, top-k + replay, fine-tune through the module surface, save and reload a
+    checkpoint.  MatterGen-shaped network: self-consistent, parity-unpinned vs upstream."""
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        import main as dropin_main
+        np.random.seed(0)
+        tiny = [f"+model.gemnet.{k}={v}" for k, v in dict(emb_atom=64, emb_edge=64, emb_trip=32, emb_rbf=8, emb_cbf=8, emb_bil=32, num_radial=16,
+                                                           num_spherical=4, num_blocks=2, num_after_skip=1, num_atom=1, cutoff=5.0, max_neighbors=8,
+                                                           max_images=3).items()]
+        rl = dropin_main.main(["expname=mg", "model=mattergen", "eval_size=3", "rl_epoch=2", "+model.sampling_steps=200", "model.finetune_cfg.timesteps=4",
+                               "pipeline.finetune_cfg.accum_steps=2", "pipeline.finetune_cfg.epochs=1", "device=cuda:0",
+                               "+sample_cfg.geometric_filter=false"] + tiny)
+        run = tmp_path / "exp_res" / "mg"
+        rows = (run / "metrics.csv").read_text().strip().splitlines()
+        assert len(rows) == 3 and "reward mean" in rows[0]
+        from matinvent_amd.mattergen import MatterGenModule
+        assert isinstance(rl.agent, MatterGenModule)
+        d = (rl.agent.decoder.theta - rl.prior.decoder.theta).abs().max().item()
+        assert 0 < d < 1e-2                                 # the agent moved, the frozen prior did not
+        ck = torch.load(run / "models" / "final" / "last.ckpt", map_location="cpu", weights_only=False)
+        assert "decoder.int_blocks.1.bilinear.weight" in ck["state_dict"] and (run / "models" / "final" / "config.yaml").exists()
+        from matinvent_amd.suite import MatterGenSuite
+        s = MatterGenSuite("mattergen_base", {"batch_size": 2, "num_batches": 1}, {"batch_size": 2}, model_path=str(run / "models" / "final"), device="cuda:0")
+        m2 = s.load_model()
+        assert torch.equal(m2.decoder.theta.cpu(), rl.agent.decoder.theta.detach().cpu())
+        # the loader the reference's ft_step would iterate (models/suite/mattergen.py:101-118)
+        data, strucs = rl.sampler.generate(model=rl.agent, batch_size=3, num_batches=1)
+        assert len(data) == 3 and all(int((g.atomic_numbers == 101).sum()) == 0 for g in data)
+        batches = list(s.get_dataloader(data, np.array([0.2, 0.4, 0.6]), batch_size=2, shuffle=False))
+        assert [b.get_batch_size() for b in batches] == [2, 1] and torch.allclose(batches[0].reward, torch.tensor([0.2, 0.4]))
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(os.path.join(ROOT, "dropin"))
+
+
 def test_baseline_config0_shape_vs_oracle(tmp_path):
     """BASELINE configs[0]: DiffCSP unconditional sample, batch 4, 100 denoising steps, <= 10 atoms per cell,
     pipeline=baseline (sample + score, no RL).  The sampled structures are compared with the CPU oracle
