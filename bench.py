@@ -245,6 +245,130 @@ def main_ft(args):
         dist.destroy_process_group()
 
 
+def main_reference_defaults(args):
+    """Secondary lines on the reference's REAL default workloads (not the headline):
+      sample-default: ragged mp_20 atom counts (models/diffcsp/sample.py:42-62, numpy seed 0), B = 192 = eval_size x 12
+                      (configs/model/diffcsp.yaml:7), T = 1000, automatic concurrent chains;
+      ft-default:     the default fine-tune set of 18 crystals = top-k 8 + replay <= 10 (configs/pipeline/mat_invent.yaml), stacked
+                      timesteps (the set is bound by the host's launch rate otherwise), accum_steps 50, fused Adam."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from matinvent_amd import _lib
+    from matinvent_amd.sampling import ATOM_DIST
+    _lib.load()
+    np.random.seed(0)
+    p = ATOM_DIST["mp_20"]
+    if args.mode == "sample-default":
+        Bd = 192
+        na = np.random.choice(len(p), Bd, p=p)
+        K, W = (args.steps if args.steps != 1000 else 50), max(1, args.warmup)
+        m = build_module(dev)
+
+        class Counts:
+            num_atoms = torch.tensor(na)
+        cb = Counts()
+        m.sample(cb, seed=SEED_NOISE + 1, step_lr=STEP_LR, t_start=T, t_stop=T - W)
+        final, _ = m.sample(cb, seed=SEED_NOISE, step_lr=STEP_LR, t_start=T, t_stop=T)
+        state = (final["frac_coords"], final["lattices"], final["atom_types"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.sample(cb, seed=SEED_NOISE, step_lr=STEP_LR, init=state, t_start=T, t_stop=T - K)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        out = {"metric": "crystal structures/sec (1000-step reverse diffusion), reference default sampling batch", "value": Bd * K / (T * elapsed),
+               "unit": "structures/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32 via 2-plane fp16 split", "data": "synthetic",
+               "config": {"workload": "reference default: 192 crystals with mp_20 atom counts (1..20, numpy seed 0), T=1000, DiffCSP CSPNet H=512 L=6 F=128",
+                          "batch_per_gpu": Bd, "atoms_total": int(na.sum()), "edges_total": int((na.astype(np.int64) ** 2).sum())}}
+    else:
+        from matinvent_amd.data import CrystalData
+        from matinvent_amd.finetune import ft_step
+        nset = 18
+        na = np.random.choice(len(p), nset, p=p)
+        K, W = (args.steps if args.steps != 1000 else 100), max(1, args.warmup)
+        agent, prior = build_module(dev), build_module(dev)
+        prior.requires_grad_(False)
+        g = torch.Generator().manual_seed(7)
+        data = [CrystalData(torch.rand(int(n), 3, generator=g), torch.randint(1, 95, (int(n),), generator=g), 4 + 6 * torch.rand(1, 3, generator=g),
+                            70 + 40 * torch.rand(1, 3, generator=g)) for n in na]
+        rewards = torch.rand(nset, generator=g).numpy()
+        cfg = dict(lr=1e-4, accum_steps=50, epochs=1, sigma=0.025)
+        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=max(W, 50)), log=lambda *_: None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=K), log=lambda *_: None)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        out = {"metric": "fine-tune crystal-timesteps/sec, reference default fine-tune set", "value": nset * K / elapsed, "unit": "crystal-timesteps/s",
+               "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 via 2-plane fp16 / 3-plane bf16 splits", "data": "synthetic",
+               "config": {"workload": "reference default fine-tune set: 18 crystals with mp_20 atom counts (top-k 8 + replay 10), accum_steps 50, stacked "
+                                      "timesteps (automatic), fused Adam; an RL step runs 3 x 1000 such timesteps",
+                          "set_size": nset, "atoms_total": int(na.sum()), "edges_total": int((na.astype(np.int64) ** 2).sum()),
+                          "seconds_per_rl_step_finetune": 3000 * elapsed / K}}
+    print(json.dumps(out), flush=True)
+
+
+def main_mg(args):
+    """Secondary line, MatterGen-LABELLED form of BASELINE configs[1]: the predictor-corrector reverse sampler of the MatterGen-shaped
+    network (GemNet-T shape: 4 blocks at 512 / 512 / 64 / 16 / 16, cutoff 7 A, <= 50 neighbours, triplet basis; 28.3 M parameters),
+    batch 256 x 20 atoms, 1000-point grid, two denoiser evaluations per step.  SELF-CONSISTENT, PARITY-UNPINNED vs upstream (the
+    reference's MatterGen arithmetic is an un-vendored dependency); the headline `value` stays on the pinned DiffCSP network."""
+    K, W = (args.steps if args.steps != 1000 else 10), max(1, min(args.warmup, 2))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from matinvent_amd import _lib
+    from matinvent_amd.mattergen import MatterGenModule
+    lib = _lib.load()
+    torch.manual_seed(SEED_W)
+    m = MatterGenModule(device=dev)
+    # random-init heads scaled so that score x std is of order one (a trained denoiser's range): the signal-to-noise Langevin step
+    # is 2 (snr |z| / |score|)^2, and a network with tiny outputs would random-walk the cells out of the cutoff within a few steps
+    m.decoder.reset_parameters(head_scale=20.0, cell_head_scale=400.0)
+    Bm = args.mg_batch
+    na = [NATOM] * Bm
+    # a mid-chain state (t ~ 0.5): cells around the limit mean, the regime most of the chain runs in
+    g = torch.Generator().manual_seed(3)
+    N = Bm * NATOM
+    mu = (NATOM / 0.05771451654022283) ** (1 / 3)
+    state = dict(pos=torch.rand(N, 3, generator=g), cell=mu * torch.eye(3)[None].repeat(Bm, 1, 1) + 0.3 * torch.randn(Bm, 3, 3, generator=g),
+                 atomic_numbers=torch.randint(1, 101, (N,), generator=g))
+    state["cell"] = 0.5 * (state["cell"] + state["cell"].transpose(1, 2))
+    i0 = 500
+    E0 = int(m._batch_for(torch.tensor(na)).graph(state["pos"], state["cell"])["src"].shape[0])
+    s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state)
+    st = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gr = m._batch_for(torch.tensor(na)).graph(s["pos"], s["cell"])
+    E = int(gr["src"].shape[0])
+    finite = bool(torch.isfinite(mean["pos"]).all()) and bool(torch.isfinite(mean["cell"]).all())
+    hp = m.decoder.hp
+    Ed, A = hp["emb_edge"], hp["emb_atom"]
+    # dense-layer flops of one evaluation at this edge count (the matrix-pipe work; oracle/mattergen_oracle.py op by op)
+    per_edge_block = 2 * Ed * (Ed * (2 + 2 * hp["num_before_skip"] + 2 * hp["num_after_skip"] + 1 + 2 * hp["num_concat"]) + hp["emb_rbf"] * 2
+                               + hp["emb_trip"] + 2 * hp["emb_bil"]) + 2 * hp["emb_cbf"] * hp["emb_trip"] * hp["emb_bil"]
+    per_edge_out = 2 * Ed * (Ed * 4 + 2 * hp["emb_rbf"])
+    per_node_block = 2 * A * (Ed + A * 2 * hp["num_atom"] + 2 * Ed)
+    Em = 0.5 * (E0 + E)
+    flops_eval = Em * (hp["num_blocks"] * (per_edge_block + per_edge_out) + per_edge_out + 2 * hp["num_radial"] * (Ed + 3 * hp["emb_rbf"] + hp["num_spherical"] * hp["emb_cbf"])) \
+        + N * (hp["num_blocks"] * per_node_block + 2 * A * (A + 2 * Ed + 101))
+    out = {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": Bm * K / (T * elapsed), "unit": "structures/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 via 3-plane bf16 split (6 MFMA terms, f32 accumulate)", "data": "synthetic",
+           "config": {"workload": f"MatterGen-labelled form of BASELINE configs[1]: predictor-corrector sampler of the MatterGen-shaped network, batch={Bm} "
+                                  "crystals x 20 atoms, 2 denoiser evals/step, mid-chain state; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
+                      "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "edges_first_step": E0, "edges_last_step": E, "parameters": int(m.decoder.theta.numel()), "final_state_finite": finite},
+           "roofline": {"bound": "mfma", "kernel": "gemm_nt_split_kernel (dense layers of the interaction / output blocks)", "achieved": 6 * flops_eval * 2 * K / elapsed / 1e12,
+                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 6 * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                        "achieved_fp32_equivalent": flops_eval * 2 * K / elapsed / 1e12, "flops_per_evaluation": flops_eval,
+                        "note": "end-to-end rate of the dense-layer flops (whole step time, all kernels); per-kernel durations and HBM GB/s: profiles/"}}
+    print(json.dumps(out), flush=True)
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): start the N ranks ourselves, one
     process per GPU, through torch.distributed.run on the loopback address, and pass their output through -- rank 0 prints
@@ -272,13 +396,18 @@ def main():
     ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused"], default="split-gemm",
                     help="arithmetic path: split-gemm (default) = bf16 three-plane split GEMMs, fp32-class accuracy; "
                          "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage")
-    ap.add_argument("--mode", choices=["sample", "ft"], default="sample",
+    ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
+    ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "sample-default", "ft-default"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))
     if args.mode == "ft":
         return main_ft(args)
+    if args.mode == "mg-sample":
+        return main_mg(args)
+    if args.mode in ("sample-default", "ft-default"):
+        return main_reference_defaults(args)
     K, W = args.steps, args.warmup
     assert 1 <= K <= T and 0 <= W <= T, f"steps and warmup must be <= T = {T}"
 

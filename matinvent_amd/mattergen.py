@@ -236,7 +236,7 @@ class GemNetTDenoiser(nn.Module):
         return OrderedDict((k, self.theta.data[o:o + n].view(shape)) for k, (o, n, shape) in self.layout.items())
 
     @torch.no_grad()
-    def reset_parameters(self, head_scale=1.0):
+    def reset_parameters(self, head_scale=1.0, cell_head_scale=None):
         """Variance-preserving normal init (std 1/sqrt(fan_in)), zero biases -- random-init runs only (the upstream checkpoints are
         unreachable offline)."""
         for name, w in self.views().items():
@@ -247,7 +247,7 @@ class GemNetTDenoiser(nn.Module):
             else:
                 w.copy_(torch.randn(w.shape) / math.sqrt(w.shape[1]))
                 if ".out_F." in name or ".out_S." in name or name == "fc_atom.weight":
-                    w.mul_(head_scale)
+                    w.mul_(cell_head_scale if (cell_head_scale is not None and ".out_S." in name) else head_scale)
         self._dirty = True
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
