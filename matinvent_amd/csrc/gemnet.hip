@@ -453,39 +453,70 @@ __device__ __forceinline__ void sph_l(float c, float (&y)[S]) {
         pm1 = p;
     }
 }
+// Edges are processed in chunks of TFC: phase 1 -- every thread takes (edge, neighbour) pairs of the chunk and writes Y_l(cos) to LDS
+// (the angle work is per PAIR, not per feature: done once instead of once per lane); phase 2 -- a wave per edge, lane = feature,
+// reads the pair's eight Y values as two broadcast ds_read_b128 and one feature value per neighbour.
+constexpr int TFC = 8;
 template <int S>
-__global__ __launch_bounds__(256) void triplet_fwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
+__global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
                                                           const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB) {
-    extern __shared__ float sm[];  // V [GN_DEG][3] | xd [GN_DEG][TR]
-    float* Vs = sm;
-    float* xs = sm + GN_DEG * 3;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // Y [TFC][GN_DEG][8] | V [GN_DEG][3] | xd [GN_DEG][TR] | cbfW [TFC][S * CB]
+    float* Ys = sm;
+    float* Vs = sm + TFC * GN_DEG * 8;
+    float* xs = Vs + GN_DEG * 3;
+    float* ws = xs + GN_DEG * TR;
     const int a = blockIdx.x, lo = rowptr[a], deg = rowptr[a + 1] - lo, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < deg * 3; i += 256) Vs[i] = V[(size_t)lo * 3 + i];
-    for (int i = tid; i < deg * TR; i += 256) xs[i] = xd[(size_t)lo * TR + i];
+    for (int i = tid; i < deg * 3; i += 512) Vs[i] = V[(size_t)lo * 3 + i];
+    for (int i = tid; i < deg * TR; i += 512) xs[i] = xd[(size_t)lo * TR + i];
     __syncthreads();
-    for (int e = wave; e < deg; e += 4) {
-        const float vx = Vs[e * 3], vy = Vs[e * 3 + 1], vz = Vs[e * 3 + 2];
-        float acc[S];
-#pragma unroll
-        for (int l = 0; l < S; ++l) acc[l] = 0.f;
-        for (int k = 0; k < deg; ++k) {
-            if (k == e) continue;
-            float c = vx * Vs[k * 3] + vy * Vs[k * 3 + 1] + vz * Vs[k * 3 + 2];
+    for (int c0 = 0; c0 < deg; c0 += TFC) {
+        const int ne = deg - c0 < TFC ? deg - c0 : TFC;
+        for (int p = tid; p < ne * deg; p += 512) {
+            const int ee = p / deg, k = p - ee * deg, e = c0 + ee;
+            float c = Vs[e * 3] * Vs[k * 3] + Vs[e * 3 + 1] * Vs[k * 3 + 1] + Vs[e * 3 + 2] * Vs[k * 3 + 2];
             c = fminf(fmaxf(c, -1.f), 1.f);
             float y[S];
             sph_l<S>(c, y);
-            const float x = lane < TR ? xs[k * TR + lane] : 0.f;
+            float o[8];
 #pragma unroll
-            for (int l = 0; l < S; ++l) acc[l] += y[l] * x;
+            for (int l = 0; l < 8; ++l) o[l] = (l < S && k != e) ? y[l < S ? l : 0] : 0.f;
+            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+            dst[0] = f32x4{o[0], o[1], o[2], o[3]};
+            dst[1] = f32x4{o[4], o[5], o[6], o[7]};
         }
-        const float* w = cbfW + (size_t)(lo + e) * S * CB;
-        if (lane < TR)
-            for (int i = 0; i < CB; ++i) {
-                float s = 0.f;
+        for (int i = tid; i < ne * S * CB; i += 512) ws[i] = cbfW[(size_t)(lo + c0) * S * CB + i];  // (read through LDS: per-lane global loads of
+        __syncthreads();                                                                              //  wave-uniform weights were pure latency)
+        for (int ee = wave; ee < ne; ee += 8) {
+            const int e = c0 + ee;
+            float acc[8];
 #pragma unroll
-                for (int l = 0; l < S; ++l) s += w[l * CB + i] * acc[l];
-                Tm[((size_t)(lo + e) * CB + i) * TR + lane] = s;
+            for (int l = 0; l < 8; ++l) acc[l] = 0.f;
+            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * GN_DEG * 8);
+#pragma unroll 4
+            for (int k = 0; k < deg; ++k) {
+                const f32x4 y0 = yr[2 * k], y1 = yr[2 * k + 1];
+                const float x = lane < TR ? xs[k * TR + lane] : 0.f;
+                acc[0] += y0[0] * x;
+                acc[1] += y0[1] * x;
+                acc[2] += y0[2] * x;
+                acc[3] += y0[3] * x;
+                if (S > 4) {
+                    acc[4] += y1[0] * x;
+                    acc[5] += y1[1] * x;
+                    acc[6] += y1[2] * x;
+                    acc[7] += y1[3] * x;
+                }
             }
+            const float* w = ws + ee * S * CB;
+            if (lane < TR)
+                for (int i = 0; i < CB; ++i) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int l = 0; l < S; ++l) sacc += w[l * CB + i] * acc[l];
+                    Tm[((size_t)(lo + e) * CB + i) * TR + lane] = sacc;
+                }
+        }
+        __syncthreads();
     }
 }
 // backward: dxd[k][j] += sum_{e != k} sum_l Y_l(cos_ek) dacc_e[l][j],  dacc_e[l][j] = sum_i cbfW[e][l][i] dTm[e][i][j];
@@ -956,10 +987,11 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     const int64_t E = c.b->E;
     float* Y = c.take((size_t)E * g.emb_cbf * g.emb_trip);
     if (c.dry || !CTX_OK(c) || E == 0) return Y;
-    const size_t sh = (size_t)(GN_DEG * 3 + GN_DEG * g.emb_trip) * sizeof(float);
+    const size_t sh = (size_t)(TFC * GN_DEG * 8 + GN_DEG * 3 + GN_DEG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
 #define TRIP_FWD(SS)                                                                                                                       \
     case SS:                                                                                                                               \
-        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(256), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, Y, g.emb_trip, g.emb_cbf); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_fwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, Y, g.emb_trip, g.emb_cbf); \
         break;
     switch (g.num_spherical) {
         TRIP_FWD(1) TRIP_FWD(2) TRIP_FWD(3) TRIP_FWD(4) TRIP_FWD(5) TRIP_FWD(6) TRIP_FWD(7) TRIP_FWD(8)
