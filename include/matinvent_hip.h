@@ -384,6 +384,10 @@ int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const floa
 /* grad_theta += dLoss/dtheta given dLoss/d(out_pos, out_cell, out_logits) (any may be NULL = zero) */
 int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const float* d_cell, const float* d_logits,
                        float* grad_theta, void* stream);
+/* Arithmetic of the large dense layers of the forward pass: 0 (default) = three bf16 planes split on the fly (six MFMA terms),
+ * 1 = TWO fp16 planes with power-of-two scales from the operands' exact absmax (three terms; saturation impossible by
+ * construction; measured no faster: the fp32-operand kernel is bound by its operand path).  Both are fp32-class; the tests run both. */
+int mi_debug_set_mg_f16(int on);
 /* parity taps of the most recent forward: "h<i>" [N,emb_atom], "m<i>" [E,emb_edge] after block i (0 = embedding), "rbf" [E,num_radial] */
 int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream);
 

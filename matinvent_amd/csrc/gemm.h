@@ -39,6 +39,7 @@ struct GemmEpilogue {
     int ld_pre_add = 0;
     const float* residual = nullptr;  // [M, ld_res] added AFTER the activation
     int ld_res = 0;
+    float out_scale = 1.f;            // applied last: y = (act(z) + residual) * out_scale  (GemNet's (x + f(x)) / sqrt(2) merges)
     int act = ACT_NONE;
     float* pre_act = nullptr;         // optional [M, ld_pre]: value before the activation (saved for backward)
     int ld_pre = 0;
@@ -59,6 +60,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     if (ep.act == ACT_SILU) v = FAST ? silu_fast(v) : silu(v);
     else if (ep.act == ACT_SSILU) v = (FAST ? silu_fast(v) : silu(v)) * 1.66666666666666667f;
     if (ep.residual) v += ep.residual[(size_t)row * ep.ld_res + col];
+    if (ep.out_scale != 1.f) v *= ep.out_scale;
     return v;
 }
 

@@ -125,10 +125,31 @@ __device__ __forceinline__ void pl_split(float x, float scale, u16& p0, u16& p1,
 #endif
 }
 
-template <int BM, int BN>
+// scale of an on-the-fly two-plane fp16 split from the operand's exact absmax (bit pattern): 2^floor(log2(16384 / absmax)), so that
+// the largest stored magnitude stays below 32768 -- saturation is impossible by construction
+__device__ __forceinline__ float f16_scale_from_absmax(unsigned bits) {
+    const float m = __uint_as_float(bits);
+    if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
+    int e = 14 - (int)ceilf(log2f(m));
+    e = e > 40 ? 40 : (e < -100 ? -100 : e);
+    return exp2f((float)e);
+}
+// max |x| of a tensor as a bit pattern (order-independent: deterministic); the slot must be zero before the launch
+static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// F16 = true: the fp32 operands are split on the fly into TWO fp16 planes (three MFMA terms instead of six) with power-of-two scales
+// derived from their exact absmax (amax_a / amax_w: device bit patterns); the accumulator is rescaled before the epilogue.
+template <int BM, int BN, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                             float* __restrict__ C, int ldc, int M, int N, int K, GemmEpilogue ep, int kchunk,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, const unsigned* __restrict__ amax_a = nullptr,
+                                                            const unsigned* __restrict__ amax_w = nullptr) {
     constexpr int BK = 32, ROWB = 80;            // bytes per row per plane (64 + 16 pad: conflict-free b128 reads)
     constexpr int TM = BM / 64, TN = BN / 64;    // 32x32 tiles per wave along M / N
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -170,22 +191,36 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
             qw[v] = val;
         }
     };
-    auto store_split = [&](unsigned char* base, int rows, const f32x4& val, int f) {
+    float sc_a = 1.f, sc_w = 1.f;
+    if (F16) {
+        sc_a = f16_scale_from_absmax(*amax_a);
+        sc_w = f16_scale_from_absmax(*amax_w);
+    }
+    auto store_split = [&](unsigned char* base, int rows, const f32x4& val, int f, float sc) {
         int r = f >> 3, c = (f & 7) * 4;
         unsigned lo[3], hi[3];
-        split3_pair(val[0], val[1], lo);
-        split3_pair(val[2], val[3], hi);
+        if (F16) {
+            const float x0 = val[0] * sc, x1 = val[1] * sc, x2 = val[2] * sc, x3 = val[3] * sc;
+            const f16x2 h0 = {(_Float16)x0, (_Float16)x1}, h1 = {(_Float16)x2, (_Float16)x3};
+            lo[0] = __builtin_bit_cast(unsigned, h0);
+            hi[0] = __builtin_bit_cast(unsigned, h1);
+            lo[1] = pack_f16(x0 - (float)h0[0], x1 - (float)h0[1]);
+            hi[1] = pack_f16(x2 - (float)h1[0], x3 - (float)h1[1]);
+        } else {
+            split3_pair(val[0], val[1], lo);
+            split3_pair(val[2], val[3], hi);
+        }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < (F16 ? 2 : 3); ++pl) {
             uint2 pk = {lo[pl], hi[pl]};
             *reinterpret_cast<uint2*>(base + ((size_t)pl * rows + r) * ROWB + c * 2) = pk;
         }
     };
     auto step = [&](int k0, f32x4 (&qa)[A_V], f32x4 (&qw)[W_V]) {
 #pragma unroll
-        for (int v = 0; v < A_V; ++v) store_split(As, BM, qa[v], tid + v * 256);
+        for (int v = 0; v < A_V; ++v) store_split(As, BM, qa[v], tid + v * 256, sc_a);
 #pragma unroll
-        for (int v = 0; v < W_V; ++v) store_split(Ws, BN, qw[v], tid + v * 256);
+        for (int v = 0; v < W_V; ++v) store_split(Ws, BN, qw[v], tid + v * 256, sc_w);
         __syncthreads();
         load_tiles(k0 + 2 * BK, qa, qw);  // past-the-end tiles load as zeros
 #pragma unroll
@@ -194,17 +229,23 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < (F16 ? 2 : 3); ++pl)
                     a[i][pl] = *reinterpret_cast<const bf16x8*>(As + ((size_t)pl * BM + (wm * TM + i) * 32 + l31) * ROWB + (16 * s + 8 * kg) * 2);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < (F16 ? 2 : 3); ++pl)
                     b[j][pl] = *reinterpret_cast<const bf16x8*>(Ws + ((size_t)pl * BN + (wn * TN + j) * 32 + l31) * ROWB + (16 * s + 8 * kg) * 2);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    if (F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+                        continue;
+                    }
                     // smallest terms first, so that they are not lost against a large accumulator
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
@@ -235,11 +276,12 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) {
                 int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (row >= M) continue;
+                const float av = F16 ? acc[i][j][r] * (1.0f / (sc_a * sc_w)) : acc[i][j][r];   // (powers of two: exact)
                 if (gridDim.z > 1) {
-                    part[((size_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    part[((size_t)blockIdx.z * M + row) * N + col] = av;
                     continue;
                 }
-                float v = acc[i][j][r] + bcol;
+                float v = av + bcol;
                 v = apply_epilogue(ep, v, row, col);
                 C[(size_t)row * ldc + col] = v;
             }
@@ -257,13 +299,17 @@ static __global__ void splitk_reduce_kernel(const float* __restrict__ part, int 
 }
 
 inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-                         hipStream_t s, const SplitK* sk = nullptr) {
+                         hipStream_t s, const SplitK* sk = nullptr, const unsigned* amax_a = nullptr, const unsigned* amax_w = nullptr) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt_split: K/lda/ldw must be multiples of 4");
     if (M <= 0 || N <= 0) return MI_OK;
     if ((int64_t)cdiv(M, 128) * cdiv(N, 128) >= 256) {
         constexpr int BM = 128, BN = 128;
-        hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C, ldc,
-                           M, N, K, ep, K, (float*)nullptr);
+        if (amax_a && amax_w)   // two fp16 planes split on the fly, three MFMA terms (scales from the operands' exact absmax)
+            hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C,
+                               ldc, M, N, K, ep, K, (float*)nullptr, amax_a, amax_w);
+        else
+            hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C, ldc,
+                               M, N, K, ep, K, (float*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr);
     } else {
         constexpr int BM = 64, BN = 64;
         // few output tiles and a long reduction: the serial k-loop is the latency -- cut it into slices
@@ -276,7 +322,7 @@ inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float
         const int kchunk = S > 1 ? cdiv(cdiv(K, S), 64) * 64 : K;
         S = cdiv(K, kchunk);
         hipLaunchKernelGGL((gemm_nt_split_kernel<BM, BN>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 3 * (BM + BN) * 80, s, A, lda, W, ldw, C,
-                           ldc, M, N, K, ep, kchunk, S > 1 ? sk->buf : (float*)nullptr);
+                           ldc, M, N, K, ep, kchunk, S > 1 ? sk->buf : (float*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr);
         if (S > 1) hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, s, sk->buf, S, M, N, C, ldc, ep);
     }
     MI_KERNEL_CHECK();
@@ -863,6 +909,12 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    if (F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+                        continue;
+                    }
                     // smallest terms first, so that they are not lost against a large accumulator
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);

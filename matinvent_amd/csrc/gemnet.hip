@@ -28,6 +28,11 @@ constexpr int GN_DEG = 128;    // in-degree capacity after symmetrisation
 constexpr int GN_CODE_BITS = 11;  // image code < (2 * 5 + 1)^3 = 1331
 constexpr float GN_ACT = 1.66666666666666667f;
 constexpr float GN_ISQ2 = 0.70710678118654752440f;
+// large dense layers of the forward: two fp16 planes split on the fly (3 MFMA terms) instead of three bf16 planes (6).  OFF by default:
+// measured at 256k edges the fp32-operand kernel is bound by loading / splitting / staging its operands, not by the matrix pipe
+// (741 -> 722 us per product), and the absmax passes the scales need cost 12 % of the step -- kept as a tested option
+int g_mg_f16 = 0;
+constexpr int AMAX_SLOTS = 2048;
 constexpr int LOGIT_LD = 104;  // row stride of the logits buffer (101 padded to a multiple of 4: GEMM operand alignment)
 
 enum : uint32_t {  // Philox draw ids of this path (DESIGN.md "RNG"; mirrored by oracle-side helpers in the tests)
@@ -411,13 +416,16 @@ __global__ void axpby_bwd_kernel(const float* __restrict__ dy, const int* __rest
     if (db) db[i] += s * dy[(perm ? (int64_t)perm[r] : r) * cols + c];
 }
 __device__ __forceinline__ float ssilu_grad(float z) { return silu_grad(z) * GN_ACT; }
-// dZ = dY * act'(Z)
-__global__ void act_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ z, float* __restrict__ dz, int64_t rows, int cols) {
+// y = (act(z) + res) * s:   dres += s dY,   dZ = s dY act'(Z)   (z == NULL: no activation)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ z, float s, float* __restrict__ dres,
+                               float* __restrict__ dz, int64_t rows, int cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int64_t r = i / cols;
     const int c = (int)(i % cols);
-    dz[i] = dy[r * ldy + c] * ssilu_grad(z[i]);
+    const float g = dy[r * ldy + c] * s;
+    if (dres) dres[i] += g;
+    dz[i] = z ? g * ssilu_grad(z[i]) : g;
 }
 // Y[v] (+)= sum over the rows of segment v of X[perm ? perm[e] : e]
 __global__ void segsum_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ segptr, const int* __restrict__ perm, float* __restrict__ Y,
@@ -753,6 +761,7 @@ struct mi_gemnet {
     int64_t nparams = 0, ntrans = 0;
     const float* theta = nullptr;
     float* thetaT = nullptr;
+    unsigned* wamax = nullptr;   // [tensors] max |w| bit patterns (scales of the on-the-fly fp16 split)
     const GParam& P(const std::string& n) const {
         auto it = index.find(n);
         if (it == index.end()) {
@@ -818,6 +827,9 @@ struct mi_gbatch {
     float *pos_copy = nullptr, *cell_copy = nullptr, *t_buf = nullptr;
     // sampler scratch
     float *sp_pos = nullptr, *sp_cell = nullptr, *sp_logits = nullptr, *ts_dev = nullptr;
+    unsigned* amax_pool = nullptr;                  // [AMAX_SLOTS] absmax bit patterns of this forward's GEMM inputs
+    std::map<const float*, unsigned*> amax_of;      // tensor -> its slot (several layers read the same tensor)
+    int amax_used = 0;
     std::vector<float> ts_h;
     std::vector<void*> allocs;
 };
@@ -884,7 +896,7 @@ static inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t -
 // Y[M,N] = act( X[M,K] W[:, wcol0 : wcol0+K]^T + bias + G1[idx1] + G2[idx2] )
 static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::string& wname, int wcol0 = 0, int act = ACT_NONE, bool x_grad = true,
                        const std::string& bname = "", const float* G1 = nullptr, int gk1 = GK_NONE, const float* G2 = nullptr, int gk2 = GK_NONE,
-                       int ldy = 0) {
+                       int ldy = 0, const float* res = nullptr, float scale = 1.f) {
     const GParam& w = c.net->P(wname);
     const int N = w.rows;
     if (ldy == 0) ldy = N;
@@ -908,8 +920,23 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         ep.pre_act = Z;
         ep.ld_pre = N;
     }
+    if (res) {   // y = (act(z) + res) * scale: the residual merge folded into the product's epilogue (one pass over [M, N] less)
+        ep.residual = res;
+        ep.ld_res = N;
+    }
+    ep.out_scale = scale;
     if (ldy != N) MI_HIP_VOID(hipMemsetAsync(Y, 0, (size_t)M * ldy * sizeof(float), c.s));
-    CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
+    const bool use16 = g_mg_f16 && g_gemm_mode != 0 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 256 && c.b->amax_used < AMAX_SLOTS;
+    if (use16) {
+        unsigned*& slot = c.b->amax_of[X];
+        if (!slot) {   // the operand's exact absmax, once per tensor and forward (one extra read of it; the product then issues half the MFMA work)
+            slot = c.b->amax_pool + c.b->amax_used++;
+            hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot);
+        }
+        CTX_TRY(c, gemm_nt_split(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s, nullptr, slot, c.net->wamax + c.net->index.at(wname)));
+    } else {
+        CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
+    }
     if (c.train) {
         GOp o;
         o.type = OP_DENSE;
@@ -929,6 +956,8 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         o.G2 = G2;
         o.gk1 = gk1;
         o.gk2 = gk2;
+        o.X2 = res;
+        o.s = scale;
         c.b->tape.push_back(o);
     }
     return Y;
@@ -1030,8 +1059,7 @@ static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int6
     for (int k = 0; k < n; ++k) {
         const std::string p = prefix + "." + std::to_string(k);
         float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU);
-        float* y2 = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU);
-        x = op_axpby(c, x, y2, M, W);
+        x = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x, GN_ISQ2);  // (x + f(x)) / sqrt(2)
     }
     return x;
 }
@@ -1060,6 +1088,9 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     b->fwd.top = 0;
     b->tape.clear();
     b->taps.clear();
+    b->amax_of.clear();
+    b->amax_used = 0;
+    if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, AMAX_SLOTS * sizeof(unsigned), c.s));
     float* rbf = c.take((size_t)E * R);
     float* z = c.take((size_t)B * A);
     float* H0 = c.take((size_t)N * A);
@@ -1097,7 +1128,6 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     out_block(c, 0, m, rbf_out, true);
     for (int i = 0; i < g.num_blocks; ++i) {
         const std::string p = "int_blocks." + std::to_string(i);
-        float* x_ca = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU);
         float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
         float* rr = op_dense(c, rbf3, E, Rb, p + ".mlp_rbf.weight");
         float* x_ba = op_mul(c, tb, rr, E, Ed);
@@ -1108,7 +1138,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU);
         float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU);
         float* x3b = op_axpby(c, u1, u2, E, Ed, true);
-        float* x = op_axpby(c, x_ca, x3b, E, Ed);
+        float* x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2);  // (x_ca + x3) / sqrt(2)
         x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
         m = op_axpby(c, m, x, E, Ed);
         m = res_stack(c, p + ".after_skip", g.num_after_skip, m, E, Ed);
@@ -1224,8 +1254,9 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 const GParam& w = net->params[o.pidx];
                 const float* dZ = dY;
                 int ldz = o.ldy;
-                if (o.act != ACT_NONE) {
-                    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.ldy, o.Z, dz, o.M, o.N);
+                if (o.act != ACT_NONE || o.X2 || o.s != 1.f) {
+                    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.ldy, o.act != ACT_NONE ? o.Z : (const float*)nullptr, o.s,
+                                       G(o.X2), dz, o.M, o.N);
                     dZ = dz;
                     ldz = o.N;
                 }
@@ -1385,6 +1416,7 @@ int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out) {
 void mi_gemnet_destroy(mi_gemnet* net) {
     if (!net) return;
     if (net->thetaT) (void)hipFree(net->thetaT);
+    if (net->wamax) (void)hipFree(net->wamax);
     delete net;
 }
 int64_t mi_gemnet_num_params(const mi_gemnet* net) { return net ? net->nparams : 0; }
@@ -1407,6 +1439,12 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
     if (!net->thetaT) {
         MI_HIP(hipMalloc((void**)&net->thetaT, (size_t)net->ntrans * sizeof(float)));
         MI_HIP(hipMemsetAsync(net->thetaT, 0, (size_t)net->ntrans * sizeof(float), s));
+    }
+    if (!net->wamax) MI_HIP(hipMalloc((void**)&net->wamax, net->params.size() * sizeof(unsigned)));
+    MI_HIP(hipMemsetAsync(net->wamax, 0, net->params.size() * sizeof(unsigned), s));
+    for (size_t i = 0; i < net->params.size(); ++i) {
+        const GParam& p = net->params[i];
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, theta + p.off, p.numel, net->wamax + i);
     }
     for (const GParam& p : net->params) {
         if (p.rows == 1) continue;  // biases and the row-dot weights are never a data-gradient operand
@@ -1465,6 +1503,7 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     GA(sp_pos, (size_t)N * 3);
     GA(sp_cell, (size_t)B * 9);
     GA(sp_logits, (size_t)N * MI_MG_CLASSES);
+    GA(amax_pool, AMAX_SLOTS);
 #undef GA
     if (rc != MI_OK) {
         mi_gbatch_destroy(b);
@@ -1560,6 +1599,11 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
     MI_CHECK(net && b && grad_theta, MI_EINVAL, "null argument");
     if (b->N == 0 || b->B == 0) return MI_OK;
     return backward_impl(net, b, d_pos, d_cell, d_logits, grad_theta, (hipStream_t)stream);
+}
+
+int mi_debug_set_mg_f16(int on) {
+    mi::g_mg_f16 = on != 0 && MI_PLANES_FP16;
+    return MI_OK;
 }
 
 int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream) {

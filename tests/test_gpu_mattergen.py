@@ -278,3 +278,27 @@ def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
         bad += int((d > 1e-5).sum())
         tot_n += d.numel()
     assert bad <= 0.02 * tot_n, f"{bad} of {tot_n} parameters differ by more than 1e-5 after the Adam step"
+
+
+@pytest.mark.parametrize("f16", [1, 0], ids=["fp16-2plane-on-the-fly", "bf16-3plane"])
+def test_forward_at_a_size_where_the_large_tile_products_run(f16):
+    """110 crystals x 20 atoms at width 256 (>= 16k edges): the dense layers take the 128 x 128-tile kernel, with the operands split on
+    the fly into three bf16 planes (default) or two fp16 planes scaled by their exact absmax (three MFMA terms); both against the oracle."""
+    from matinvent_amd import _lib
+    hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
+    hp = M.GemNetHParams(**hpd)
+    P = M.init_params(hp, seed=8, head_scale=0.5)
+    m = _module(hpd, P)
+    na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
+    _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
+    try:
+        gb = m.decoder.make_batch(na)
+        E = gb.graph(frac, cell)["src"].shape[0]
+        assert E * 2 >= 256 * 128, E   # (E / 128) x (256 / 128) output tiles: the large-tile branch
+        ref = M.gemnet_forward(P, hp, frac, cell, a, na, t)
+        with torch.no_grad():
+            out = m.decoder(frac, cell, a, t, gb)
+        for k in ("pos", "cell", "atomic_numbers"):
+            _rel(out[k], ref[k], 2e-5, f"{k} (f16={f16})")
+    finally:
+        _lib.check(_lib.load().mi_debug_set_mg_f16(0))
