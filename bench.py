@@ -539,11 +539,13 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
         # separate passes, corrected as the MI355X guide prescribes; scripts/rocprof_summary.py writes the file).  bench.py cannot
         # read hardware counters itself, so the figure is the profiled one and carries its provenance; absent file -> null.
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_rocprofv3_summary_traffic.json")
-        if args.path == "split-gemm" and world == 1 and os.path.exists(tpath):
-            tr = json.load(open(tpath))
+        traffic, traffic_src = None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_rocprofv3_summary_traffic.json")))
+        if args.path == "split-gemm" and world == 1 and cands:   # the newest committed PMC passes; their HEAD is stated next to the number
+            tr = json.load(open(cands[-1]))
             traffic = tr["bytes_per_dispatch"] * tr["dispatches_per_bench_launch"]
+            traffic_src = {"file": os.path.relpath(cands[-1], os.path.dirname(os.path.abspath(__file__))), "profiled_head": tr.get("head", "round 1")}
         out = {
             "metric": "crystal structures/sec (1000-step reverse diffusion)", "value": value, "unit": "structures/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
@@ -556,7 +558,7 @@ def main():
                        "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite,
                        "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": issued, "peak": peak,
-                         "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(n_launch.value), "avg_launch_ms": avg_ms, "concurrent_streams": S,
                          "stage_busy_ms": busy_ms, "stage_busy_share_of_timed_region": busy_ms / (elapsed * 1e3),
                          "achieved_fp32_equivalent": fp32_equiv,

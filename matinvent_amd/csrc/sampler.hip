@@ -14,11 +14,11 @@ namespace mi {
 
 // SinusoidalTimeEmbeddings.forward (diffusion.py:59-66): out[b] = [sin(t*f_k) | cos(t*f_k)]
 __global__ void time_embedding_kernel(const int* __restrict__ times, const float* __restrict__ freqs, float* __restrict__ out,
-                                      int B, int TD) {
+                                      int B, int TD, int t_all = 0) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * TD) return;
     int b = idx / TD, k = idx % TD, half = TD / 2;
-    float arg = (float)times[b] * freqs[k < half ? k : k - half];
+    float arg = (float)(times ? times[b] : t_all) * freqs[k < half ? k : k - half];   // times == NULL: every crystal at time t_all
     out[idx] = k < half ? sinf(arg) : cosf(arg);
 }
 
@@ -158,21 +158,33 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
     }
     lp_x = block_sum_256(lp_x, red);
 
-    // atom-type logits: one wave per atom
+    // atom-type logits: one wave per atom; a lane owns a QUAD of consecutive logits = one Philox call (100 logits = 25 quads, and the
+    // global element index of a logit row starts at a multiple of 4), instead of one call -- four Box-Muller normals -- per logit
     float lp_t = 0.f;
     for (int i = n0 + wave; i < n1; i += 4) {
         float s = 0.f;
-        for (int k = lane; k < MI_NUM_TYPES; k += 64) {
-            int64_t idx = (int64_t)i * MI_NUM_TYPES + k;
-            float z = 0.f;
-            if (t > 1)
-                z = a.noise_t ? a.noise_t[idx]
-                              : philox_normal1(a.seed, (uint32_t)t, DRAW_PRED_T, (uint64_t)a.node_offset * MI_NUM_TYPES + idx);
-            float mu = c.c0 * (a.atom_types[idx] - c.c1 * a.pred_t[idx]);
-            float v = mu + c.sigma * z;
-            a.atom_types[idx] = v;
-            if (a.rec_types) a.rec_types[idx] = v;
-            if (t > 1) s += normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+        if (lane < MI_NUM_TYPES / 4) {
+            const int64_t idx0 = (int64_t)i * MI_NUM_TYPES + 4 * lane;
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t > 1) {
+                if (a.noise_t) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] = a.noise_t[idx0 + q];
+                } else {
+                    philox_normal4(a.seed, (uint32_t)t, DRAW_PRED_T, ((uint64_t)a.node_offset * MI_NUM_TYPES + idx0) >> 2, z);
+                }
+            }
+            const f32x4 at = *reinterpret_cast<const f32x4*>(a.atom_types + idx0), pt = *reinterpret_cast<const f32x4*>(a.pred_t + idx0);
+            f32x4 vout;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float mu = c.c0 * (at[q] - c.c1 * pt[q]);
+                const float v = mu + c.sigma * z[q];
+                vout[q] = v;
+                if (t > 1) s += normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+            }
+            *reinterpret_cast<f32x4*>(a.atom_types + idx0) = vout;
+            if (a.rec_types) *reinterpret_cast<f32x4*>(a.rec_types + idx0) = vout;
         }
         s = wave_sum(s);
         lp_t += s / (float)MI_NUM_TYPES;  // mean over the 100 logits (:358)
@@ -260,8 +272,8 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
             hipLaunchKernelGGL(wrap_copy_kernel, dim3(cdiv(n3, 256)), dim3(256), 0, s, frac, rec->frac_coords + t_start * n3, (int64_t)n3);
     }
     for (int t = t_start; t > t_stop; --t) {
-        hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, b->times, t, B);
-        MI_TRY(mi_time_embedding(b->times, time_freqs, B, net->TD, b->temb, stream));
+        hipLaunchKernelGGL(time_embedding_kernel, dim3(cdiv((int64_t)B * net->TD, 256)), dim3(256), 0, s, (const int*)nullptr, time_freqs, b->temb, B,
+                           net->TD, t);
         // corrector
         MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s));
         hipLaunchKernelGGL(corrector_kernel, dim3(B), dim3(64), 0, s, frac, b->pred_x, noise ? noise->corr_x + t * n3 : nullptr,
