@@ -18,6 +18,7 @@ p = "gpurun_out/${TAG}_rocprofv3_summary_traffic.json"
 d = json.load(open(p)); d["head"] = "$HEAD"; d["command"] = "$CMD"
 json.dump(d, open(p, "w"), indent=1)
 PY
+rm -rf $O   # the raw databases are tens of MiB; the summaries are what is kept
 python bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench_default_steps20.json 2>/dev/null
 python bench.py > gpurun_out/${TAG}_bench_default.json 2>/dev/null
 python bench.py --mode ft > gpurun_out/${TAG}_bench_finetune.json 2>/dev/null
