@@ -309,6 +309,36 @@ def main_reference_defaults(args):
     print(json.dumps(out), flush=True)
 
 
+def cpu_baseline_mg(budget_s=20.0):
+    """oracle/mattergen_oracle.py (plain torch fp32 CPU) on this host's cores: predictor-corrector steps of the same network on a bounded
+    slice (2 of the 256 crystals, a few of the 1000 grid points from the same mid-chain state), scaled linearly."""
+    from oracle import mattergen_oracle as MO
+    hp = MO.GemNetHParams()
+    P = MO.init_params(hp, seed=SEED_W, head_scale=20.0)
+    Bc = 2
+    na = torch.full((Bc,), NATOM, dtype=torch.long)
+    N = Bc * NATOM
+    g = torch.Generator().manual_seed(3)
+    mu = (NATOM / 0.05771451654022283) ** (1 / 3)
+    cell = mu * torch.eye(3)[None].repeat(Bc, 1, 1) + 0.3 * torch.randn(Bc, 3, 3, generator=g)
+    state = dict(pos=torch.rand(N, 3, generator=g), cell=0.5 * (cell + cell.transpose(1, 2)), atomic_numbers=torch.randint(1, 101, (N,), generator=g))
+    done, t_total, i0 = 0, 0.0, 500
+    with torch.no_grad():
+        while t_total < budget_s and done < 8:
+            nz = dict(init_pos=None, init_cell=None)
+            for k, shp, fn in (("corr_pos", (N, 3), torch.randn), ("corr_cell", (Bc, 3, 3), torch.randn), ("pred_pos", (N, 3), torch.randn),
+                               ("pred_cell", (Bc, 3, 3), torch.randn), ("pred_u1", (N,), torch.rand), ("pred_u2", (N,), torch.rand)):
+                nz[k] = [None] * (i0 + done) + [fn(*shp, generator=g)]
+            t0 = time.perf_counter()
+            s, _ = MO.pc_sample(P, hp, MO.Corruption(), na, nz, n_steps=T, t_stop_index=i0 + done + 1, start_index=i0 + done, state=state)
+            t_total += time.perf_counter() - t0
+            state = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
+            done += 1
+    return {"value": Bc * done / (T * t_total), "unit": "structures/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/mattergen_oracle.py (plain torch fp32 CPU; graph and triplet sums are Python loops), {Bc} crystals x {NATOM} atoms, {done} of {T} "
+                      f"predictor-corrector steps in {t_total:.1f} s, scaled linearly"}
+
+
 def main_mg(args):
     """Secondary line, MatterGen-LABELLED form of BASELINE configs[1]: the predictor-corrector reverse sampler of the MatterGen-shaped
     network (GemNet-T shape: 4 blocks at 512 / 512 / 64 / 16 / 16, cutoff 7 A, <= 50 neighbours, triplet basis; 28.3 M parameters),
@@ -366,6 +396,8 @@ def main_mg(args):
                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 6 * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                         "achieved_fp32_equivalent": flops_eval * 2 * K / elapsed / 1e12, "flops_per_evaluation": flops_eval,
                         "note": "end-to-end rate of the dense-layer flops (whole step time, all kernels); per-kernel durations and HBM GB/s: profiles/"}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_mg()
     print(json.dumps(out), flush=True)
 
 

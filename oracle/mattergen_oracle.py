@@ -462,9 +462,10 @@ def pc_sample(P, hp: GemNetHParams, corr: Corruption, num_atoms: torch.Tensor, n
     n2g = torch.repeat_interleave(torch.arange(B), num_atoms)
     eye = torch.eye(3)[None]
     mu, kap = corr.cell_limit(num_atoms)
-    pos = noise["init_pos"] % 1.0
-    cell = mu[:, None, None] * eye + kap[:, None, None] * symmetric_noise(noise["init_cell"])
     types = torch.full((N,), MASK, dtype=torch.long)
+    if state is None:
+        pos = noise["init_pos"] % 1.0
+        cell = mu[:, None, None] * eye + kap[:, None, None] * symmetric_noise(noise["init_cell"])
     if state is not None:   # resume a chain at grid point `start_index` from a given state (teacher-forced tests)
         pos, cell, types = state["pos"] % 1.0, state["cell"], state["atomic_numbers"]
     ts = torch.linspace(corr.T, eps_t, n_steps)
