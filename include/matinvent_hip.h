@@ -388,6 +388,8 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
  * 1 = TWO fp16 planes with power-of-two scales from the operands' exact absmax (three terms; saturation impossible by
  * construction; measured no faster: the fp32-operand kernel is bound by its operand path).  Both are fp32-class; the tests run both. */
 int mi_debug_set_mg_f16(int on);
+/* Edge-level dense layers (from 4096 edges up) on the pre-split plane-set kernel: 1 (default) / 0 = the fp32-operand kernel everywhere. */
+int mi_debug_set_mg_planes(int on);
 /* parity taps of the most recent forward: "h<i>" [N,emb_atom], "m<i>" [E,emb_edge] after block i (0 = embedding), "rbf" [E,num_radial] */
 int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream);
 

@@ -592,8 +592,15 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                     if (ep.act == ACT_SILU) {  // hardware exp2/rcp form (~3 ulp): E*H activations per launch, not hidden behind MFMAs
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
+                    } else if (ep.act == ACT_SSILU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]) * 1.66666666666666667f;
                     }
                     if (ep.residual) add8(v, ep.residual + (size_t)row * ep.ld_res + col);
+                    if (ep.out_scale != 1.f) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] *= ep.out_scale;
+                    }
                     if (pe.absmax) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));

@@ -32,6 +32,11 @@ constexpr float GN_ISQ2 = 0.70710678118654752440f;
 // measured at 256k edges the fp32-operand kernel is bound by loading / splitting / staging its operands, not by the matrix pipe
 // (741 -> 722 us per product), and the absmax passes the scales need cost 12 % of the step -- kept as a tested option
 int g_mg_f16 = 0;
+// edge-level dense layers on the pre-split plane-set kernel (gemm_planes: operands split ONCE where they are produced -- weights at
+// mi_gemnet_set_params, activations in their producer's epilogue, scaled by a power of two from a rigorous one-layer bound on the exact
+// absmax of the producer's inputs): measured 2.0-2.6x the fp32-operand kernel on every shape of this network
+int g_mg_planes = 1;
+constexpr int64_t MG_PLANES_MIN_ROWS = 4096;
 constexpr int AMAX_SLOTS = 2048;
 constexpr int LOGIT_LD = 104;  // row stride of the logits buffer (101 padded to a multiple of 4: GEMM operand alignment)
 
@@ -444,6 +449,91 @@ __global__ void gather_add_kernel(const float* __restrict__ dY, const int* __res
     dX[i] += dY[(size_t)seg_of[i / cols] * cols + i % cols];
 }
 
+// ---- plane-set plumbing of the forward (fp16 two-plane / bf16 three-plane format of gemm_split.h) ---------------------------------
+// {scale, 1 / scale} of an output plane set from a rigorous bound:  bound = (fa (a * rs * b2 * deg * kmul + g1 + g2) + res) * s
+// with a, b2, g1, g2, res = exact absmax bit patterns of the inputs (NULL = absent), rs = largest row sum of |W| of the layer
+__global__ void mg_scale_kernel(const unsigned* a, const float* rs, const unsigned* b2, const int* degp, float kmul, const unsigned* g1, const unsigned* g2,
+                                const unsigned* res, float fa, float s, float* dsc) {
+    float t = __uint_as_float(*a) * (rs ? *rs : 1.f) * (b2 ? __uint_as_float(*b2) : 1.f) * (degp ? (float)*degp : 1.f) * kmul;
+    if (g1) t += __uint_as_float(*g1);
+    if (g2) t += __uint_as_float(*g2);
+    t = fa * t + (res ? __uint_as_float(*res) : 0.f);
+    t *= s;
+    int e = 14 - (int)ceilf(log2f(fmaxf(t, 1e-30f)));
+    if (!(t == t) || t > 3e38f) e = -100;
+    e = e > 30 ? 30 : (e < -100 ? -100 : e);
+    dsc[0] = exp2f((float)e);
+    dsc[1] = exp2f(-(float)e);
+}
+// max over rows of sum_k |W[row][k]|, k in [0, K)
+__global__ __launch_bounds__(256) void rowsum_max_kernel(const float* __restrict__ W, int ldw, int rows, int K, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int r = threadIdx.x >> 6; r < rows; r += 4) {
+        float sacc = 0.f;
+        for (int k = threadIdx.x & 63; k < K; k += 64) sacc += fabsf(W[(size_t)r * ldw + k]);
+        m = fmaxf(m, wave_sum(sacc));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ void store_pl_pair(const Planes& P, int64_t row, int col, float x, float y) {
+    unsigned pr[3];
+    pl_split_pair(x, y, P.s(), pr);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(P.base + P.elem((int)row, col, k)) = pr[k];
+}
+__device__ __forceinline__ void note_absmax(unsigned* slot, float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && slot) atomicMax(slot, __float_as_uint(m));
+}
+// y = a * b (fp32) + plane set + absmax; grid-stride over column pairs (one atomic per wave of a FIXED-size grid: a wave-per-pair-block
+// launch serialised a million atomics on one address -- 8.8 ms instead of 0.3)
+constexpr int EW_GRID = 4096;
+__global__ __launch_bounds__(256) void mul_pl_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, Planes P, unsigned* amax,
+                                                     int64_t rows, int cols) {
+    float m = 0.f;
+    const int64_t n = rows * (cols / 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (cols / 2);
+        const int c = (int)(i % (cols / 2)) * 2;
+        const f32x2 av = *reinterpret_cast<const f32x2*>(a + r * cols + c), bv = *reinterpret_cast<const f32x2*>(b + r * cols + c);
+        const float y0 = av[0] * bv[0], y1 = av[1] * bv[1];
+        *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
+        store_pl_pair(P, r, c, y0, y1);
+        m = fmaxf(m, fmaxf(fabsf(y0), fabsf(y1)));
+    }
+    note_absmax(amax, m);
+}
+// y = (a + b[perm]) * s (fp32) + optional plane set + absmax
+__global__ __launch_bounds__(256) void axpby_pl_kernel(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ perm, float s,
+                                                       float* __restrict__ y, Planes P, unsigned* amax, int64_t rows, int cols) {
+    float m = 0.f;
+    const int64_t n = rows * (cols / 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (cols / 2);
+        const int c = (int)(i % (cols / 2)) * 2;
+        const f32x2 av = *reinterpret_cast<const f32x2*>(a + r * cols + c);
+        const f32x2 bv = *reinterpret_cast<const f32x2*>(b + (perm ? (int64_t)perm[r] : r) * cols + c);
+        const float y0 = (av[0] + bv[0]) * s, y1 = (av[1] + bv[1]) * s;
+        *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
+        if (P.base) store_pl_pair(P, r, c, y0, y1);
+        m = fmaxf(m, fmaxf(fabsf(y0), fabsf(y1)));
+    }
+    note_absmax(amax, m);
+}
+// fp32 [rows][cols] -> plane set with the fixed scale of P (the radial basis, |x| <= 1); column padding written as zero
+__global__ void split_fixed_kernel(const float* __restrict__ x, Planes P, int64_t rows, int cols) {
+    const int cp = P.KT * 16;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cp) return;
+    const int64_t r = i / cp;
+    const int c = (int)(i % cp) * 2;
+    store_pl_pair(P, r, c, c < cols ? x[r * cols + c] : 0.f, c + 1 < cols ? x[r * cols + c + 1] : 0.f);
+}
+
 // ---- triplet contraction ---------------------------------------------------------------------------------------------------
 // One block per target atom a; its in-edges e (rows lo..hi) see each other as triplets (e, k), k != e, with angle cos = V_e . V_k.
 //   Tm[e][i][j] = sum_l cbfW[e][l][i] * sum_{k != e} Y_l(cos_ek) xd[k][j],   Y_l = sqrt((2l+1)/(4 pi)) P_l
@@ -467,7 +557,7 @@ __device__ __forceinline__ void sph_l(float c, float (&y)[S]) {
 constexpr int TFC = 8;
 template <int S>
 __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
-                                                          const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB) {
+                                                          const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB, Planes P, unsigned* amax) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // Y [TFC][GN_DEG][8] | V [GN_DEG][3] | xd [GN_DEG][TR] | cbfW [TFC][S * CB]
     float* Ys = sm;
     float* Vs = sm + TFC * GN_DEG * 8;
@@ -477,6 +567,7 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
     for (int i = tid; i < deg * 3; i += 512) Vs[i] = V[(size_t)lo * 3 + i];
     for (int i = tid; i < deg * TR; i += 512) xs[i] = xd[(size_t)lo * TR + i];
     __syncthreads();
+    float tmax = 0.f;
     for (int c0 = 0; c0 < deg; c0 += TFC) {
         const int ne = deg - c0 < TFC ? deg - c0 : TFC;
         for (int p = tid; p < ne * deg; p += 512) {
@@ -521,10 +612,27 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
                     float sacc = 0.f;
 #pragma unroll
                     for (int l = 0; l < S; ++l) sacc += w[l * CB + i] * acc[l];
-                    Tm[((size_t)(lo + e) * CB + i) * TR + lane] = sacc;
+                    if (Tm) Tm[((size_t)(lo + e) * CB + i) * TR + lane] = sacc;
+                    if (P.base) {   // the operand of the bilinear product: lanes pair up, the even one stores both halves of a 32-bit plane word
+                        const float nb = __shfl_down(sacc, 1, 64);
+                        if ((lane & 1) == 0) store_pl_pair(P, lo + e, i * TR + lane, sacc, nb);
+                        tmax = fmaxf(tmax, fabsf(sacc));
+                    }
                 }
         }
         __syncthreads();
+    }
+    if (P.base) {   // one atomic per workgroup
+        __shared__ float wmax[8];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        if (lane == 0) wmax[wave] = tmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = wmax[0];
+            for (int k = 1; k < 8; ++k) m = fmaxf(m, wmax[k]);
+            atomicMax(amax, __float_as_uint(m));
+        }
     }
 }
 // backward: dxd[k][j] += sum_{e != k} sum_l Y_l(cos_ek) dacc_e[l][j],  dacc_e[l][j] = sum_i cbfW[e][l][i] dTm[e][i][j];
@@ -762,6 +870,18 @@ struct mi_gemnet {
     const float* theta = nullptr;
     float* thetaT = nullptr;
     unsigned* wamax = nullptr;   // [tensors] max |w| bit patterns (scales of the on-the-fly fp16 split)
+    // plane sets of the weight blocks the edge-level dense layers use, built lazily after every mi_gemnet_set_params
+    struct WPl {
+        mi::u16* pl;
+        float* rowsum;   // device: largest row sum of |W| of the block (output bounds)
+        float scale;     // host: power-of-two scale of the block's plane set
+    };
+    std::map<int64_t, WPl> wplanes;
+    mi::u16* warena = nullptr;
+    size_t warena_elems = 0, warena_top = 0;
+    float* wrowsum = nullptr;          // [1024] device floats handed out with the blocks
+    int wrowsum_used = 0;
+    std::vector<float> wscale_h;       // per tensor, from its absmax (host copy refreshed by set_params)
     const GParam& P(const std::string& n) const {
         auto it = index.find(n);
         if (it == index.end()) {
@@ -797,7 +917,7 @@ struct Arena {
     size_t cap = 0, top = 0;
     float* take(size_t nfloats) {
         const size_t bytes = (nfloats * sizeof(float) + 255) / 256 * 256;
-        float* p = reinterpret_cast<float*>(base + top);
+        float* p = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(base) + top);
         top += bytes;
         return p;
     }
@@ -827,9 +947,18 @@ struct mi_gbatch {
     float *pos_copy = nullptr, *cell_copy = nullptr, *t_buf = nullptr;
     // sampler scratch
     float *sp_pos = nullptr, *sp_cell = nullptr, *sp_logits = nullptr, *ts_dev = nullptr;
-    unsigned* amax_pool = nullptr;                  // [AMAX_SLOTS] absmax bit patterns of this forward's GEMM inputs
+    unsigned* amax_pool = nullptr;                  // [AMAX_SLOTS] absmax bit patterns of this forward's tensors
     std::map<const float*, unsigned*> amax_of;      // tensor -> its slot (several layers read the same tensor)
     int amax_used = 0;
+    struct PlInfo {
+        mi::u16* pl;
+        float* dsc;     // device {scale, 1 / scale}, or NULL for a fixed scale
+        float scale;
+    };
+    std::map<const float*, PlInfo> pl_of;           // fp32 tensor -> the plane set its producer wrote next to it
+    float* dsc_pool = nullptr;                      // [AMAX_SLOTS][2]
+    int dsc_used = 0;
+    bool planes_mode = false;
     std::vector<float> ts_h;
     std::vector<void*> allocs;
 };
@@ -874,6 +1003,26 @@ struct Ctx {
     bool dry, train;
     int rc = MI_OK;
     float* take(size_t n) { return b->fwd.take(n); }
+    u16* take_planes(int64_t rows, int cols) {
+        if (getenv("MI_DEBUG_ARENA")) fprintf(stderr, "[arena %s] planes %lld x %d at %zu\n", dry ? "dry" : "run", (long long)rows, cols, b->fwd.top);
+        return reinterpret_cast<u16*>(b->fwd.take((planes_elems(rows, cols) + 1) / 2));
+    }
+    bool pm() const { return b->planes_mode; }
+    // the exact absmax slot of a tensor: the producer's if it tracked one, otherwise one extra pass over the tensor (node-level tensors)
+    unsigned* amax(const float* x, int64_t n) {
+        unsigned*& slot = b->amax_of[x];
+        if (!slot && b->amax_used < AMAX_SLOTS) {
+            slot = b->amax_pool + b->amax_used++;
+            if (!dry && n > 0) hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot);
+        }
+        return slot;
+    }
+    unsigned* new_amax(const float* y) {   // a fresh (zeroed) slot the producer of y fills itself
+        unsigned* slot = b->amax_used < AMAX_SLOTS ? b->amax_pool + b->amax_used++ : nullptr;
+        if (slot) b->amax_of[y] = slot;
+        return slot;
+    }
+    float* new_dsc() { return b->dsc_used < AMAX_SLOTS ? b->dsc_pool + 2 * b->dsc_used++ : nullptr; }
     const int* gidx(int kind) const { return kind == GK_SRC ? b->src : kind == GK_DST ? b->dst : b->node2graph; }
 };
 
@@ -893,16 +1042,117 @@ struct Ctx {
 
 static inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
+// plane set (+ largest |row| sum) of the weight block W[:, wcol0 : wcol0 + K], built on first use after mi_gemnet_set_params
+static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) {
+    mi_gemnet* net = c.net;
+    const int64_t key = ((int64_t)pidx << 40) | ((int64_t)wcol0 << 16) | (int64_t)K;
+    auto it = net->wplanes.find(key);
+    if (it != net->wplanes.end()) {
+        *out = it->second;
+        return MI_OK;
+    }
+    const GParam& w = net->params[pidx];
+    if (!net->warena) {
+        size_t tot = 0;
+        for (const GParam& q : net->params) tot += planes_elems(q.rows, q.cols) + 3 * planes_elems(q.rows, 32);
+        MI_HIP(hipMalloc((void**)&net->warena, tot * sizeof(u16)));
+        MI_HIP(hipMalloc((void**)&net->wrowsum, 1024 * sizeof(float)));
+        net->warena_elems = tot;
+    }
+    const size_t need = planes_elems(w.rows, K);
+    MI_CHECK(net->warena_top + need <= net->warena_elems && net->wrowsum_used < 1024, MI_ENOMEM, "weight plane arena exhausted");
+    mi_gemnet::WPl e{net->warena + net->warena_top, net->wrowsum + net->wrowsum_used++, net->wscale_h[pidx]};
+    net->warena_top += need;
+    Planes P = make_planes(e.pl, K, e.scale);
+    const int64_t nthr = (int64_t)((w.rows + 127) / 128 * 128) * P.KT * 16;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->theta + w.off + wcol0, w.cols, w.rows, K, P, 0);
+    hipLaunchKernelGGL(rowsum_max_kernel, dim3(1), dim3(256), 0, c.s, net->theta + w.off + wcol0, w.cols, w.rows, K, e.rowsum);
+    MI_KERNEL_CHECK();
+    net->wplanes[key] = e;
+    *out = e;
+    return MI_OK;
+}
+
 // Y[M,N] = act( X[M,K] W[:, wcol0 : wcol0+K]^T + bias + G1[idx1] + G2[idx2] )
 static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::string& wname, int wcol0 = 0, int act = ACT_NONE, bool x_grad = true,
                        const std::string& bname = "", const float* G1 = nullptr, int gk1 = GK_NONE, const float* G2 = nullptr, int gk2 = GK_NONE,
-                       int ldy = 0, const float* res = nullptr, float scale = 1.f) {
+                       int ldy = 0, const float* res = nullptr, float scale = 1.f, bool want_pl = false) {
     const GParam& w = c.net->P(wname);
     const int N = w.rows;
     if (ldy == 0) ldy = N;
     float* Y = c.take((size_t)M * ldy);
     float* Z = (act != ACT_NONE && c.train) ? c.take((size_t)M * N) : nullptr;
+    // edge-level layers whose input carries a plane set run on the pre-split plane kernel
+    auto xin = c.b->pl_of.find(X);
+    const bool planes = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 7) == 0 && ldy == N && bname.empty() && xin != c.b->pl_of.end();
+    u16* Ypl = (planes && want_pl) ? c.take_planes(M, N) : nullptr;
+    if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};   // (registered in the dry run too: both runs must take the same decisions)
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    if (planes) {
+        const int pidx = c.net->index.at(wname);
+        mi_gemnet::WPl wp;
+        CTX_TRY(c, get_wplanes(c, pidx, wcol0, K, &wp));
+        if (!CTX_OK(c)) return Y;
+        const mi_gbatch::PlInfo& xi = xin->second;
+        PlanesEpilogue pe;
+        if (G1) {
+            pe.ep.row_bias = G1;
+            pe.ep.row_group = c.gidx(gk1);
+            pe.ep.ld_row_bias = N;
+        }
+        if (G2) {
+            pe.ep.row_bias2 = G2;
+            pe.ep.row_group2 = c.gidx(gk2);
+            pe.ep.ld_row_bias2 = N;
+        }
+        pe.ep.act = act;
+        if (Z) {
+            pe.ep.pre_act = Z;
+            pe.ep.ld_pre = N;
+        }
+        if (res) {
+            pe.ep.residual = res;
+            pe.ep.ld_res = N;
+        }
+        pe.ep.out_scale = scale;
+        pe.C = Y;
+        pe.ldc = N;
+        pe.absmax = c.new_amax(Y);
+        if (Ypl) {   // scale of the output plane set from the one-layer bound on the exact absmax of everything that enters
+            float* dsc = c.new_dsc();
+            const int rows_g = gk1 == GK_NODE ? c.b->B : c.b->N;
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+                               G1 ? c.amax(G1, (int64_t)rows_g * N) : (const unsigned*)nullptr, G2 ? c.amax(G2, (int64_t)c.b->N * N) : (const unsigned*)nullptr,
+                               res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc);
+            if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));   // the k-padding of the next product must be zero
+            pe.Cp = make_planes(Ypl, N, 1.f, dsc);
+            c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
+        }
+        CTX_TRY(c, gemm_planes(make_planes(xi.pl, K, xi.scale, xi.dsc), make_planes(wp.pl, K, wp.scale), (int)M, N, K, pe, c.s));
+        if (c.train) {
+            GOp o;
+            o.type = OP_DENSE;
+            o.X = X;
+            o.Y = Y;
+            o.Z = Z;
+            o.M = M;
+            o.N = N;
+            o.K = K;
+            o.ldy = ldy;
+            o.pidx = pidx;
+            o.wcol0 = wcol0;
+            o.act = act;
+            o.x_grad = x_grad;
+            o.G1 = G1;
+            o.G2 = G2;
+            o.gk1 = gk1;
+            o.gk2 = gk2;
+            o.X2 = res;
+            o.s = scale;
+            c.b->tape.push_back(o);
+        }
+        return Y;
+    }
     GemmEpilogue ep;
     if (!bname.empty()) ep.bias = c.net->theta + c.net->P(bname).off;
     if (G1) {
@@ -962,9 +1212,20 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     }
     return Y;
 }
-static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N) {
+static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool want_pl = false) {
     float* Y = c.take((size_t)M * N);
+    const bool pl = c.pm() && want_pl && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;
+    u16* Ypl = pl ? c.take_planes(M, N) : nullptr;
+    if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    if (pl) {
+        float* dsc = c.new_dsc();
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(A, M * N), (const float*)nullptr, c.amax(Bm, M * N), (const int*)nullptr, 1.f,
+                           (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, 1.f, 1.f, dsc);
+        if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
+        c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
+        hipLaunchKernelGGL(mul_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, A, Bm, Y, make_planes(Ypl, N, 1.f, dsc), c.new_amax(Y), M, N);
+    } else
     hipLaunchKernelGGL(mul_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, Y, M * N);
     if (c.train) {
         GOp o;
@@ -978,9 +1239,24 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N) 
     }
     return Y;
 }
-static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool perm = false) {
+static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool perm = false, bool want_pl = false) {
     float* Y = c.take((size_t)M * N);
+    const bool big = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;   // edge-level: the output's absmax is tracked on the way
+    u16* Ypl = (big && want_pl) ? c.take_planes(M, N) : nullptr;
+    if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    if (big) {
+        float* dsc = nullptr;
+        if (Ypl) {
+            dsc = c.new_dsc();
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(A, M * N), (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+                               (const unsigned*)nullptr, (const unsigned*)nullptr, c.amax(Bm, M * N), 1.f, GN_ISQ2, dsc);
+            if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
+            c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
+        }
+        hipLaunchKernelGGL(axpby_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y,
+                           Ypl ? make_planes(Ypl, N, 1.f, dsc) : Planes(), c.new_amax(Y), M, N);
+    } else
     hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y, M, N);
     if (c.train) {
         GOp o;
@@ -1015,12 +1291,28 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     const mi_gemnet_config& g = c.net->cfg;
     const int64_t E = c.b->E;
     float* Y = c.take((size_t)E * g.emb_cbf * g.emb_trip);
+    const int NT = g.emb_cbf * g.emb_trip;
+    const bool pl = c.pm() && E >= MG_PLANES_MIN_ROWS && (g.emb_trip & 1) == 0;
+    u16* Ypl = pl ? c.take_planes(E, NT) : nullptr;
+    if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     if (c.dry || !CTX_OK(c) || E == 0) return Y;
+    Planes P;
+    unsigned* ymax = nullptr;
+    if (pl) {   // |Tm| <= max|cbfW| max|xd| S max|Y_l| deg_max
+        float* dsc = c.new_dsc();
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(cbfW, E * g.num_spherical * g.emb_cbf), (const float*)nullptr, c.amax(xd, E * g.emb_trip),
+                           (const int*)(c.b->meta + 1), 1.1f * (float)g.num_spherical, (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr,
+                           1.f, 1.f, dsc);
+        if (NT % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(E, NT) * sizeof(u16), c.s));
+        P = make_planes(Ypl, NT, 1.f, dsc);
+        ymax = c.new_amax(Y);
+        c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
+    }
     const size_t sh = (size_t)(TFC * GN_DEG * 8 + GN_DEG * 3 + GN_DEG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
 #define TRIP_FWD(SS)                                                                                                                       \
     case SS:                                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_fwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, Y, g.emb_trip, g.emb_cbf); \
+        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, (pl && !c.train) ? (float*)nullptr : Y, g.emb_trip, g.emb_cbf, P, ymax); \
         break;
     switch (g.num_spherical) {
         TRIP_FWD(1) TRIP_FWD(2) TRIP_FWD(3) TRIP_FWD(4) TRIP_FWD(5) TRIP_FWD(6) TRIP_FWD(7) TRIP_FWD(8)
@@ -1055,11 +1347,13 @@ static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string
     }
 }
 
-static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W) {
+// `out_pl`: the stack's result feeds another dense layer (its plane set is wanted)
+static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W, bool out_pl = false) {
     for (int k = 0; k < n; ++k) {
         const std::string p = prefix + "." + std::to_string(k);
-        float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU);
-        x = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x, GN_ISQ2);  // (x + f(x)) / sqrt(2)
+        float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+        x = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x, GN_ISQ2,
+                     k + 1 < n || out_pl);  // (x + f(x)) / sqrt(2)
     }
     return x;
 }
@@ -1069,7 +1363,7 @@ static void out_block(Ctx& c, int i, const float* m, const float* rbf_out, bool 
     const int64_t E = c.b->E;
     const int Ed = g.emb_edge;
     const std::string p = "out_blocks." + std::to_string(i);
-    float* t1 = op_dense(c, m, E, Ed, p + ".dense_F.weight", 0, ACT_SSILU);
+    float* t1 = op_dense(c, m, E, Ed, p + ".dense_F.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
     float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed);
     float* rF = op_dense(c, rbf_out, E, g.emb_rbf, p + ".rbf_F.weight");
     op_rowdot(c, xF, rF, p + ".out_F.weight", c.b->Fe, Ed, !first);
@@ -1090,8 +1384,13 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     b->taps.clear();
     b->amax_of.clear();
     b->amax_used = 0;
+    b->pl_of.clear();
+    b->dsc_used = 0;
+    b->planes_mode = g_mg_planes && g_gemm_mode != 0 && E >= MG_PLANES_MIN_ROWS;
     if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, AMAX_SLOTS * sizeof(unsigned), c.s));
     float* rbf = c.take((size_t)E * R);
+    u16* rbf_pl = c.pm() ? c.take_planes(E, R) : nullptr;
+    if (rbf_pl) b->pl_of[rbf] = mi_gbatch::PlInfo{rbf_pl, nullptr, PL_S_UNIT};   // |rbf| <= 1: the fixed unit-range scale
     float* z = c.take((size_t)B * A);
     float* H0 = c.take((size_t)N * A);
     b->Fe = c.take((size_t)E);
@@ -1102,6 +1401,12 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         if (E > 0)
             hipLaunchKernelGGL(edge_geom_rbf_kernel, dim3(nblk(E * R)), dim3(256), 0, c.s, pos, cell, b->src, b->dst, b->code, b->edge_graph, g.max_images,
                                g.cutoff, R, E, b->D, b->V, rbf);
+        if (rbf_pl && E > 0) {
+            const Planes P = make_planes(rbf_pl, R, PL_S_UNIT);
+            hipLaunchKernelGGL(split_fixed_kernel, dim3(nblk(E * P.KT * 16)), dim3(256), 0, c.s, rbf, P, E, R);
+            unsigned* one = c.new_amax(rbf);   // bound 1 (envelope x Gaussian)
+            if (one) MI_HIP_VOID(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, c.s));
+        }
         hipLaunchKernelGGL(nle_kernel, dim3(nblk((int64_t)B * A)), dim3(256), 0, c.s, t, z, B, A);
         hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk((int64_t)N * A)), dim3(256), 0, c.s, c.net->theta + c.net->P("atom_emb.weight").off, types, H0, N, A);
         if (c.train) {
@@ -1117,11 +1422,11 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     float* h = op_dense(c, H0, N, A, "atom_latent_emb.weight", 0, ACT_NONE, true, "atom_latent_emb.bias", ZP, GK_NODE);
     float* HS = op_dense(c, h, N, A, "edge_emb.weight", 0);
     float* HT = op_dense(c, h, N, A, "edge_emb.weight", A);
-    float* m = op_dense(c, rbf, E, R, "edge_emb.weight", 2 * A, ACT_SSILU, false, "", HS, GK_SRC, HT, GK_DST);
-    float* rbf3 = op_dense(c, rbf, E, R, "mlp_rbf3.weight", 0, ACT_NONE, false);
+    float* m = op_dense(c, rbf, E, R, "edge_emb.weight", 2 * A, ACT_SSILU, false, "", HS, GK_SRC, HT, GK_DST, 0, nullptr, 1.f, true);
+    float* rbf3 = op_dense(c, rbf, E, R, "mlp_rbf3.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
     float* cbfW = op_dense(c, rbf, E, R, "mlp_cbf3.weight", 0, ACT_NONE, false);
-    float* rbf_h = op_dense(c, rbf, E, R, "mlp_rbf_h.weight", 0, ACT_NONE, false);
-    float* rbf_out = op_dense(c, rbf, E, R, "mlp_rbf_out.weight", 0, ACT_NONE, false);
+    float* rbf_h = op_dense(c, rbf, E, R, "mlp_rbf_h.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+    float* rbf_out = op_dense(c, rbf, E, R, "mlp_rbf_out.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
     b->taps["rbf"] = {rbf, E * R};
     b->taps["h0"] = {h, (int64_t)N * A};
     b->taps["m0"] = {m, E * Ed};
@@ -1130,18 +1435,19 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         const std::string p = "int_blocks." + std::to_string(i);
         float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
         float* rr = op_dense(c, rbf3, E, Rb, p + ".mlp_rbf.weight");
-        float* x_ba = op_mul(c, tb, rr, E, Ed);
+        float* x_ba = op_mul(c, tb, rr, E, Ed, true);
         float* xd = op_dense(c, x_ba, E, Ed, p + ".down_projection.weight");
         float* Tm = op_triplet(c, xd, cbfW);
-        float* x3 = op_dense(c, Tm, E, Cb * Tr, p + ".bilinear.weight");
+        float* x3 = op_dense(c, Tm, E, Cb * Tr, p + ".bilinear.weight", 0, ACT_NONE, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
         b->taps["x3_" + std::to_string(i)] = {x3, E * g.emb_bil};
         float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU);
         float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU);
         float* x3b = op_axpby(c, u1, u2, E, Ed, true);
-        float* x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2);  // (x_ca + x3) / sqrt(2)
+        float* x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2,
+                            g.num_before_skip > 0);  // (x_ca + x3) / sqrt(2)
         x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
-        m = op_axpby(c, m, x, E, Ed);
-        m = res_stack(c, p + ".after_skip", g.num_after_skip, m, E, Ed);
+        m = op_axpby(c, m, x, E, Ed, false, true);
+        m = res_stack(c, p + ".after_skip", g.num_after_skip, m, E, Ed, true);
         float* ru = op_dense(c, rbf_h, E, Rb, p + ".atom_update.rbf.weight");
         float* mm = op_mul(c, m, ru, E, Ed);
         float* h2 = op_segsum(c, mm, Ed);
@@ -1150,9 +1456,9 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         h = op_axpby(c, h, h2, N, A);
         HS = op_dense(c, h, N, A, p + ".concat.weight", 0);
         HT = op_dense(c, h, N, A, p + ".concat.weight", A);
-        float* m2 = op_dense(c, m, E, Ed, p + ".concat.weight", 2 * A, ACT_SSILU, true, "", HS, GK_SRC, HT, GK_DST);
+        float* m2 = op_dense(c, m, E, Ed, p + ".concat.weight", 2 * A, ACT_SSILU, true, "", HS, GK_SRC, HT, GK_DST, 0, nullptr, 1.f, g.num_concat > 0);
         m2 = res_stack(c, p + ".residual_m", g.num_concat, m2, E, Ed);
-        m = op_axpby(c, m, m2, E, Ed);
+        m = op_axpby(c, m, m2, E, Ed, false, true);
         b->taps["h" + std::to_string(i + 1)] = {h, (int64_t)N * A};
         b->taps["m" + std::to_string(i + 1)] = {m, E * Ed};
         out_block(c, i + 1, m, rbf_out, false);
@@ -1193,7 +1499,10 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
     b->tape_valid = false;
     MI_TRY(graph_build(net, b, pos, cell, s));
     Ctx dry{net, b, s, true, train};
+    char* const real_base = b->fwd.base;
+    if (!real_base) b->fwd.base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // (the dry run keys tables by tensor address: never a null one)
     run_program(dry, pos, cell, types, t);
+    b->fwd.base = real_base;
     const size_t need = b->fwd.top;
     MI_TRY(arena_ensure(b->fwd, need));
     const mi_gemnet_config& g = net->cfg;
@@ -1213,6 +1522,7 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
     }
     Ctx run{net, b, s, false, train};
     run_program(run, pos, train ? b->cell_copy : cell, types, t);
+    MI_CHECK(b->fwd.top <= need, MI_ESTATE, "activation arena: the program used %zu bytes, its dry run %zu", b->fwd.top, need);
     MI_TRY(run.rc);
     MI_KERNEL_CHECK();
     b->tape_valid = train;
@@ -1417,6 +1727,8 @@ void mi_gemnet_destroy(mi_gemnet* net) {
     if (!net) return;
     if (net->thetaT) (void)hipFree(net->thetaT);
     if (net->wamax) (void)hipFree(net->wamax);
+    if (net->warena) (void)hipFree(net->warena);
+    if (net->wrowsum) (void)hipFree(net->wrowsum);
     delete net;
 }
 int64_t mi_gemnet_num_params(const mi_gemnet* net) { return net ? net->nparams : 0; }
@@ -1445,6 +1757,20 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
     for (size_t i = 0; i < net->params.size(); ++i) {
         const GParam& p = net->params[i];
         hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, theta + p.off, p.numel, net->wamax + i);
+    }
+    {   // per-tensor plane scales on the host (2^floor(log2(16384 / absmax))); the lazily built weight plane sets are stale now
+        std::vector<unsigned> bits(net->params.size());
+        MI_HIP(hipMemcpyAsync(bits.data(), net->wamax, bits.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        net->wscale_h.assign(bits.size(), 1.f);
+        for (size_t i = 0; i < bits.size(); ++i) {
+            float m;
+            memcpy(&m, &bits[i], 4);
+            if (m > 0.f && m < 3e38f) net->wscale_h[i] = exp2f((float)std::min(30, 14 - (int)ceilf(log2f(m))));
+        }
+        net->wplanes.clear();
+        net->warena_top = 0;
+        net->wrowsum_used = 0;
     }
     for (const GParam& p : net->params) {
         if (p.rows == 1) continue;  // biases and the row-dot weights are never a data-gradient operand
@@ -1504,6 +1830,7 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     GA(sp_cell, (size_t)B * 9);
     GA(sp_logits, (size_t)N * MI_MG_CLASSES);
     GA(amax_pool, AMAX_SLOTS);
+    GA(dsc_pool, 2 * AMAX_SLOTS);
 #undef GA
     if (rc != MI_OK) {
         mi_gbatch_destroy(b);
@@ -1599,6 +1926,11 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
     MI_CHECK(net && b && grad_theta, MI_EINVAL, "null argument");
     if (b->N == 0 || b->B == 0) return MI_OK;
     return backward_impl(net, b, d_pos, d_cell, d_logits, grad_theta, (hipStream_t)stream);
+}
+
+int mi_debug_set_mg_planes(int on) {
+    mi::g_mg_planes = on != 0;
+    return MI_OK;
 }
 
 int mi_debug_set_mg_f16(int on) {

@@ -280,10 +280,11 @@ def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
     assert bad <= 0.02 * tot_n, f"{bad} of {tot_n} parameters differ by more than 1e-5 after the Adam step"
 
 
-@pytest.mark.parametrize("f16", [1, 0], ids=["fp16-2plane-on-the-fly", "bf16-3plane"])
-def test_forward_at_a_size_where_the_large_tile_products_run(f16):
-    """110 crystals x 20 atoms at width 256 (>= 16k edges): the dense layers take the 128 x 128-tile kernel, with the operands split on
-    the fly into three bf16 planes (default) or two fp16 planes scaled by their exact absmax (three MFMA terms); both against the oracle."""
+@pytest.mark.parametrize("planes,f16", [(1, 0), (0, 1), (0, 0)], ids=["pre-split-plane-sets", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
+def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16):
+    """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
+    (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values) or on the fp32-operand
+    kernel (three bf16 planes or two fp16 planes split on the fly); all three against the oracle, the default also through the backward."""
     from matinvent_amd import _lib
     hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
     hp = M.GemNetHParams(**hpd)
@@ -291,6 +292,7 @@ def test_forward_at_a_size_where_the_large_tile_products_run(f16):
     m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
+    _lib.check(_lib.load().mi_debug_set_mg_planes(planes))
     try:
         gb = m.decoder.make_batch(na)
         E = gb.graph(frac, cell)["src"].shape[0]
@@ -299,6 +301,18 @@ def test_forward_at_a_size_where_the_large_tile_products_run(f16):
         with torch.no_grad():
             out = m.decoder(frac, cell, a, t, gb)
         for k in ("pos", "cell", "atomic_numbers"):
-            _rel(out[k], ref[k], 2e-5, f"{k} (f16={f16})")
+            _rel(out[k], ref[k], 2e-5, f"{k} (planes={planes} f16={f16})")
+        assert _lib.saturation_events(reset=True) == 0
+        if planes:   # the training forward + backward through the same plane-set layers: parameter gradients vs the oracle's autograd
+            N, B = int(na.sum()), len(na)
+            up, uc, ul = torch.randn(N, 3, generator=g), M.symmetric_noise(torch.randn(B, 3, 3, generator=g)), torch.randn(N, 101, generator=g)
+            Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            refg = M.gemnet_forward(Pg, hp, frac, cell, a, na, t)
+            ((refg["pos"] * up).sum() + (refg["cell"] * uc).sum() + (refg["atomic_numbers"] * ul).sum()).backward()
+            o2 = m.decoder(frac, cell, a, t, gb)
+            ((o2["pos"] * up.cuda()).sum() + (o2["cell"] * uc.cuda()).sum() + (o2["atomic_numbers"] * ul.cuda()).sum()).backward()
+            for k, (o, n, shape) in m.decoder.layout.items():
+                _rel(m.decoder.theta.grad[o:o + n].view(shape), Pg[k].grad, 5e-5, f"grad {k}")
     finally:
         _lib.check(_lib.load().mi_debug_set_mg_f16(0))
+        _lib.check(_lib.load().mi_debug_set_mg_planes(1))
