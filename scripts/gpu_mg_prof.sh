@@ -1,9 +1,10 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_mattergen.py -q 2>&1 | tail -3
-python bench.py --mode mg-sample --steps 6 --warmup 1 2>/dev/null | tail -1 | cut -c1-330
+# kernel trace + FETCH_SIZE / WRITE_SIZE passes of the MatterGen-shaped sampler line, summarised on the box
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_mg3 -o mg -- python bench.py --mode mg-sample --steps 2 --warmup 1 > gpurun_out/prof_mg3.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_mg3_f -o mg -- python bench.py --mode mg-sample --steps 2 --warmup 1 > gpurun_out/prof_mg3_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_mg3_w -o mg -- python bench.py --mode mg-sample --steps 2 --warmup 1 > gpurun_out/prof_mg3_w.log 2>&1
-ls gpurun_out/prof_mg3*
+CMD="python bench.py --mode mg-sample --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d gpurun_out/pm_t -o mg -- $CMD > gpurun_out/pm_t.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pm_f -o mg -- $CMD > gpurun_out/pm_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pm_w -o mg -- $CMD > gpurun_out/pm_w.log 2>&1
+python scripts/rocprof_summary.py gpurun_out/r2_rocprofv3_summary_mattergen_sampler.md gpurun_out/pm_t/mg_results.db gpurun_out/pm_f/mg_results.db gpurun_out/pm_w/mg_results.db > /dev/null
+rm -rf gpurun_out/pm_t gpurun_out/pm_f gpurun_out/pm_w
+grep -n "HBM-side traffic per" -A16 gpurun_out/r2_rocprofv3_summary_mattergen_sampler.md | cut -c1-130
