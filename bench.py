@@ -350,6 +350,8 @@ def main_mg(args):
     from matinvent_amd import _lib
     from matinvent_amd.mattergen import MatterGenModule
     lib = _lib.load()
+    if os.environ.get("MI_MG_LEAN"):   # ablation of the lean-inference switches (scripts/gpu_mg_ab.sh); negative = raw bit mask
+        _lib.check(lib.mi_debug_set_mg_lean(-int(os.environ["MI_MG_LEAN"])))
     torch.manual_seed(SEED_W)
     m = MatterGenModule(device=dev)
     # random-init heads scaled so that score x std is of order one (a trained denoiser's range): the signal-to-noise Langevin step

@@ -390,6 +390,11 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
 int mi_debug_set_mg_f16(int on);
 /* Edge-level dense layers (from 4096 edges up) on the pre-split plane-set kernel: 1 (default) / 0 = the fp32-operand kernel everywhere. */
 int mi_debug_set_mg_planes(int on);
+/* Inference forwards in plane mode keep each edge-level tensor in ONE format (the plane set where a dense layer reads it, fp32 rows
+ * otherwise; other consumers reconstruct the exact value from the planes), fold the skip-connection merges into the last layer of the
+ * residual stack they close and the radial weighting into the edge -> atom sum: 1 (default) / 0 = both formats and separate passes,
+ * as the training forward always does.  Same results to fp32 rounding; the tests run both. */
+int mi_debug_set_mg_lean(int on);
 /* parity taps of the most recent forward: "h<i>" [N,emb_atom], "m<i>" [E,emb_edge] after block i (0 = embedding), "rbf" [E,num_radial] */
 int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream);
 

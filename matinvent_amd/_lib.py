@@ -101,6 +101,7 @@ SIGNATURES = {
     "mi_gemnet_backward": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "mi_debug_set_mg_f16": (_I, [_I]),
     "mi_debug_set_mg_planes": (_I, [_I]),
+    "mi_debug_set_mg_lean": (_I, [_I]),
     "mi_gemnet_tap": (_I, [_P, C.c_char_p, _P, _L, C.POINTER(_L), _P]),
     "mi_mg_sample_marginal": (_I, [_P, C.POINTER(MGCorruption), _P, _P, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi_mg_sampler_init": (_I, [_P, C.POINTER(MGCorruption), _U64, _P, _P, _P, _P, _P, _P]),

@@ -409,6 +409,15 @@ struct PlanesEpilogue {
     float* C = nullptr;    // optional fp32 output [M][ldc]
     int ldc = 0;
     Planes Cp;             // optional plane-set output (the A operand of the next GEMM)
+    // optional (row-major epilogue only): the residual given as a PLANE SET instead of ep.residual -- inference runs that keep an
+    // edge-level tensor only in the format its consumers read (x = (h0 + h1) / scale: exact in fp32)
+    Planes res_pl;
+    // optional (row-major epilogue only) second merge behind the first:  y = ((act(z) + residual) * ep.out_scale + residual2) * out_scale2
+    // (a skip connection folded into the last layer of the residual stack it closes); residual2 as fp32 rows or as a plane set
+    const float* residual2 = nullptr;
+    int ld_res2 = 0;
+    Planes res2_pl;
+    float out_scale2 = 1.f;
     // optional fused segmented sum over rows (edge -> node aggregation, cspnet.py:79): rows are edges sorted by
     // `seg_src`; every 32-row block writes the partial sum of each node run it contains to
     // seg_part[slot][node][col], slot = block - first block of that node (fixed order, no atomics);
@@ -538,6 +547,30 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
     }
 }
 
+// dst[0..7] += the eight consecutive elements (row, col .. col + 7) of a plane set (col % 8 == 0: one 16-byte load per plane)
+__device__ __forceinline__ void pl_add8(float (&dst)[8], const Planes& P, int row, int col) {
+    const float inv = P.dscale ? P.dscale[1] : 1.f / P.scale;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pl = NPL - 1; pl >= 0; --pl) {   // smallest plane first: the sum of the planes is exact in fp32
+        const u32x4 w = *reinterpret_cast<const u32x4*>(P.base + P.elem(row, col, pl));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned wk = w[k];   // (a scalar copy: __builtin_bit_cast of the vector ELEMENT expression read element 0 every time)
+#if MI_PLANES_FP16
+            const f16x2 h = __builtin_bit_cast(f16x2, wk);
+            acc[2 * k] += (float)h[0];
+            acc[2 * k + 1] += (float)h[1];
+#else
+            acc[2 * k] += __uint_as_float(wk << 16);
+            acc[2 * k + 1] += __uint_as_float(wk & 0xFFFF0000u);
+#endif
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] += acc[k] * inv;
+}
+
 // Row-major variant of the epilogue for GEMMs that write a plane set (the first edge GEMM).  In the MFMA result layout a lane
 // owns ONE column of 16 rows, so the three row-gathered addends cost 48 four-byte loads and the plane output 48 two-byte
 // stores per 32x32 tile and lane.  Here each tile goes through a per-wave LDS patch (32 x 36 floats) and comes back as
@@ -597,9 +630,16 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                         for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]) * 1.66666666666666667f;
                     }
                     if (ep.residual) add8(v, ep.residual + (size_t)row * ep.ld_res + col);
+                    else if (pe.res_pl.base) pl_add8(v, pe.res_pl, row, col);
                     if (ep.out_scale != 1.f) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] *= ep.out_scale;
+                    }
+                    if (pe.residual2 || pe.res2_pl.base) {
+                        if (pe.residual2) add8(v, pe.residual2 + (size_t)row * pe.ld_res2 + col);
+                        else pl_add8(v, pe.res2_pl, row, col);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] *= pe.out_scale2;
                     }
                     if (pe.absmax) {
 #pragma unroll
@@ -767,8 +807,9 @@ __device__ __forceinline__ bool planes_preact_rows_applies(const PlanesEpilogue&
 }
 
 // whether the row-major epilogue applies (otherwise the result-layout one, which also carries the fused segmented sum)
-__device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
-    return (pe.Cp.base != nullptr || pe.C != nullptr) && pe.seg_part == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 && (pe.ep.ld_res & 3) == 0 && (pe.ep.ld_pre_add & 3) == 0 &&
+__host__ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpilogue& pe, int N) {
+    return (pe.Cp.base != nullptr || pe.C != nullptr) && pe.seg_part == nullptr && (N & 7) == 0 && (pe.ldc & 3) == 0 && (pe.ep.ld_res & 3) == 0 && (pe.ld_res2 & 3) == 0 &&
+           (pe.ep.ld_pre_add & 3) == 0 &&
            (pe.ep.ld_pre & 3) == 0 && (pe.ep.ld_row_bias & 3) == 0 && (pe.ep.ld_row_bias2 & 3) == 0 && (pe.ep.ld_row_bias3 & 3) == 0;
 }
 
@@ -1333,6 +1374,8 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     pe.out_scale = 1.f / ((A.dscale ? 1.f : A.scale) * W.scale);
     pe.a_dinv = A.dscale ? A.dscale + 1 : nullptr;
     const bool pair = pe.pair_i != nullptr;
+    MI_CHECK(!(pe.res_pl.base || pe.residual2 || pe.res2_pl.base) || (!pair && planes_epilogue_is_rows(pe, N)), MI_EINVAL,
+             "gemm_planes: plane-set residuals / the second merge exist in the row-major epilogue only");
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);

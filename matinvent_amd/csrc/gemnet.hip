@@ -36,6 +36,11 @@ int g_mg_f16 = 0;
 // mi_gemnet_set_params, activations in their producer's epilogue, scaled by a power of two from a rigorous one-layer bound on the exact
 // absmax of the producer's inputs): measured 2.0-2.6x the fp32-operand kernel on every shape of this network
 int g_mg_planes = 1;
+// inference forwards in plane mode keep every edge-level tensor in ONE format -- the plane set where a dense layer reads it, fp32 rows
+// otherwise -- instead of both (elementwise consumers and residual merges reconstruct x = (h0 + h1) / scale, exact in fp32), fold the
+// skip-connection merges into the last layer of the residual stack they close and the radial weighting into the edge -> atom sum.
+// Training forwards keep both formats (the tape's gradient kernels read fp32 rows).
+int g_mg_lean = 15;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass
 constexpr int64_t MG_PLANES_MIN_ROWS = 4096;
 constexpr int AMAX_SLOTS = 2048;
 constexpr int LOGIT_LD = 104;  // row stride of the logits buffer (101 padded to a multiple of 4: GEMM operand alignment)
@@ -453,12 +458,13 @@ __global__ void gather_add_kernel(const float* __restrict__ dY, const int* __res
 // {scale, 1 / scale} of an output plane set from a rigorous bound:  bound = (fa (a * rs * b2 * deg * kmul + g1 + g2) + res) * s
 // with a, b2, g1, g2, res = exact absmax bit patterns of the inputs (NULL = absent), rs = largest row sum of |W| of the layer
 __global__ void mg_scale_kernel(const unsigned* a, const float* rs, const unsigned* b2, const int* degp, float kmul, const unsigned* g1, const unsigned* g2,
-                                const unsigned* res, float fa, float s, float* dsc) {
+                                const unsigned* res, float fa, float s, float* dsc, const unsigned* res2 = nullptr, float s2 = 1.f) {
     float t = __uint_as_float(*a) * (rs ? *rs : 1.f) * (b2 ? __uint_as_float(*b2) : 1.f) * (degp ? (float)*degp : 1.f) * kmul;
     if (g1) t += __uint_as_float(*g1);
     if (g2) t += __uint_as_float(*g2);
     t = fa * t + (res ? __uint_as_float(*res) : 0.f);
     t *= s;
+    if (res2) t = (t + __uint_as_float(*res2)) * s2;   // the folded second merge
     int e = 14 - (int)ceilf(log2f(fmaxf(t, 1e-30f)));
     if (!(t == t) || t > 3e38f) e = -100;
     e = e > 30 ? 30 : (e < -100 ? -100 : e);
@@ -489,36 +495,82 @@ __device__ __forceinline__ void note_absmax(unsigned* slot, float m) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && slot) atomicMax(slot, __float_as_uint(m));
 }
+// An edge-level operand as its consumer finds it: fp32 rows, or -- where an inference run kept only the plane set -- the planes
+struct Src {
+    const float* f = nullptr;
+    Planes P;
+};
+__device__ __forceinline__ f32x2 src_load2(const Src& s, int64_t r, int c, int cols) {
+    if (s.f) return *reinterpret_cast<const f32x2*>(s.f + r * cols + c);
+    const float inv = s.P.dscale ? s.P.dscale[1] : 1.f / s.P.scale;
+    float x = 0.f, y = 0.f;
+#pragma unroll
+    for (int pl = NPL - 1; pl >= 0; --pl) {   // smallest plane first; the sum is exact in fp32
+        const unsigned w = *reinterpret_cast<const unsigned*>(s.P.base + s.P.elem((int)r, c, pl));
+#if MI_PLANES_FP16
+        const f16x2 h = __builtin_bit_cast(f16x2, w);
+        x += (float)h[0];
+        y += (float)h[1];
+#else
+        x += __uint_as_float(w << 16);
+        y += __uint_as_float(w & 0xFFFF0000u);
+#endif
+    }
+    return f32x2{x * inv, y * inv};
+}
+// plane set -> fp32 rows (a consumer without a plane-reading form, or a debug tap, asked for a tensor kept as planes only)
+__global__ __launch_bounds__(256) void pl_to_f32_kernel(Src a, float* __restrict__ y, int64_t rows, int cols) {
+    const int64_t n = rows * (cols / 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (cols / 2);
+        const int c = (int)(i % (cols / 2)) * 2;
+        *reinterpret_cast<f32x2*>(y + r * cols + c) = src_load2(a, r, c, cols);
+    }
+}
+// Y[v] = sum over the in-edges e of atom v of X[e] * Wt[e]  (the radially weighted edge -> atom sum in one pass: the product is never
+// written); a block per atom, a thread per column pair
+__global__ __launch_bounds__(256) void segsum_mul_kernel(Src X, const float* __restrict__ Wt, const int* __restrict__ segptr, float* __restrict__ Y, int cols) {
+    const int v = blockIdx.x;
+    const int e0 = segptr[v], e1 = segptr[v + 1];
+    for (int c = 2 * threadIdx.x; c < cols; c += 2 * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const f32x2 x = src_load2(X, e, c, cols), w = *reinterpret_cast<const f32x2*>(Wt + (size_t)e * cols + c);
+            s0 += x[0] * w[0];
+            s1 += x[1] * w[1];
+        }
+        *reinterpret_cast<f32x2*>(Y + (size_t)v * cols + c) = f32x2{s0, s1};
+    }
+}
 // y = a * b (fp32) + plane set + absmax; grid-stride over column pairs (one atomic per wave of a FIXED-size grid: a wave-per-pair-block
 // launch serialised a million atomics on one address -- 8.8 ms instead of 0.3)
 constexpr int EW_GRID = 4096;
-__global__ __launch_bounds__(256) void mul_pl_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, Planes P, unsigned* amax,
-                                                     int64_t rows, int cols) {
+__global__ __launch_bounds__(256) void mul_pl_kernel(Src a, Src b, float* __restrict__ y, Planes P, unsigned* amax, int64_t rows, int cols) {
     float m = 0.f;
     const int64_t n = rows * (cols / 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (cols / 2);
         const int c = (int)(i % (cols / 2)) * 2;
-        const f32x2 av = *reinterpret_cast<const f32x2*>(a + r * cols + c), bv = *reinterpret_cast<const f32x2*>(b + r * cols + c);
+        const f32x2 av = src_load2(a, r, c, cols), bv = src_load2(b, r, c, cols);
         const float y0 = av[0] * bv[0], y1 = av[1] * bv[1];
-        *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
+        if (y) *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
         store_pl_pair(P, r, c, y0, y1);
         m = fmaxf(m, fmaxf(fabsf(y0), fabsf(y1)));
     }
     note_absmax(amax, m);
 }
 // y = (a + b[perm]) * s (fp32) + optional plane set + absmax
-__global__ __launch_bounds__(256) void axpby_pl_kernel(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ perm, float s,
-                                                       float* __restrict__ y, Planes P, unsigned* amax, int64_t rows, int cols) {
+__global__ __launch_bounds__(256) void axpby_pl_kernel(Src a, Src b, const int* __restrict__ perm, float s, float* __restrict__ y, Planes P, unsigned* amax,
+                                                       int64_t rows, int cols) {
     float m = 0.f;
     const int64_t n = rows * (cols / 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (cols / 2);
         const int c = (int)(i % (cols / 2)) * 2;
-        const f32x2 av = *reinterpret_cast<const f32x2*>(a + r * cols + c);
-        const f32x2 bv = *reinterpret_cast<const f32x2*>(b + (perm ? (int64_t)perm[r] : r) * cols + c);
+        const f32x2 av = src_load2(a, r, c, cols);
+        const f32x2 bv = src_load2(b, perm ? (int64_t)perm[r] : r, c, cols);
         const float y0 = (av[0] + bv[0]) * s, y1 = (av[1] + bv[1]) * s;
-        *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
+        if (y) *reinterpret_cast<f32x2*>(y + r * cols + c) = f32x2{y0, y1};
         if (P.base) store_pl_pair(P, r, c, y0, y1);
         m = fmaxf(m, fmaxf(fabsf(y0), fabsf(y1)));
     }
@@ -956,6 +1008,11 @@ struct mi_gbatch {
         float scale;
     };
     std::map<const float*, PlInfo> pl_of;           // fp32 tensor -> the plane set its producer wrote next to it
+    struct Dims {
+        int64_t rows;
+        int cols;
+    };
+    std::map<const float*, Dims> absent;            // tensors of the last (inference) forward whose fp32 rows were NOT written: plane set only
     float* dsc_pool = nullptr;                      // [AMAX_SLOTS][2]
     int dsc_used = 0;
     bool planes_mode = false;
@@ -1012,6 +1069,7 @@ struct Ctx {
     unsigned* amax(const float* x, int64_t n) {
         unsigned*& slot = b->amax_of[x];
         if (!slot && b->amax_used < AMAX_SLOTS) {
+            need_f32(x);
             slot = b->amax_pool + b->amax_used++;
             if (!dry && n > 0) hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot);
         }
@@ -1023,8 +1081,37 @@ struct Ctx {
         return slot;
     }
     float* new_dsc() { return b->dsc_used < AMAX_SLOTS ? b->dsc_pool + 2 * b->dsc_used++ : nullptr; }
+    // lean inference (see g_mg_lean): one format per edge-level tensor
+    bool lean() const { return !train && b->planes_mode && (g_mg_lean & 1); }
+    bool lean_fold() const { return lean() && (g_mg_lean & 2); }
+    bool lean_segsum() const { return lean() && (g_mg_lean & 4); }
+    void drop_f32(const float* Y, int64_t rows, int cols) { b->absent[Y] = mi_gbatch::Dims{rows, cols}; }
+    bool is_absent(const float* X) const { return b->absent.find(X) != b->absent.end(); }
+    Planes planes_of(const float* X, int cols) const {
+        const mi_gbatch::PlInfo& pi = b->pl_of.at(X);
+        return make_planes(pi.pl, cols, pi.scale, pi.dsc);
+    }
+    Src src(const float* X, int cols) const { return is_absent(X) ? Src{nullptr, planes_of(X, cols)} : Src{X, Planes()}; }
+    // a consumer that reads fp32 rows: materialise them from the plane set if the producer skipped them
+    void need_f32(const float* X);
     const int* gidx(int kind) const { return kind == GK_SRC ? b->src : kind == GK_DST ? b->dst : b->node2graph; }
 };
+
+static void materialize_f32(mi_gbatch* b, const float* X, hipStream_t s) {
+    auto it = b->absent.find(X);
+    if (it == b->absent.end()) return;
+    const mi_gbatch::Dims d = it->second;
+    const mi_gbatch::PlInfo& pi = b->pl_of.at(X);
+    if (d.rows > 0)
+        hipLaunchKernelGGL(pl_to_f32_kernel, dim3((unsigned)std::min<int64_t>(4096, (d.rows * (d.cols / 2) + 255) / 256)), dim3(256), 0, s,
+                           Src{nullptr, make_planes(pi.pl, d.cols, pi.scale, pi.dsc)}, const_cast<float*>(X), d.rows, d.cols);
+    b->absent.erase(it);
+}
+void Ctx::need_f32(const float* X) {
+    if (!X || !is_absent(X)) return;
+    if (dry) b->absent.erase(X);
+    else materialize_f32(b, X, s);
+}
 
 #define CTX_OK(c) ((c).rc == MI_OK)
 #define MI_HIP_VOID(call)                                                                   \
@@ -1076,7 +1163,8 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
 // Y[M,N] = act( X[M,K] W[:, wcol0 : wcol0+K]^T + bias + G1[idx1] + G2[idx2] )
 static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::string& wname, int wcol0 = 0, int act = ACT_NONE, bool x_grad = true,
                        const std::string& bname = "", const float* G1 = nullptr, int gk1 = GK_NONE, const float* G2 = nullptr, int gk2 = GK_NONE,
-                       int ldy = 0, const float* res = nullptr, float scale = 1.f, bool want_pl = false) {
+                       int ldy = 0, const float* res = nullptr, float scale = 1.f, bool want_pl = false, const float* res2 = nullptr, float scale2 = 1.f) {
+    // res2 / scale2 (inference only): a second merge folded in behind the first,  y = ((act(z) + res) * scale + res2) * scale2
     const GParam& w = c.net->P(wname);
     const int N = w.rows;
     if (ldy == 0) ldy = N;
@@ -1087,6 +1175,15 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     const bool planes = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 7) == 0 && ldy == N && bname.empty() && xin != c.b->pl_of.end();
     u16* Ypl = (planes && want_pl) ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};   // (registered in the dry run too: both runs must take the same decisions)
+    const bool lean_y = Ypl && c.lean();   // the consumers of Y read the plane set: its fp32 rows are not written
+    if (!planes) {   // the fp32-operand kernels read rows
+        c.need_f32(X);
+        c.need_f32(res);
+        c.need_f32(res2);
+    }
+    if (lean_y) c.drop_f32(Y, M, N);
+    if (getenv("MI_DEBUG_LEAN")) fprintf(stderr, "[dense %s] %s planes=%d lean_y=%d res=%p absent=%d res2=%p absent=%d Xabsent=%d\n", c.dry ? "dry" : "run", wname.c_str(), (int)planes, (int)lean_y,
+                                         (const void*)res, res ? (int)c.is_absent(res) : -1, (const void*)res2, res2 ? (int)c.is_absent(res2) : -1, (int)c.is_absent(X));
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (planes) {
         const int pidx = c.net->index.at(wname);
@@ -1111,11 +1208,23 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             pe.ep.ld_pre = N;
         }
         if (res) {
-            pe.ep.residual = res;
-            pe.ep.ld_res = N;
+            if (!(g_mg_lean & 8)) c.need_f32(res);
+            if (c.is_absent(res)) pe.res_pl = c.planes_of(res, N);
+            else {
+                pe.ep.residual = res;
+                pe.ep.ld_res = N;
+            }
         }
         pe.ep.out_scale = scale;
-        pe.C = Y;
+        if (res2) {
+            if (c.is_absent(res2)) pe.res2_pl = c.planes_of(res2, N);
+            else {
+                pe.residual2 = res2;
+                pe.ld_res2 = N;
+            }
+            pe.out_scale2 = scale2;
+        }
+        pe.C = lean_y ? nullptr : Y;
         pe.ldc = N;
         pe.absmax = c.new_amax(Y);
         if (Ypl) {   // scale of the output plane set from the one-layer bound on the exact absmax of everything that enters
@@ -1123,7 +1232,8 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             const int rows_g = gk1 == GK_NODE ? c.b->B : c.b->N;
             hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
                                G1 ? c.amax(G1, (int64_t)rows_g * N) : (const unsigned*)nullptr, G2 ? c.amax(G2, (int64_t)c.b->N * N) : (const unsigned*)nullptr,
-                               res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc);
+                               res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc,
+                               res2 ? c.amax(res2, M * N) : (const unsigned*)nullptr, scale2);
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));   // the k-padding of the next product must be zero
             pe.Cp = make_planes(Ypl, N, 1.f, dsc);
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1187,6 +1297,10 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     } else {
         CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
     }
+    if (res2) {   // (the plane-set kernel folds this in; here it is one more pass, in place)
+        if (ldy != N || c.train) c.rc = MI_EINVAL;
+        else hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, Y, res2, (const int*)nullptr, scale2, Y, M, N);
+    }
     if (c.train) {
         GOp o;
         o.type = OP_DENSE;
@@ -1217,6 +1331,13 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
     const bool pl = c.pm() && want_pl && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;
     u16* Ypl = pl ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
+    const bool lean_y = Ypl && c.lean();
+    if (!pl) {
+        c.need_f32(A);
+        c.need_f32(Bm);
+    }
+    const Src sa = c.src(A, N), sb = c.src(Bm, N);
+    if (lean_y) c.drop_f32(Y, M, N);
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (pl) {
         float* dsc = c.new_dsc();
@@ -1224,7 +1345,8 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
                            (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, 1.f, 1.f, dsc);
         if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
         c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
-        hipLaunchKernelGGL(mul_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, A, Bm, Y, make_planes(Ypl, N, 1.f, dsc), c.new_amax(Y), M, N);
+        hipLaunchKernelGGL(mul_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, sa, sb, lean_y ? (float*)nullptr : Y,
+                           make_planes(Ypl, N, 1.f, dsc), c.new_amax(Y), M, N);
     } else
     hipLaunchKernelGGL(mul_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, Y, M * N);
     if (c.train) {
@@ -1244,6 +1366,13 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
     const bool big = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;   // edge-level: the output's absmax is tracked on the way
     u16* Ypl = (big && want_pl) ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
+    const bool lean_y = Ypl && c.lean();
+    if (!big) {
+        c.need_f32(A);
+        c.need_f32(Bm);
+    }
+    const Src sa = c.src(A, N), sb = c.src(Bm, N);
+    if (lean_y) c.drop_f32(Y, M, N);
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (big) {
         float* dsc = nullptr;
@@ -1254,8 +1383,8 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
         }
-        hipLaunchKernelGGL(axpby_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y,
-                           Ypl ? make_planes(Ypl, N, 1.f, dsc) : Planes(), c.new_amax(Y), M, N);
+        hipLaunchKernelGGL(axpby_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, sa, sb, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2,
+                           lean_y ? (float*)nullptr : Y, Ypl ? make_planes(Ypl, N, 1.f, dsc) : Planes(), c.new_amax(Y), M, N);
     } else
     hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y, M, N);
     if (c.train) {
@@ -1272,8 +1401,18 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
     }
     return Y;
 }
+// edges -> atoms by target with the per-edge weights Wt multiplied in on the way (inference: the weighted messages are never written)
+static float* op_segsum_mul(Ctx& c, const float* X, const float* Wt, int cols) {
+    float* Y = c.take((size_t)c.b->N * cols);
+    c.need_f32(Wt);
+    const Src sx = c.src(X, cols);
+    if (c.dry || !CTX_OK(c) || c.train) return Y;
+    hipLaunchKernelGGL(segsum_mul_kernel, dim3(c.b->N), dim3(256), 0, c.s, sx, Wt, c.b->rowptr, Y, cols);
+    return Y;
+}
 static float* op_segsum(Ctx& c, const float* X, int cols) {  // edges -> atoms by target
     float* Y = c.take((size_t)c.b->N * cols);
+    c.need_f32(X);
     if (c.dry || !CTX_OK(c)) return Y;
     hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)c.b->N * cols)), dim3(256), 0, c.s, X, cols, c.b->rowptr, (const int*)nullptr, Y, c.b->N, cols, 0);
     if (c.train) {
@@ -1295,6 +1434,8 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     const bool pl = c.pm() && E >= MG_PLANES_MIN_ROWS && (g.emb_trip & 1) == 0;
     u16* Ypl = pl ? c.take_planes(E, NT) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
+    c.need_f32(xd);
+    c.need_f32(cbfW);
     if (c.dry || !CTX_OK(c) || E == 0) return Y;
     Planes P;
     unsigned* ymax = nullptr;
@@ -1331,6 +1472,8 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     return Y;
 }
 static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string& wname, float* y, int K, bool acc) {
+    c.need_f32(A);
+    c.need_f32(Bm);
     if (c.dry || !CTX_OK(c) || c.b->E == 0) return;
     const GParam& w = c.net->P(wname);
     hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(nblk(c.b->E, 4)), dim3(256), 0, c.s, A, Bm, c.net->theta + w.off, y, c.b->E, K, acc ? 1 : 0);
@@ -1348,12 +1491,13 @@ static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string
 }
 
 // `out_pl`: the stack's result feeds another dense layer (its plane set is wanted)
-static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W, bool out_pl = false) {
+// `outer` (lean inference, n > 0): the skip connection the stack closes, (outer + stack(x)) / sqrt(2), folded into its last layer
+static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W, bool out_pl = false, const float* outer = nullptr) {
     for (int k = 0; k < n; ++k) {
         const std::string p = prefix + "." + std::to_string(k);
         float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
         x = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x, GN_ISQ2,
-                     k + 1 < n || out_pl);  // (x + f(x)) / sqrt(2)
+                     k + 1 < n || out_pl, k + 1 == n ? outer : nullptr, GN_ISQ2);  // (x + f(x)) / sqrt(2)
     }
     return x;
 }
@@ -1385,6 +1529,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     b->amax_of.clear();
     b->amax_used = 0;
     b->pl_of.clear();
+    b->absent.clear();
     b->dsc_used = 0;
     b->planes_mode = g_mg_planes && g_gemm_mode != 0 && E >= MG_PLANES_MIN_ROWS;
     if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, AMAX_SLOTS * sizeof(unsigned), c.s));
@@ -1445,20 +1590,30 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         float* x3b = op_axpby(c, u1, u2, E, Ed, true);
         float* x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2,
                             g.num_before_skip > 0);  // (x_ca + x3) / sqrt(2)
-        x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
-        m = op_axpby(c, m, x, E, Ed, false, true);
+        if (c.lean_fold() && g.num_before_skip > 0) m = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed, true, m);
+        else {
+            x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
+            m = op_axpby(c, m, x, E, Ed, false, true);
+        }
         m = res_stack(c, p + ".after_skip", g.num_after_skip, m, E, Ed, true);
         float* ru = op_dense(c, rbf_h, E, Rb, p + ".atom_update.rbf.weight");
-        float* mm = op_mul(c, m, ru, E, Ed);
-        float* h2 = op_segsum(c, mm, Ed);
+        float* h2;
+        if (c.lean_segsum()) h2 = op_segsum_mul(c, m, ru, Ed);
+        else {
+            float* mm = op_mul(c, m, ru, E, Ed);
+            h2 = op_segsum(c, mm, Ed);
+        }
         h2 = op_dense(c, h2, N, Ed, p + ".atom_update.dense.weight", 0, ACT_SSILU);
         h2 = res_stack(c, p + ".atom_update.res", g.num_atom, h2, N, A);
         h = op_axpby(c, h, h2, N, A);
         HS = op_dense(c, h, N, A, p + ".concat.weight", 0);
         HT = op_dense(c, h, N, A, p + ".concat.weight", A);
         float* m2 = op_dense(c, m, E, Ed, p + ".concat.weight", 2 * A, ACT_SSILU, true, "", HS, GK_SRC, HT, GK_DST, 0, nullptr, 1.f, g.num_concat > 0);
-        m2 = res_stack(c, p + ".residual_m", g.num_concat, m2, E, Ed);
-        m = op_axpby(c, m, m2, E, Ed, false, true);
+        if (c.lean_fold() && g.num_concat > 0) m = res_stack(c, p + ".residual_m", g.num_concat, m2, E, Ed, true, m);
+        else {
+            m2 = res_stack(c, p + ".residual_m", g.num_concat, m2, E, Ed);
+            m = op_axpby(c, m, m2, E, Ed, false, true);
+        }
         b->taps["h" + std::to_string(i + 1)] = {h, (int64_t)N * A};
         b->taps["m" + std::to_string(i + 1)] = {m, E * Ed};
         out_block(c, i + 1, m, rbf_out, false);
@@ -1933,6 +2088,11 @@ int mi_debug_set_mg_planes(int on) {
     return MI_OK;
 }
 
+int mi_debug_set_mg_lean(int on) {
+    mi::g_mg_lean = on == 1 ? 15 : on < 0 ? -on : on;   // (0 = off, 1 = everything; other values: the bit mask of g_mg_lean, for ablations)
+    return MI_OK;
+}
+
 int mi_debug_set_mg_f16(int on) {
     mi::g_mg_f16 = on != 0 && MI_PLANES_FP16;
     return MI_OK;
@@ -1945,6 +2105,7 @@ int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, 
     if (numel) *numel = it->second.second;
     if (out) {
         MI_CHECK(capacity >= it->second.second, MI_EINVAL, "tap %s needs %lld floats", name, (long long)it->second.second);
+        mi::materialize_f32(b, it->second.first, (hipStream_t)stream);   // (a lean inference forward kept this tensor as a plane set only)
         MI_HIP(hipMemcpyAsync(out, it->second.first, (size_t)it->second.second * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return MI_OK;

@@ -280,11 +280,14 @@ def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
     assert bad <= 0.02 * tot_n, f"{bad} of {tot_n} parameters differ by more than 1e-5 after the Adam step"
 
 
-@pytest.mark.parametrize("planes,f16", [(1, 0), (0, 1), (0, 0)], ids=["pre-split-plane-sets", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
-def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16):
+@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 0, 1)],
+                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
+def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
-    (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values) or on the fp32-operand
-    kernel (three bf16 planes or two fp16 planes split on the fly); all three against the oracle, the default also through the backward."""
+    (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values; inference keeps one
+    format per edge-level tensor and folds the skip merges into the residual stacks -- `lean`, also run switched off) or on the
+    fp32-operand kernel (three bf16 planes or two fp16 planes split on the fly); all against the oracle, outputs and per-block taps,
+    the default also through the backward."""
     from matinvent_amd import _lib
     hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
     hp = M.GemNetHParams(**hpd)
@@ -293,15 +296,20 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16):
     na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
     _lib.check(_lib.load().mi_debug_set_mg_planes(planes))
+    _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
     try:
         gb = m.decoder.make_batch(na)
         E = gb.graph(frac, cell)["src"].shape[0]
         assert E * 2 >= 256 * 128, E   # (E / 128) x (256 / 128) output tiles: the large-tile branch
-        ref = M.gemnet_forward(P, hp, frac, cell, a, na, t)
+        taps = {}
+        ref = M.gemnet_forward(P, hp, frac, cell, a, na, t, taps=taps)
         with torch.no_grad():
             out = m.decoder(frac, cell, a, t, gb)
         for k in ("pos", "cell", "atomic_numbers"):
-            _rel(out[k], ref[k], 2e-5, f"{k} (planes={planes} f16={f16})")
+            _rel(out[k], ref[k], 2e-5, f"{k} (planes={planes} f16={f16} lean={lean})")
+        for i in range(hp.num_blocks):   # (tensors a lean forward kept as plane sets only are rebuilt from them for the tap)
+            for name in (f"x3_{i}", f"h{i + 1}", f"m{i + 1}"):
+                _rel(gb.tap(name), taps[name].reshape(-1), 2e-5, f"{name} (planes={planes} f16={f16} lean={lean})")
         assert _lib.saturation_events(reset=True) == 0
         if planes:   # the training forward + backward through the same plane-set layers: parameter gradients vs the oracle's autograd
             N, B = int(na.sum()), len(na)
@@ -316,3 +324,4 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16):
     finally:
         _lib.check(_lib.load().mi_debug_set_mg_f16(0))
         _lib.check(_lib.load().mi_debug_set_mg_planes(1))
+        _lib.check(_lib.load().mi_debug_set_mg_lean(1))
