@@ -135,12 +135,14 @@ __device__ __forceinline__ float f16_scale_from_absmax(unsigned bits) {
     return exp2f((float)e);
 }
 // max |x| of a tensor as a bit pattern (order-independent: deterministic); the slot must be zero before the launch
-static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+// (spread_mask: the waves' atomics go to out[blockIdx & mask] -- same-address atomics serialise at ~8.5 ns each in the L2, so a
+// launch of thousands of waves spreads them over a power-of-two row of sub-slots that the reader folds; 0 = one slot)
+static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out, int spread_mask = 0) {
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + (blockIdx.x & spread_mask), __float_as_uint(m));
 }
 
 // F16 = true: the fp32 operands are split on the fly into TWO fp16 planes (three MFMA terms instead of six) with power-of-two scales
@@ -405,6 +407,7 @@ struct PlanesEpilogue {
     float out_scale = 1.f; // 1 / (A.scale * W.scale), set by gemm_planes: applied to the accumulator first
     const float* a_dinv = nullptr;  // device-side 1 / (dynamic scale of A), multiplied in as well (set by gemm_planes)
     unsigned* absmax = nullptr;     // optional: atomicMax of the bit pattern of max |output| (row-major epilogue only)
+    int absmax_mask = 0;            // the atomics of workgroup w go to absmax[w & mask] (see absmax_bits_kernel); 0 = one slot
     __device__ __forceinline__ float oscale() const { return a_dinv ? out_scale * a_dinv[0] : out_scale; }
     float* C = nullptr;    // optional fp32 output [M][ldc]
     int ldc = 0;
@@ -645,10 +648,9 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
                     }
-                    if (pe.C) {
-                        float* d = pe.C + (size_t)row * pe.ldc + col;
-                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    if (pe.C) {   // back into the patch (this lane's own eight slots); stored below in whole 128-byte lines
+                        *reinterpret_cast<f32x4*>(stage + rl * 36 + c8) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(stage + rl * 36 + c8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     }
                     if (pe.Cp.base) {
                         u32x4 o[3];
@@ -666,11 +668,24 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (pe.C) {
+                // fp32 rows: eight lanes write one 128-byte line (a row of the 32 x 32 tile), a wave instruction eight whole lines.
+                // In the eight-columns-per-lane mapping above the same data left as 2 x 64 sixteen-byte pieces spread over 16 rows,
+                // and a K = 16 layer that only writes its [E, 512] result ran at 1.3 TB/s (393 us at 256k edges).
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = rb + rl, col = cb + c4;
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c4);
+                    if (row < M && col < N) *reinterpret_cast<f32x4*>(pe.C + (size_t)row * pe.ldc + col) = z;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     if (pe.absmax) {  // max |output| of this wave's block: order-independent, so the atomic keeps the result deterministic
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        if (lane == 0) atomicMax(pe.absmax, __float_as_uint(amax));
+        if (lane == 0) atomicMax(pe.absmax + (blockIdx.x & pe.absmax_mask), __float_as_uint(amax));
     }
 }
 // PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major

@@ -14,6 +14,7 @@
 // fp32-class accuracy), weight gradients on gemm_tn_auto, data gradients on gemm_nt against transposed weight copies.
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -40,9 +41,13 @@ int g_mg_planes = 1;
 // otherwise -- instead of both (elementwise consumers and residual merges reconstruct x = (h0 + h1) / scale, exact in fp32), fold the
 // skip-connection merges into the last layer of the residual stack they close and the radial weighting into the edge -> atom sum.
 // Training forwards keep both formats (the tape's gradient kernels read fp32 rows).
-int g_mg_lean = 15;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass
+int g_mg_lean = 15;
+static const bool g_optime = getenv("MI_DEBUG_OPTIME") != nullptr;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass
 constexpr int64_t MG_PLANES_MIN_ROWS = 4096;
 constexpr int AMAX_SLOTS = 2048;
+// an absmax slot is a row of AMAX_W sub-slots: a producer's waves spread their atomicMax over them (32k same-address atomics of one
+// [256k, 512] product were a 270 us floor under every edge-level layer), readers fold the row
+constexpr int AMAX_W = 64;
 constexpr int LOGIT_LD = 104;  // row stride of the logits buffer (101 padded to a multiple of 4: GEMM operand alignment)
 
 enum : uint32_t {  // Philox draw ids of this path (DESIGN.md "RNG"; mirrored by oracle-side helpers in the tests)
@@ -455,21 +460,36 @@ __global__ void gather_add_kernel(const float* __restrict__ dY, const int* __res
 }
 
 // ---- plane-set plumbing of the forward (fp16 two-plane / bf16 three-plane format of gemm_split.h) ---------------------------------
+// the value of an absmax slot: the largest of its sub-slots (all lanes of the calling wave get it)
+__device__ __forceinline__ float amax_read(const unsigned* slot) {
+    float m = __uint_as_float(slot[threadIdx.x & (AMAX_W - 1)]);   // (non-negative floats order like their bit patterns)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+// slot[0] = the folded value (for readers that take one word: the on-the-fly fp16 split of the fp32-operand kernel)
+__global__ void amax_fold_kernel(unsigned* slot) {
+    const float m = amax_read(slot);
+    if (threadIdx.x == 0) slot[0] = __float_as_uint(m);
+}
 // {scale, 1 / scale} of an output plane set from a rigorous bound:  bound = (fa (a * rs * b2 * deg * kmul + g1 + g2) + res) * s
 // with a, b2, g1, g2, res = exact absmax bit patterns of the inputs (NULL = absent), rs = largest row sum of |W| of the layer
 __global__ void mg_scale_kernel(const unsigned* a, const float* rs, const unsigned* b2, const int* degp, float kmul, const unsigned* g1, const unsigned* g2,
                                 const unsigned* res, float fa, float s, float* dsc, const unsigned* res2 = nullptr, float s2 = 1.f) {
-    float t = __uint_as_float(*a) * (rs ? *rs : 1.f) * (b2 ? __uint_as_float(*b2) : 1.f) * (degp ? (float)*degp : 1.f) * kmul;
-    if (g1) t += __uint_as_float(*g1);
-    if (g2) t += __uint_as_float(*g2);
-    t = fa * t + (res ? __uint_as_float(*res) : 0.f);
+    // (one wave: every input is a row of AMAX_W sub-slots)
+    float t = amax_read(a) * (rs ? *rs : 1.f) * (b2 ? amax_read(b2) : 1.f) * (degp ? (float)*degp : 1.f) * kmul;
+    if (g1) t += amax_read(g1);
+    if (g2) t += amax_read(g2);
+    t = fa * t + (res ? amax_read(res) : 0.f);
     t *= s;
-    if (res2) t = (t + __uint_as_float(*res2)) * s2;   // the folded second merge
+    if (res2) t = (t + amax_read(res2)) * s2;   // the folded second merge
     int e = 14 - (int)ceilf(log2f(fmaxf(t, 1e-30f)));
     if (!(t == t) || t > 3e38f) e = -100;
     e = e > 30 ? 30 : (e < -100 ? -100 : e);
-    dsc[0] = exp2f((float)e);
-    dsc[1] = exp2f(-(float)e);
+    if (threadIdx.x == 0) {
+        dsc[0] = exp2f((float)e);
+        dsc[1] = exp2f(-(float)e);
+    }
 }
 // max over rows of sum_k |W[row][k]|, k in [0, K)
 __global__ __launch_bounds__(256) void rowsum_max_kernel(const float* __restrict__ W, int ldw, int rows, int K, float* __restrict__ out) {
@@ -493,7 +513,7 @@ __device__ __forceinline__ void store_pl_pair(const Planes& P, int64_t row, int 
 __device__ __forceinline__ void note_absmax(unsigned* slot, float m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && slot) atomicMax(slot, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && slot) atomicMax(slot + (blockIdx.x & (AMAX_W - 1)), __float_as_uint(m));
 }
 // An edge-level operand as its consumer finds it: fp32 rows, or -- where an inference run kept only the plane set -- the planes
 struct Src {
@@ -683,7 +703,7 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
         if (tid == 0) {
             float m = wmax[0];
             for (int k = 1; k < 8; ++k) m = fmaxf(m, wmax[k]);
-            atomicMax(amax, __float_as_uint(m));
+            atomicMax(amax + (blockIdx.x & (AMAX_W - 1)), __float_as_uint(m));
         }
     }
 }
@@ -1070,13 +1090,13 @@ struct Ctx {
         unsigned*& slot = b->amax_of[x];
         if (!slot && b->amax_used < AMAX_SLOTS) {
             need_f32(x);
-            slot = b->amax_pool + b->amax_used++;
-            if (!dry && n > 0) hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot);
+            slot = b->amax_pool + (size_t)AMAX_W * b->amax_used++;
+            if (!dry && n > 0) hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1);
         }
         return slot;
     }
     unsigned* new_amax(const float* y) {   // a fresh (zeroed) slot the producer of y fills itself
-        unsigned* slot = b->amax_used < AMAX_SLOTS ? b->amax_pool + b->amax_used++ : nullptr;
+        unsigned* slot = b->amax_used < AMAX_SLOTS ? b->amax_pool + (size_t)AMAX_W * b->amax_used++ : nullptr;
         if (slot) b->amax_of[y] = slot;
         return slot;
     }
@@ -1112,6 +1132,27 @@ void Ctx::need_f32(const float* X) {
     if (dry) b->absent.erase(X);
     else materialize_f32(b, X, s);
 }
+
+// MI_DEBUG_OPTIME=1: every op of the program is bracketed by stream synchronisations and its wall time printed (a per-layer profile
+// with the layer's NAME, which a kernel trace does not carry); serialises the stream, never on in a timed run
+struct OpTimer {
+    Ctx& c;
+    std::string what;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    OpTimer(Ctx& c_, const std::string& w, int64_t M, int N, int K) : c(c_), on(!c_.dry && g_optime) {
+        if (!on) return;
+        what = w + " [" + std::to_string(M) + " x " + std::to_string(N) + " x " + std::to_string(K) + "]";
+        (void)hipStreamSynchronize(c.s);
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~OpTimer() {
+        if (!on) return;
+        (void)hipStreamSynchronize(c.s);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[optime] %-52s %9.1f us\n", what.c_str(), us);
+    }
+};
 
 #define CTX_OK(c) ((c).rc == MI_OK)
 #define MI_HIP_VOID(call)                                                                   \
@@ -1168,6 +1209,7 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     const GParam& w = c.net->P(wname);
     const int N = w.rows;
     if (ldy == 0) ldy = N;
+    OpTimer optimer(c, "dense " + wname, M, N, K);
     float* Y = c.take((size_t)M * ldy);
     float* Z = (act != ACT_NONE && c.train) ? c.take((size_t)M * N) : nullptr;
     // edge-level layers whose input carries a plane set run on the pre-split plane kernel
@@ -1182,8 +1224,6 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         c.need_f32(res2);
     }
     if (lean_y) c.drop_f32(Y, M, N);
-    if (getenv("MI_DEBUG_LEAN")) fprintf(stderr, "[dense %s] %s planes=%d lean_y=%d res=%p absent=%d res2=%p absent=%d Xabsent=%d\n", c.dry ? "dry" : "run", wname.c_str(), (int)planes, (int)lean_y,
-                                         (const void*)res, res ? (int)c.is_absent(res) : -1, (const void*)res2, res2 ? (int)c.is_absent(res2) : -1, (int)c.is_absent(X));
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (planes) {
         const int pidx = c.net->index.at(wname);
@@ -1227,10 +1267,11 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         pe.C = lean_y ? nullptr : Y;
         pe.ldc = N;
         pe.absmax = c.new_amax(Y);
+        pe.absmax_mask = AMAX_W - 1;
         if (Ypl) {   // scale of the output plane set from the one-layer bound on the exact absmax of everything that enters
             float* dsc = c.new_dsc();
             const int rows_g = gk1 == GK_NODE ? c.b->B : c.b->N;
-            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
                                G1 ? c.amax(G1, (int64_t)rows_g * N) : (const unsigned*)nullptr, G2 ? c.amax(G2, (int64_t)c.b->N * N) : (const unsigned*)nullptr,
                                res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc,
                                res2 ? c.amax(res2, M * N) : (const unsigned*)nullptr, scale2);
@@ -1290,9 +1331,10 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     if (use16) {
         unsigned*& slot = c.b->amax_of[X];
         if (!slot) {   // the operand's exact absmax, once per tensor and forward (one extra read of it; the product then issues half the MFMA work)
-            slot = c.b->amax_pool + c.b->amax_used++;
-            hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot);
+            slot = c.b->amax_pool + (size_t)AMAX_W * c.b->amax_used++;
+            hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot, AMAX_W - 1);
         }
+        hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_W), 0, c.s, slot);   // (the kernel reads one word)
         CTX_TRY(c, gemm_nt_split(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s, nullptr, slot, c.net->wamax + c.net->index.at(wname)));
     } else {
         CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
@@ -1327,6 +1369,7 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     return Y;
 }
 static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool want_pl = false) {
+    OpTimer optimer(c, "mul", M, N, 0);
     float* Y = c.take((size_t)M * N);
     const bool pl = c.pm() && want_pl && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;
     u16* Ypl = pl ? c.take_planes(M, N) : nullptr;
@@ -1341,7 +1384,7 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (pl) {
         float* dsc = c.new_dsc();
-        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(A, M * N), (const float*)nullptr, c.amax(Bm, M * N), (const int*)nullptr, 1.f,
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M * N), (const float*)nullptr, c.amax(Bm, M * N), (const int*)nullptr, 1.f,
                            (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, 1.f, 1.f, dsc);
         if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
         c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1362,6 +1405,7 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
     return Y;
 }
 static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool perm = false, bool want_pl = false) {
+    OpTimer optimer(c, perm ? "axpby (row-permuted)" : "axpby", M, N, 0);
     float* Y = c.take((size_t)M * N);
     const bool big = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;   // edge-level: the output's absmax is tracked on the way
     u16* Ypl = (big && want_pl) ? c.take_planes(M, N) : nullptr;
@@ -1378,7 +1422,7 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
         float* dsc = nullptr;
         if (Ypl) {
             dsc = c.new_dsc();
-            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(A, M * N), (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M * N), (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
                                (const unsigned*)nullptr, (const unsigned*)nullptr, c.amax(Bm, M * N), 1.f, GN_ISQ2, dsc);
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1403,6 +1447,7 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
 }
 // edges -> atoms by target with the per-edge weights Wt multiplied in on the way (inference: the weighted messages are never written)
 static float* op_segsum_mul(Ctx& c, const float* X, const float* Wt, int cols) {
+    OpTimer optimer(c, "segsum_mul", c.b->E, cols, 0);
     float* Y = c.take((size_t)c.b->N * cols);
     c.need_f32(Wt);
     const Src sx = c.src(X, cols);
@@ -1411,6 +1456,7 @@ static float* op_segsum_mul(Ctx& c, const float* X, const float* Wt, int cols) {
     return Y;
 }
 static float* op_segsum(Ctx& c, const float* X, int cols) {  // edges -> atoms by target
+    OpTimer optimer(c, "segsum", c.b->E, cols, 0);
     float* Y = c.take((size_t)c.b->N * cols);
     c.need_f32(X);
     if (c.dry || !CTX_OK(c)) return Y;
@@ -1427,6 +1473,7 @@ static float* op_segsum(Ctx& c, const float* X, int cols) {  // edges -> atoms b
     return Y;
 }
 static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
+    OpTimer optimer(c, "triplet", c.b->E, 0, 0);
     const mi_gemnet_config& g = c.net->cfg;
     const int64_t E = c.b->E;
     float* Y = c.take((size_t)E * g.emb_cbf * g.emb_trip);
@@ -1441,7 +1488,7 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     unsigned* ymax = nullptr;
     if (pl) {   // |Tm| <= max|cbfW| max|xd| S max|Y_l| deg_max
         float* dsc = c.new_dsc();
-        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(1), 0, c.s, c.amax(cbfW, E * g.num_spherical * g.emb_cbf), (const float*)nullptr, c.amax(xd, E * g.emb_trip),
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(cbfW, E * g.num_spherical * g.emb_cbf), (const float*)nullptr, c.amax(xd, E * g.emb_trip),
                            (const int*)(c.b->meta + 1), 1.1f * (float)g.num_spherical, (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr,
                            1.f, 1.f, dsc);
         if (NT % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(E, NT) * sizeof(u16), c.s));
@@ -1472,6 +1519,7 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     return Y;
 }
 static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string& wname, float* y, int K, bool acc) {
+    OpTimer optimer(c, "rowdot " + wname, c.b->E, 1, K);
     c.need_f32(A);
     c.need_f32(Bm);
     if (c.dry || !CTX_OK(c) || c.b->E == 0) return;
@@ -1532,7 +1580,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     b->absent.clear();
     b->dsc_used = 0;
     b->planes_mode = g_mg_planes && g_gemm_mode != 0 && E >= MG_PLANES_MIN_ROWS;
-    if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, AMAX_SLOTS * sizeof(unsigned), c.s));
+    if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, (size_t)AMAX_SLOTS * AMAX_W * sizeof(unsigned), c.s));
     float* rbf = c.take((size_t)E * R);
     u16* rbf_pl = c.pm() ? c.take_planes(E, R) : nullptr;
     if (rbf_pl) b->pl_of[rbf] = mi_gbatch::PlInfo{rbf_pl, nullptr, PL_S_UNIT};   // |rbf| <= 1: the fixed unit-range scale
@@ -1984,7 +2032,7 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     GA(sp_pos, (size_t)N * 3);
     GA(sp_cell, (size_t)B * 9);
     GA(sp_logits, (size_t)N * MI_MG_CLASSES);
-    GA(amax_pool, AMAX_SLOTS);
+    GA(amax_pool, (size_t)AMAX_SLOTS * AMAX_W);
     GA(dsc_pool, 2 * AMAX_SLOTS);
 #undef GA
     if (rc != MI_OK) {
