@@ -421,6 +421,13 @@ struct PlanesEpilogue {
     int ld_res2 = 0;
     Planes res2_pl;
     float out_scale2 = 1.f;
+    const int* res2_rows = nullptr;   // optional row map of residual2 (fp32 form): row r adds residual2[res2_rows[r]]
+    // optional (row-major epilogue only) multiplicand applied right after the activation:  act(z) * post_mul[row][col]
+    const float* post_mul = nullptr;
+    int ld_post_mul = 0;
+    // The four extensions above (plane-set residual, second merge, row map, multiplicand) live in the EXT instantiation of the
+    // kernel only, so that the launches that do not use them keep their register budget (gemm_planes picks the instantiation).
+    __host__ __device__ bool extended() const { return res_pl.base || residual2 || res2_pl.base || post_mul; }
     // optional fused segmented sum over rows (edge -> node aggregation, cspnet.py:79): rows are edges sorted by
     // `seg_src`; every 32-row block writes the partial sum of each node run it contains to
     // seg_part[slot][node][col], slot = block - first block of that node (fixed order, no atomics);
@@ -579,7 +586,7 @@ __device__ __forceinline__ void pl_add8(float (&dst)[8], const Planes& P, int ro
 // stores per 32x32 tile and lane.  Here each tile goes through a per-wave LDS patch (32 x 36 floats) and comes back as
 // 8 consecutive columns of one row per lane: every gather, the optional pre-activation save and the three plane stores are
 // 16-byte accesses (12 loads + 6..8 stores per tile and lane).  Needs N % 8 == 0; `stage` = this wave's 4608-byte patch.
-template <int TM, int TN>
+template <int TM, int TN, bool EXT = false>
 __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int row_w, int col_w, int M, int N,
                                                      int lane, float* stage) {
     const GemmEpilogue& ep = pe.ep;
@@ -632,17 +639,32 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]) * 1.66666666666666667f;
                     }
+                    if constexpr (EXT) {
+                        if (pe.post_mul) {
+                            const float* src = pe.post_mul + (size_t)row * pe.ld_post_mul + col;
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                v[k] *= a[k];
+                                v[4 + k] *= b[k];
+                            }
+                        }
+                    }
                     if (ep.residual) add8(v, ep.residual + (size_t)row * ep.ld_res + col);
-                    else if (pe.res_pl.base) pl_add8(v, pe.res_pl, row, col);
+                    else if constexpr (EXT) {
+                        if (pe.res_pl.base) pl_add8(v, pe.res_pl, row, col);
+                    }
                     if (ep.out_scale != 1.f) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] *= ep.out_scale;
                     }
-                    if (pe.residual2 || pe.res2_pl.base) {
-                        if (pe.residual2) add8(v, pe.residual2 + (size_t)row * pe.ld_res2 + col);
-                        else pl_add8(v, pe.res2_pl, row, col);
+                    if constexpr (EXT) {
+                        if (pe.residual2 || pe.res2_pl.base) {
+                            if (pe.residual2) add8(v, pe.residual2 + (size_t)(pe.res2_rows ? pe.res2_rows[row] : row) * pe.ld_res2 + col);
+                            else pl_add8(v, pe.res2_pl, row, col);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] *= pe.out_scale2;
+                            for (int k = 0; k < 8; ++k) v[k] *= pe.out_scale2;
+                        }
                     }
                     if (pe.absmax) {
 #pragma unroll
@@ -840,7 +862,7 @@ __host__ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpi
 // share a CU (3 x 48 KiB LDS) and cover each other's staging, barriers and epilogues; in situ this beats the 256-row
 // double-buffered kernel below (one workgroup per CU), which is kept as an option.  V = 1: PAIR mode (see PlanesEpilogue) -- a
 // second accumulator set, 196 registers, two workgroups per CU.
-template <int V, int TM>
+template <int V, int TM, bool EXT = false>
 __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int N, int K, const PlanesEpilogue& pe, int rt_base) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32, TN = 2, PLA = BM * 64, PLB = 128 * 64;  // bytes per plane tile in LDS (A, W)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1019,7 +1041,7 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
 
     if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
         __syncthreads();                   // the staging patches overlay the operand tiles
-        planes_epilogue_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+        planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
     } else if (planes_preact_rows_applies(pe, N)) {  // training forward: pre-activation rows through LDS, the rest in registers
         __syncthreads();
         planes_store_preact_rows<TM, TN>(pe, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
@@ -1040,10 +1062,10 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
 #ifndef MI_PLANES_OCC1
 #define MI_PLANES_OCC1 2
 #endif
-template <int V, int TM = 2>
+template <int V, int TM = 2, bool EXT = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0, V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0)))
 void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
-    gemm_planes_body<V, TM>(A, W, M, N, K, pe, rt_base);
+    gemm_planes_body<V, TM, EXT>(A, W, M, N, K, pe, rt_base);
 }
 // dynamic LDS of gemm_planes_kernel: the operand tiles, overlaid after the loop by the epilogue's per-wave staging patches
 constexpr int planes_lds_bytes(int V, int TM) {
@@ -1389,8 +1411,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     pe.out_scale = 1.f / ((A.dscale ? 1.f : A.scale) * W.scale);
     pe.a_dinv = A.dscale ? A.dscale + 1 : nullptr;
     const bool pair = pe.pair_i != nullptr;
-    MI_CHECK(!(pe.res_pl.base || pe.residual2 || pe.res2_pl.base) || (!pair && planes_epilogue_is_rows(pe, N)), MI_EINVAL,
-             "gemm_planes: plane-set residuals / the second merge exist in the row-major epilogue only");
+    const bool ext = pe.extended();
+    MI_CHECK(!ext || (!pair && planes_epilogue_is_rows(pe, N) && (pe.ld_post_mul & 3) == 0 && (MI_PLANES_FP16 || g_planes_variant != 1)), MI_EINVAL,
+             "gemm_planes: plane-set residuals / the second merge / the multiplicand exist in the row-major epilogue of the 128-row kernel only");
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);
@@ -1418,9 +1441,11 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
-        hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
+        if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
     } else {
-        hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+        if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 2, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
     }
     MI_KERNEL_CHECK();
     return MI_OK;

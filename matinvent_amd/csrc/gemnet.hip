@@ -41,8 +41,8 @@ int g_mg_planes = 1;
 // otherwise -- instead of both (elementwise consumers and residual merges reconstruct x = (h0 + h1) / scale, exact in fp32), fold the
 // skip-connection merges into the last layer of the residual stack they close and the radial weighting into the edge -> atom sum.
 // Training forwards keep both formats (the tape's gradient kernels read fp32 rows).
-int g_mg_lean = 15;
-static const bool g_optime = getenv("MI_DEBUG_OPTIME") != nullptr;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass
+int g_mg_lean = 63;
+static const bool g_optime = getenv("MI_DEBUG_OPTIME") != nullptr;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass, bit 3: residuals read from plane sets, bit 4: scalar heads through the derived tensors, bit 5: radial multiplicand / reversed-edge merge in the dense epilogues
 constexpr int64_t MG_PLANES_MIN_ROWS = 4096;
 constexpr int AMAX_SLOTS = 2048;
 // an absmax slot is a row of AMAX_W sub-slots: a producer's waves spread their atomicMax over them (32k same-address atomics of one
@@ -475,12 +475,12 @@ __global__ void amax_fold_kernel(unsigned* slot) {
 // {scale, 1 / scale} of an output plane set from a rigorous bound:  bound = (fa (a * rs * b2 * deg * kmul + g1 + g2) + res) * s
 // with a, b2, g1, g2, res = exact absmax bit patterns of the inputs (NULL = absent), rs = largest row sum of |W| of the layer
 __global__ void mg_scale_kernel(const unsigned* a, const float* rs, const unsigned* b2, const int* degp, float kmul, const unsigned* g1, const unsigned* g2,
-                                const unsigned* res, float fa, float s, float* dsc, const unsigned* res2 = nullptr, float s2 = 1.f) {
+                                const unsigned* res, float fa, float s, float* dsc, const unsigned* res2 = nullptr, float s2 = 1.f, const unsigned* pmul = nullptr) {
     // (one wave: every input is a row of AMAX_W sub-slots)
     float t = amax_read(a) * (rs ? *rs : 1.f) * (b2 ? amax_read(b2) : 1.f) * (degp ? (float)*degp : 1.f) * kmul;
     if (g1) t += amax_read(g1);
     if (g2) t += amax_read(g2);
-    t = fa * t + (res ? amax_read(res) : 0.f);
+    t = fa * t * (pmul ? amax_read(pmul) : 1.f) + (res ? amax_read(res) : 0.f);   // (pmul: the multiplicand applied right after the activation)
     t *= s;
     if (res2) t = (t + amax_read(res2)) * s2;   // the folded second merge
     int e = 14 - (int)ceilf(log2f(fmaxf(t, 1e-30f)));
@@ -794,9 +794,17 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     float s = 0.f;
-    for (int k = lane; k < K; k += 64) s += A[r * K + k] * Bm[r * K + k] * w[k];
+    for (int k = lane; k < K; k += 64) s += A[r * K + k] * Bm[r * K + k] * (w ? w[k] : 1.f);
     s = wave_sum(s);
     if (lane == 0) y[r] = acc ? y[r] + s : s;
+}
+// short rows (K <= 16, a power of two): y[e] (+)= sum_k A[e][k] B[e][k], 64 / K rows per wave
+__global__ __launch_bounds__(256) void rowdot_short_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ y, int64_t rows, int K, int acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = i / K;
+    float s = r < rows ? A[i] * Bm[i] : 0.f;
+    for (int o = K >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (r < rows && (i % K) == 0) y[r] = acc ? y[r] + s : s;
 }
 __global__ void rowdot_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ w, const float* __restrict__ dy,
                                   float* __restrict__ dA, float* __restrict__ dB, int64_t rows, int K) {
@@ -907,6 +915,13 @@ __global__ void stress_bwd_kernel(const float* __restrict__ dS, const float* __r
     dSc[e] += s / (float)(cnt > 0 ? cnt : 1);
 }
 // W [rows][cols] (row stride cols) -> WT [cols][ldt]
+// q[k][c] = w_out[c] * Wr[c][k]   (Wr [Ed][Rb], q [Rb][Ed]; see mi_gemnet::dtheta)
+__global__ void derive_q_kernel(const float* __restrict__ w_out, const float* __restrict__ Wr, float* __restrict__ q, int Ed, int Rb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Ed * Rb) return;
+    const int k = (int)(i / Ed), c = (int)(i % Ed);
+    q[i] = w_out[c] * Wr[(size_t)c * Rb + k];
+}
 __global__ void gn_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int rows, int cols, int ldt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * cols) return;
@@ -932,6 +947,7 @@ struct GParam {
     std::string name;
     int64_t off, numel, toff;  // toff: offset of the transposed copy
     int rows, cols, ldt;
+    bool derived = false;      // an inference-only tensor computed from the parameters at mi_gemnet_set_params; `off` then indexes mi_gemnet::dtheta
 };
 
 struct mi_gemnet {
@@ -941,6 +957,14 @@ struct mi_gemnet {
     int64_t nparams = 0, ntrans = 0;
     const float* theta = nullptr;
     float* thetaT = nullptr;
+    // derived tensors (entries of `params` behind the first n_real, not part of theta / the gradient / the public parameter list):
+    //   out_blocks.<i>.q_F / q_S [emb_rbf, emb_edge]:  q[k][c] = out_weight[c] * rbf_weight[c][k].  The per-edge scalar heads are
+    //   y[e] = sum_c x[e][c] (sum_k rbf[e][k] Wr[c][k]) w[c] = sum_k rbf[e][k] (x Q^T)[e][k]: a 16-wide product and a 16-term row dot
+    //   instead of materialising the [E, emb_edge] radial weights and reading them back beside x.
+    float* dtheta = nullptr;
+    int64_t ndtheta = 0;
+    int n_real = 0;
+    const float* wptr(const GParam& p) const { return (p.derived ? dtheta : theta) + p.off; }
     unsigned* wamax = nullptr;   // [tensors] max |w| bit patterns (scales of the on-the-fly fp16 split)
     // plane sets of the weight blocks the edge-level dense layers use, built lazily after every mi_gemnet_set_params
     struct WPl {
@@ -1105,6 +1129,8 @@ struct Ctx {
     bool lean() const { return !train && b->planes_mode && (g_mg_lean & 1); }
     bool lean_fold() const { return lean() && (g_mg_lean & 2); }
     bool lean_segsum() const { return lean() && (g_mg_lean & 4); }
+    bool lean_heads() const { return lean() && (g_mg_lean & 16); }
+    bool lean_mul() const { return lean() && (g_mg_lean & 32); }
     void drop_f32(const float* Y, int64_t rows, int cols) { b->absent[Y] = mi_gbatch::Dims{rows, cols}; }
     bool is_absent(const float* X) const { return b->absent.find(X) != b->absent.end(); }
     Planes planes_of(const float* X, int cols) const {
@@ -1193,19 +1219,28 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     net->warena_top += need;
     Planes P = make_planes(e.pl, K, e.scale);
     const int64_t nthr = (int64_t)((w.rows + 127) / 128 * 128) * P.KT * 16;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->theta + w.off + wcol0, w.cols, w.rows, K, P, 0);
-    hipLaunchKernelGGL(rowsum_max_kernel, dim3(1), dim3(256), 0, c.s, net->theta + w.off + wcol0, w.cols, w.rows, K, e.rowsum);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, P, 0);
+    hipLaunchKernelGGL(rowsum_max_kernel, dim3(1), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
     MI_KERNEL_CHECK();
     net->wplanes[key] = e;
     *out = e;
     return MI_OK;
 }
 
+// inference-only extensions of a dense layer's epilogue (the plane-set kernel's EXT instantiation):
+//   y = ((act(z) * post_mul + res) * scale + res2[res2_rows]) * scale2
+struct DenseExtra {
+    const float* res2 = nullptr;      // second merge folded in behind the first (a skip connection closed by this layer)
+    float scale2 = 1.f;
+    const int* res2_rows = nullptr;   // row map of res2 (the edge <-> reversed-edge permutation)
+    const float* post_mul = nullptr;  // [M, N] multiplicand applied right after the activation (radial weights)
+};
 // Y[M,N] = act( X[M,K] W[:, wcol0 : wcol0+K]^T + bias + G1[idx1] + G2[idx2] )
 static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::string& wname, int wcol0 = 0, int act = ACT_NONE, bool x_grad = true,
                        const std::string& bname = "", const float* G1 = nullptr, int gk1 = GK_NONE, const float* G2 = nullptr, int gk2 = GK_NONE,
-                       int ldy = 0, const float* res = nullptr, float scale = 1.f, bool want_pl = false, const float* res2 = nullptr, float scale2 = 1.f) {
-    // res2 / scale2 (inference only): a second merge folded in behind the first,  y = ((act(z) + res) * scale + res2) * scale2
+                       int ldy = 0, const float* res = nullptr, float scale = 1.f, bool want_pl = false, const DenseExtra& ex = DenseExtra()) {
+    const float* const res2 = ex.res2;
+    const float scale2 = ex.scale2;
     const GParam& w = c.net->P(wname);
     const int N = w.rows;
     if (ldy == 0) ldy = N;
@@ -1223,6 +1258,8 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         c.need_f32(res);
         c.need_f32(res2);
     }
+    if (ex.res2_rows) c.need_f32(res2);   // (the row-mapped form reads fp32 rows)
+    c.need_f32(ex.post_mul);
     if (lean_y) c.drop_f32(Y, M, N);
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (planes) {
@@ -1261,8 +1298,13 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             else {
                 pe.residual2 = res2;
                 pe.ld_res2 = N;
+                pe.res2_rows = ex.res2_rows;
             }
             pe.out_scale2 = scale2;
+        }
+        if (ex.post_mul) {
+            pe.post_mul = ex.post_mul;
+            pe.ld_post_mul = N;
         }
         pe.C = lean_y ? nullptr : Y;
         pe.ldc = N;
@@ -1274,7 +1316,7 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
                                G1 ? c.amax(G1, (int64_t)rows_g * N) : (const unsigned*)nullptr, G2 ? c.amax(G2, (int64_t)c.b->N * N) : (const unsigned*)nullptr,
                                res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc,
-                               res2 ? c.amax(res2, M * N) : (const unsigned*)nullptr, scale2);
+                               res2 ? c.amax(res2, M * N) : (const unsigned*)nullptr, scale2, ex.post_mul ? c.amax(ex.post_mul, M * N) : (const unsigned*)nullptr);
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));   // the k-padding of the next product must be zero
             pe.Cp = make_planes(Ypl, N, 1.f, dsc);
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1335,12 +1377,12 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot, AMAX_W - 1);
         }
         hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_W), 0, c.s, slot);   // (the kernel reads one word)
-        CTX_TRY(c, gemm_nt_split(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s, nullptr, slot, c.net->wamax + c.net->index.at(wname)));
+        CTX_TRY(c, gemm_nt_split(X, K, c.net->wptr(w) + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s, nullptr, slot, c.net->wamax + c.net->index.at(wname)));
     } else {
-        CTX_TRY(c, gemm_nt(X, K, c.net->theta + w.off + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
+        CTX_TRY(c, gemm_nt(X, K, c.net->wptr(w) + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s));
     }
     if (res2) {   // (the plane-set kernel folds this in; here it is one more pass, in place)
-        if (ldy != N || c.train) c.rc = MI_EINVAL;
+        if (ldy != N || c.train || ex.res2_rows || ex.post_mul) c.rc = MI_EINVAL;
         else hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, Y, res2, (const int*)nullptr, scale2, Y, M, N);
     }
     if (c.train) {
@@ -1539,13 +1581,21 @@ static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string
 }
 
 // `out_pl`: the stack's result feeds another dense layer (its plane set is wanted)
+static void op_rowdot_short(Ctx& c, const float* A, const float* Bm, float* y, int K, bool acc) {
+    OpTimer optimer(c, "rowdot (short rows)", c.b->E, 1, K);
+    c.need_f32(A);
+    c.need_f32(Bm);
+    if (c.dry || !CTX_OK(c) || c.b->E == 0 || c.train) return;
+    hipLaunchKernelGGL(rowdot_short_kernel, dim3(nblk(c.b->E * K)), dim3(256), 0, c.s, A, Bm, y, c.b->E, K, acc ? 1 : 0);
+}
+
 // `outer` (lean inference, n > 0): the skip connection the stack closes, (outer + stack(x)) / sqrt(2), folded into its last layer
 static float* res_stack(Ctx& c, const std::string& prefix, int n, float* x, int64_t M, int W, bool out_pl = false, const float* outer = nullptr) {
     for (int k = 0; k < n; ++k) {
         const std::string p = prefix + "." + std::to_string(k);
         float* y1 = op_dense(c, x, M, W, p + ".0.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
         x = op_dense(c, y1, M, W, p + ".1.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x, GN_ISQ2,
-                     k + 1 < n || out_pl, k + 1 == n ? outer : nullptr, GN_ISQ2);  // (x + f(x)) / sqrt(2)
+                     k + 1 < n || out_pl, DenseExtra{k + 1 == n ? outer : nullptr, GN_ISQ2, nullptr, nullptr});  // (x + f(x)) / sqrt(2)
     }
     return x;
 }
@@ -1556,6 +1606,16 @@ static void out_block(Ctx& c, int i, const float* m, const float* rbf_out, bool 
     const int Ed = g.emb_edge;
     const std::string p = "out_blocks." + std::to_string(i);
     float* t1 = op_dense(c, m, E, Ed, p + ".dense_F.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+    const int Rb = g.emb_rbf;
+    if (c.lean_heads() && (Rb & (Rb - 1)) == 0 && Rb <= 64) {   // (see mi_gemnet::dtheta: the heads through the derived [emb_rbf, emb_edge] tensors)
+        float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed, true);
+        float* pF = op_dense(c, xF, E, Ed, p + ".q_F");
+        op_rowdot_short(c, rbf_out, pF, c.b->Fe, Rb, !first);
+        float* xS = op_dense(c, m, E, Ed, p + ".dense_S.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+        float* pS = op_dense(c, xS, E, Ed, p + ".q_S");
+        op_rowdot_short(c, rbf_out, pS, c.b->Se, Rb, !first);
+        return;
+    }
     float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed);
     float* rF = op_dense(c, rbf_out, E, g.emb_rbf, p + ".rbf_F.weight");
     op_rowdot(c, xF, rF, p + ".out_F.weight", c.b->Fe, Ed, !first);
@@ -1619,25 +1679,42 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     float* rbf3 = op_dense(c, rbf, E, R, "mlp_rbf3.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
     float* cbfW = op_dense(c, rbf, E, R, "mlp_cbf3.weight", 0, ACT_NONE, false);
     float* rbf_h = op_dense(c, rbf, E, R, "mlp_rbf_h.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
-    float* rbf_out = op_dense(c, rbf, E, R, "mlp_rbf_out.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+    const bool heads_short = c.lean_heads() && (Rb & (Rb - 1)) == 0 && Rb <= 64;   // (out_block: rbf_out then feeds a row dot, not a dense layer)
+    float* rbf_out = op_dense(c, rbf, E, R, "mlp_rbf_out.weight", 0, ACT_NONE, false, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, !heads_short);
     b->taps["rbf"] = {rbf, E * R};
     b->taps["h0"] = {h, (int64_t)N * A};
     b->taps["m0"] = {m, E * Ed};
     out_block(c, 0, m, rbf_out, true);
     for (int i = 0; i < g.num_blocks; ++i) {
         const std::string p = "int_blocks." + std::to_string(i);
-        float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
         float* rr = op_dense(c, rbf3, E, Rb, p + ".mlp_rbf.weight");
-        float* x_ba = op_mul(c, tb, rr, E, Ed, true);
+        float* x_ba;
+        if (c.lean_mul()) {   // the radial weighting as the multiplicand of dense_ba's epilogue
+            x_ba = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true,
+                            DenseExtra{nullptr, 1.f, nullptr, rr});
+        } else {
+            float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
+            x_ba = op_mul(c, tb, rr, E, Ed, true);
+        }
         float* xd = op_dense(c, x_ba, E, Ed, p + ".down_projection.weight");
         float* Tm = op_triplet(c, xd, cbfW);
         float* x3 = op_dense(c, Tm, E, Cb * Tr, p + ".bilinear.weight", 0, ACT_NONE, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
         b->taps["x3_" + std::to_string(i)] = {x3, E * g.emb_bil};
-        float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU);
-        float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU);
-        float* x3b = op_axpby(c, u1, u2, E, Ed, true);
-        float* x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2,
-                            g.num_before_skip > 0);  // (x_ca + x3) / sqrt(2)
+        float* x;
+        if (c.lean_mul()) {
+            // x = (act(m W_ca) + (u1 + u2[swap]) / sqrt(2)) / sqrt(2): both up-projections leave pre-scaled, the edge <-> reversed-edge
+            // merge and the skip merge ride in dense_ca's epilogue (second residual through the row map)
+            float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, GN_ISQ2);
+            float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, GN_ISQ2);
+            x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, u1, 1.f, g.num_before_skip > 0,
+                         DenseExtra{u2, GN_ISQ2, c.b->swap, nullptr});
+        } else {
+            float* u1 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ca.weight", 0, ACT_SSILU);
+            float* u2 = op_dense(c, x3, E, g.emb_bil, p + ".up_projection_ac.weight", 0, ACT_SSILU);
+            float* x3b = op_axpby(c, u1, u2, E, Ed, true);
+            x = op_dense(c, m, E, Ed, p + ".dense_ca.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, x3b, GN_ISQ2,
+                         g.num_before_skip > 0);  // (x_ca + x3) / sqrt(2)
+        }
         if (c.lean_fold() && g.num_before_skip > 0) m = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed, true, m);
         else {
             x = res_stack(c, p + ".before_skip", g.num_before_skip, x, E, Ed);
@@ -1922,6 +1999,26 @@ int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out) {
     add("fc_atom.bias", 1, MI_MG_CLASSES);
     n->nparams = off;
     n->ntrans = toff;
+    n->n_real = (int)n->params.size();
+    {
+        int64_t doff = 0;
+        for (int i = 0; i <= g.num_blocks; ++i)
+            for (const char* h : {"F", "S"}) {
+                GParam p;
+                p.name = "out_blocks." + std::to_string(i) + ".q_" + h;
+                p.off = doff;
+                p.numel = (int64_t)Rb * Ed;
+                p.rows = Rb;
+                p.cols = Ed;
+                p.ldt = 0;
+                p.toff = 0;
+                p.derived = true;
+                n->index[p.name] = (int)n->params.size();
+                n->params.push_back(p);
+                doff += (p.numel + 3) / 4 * 4;
+            }
+        n->ndtheta = doff;
+    }
     *out = n;
     return MI_OK;
 }
@@ -1930,14 +2027,15 @@ void mi_gemnet_destroy(mi_gemnet* net) {
     if (!net) return;
     if (net->thetaT) (void)hipFree(net->thetaT);
     if (net->wamax) (void)hipFree(net->wamax);
+    if (net->dtheta) (void)hipFree(net->dtheta);
     if (net->warena) (void)hipFree(net->warena);
     if (net->wrowsum) (void)hipFree(net->wrowsum);
     delete net;
 }
 int64_t mi_gemnet_num_params(const mi_gemnet* net) { return net ? net->nparams : 0; }
-int mi_gemnet_num_tensors(const mi_gemnet* net) { return net ? (int)net->params.size() : 0; }
+int mi_gemnet_num_tensors(const mi_gemnet* net) { return net ? net->n_real : 0; }
 int mi_gemnet_param_info(const mi_gemnet* net, int index, const char** name, int64_t* offset, int64_t* numel, int* rows, int* cols) {
-    MI_CHECK(net && index >= 0 && index < (int)net->params.size(), MI_EINVAL, "parameter index out of range");
+    MI_CHECK(net && index >= 0 && index < net->n_real, MI_EINVAL, "parameter index out of range");
     const GParam& p = net->params[index];
     if (name) *name = p.name.c_str();
     if (offset) *offset = p.off;
@@ -1956,10 +2054,17 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
         MI_HIP(hipMemsetAsync(net->thetaT, 0, (size_t)net->ntrans * sizeof(float), s));
     }
     if (!net->wamax) MI_HIP(hipMalloc((void**)&net->wamax, net->params.size() * sizeof(unsigned)));
+    if (!net->dtheta && net->ndtheta > 0) MI_HIP(hipMalloc((void**)&net->dtheta, (size_t)net->ndtheta * sizeof(float)));
+    for (int i = 0; i <= net->cfg.num_blocks; ++i)
+        for (const char* h : {"F", "S"}) {
+            const std::string pre = "out_blocks." + std::to_string(i);
+            const GParam &q = net->P(pre + ".q_" + h), &wr = net->P(pre + ".rbf_" + h + ".weight"), &wo = net->P(pre + ".out_" + h + ".weight");
+            hipLaunchKernelGGL(derive_q_kernel, dim3(nblk(q.numel)), dim3(256), 0, s, theta + wo.off, theta + wr.off, net->dtheta + q.off, q.cols, q.rows);
+        }
     MI_HIP(hipMemsetAsync(net->wamax, 0, net->params.size() * sizeof(unsigned), s));
     for (size_t i = 0; i < net->params.size(); ++i) {
         const GParam& p = net->params[i];
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, theta + p.off, p.numel, net->wamax + i);
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, net->wptr(p), p.numel, net->wamax + i);
     }
     {   // per-tensor plane scales on the host (2^floor(log2(16384 / absmax))); the lazily built weight plane sets are stale now
         std::vector<unsigned> bits(net->params.size());
@@ -1976,7 +2081,7 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
         net->wrowsum_used = 0;
     }
     for (const GParam& p : net->params) {
-        if (p.rows == 1) continue;  // biases and the row-dot weights are never a data-gradient operand
+        if (p.rows == 1 || p.derived) continue;  // biases and the row-dot weights are never a data-gradient operand; derived tensors are inference-only
         hipLaunchKernelGGL(gn_transpose_kernel, dim3(nblk(p.numel)), dim3(256), 0, s, theta + p.off, net->thetaT + p.toff, p.rows, p.cols, p.ldt);
     }
     MI_KERNEL_CHECK();
@@ -2137,7 +2242,7 @@ int mi_debug_set_mg_planes(int on) {
 }
 
 int mi_debug_set_mg_lean(int on) {
-    mi::g_mg_lean = on == 1 ? 15 : on < 0 ? -on : on;   // (0 = off, 1 = everything; other values: the bit mask of g_mg_lean, for ablations)
+    mi::g_mg_lean = on == 1 ? 63 : on < 0 ? -on : on;   // (0 = off, 1 = everything; other values: the bit mask of g_mg_lean, for ablations)
     return MI_OK;
 }
 
