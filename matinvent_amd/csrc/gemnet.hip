@@ -679,18 +679,51 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
                 }
             }
             const float* w = ws + ee * S * CB;
-            if (lane < TR)
-                for (int i = 0; i < CB; ++i) {
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int l = 0; l < S; ++l) sacc += w[l * CB + i] * acc[l];
-                    if (Tm) Tm[((size_t)(lo + e) * CB + i) * TR + lane] = sacc;
+            if (lane < TR) {
+                // plane address of (row, column i * TR + lane): the row part once per edge, TR columns = TR / 32 column tiles per step of i
+                const int row = lo + e;
+                u16* prow = P.base ? P.base + P.tile(row >> 7, 0) + (size_t)(row & 127) * 32 + (size_t)(lane >> 5) * 12288 + (lane & 31) : nullptr;
+                const float pscale = P.base ? P.s() : 1.f;
+                auto emit = [&](int i, float sacc) {
+                    if (Tm) Tm[((size_t)row * CB + i) * TR + lane] = sacc;
                     if (P.base) {   // the operand of the bilinear product: lanes pair up, the even one stores both halves of a 32-bit plane word
                         const float nb = __shfl_down(sacc, 1, 64);
-                        if ((lane & 1) == 0) store_pl_pair(P, lo + e, i * TR + lane, sacc, nb);
+                        if ((lane & 1) == 0) {
+                            unsigned pr[3];
+                            pl_split_pair(sacc, nb, pscale, pr);
+                            u16* d = prow + (size_t)i * (TR >> 5) * 12288;
+#pragma unroll
+                            for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(d + k * 4096) = pr[k];
+                        }
                         tmax = fmaxf(tmax, fabsf(sacc));
                     }
+                };
+                if ((CB & 3) == 0 && (TR & 31) == 0) {   // four output features per step: the weights as 16-byte LDS reads
+                    for (int i = 0; i < CB; i += 4) {
+                        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int l = 0; l < S; ++l) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + l * CB + i);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) s4[q] += wv[q] * acc[l];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) emit(i + q, s4[q]);
+                    }
+                } else {
+                    for (int i = 0; i < CB; ++i) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int l = 0; l < S; ++l) sacc += w[l * CB + i] * acc[l];
+                        if (Tm) Tm[((size_t)row * CB + i) * TR + lane] = sacc;
+                        if (P.base) {
+                            const float nb = __shfl_down(sacc, 1, 64);
+                            if ((lane & 1) == 0) store_pl_pair(P, row, i * TR + lane, sacc, nb);
+                            tmax = fmaxf(tmax, fabsf(sacc));
+                        }
+                    }
                 }
+            }
         }
         __syncthreads();
     }
