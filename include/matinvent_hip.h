@@ -326,6 +326,10 @@ int mi_debug_set_tn128(int on);
 int mi_debug_set_tn_split_min_rows(int n);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
+/* Plain plane-set products (row-major epilogue) with at least `min_rows` rows (default 65536; <= 0 keeps the limit) and N % 256 == 0
+ * run on the 256 x 256-tile kernel that stages its operands by LDS-DMA (fp16 two-plane build): 1 (default) / 0 = the 128 x 128
+ * kernel everywhere.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
+int mi_debug_set_planes_big(int on, int min_rows);
 /* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
  * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
  * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results

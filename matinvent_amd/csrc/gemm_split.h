@@ -338,6 +338,8 @@ extern int g_gemm_mode;
 extern int g_planes_variant;  // 0 = 128x128 tiles, 1 = 256x128 double-buffered (large M)
 extern int g_planes_db_min_tiles;
 extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
+extern int g_planes_big;          // 1: row-major-epilogue products with M >= g_planes_big_min_rows and N % 256 == 0 on the 256 x 256 LDS-DMA kernel
+extern int g_planes_big_min_rows;
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                    hipStream_t s, const SplitK* sk = nullptr) {
@@ -1073,6 +1075,131 @@ constexpr int planes_lds_bytes(int V, int TM) {
     return tiles > stage ? tiles : stage;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Large-M form (fp16 two-plane format): 256 x 256 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), operand tiles
+// brought in by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass), two 64 KiB LDS stages, ONE barrier
+// per 32-deep k-tile.  Per unit of matrix work it moves half the operand bytes through L2 and LDS of the 128 x 128 kernel (a wave
+// reads 12 fragments per 24 MFMAs instead of 8 per 12, and nothing is written to LDS by the waves), which is what bounds that kernel
+// on the [256k, 512] x [512, 512] products of the MatterGen-shaped network (LDS array ~87 % busy at the full matrix rate).
+//   LDS image of a stage: eight 8 KiB blocks [A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255] x [plane 0 | plane 1],
+//   each 128 rows x 64 B with the same XOR swizzle as above (chunk c of row r at r*64 + ((c ^ ((r >> 2) & 3)) * 16)).  LDS-DMA writes
+//   lane-linear (M0 base + lane * 16), so the swizzle is applied on the SOURCE side: lane l of a 1 KiB piece (16 rows) fetches
+//   chunk (l & 3) ^ ((l >> 4) & 3) of row l >> 2 -- a permutation inside each 64-byte row, the fetch stays one contiguous KiB.
+//   Wave w brings in block w (its eight pieces), so every DMA address is wave-uniform + the fixed lane offset.
+//   Order per k-tile:  wait own DMA (vmcnt 0) -> barrier -> issue the DMA of k-tile kt + 1 into the other stage -> MFMAs of kt.
+//   (RAW: wait, then barrier, then read.  WAR: a wave reaches the barrier of kt only after its fragment reads of kt - 1 returned.)
+// Accumulation order per output = the 128 x 128 kernel's (k-tiles in order, the three terms in the same order): bit-identical results.
+// ------------------------------------------------------------------------------------------------------------------------
+#if MI_PLANES_FP16
+constexpr int GEMM_BIG_STAGE = 8 * 8192, GEMM_BIG_LDS = 2 * GEMM_BIG_STAGE;
+template <bool EXT>
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_big_kernel(Planes A, Planes W, int M, int N, int K,
+                                                                                                               PlanesEpilogue pe) {
+    constexpr int TM = 4, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, kg = lane >> 5;
+    // XCD-aware map: both 256-column tiles of a row tile on one XCD (ids go round-robin over the eight XCDs)
+    const int nct = (N + 255) >> 8, id = blockIdx.x, slot = id >> 3;
+    const int ct = slot % nct, RT = (slot / nct) * 8 + (id & 7);
+    if (RT * 256 >= M) return;
+    const int row0 = RT * 256, col0 = ct * 256;
+    const int KT = (K + 31) >> 5;
+
+    // this wave's DMA block: operand, 128-row half, plane
+    const int blk_op = wave >> 2, blk_half = (wave >> 1) & 1, blk_pl = wave & 1;
+    const Planes& X = blk_op ? W : A;
+    const int xrt = (blk_op ? ct : RT) * 2 + blk_half, xtiles = ((blk_op ? N : M) + 127) >> 7;
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(X.base + X.tile(xrt < xtiles ? xrt : 0, 0) + blk_pl * 4096, xrt < xtiles ? KT * 24576 - blk_pl * 8192 : 0);
+    const int voff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma = [&](int kt, int stage) {
+        unsigned char* dst = smem + stage * GEMM_BIG_STAGE + wave * 8192;
+#pragma unroll
+        for (int sub = 0; sub < 8; ++sub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + sub * 1024), 16, voff, kt * 24576 + sub * 1024, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragments of one 16-deep half of a k-tile: a[i][plane] (four 32-row tiles of this wave's A half), b[j][plane]
+    struct Frag {
+        f16x8 a[TM][2], b[TN][2];
+    };
+    auto read_b = [&](const unsigned char* st, int s2, Frag& f, int j) {
+        const unsigned char* Wb = st + (4 + (wn >> 1) * 2) * 8192;   // W half wn >> 1
+        const int r = (wn & 1) * 64 + j * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) f.b[j][pl] = *reinterpret_cast<const f16x8*>(Wb + pl * 8192 + r * 64 + c * 16);
+    };
+    auto read_a = [&](const unsigned char* st, int s2, Frag& f, int i) {
+        const unsigned char* Ab = st + (wm * 2) * 8192;               // A half wm
+        const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) f.a[i][pl] = *reinterpret_cast<const f16x8*>(Ab + pl * 8192 + r * 64 + c * 16);
+    };
+    auto mma3 = [&](const Frag& f, int i, int j) {   // the three terms of one accumulator tile, in the 128 x 128 kernel's order
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
+    };
+    auto dma_piece = [&](int kt, int stage, int sub) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * GEMM_BIG_STAGE + wave * 8192 + sub * 1024), 16, voff,
+                                                 kt * 24576 + sub * 1024, 0, 0);
+    };
+
+    // Software pipeline (two register sets of fragments, F0 = first half of a k-tile, F1 = second half):
+    //   top of k-tile kt:    read F1(kt) | MFMAs of F0(kt)                         -- the reads land behind the MFMAs
+    //   middle:              wait (F1 here, own DMA(kt+1) landed) -> barrier ->
+    //                        per accumulator tile: one DMA piece of k-tile kt+2 into the stage just released, part of F0(kt+1), 3 MFMAs of F1(kt)
+    // so the matrix pipe only idles at that one barrier, with the next MFMAs' operands already in registers; DMA(kt+2) has a whole k-tile to land.
+    dma(0, 0);
+    if (KT > 1) {
+        dma(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (loads retire in order: the eight pieces of k-tile 0 are in)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    Frag F0, F1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) read_b(smem, 0, F0, j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) read_a(smem, 0, F0, i);
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char* st = smem + (kt & 1) * GEMM_BIG_STAGE;
+        const unsigned char* stn = smem + ((kt + 1) & 1) * GEMM_BIG_STAGE;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_b(st, 1, F1, j);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_a(st, 1, F1, i);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma3(F0, i, j);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = kt + 1 < KT, more2 = kt + 2 < KT;
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+            if (more2) dma_piece(kt + 2, kt & 1, q);
+            if (more) {
+                if (q < TN) read_b(stn, 0, F0, q);
+                else if (q < TN + TM) read_a(stn, 0, F0, q - TN);
+            }
+            mma3(F1, q / TN, q % TN);
+        }
+    }
+    __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
+    planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+}
+#endif
+
 // The same contraction on a 256 x 128 tile with 8 waves and DOUBLE-BUFFERED LDS (2 x 72 KiB): one barrier per k-tile instead
 // of two, and the staging writes of tile k+1 / the global loads of tile k+2 sit between the two MFMA halves of tile k, so the
 // matrix pipe only idles at that one barrier.  One workgroup per CU (LDS), two waves per SIMD as before.
@@ -1439,6 +1566,18 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
             nblk += cdiv(pe.diag_nodes, 8);
         }
         hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+    } else if (MI_PLANES_FP16 && g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && (N & 255) == 0 && planes_epilogue_is_rows(pe, N)) {
+#if MI_PLANES_FP16
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
+            attr_set = true;
+        }
+        const dim3 grid((N >> 8) * ((cdiv(M, 256) + 7) / 8 * 8));
+        if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
+        else hipLaunchKernelGGL(gemm_planes_big_kernel<false>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
+#endif
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);

@@ -94,3 +94,32 @@ def test_weight_gradient_gemm_vs_fp64(M, N, K):
             assert (out.double() - ref).abs().max().item() / scale < 3e-6, on
     finally:
         _lib.check(lib.mi_debug_set_tn128(3))
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 512, 512), (300, 256, 96), (1031, 768, 64), (256, 512, 16), (70000, 512, 512)])
+def test_plane_gemm_lds_dma_256_tiles_bit_identical(M, N, K):
+    """Large plain products run on 256 x 256 tiles whose operands arrive by LDS-DMA into two LDS stages; the k order and the order
+    of the product terms per output are the 128-row kernel's, so the two agree bit for bit (ragged M: a workgroup whose second
+    128-row half lies outside the plane set reads zeros through its buffer descriptor; K = 16: a single k-tile)."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    if lib.mi_plane_format() != 2:
+        pytest.skip("the LDS-DMA kernel exists in the fp16 two-plane build")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    outs = []
+    try:
+        for big in (0, 1):
+            _lib.check(lib.mi_debug_set_planes_big(big, 1))
+            out = torch.full((M, N), float("nan"), device="cuda")
+            for _ in range(3 if big else 1):   # (repeated: a DMA / barrier ordering slip would show as run-to-run differences)
+                _lib.check(lib.mi_debug_gemm(2, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+                torch.cuda.synchronize()
+                outs.append(out.clone())
+    finally:
+        _lib.check(lib.mi_debug_set_planes_big(1, 65536))
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    ref = A.double() @ W.double().t()
+    assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
