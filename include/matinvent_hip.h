@@ -375,6 +375,9 @@ int mi_gemnet_param_info(const mi_gemnet* net, int index, const char** name, int
 int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream);
 int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
                      mi_gbatch** out);
+/* Global ids of the batch's first atom / crystal (the Philox counters of the noising and sampler kernels): lets one batch handle --
+ * and its activation arenas -- serve several equal-shaped chunks of a larger set (the chunked fine-tune loop). */
+int mi_gbatch_set_offsets(mi_gbatch* b, int64_t node_offset, int64_t graph_offset);
 void mi_gbatch_destroy(mi_gbatch* b);
 /* Periodic radius graph of (pos, cell): cutoff, the max_neighbors nearest per target atom, symmetrised; one host
  * synchronisation (the edge count sizes the later launches).  *num_edges = E. */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "mi_gemnet_set_params": (_I, [_P, _P, _P]),
     "mi_gbatch_create": (_I, [_P, C.POINTER(_I), _I, _L, _L, C.POINTER(_P)]),
     "mi_gbatch_destroy": (None, [_P]),
+    "mi_gbatch_set_offsets": (_I, [_P, _L, _L]),
     "mi_gemnet_graph": (_I, [_P, _P, _P, _P, _P, C.POINTER(_L)]),
     "mi_gemnet_graph_read": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi_gemnet_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -66,12 +66,15 @@ struct GraphArgs {
     int *ent, *acnt, *deg, *mcount, *meta;
 };
 
-// entries of target a: key = (c << 11) | code for each selected neighbour whose pair is represented by (a, c, code)
+// entries of target a: key = (c << 11) | code for each selected neighbour whose pair is represented by (a, c, code).
+// grid (crystals, ceil(max atoms / 4)): a WAVE per target atom (one block per crystal left 256 four-wave blocks on 256 CUs for 1.5 ms:
+// a wave walked five atoms' candidate lists one after the other); the in-degree counts of the crystal's atoms are integer atomics on
+// g.deg (zeroed by the caller; order-independent), the degree-capacity flag is raised by gg_scan_kernel.
 __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
 #pragma clang fp contract(off)
     __shared__ float cart[GN_NMAX * 3];
     __shared__ float Ls[9];
-    __shared__ int degl[GN_NMAX], cntl[GN_NMAX], reps[3];
+    __shared__ int reps[3];
     __shared__ float dl_all[4][GN_CAND];
     __shared__ unsigned kl_all[4][GN_CAND];
     const int b = blockIdx.x, n0 = g.node_off[b], n = g.node_off[b + 1] - n0;
@@ -84,8 +87,6 @@ __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
         const float* f = g.pos + (size_t)(n0 + i) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) cart[i * 3 + c] = __builtin_fmaf(f[2], Lm[6 + c], __builtin_fmaf(f[1], Lm[3 + c], f[0] * Lm[c]));
-        degl[i] = 0;
-        cntl[i] = 0;
     }
     if (tid == 0) {  // images per dimension: ceil(cutoff / inter-plane spacing), at most R
         const double a0 = Lm[0], a1 = Lm[1], a2 = Lm[2], b0 = Lm[3], b1 = Lm[4], b2 = Lm[5], c0 = Lm[6], c1 = Lm[7], c2 = Lm[8];
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
     const int nimg = (2 * ra + 1) * wb * wc, nq = nimg * n;
     const float r2 = g.cutoff * g.cutoff;
     const int zero_code = (g.R * W + g.R) * W + g.R;
-    for (int a = wave; a < n; a += 4) {
+    const int a = blockIdx.y * 4 + wave;
+    if (a < n) {
         const float cx = cart[a * 3], cy = cart[a * 3 + 1], cz = cart[a * 3 + 2];
         // d^2 and key of candidate q = (image, source), or d^2 = -1 outside (1e-6, limit]
         auto cand = [&](int q, float limit, unsigned* key) -> float {
@@ -176,22 +178,15 @@ __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
             if (sel) {
                 const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
                 if (pos < g.cap) g.ent[(size_t)(n0 + a) * g.cap + pos] = (int)key;
-                atomicAdd(&degl[(int)(key >> GN_CODE_BITS)], 1);
+                atomicAdd(&g.deg[n0 + (int)(key >> GN_CODE_BITS)], 1);
             }
             cnt += __popcll(mk);
         }
         if (lane == 0) {
-            cntl[a] = cnt;
-            atomicAdd(&degl[a], cnt);
+            g.acnt[n0 + a] = cnt;
+            atomicAdd(&g.deg[n0 + a], cnt);
             if (cnt > g.cap) atomicOr(&g.meta[2], 1);
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        g.acnt[n0 + i] = cntl[i];
-        g.deg[n0 + i] = degl[i];
-        if (degl[i] > GN_DEG) atomicOr(&g.meta[2], 4);
     }
 }
 
@@ -218,6 +213,7 @@ __global__ __launch_bounds__(1024) void gg_scan_kernel(const int* __restrict__ d
         rowptr[N] = run;
         meta[0] = run;
         meta[1] = m2;
+        if (m2 > GN_DEG) atomicOr(&meta[2], 4);   // in-degree above the triplet kernels' capacity
     }
     __syncthreads();
     int run = part[tid];
@@ -1790,7 +1786,10 @@ static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const flo
     const mi_gemnet_config& g = net->cfg;
     MI_HIP(hipMemsetAsync(b->meta, 0, 4 * sizeof(int), s));
     GraphArgs ga{pos, cell, b->node_off, g.cutoff, g.max_neighbors, g.max_images, b->cap, b->ent, b->acnt, b->deg, b->mcount, b->meta};
-    hipLaunchKernelGGL(gg_select_kernel, dim3(b->B), dim3(256), 0, s, ga);
+    int nmax_sel = 1;
+    for (int v : b->num_atoms_h) nmax_sel = std::max(nmax_sel, v);
+    MI_HIP(hipMemsetAsync(b->deg, 0, (size_t)std::max(b->N, 1) * sizeof(int), s));
+    hipLaunchKernelGGL(gg_select_kernel, dim3(b->B, (nmax_sel + 3) / 4), dim3(256), 0, s, ga);
     hipLaunchKernelGGL(gg_scan_kernel, dim3(1), dim3(1024), 0, s, b->deg, b->N, b->rowptr, b->meta);
     EmitArgs ea{b->node_off, b->ent, b->acnt, b->rowptr, b->meta, b->cap, g.max_images, b->E_cap, b->src, b->dst, b->code, b->ekey, b->swap, b->edge_graph};
     int nmax = 1;
@@ -2188,6 +2187,13 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
         return MI_EHIP;
     }
     *out = b;
+    return MI_OK;
+}
+
+int mi_gbatch_set_offsets(mi_gbatch* b, int64_t node_offset, int64_t graph_offset) {
+    MI_CHECK(b && node_offset >= 0 && graph_offset >= 0, MI_EINVAL, "bad argument");
+    b->node_offset = node_offset;
+    b->graph_offset = graph_offset;
     return MI_OK;
 }
 

@@ -242,9 +242,23 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
     theta = agent.decoder.theta
     if hi == lo:
         return _ft_step_empty_shard(agent, n_global, lr, accum_steps, epochs, timesteps, log, rank)
-    batch = agent.collate(data_list[lo:hi], None if rewards is None else list(rewards[lo:hi])).to(device)
-    node_lo = sum(d.num_atoms for d in data_list[:lo])
-    agent.shard_offsets = prior.shard_offsets = (node_lo, lo)
+    # The local shard as chunks of at most FT_CHUNK_ATOMS atoms: the training forward keeps every activation for the backward, and the
+    # whole benchmark set (256 crystals x 20 atoms: 171 GB of activations + as much again for their gradients) does not fit one GPU.
+    # The update is linear in the per-crystal losses (sum / (n_global * accum_steps)), the noise is indexed by global atom / crystal ids,
+    # so chunking changes nothing but the summation order of the gradient.  Injected noise (parity tests) spans the shard: one chunk.
+    from .mattergen import FT_CHUNK_ATOMS
+    bounds, c0, atoms = [], lo, 0
+    for i in range(lo, hi):
+        n_i = int(data_list[i].num_atoms)
+        if i > c0 and atoms + n_i > FT_CHUNK_ATOMS and noise_fn is None:
+            bounds.append((c0, i))
+            c0, atoms = i, 0
+        atoms += n_i
+    bounds.append((c0, hi))
+    chunks = []
+    for (a_, b_) in bounds:
+        cb = agent.collate(data_list[a_:b_], None if rewards is None else list(rewards[a_:b_])).to(device)
+        chunks.append((cb, (sum(d.num_atoms for d in data_list[:a_]), a_)))
     optimizer = FusedAdam([theta], lr=lr)
     stats = []
     for epoch in range(epochs):
@@ -255,16 +269,20 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
         t = -1
         for t in range(timesteps):
             noise = None if noise_fn is None else noise_fn(epoch, t)
-            noised = agent.add_noise(batch, t, noise=noise)                       # :152
-            sample_loss, agent_pred = agent.calc_sample_loss(noised)              # :153
-            with torch.no_grad():
-                _, prior_pred = prior.calc_sample_loss(noised)                    # :154
-            loss_diff = batch.reward * sample_loss                                # :158
-            loss_kl = agent.calc_kl_reg(agent_pred, prior_pred, batch) * (1.1 - batch.reward)   # :160-161
-            loss = (loss_diff + loss_kl * sigma).sum() / (n_global * accum_steps)  # == .mean() / accum_steps (:163)
-            loss.backward()
-            with torch.no_grad():
-                acc += torch.stack([loss.detach() * accum_steps, loss_diff.detach().sum(), loss_kl.detach().sum()])
+            calls = getattr(agent, "_noise_calls", 0)
+            for batch, offs in chunks:
+                agent.shard_offsets = prior.shard_offsets = offs
+                agent._noise_calls = calls                                            # (every chunk of a timestep draws from the same Philox step)
+                noised = agent.add_noise(batch, t, noise=noise)                       # :152
+                sample_loss, agent_pred = agent.calc_sample_loss(noised)              # :153
+                with torch.no_grad():
+                    _, prior_pred = prior.calc_sample_loss(noised)                    # :154
+                loss_diff = batch.reward * sample_loss                                # :158
+                loss_kl = agent.calc_kl_reg(agent_pred, prior_pred, batch) * (1.1 - batch.reward)   # :160-161
+                loss = (loss_diff + loss_kl * sigma).sum() / (n_global * accum_steps)  # == .mean() / accum_steps (:163)
+                loss.backward()
+                with torch.no_grad():
+                    acc += torch.stack([loss.detach() * accum_steps, loss_diff.detach().sum(), loss_kl.detach().sum()])
             if (t + 1) % accum_steps == 0:                                        # :165-167
                 allreduce_flat_(theta.grad)
                 optimizer.step()

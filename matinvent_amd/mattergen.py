@@ -137,6 +137,11 @@ class ChemGraphLoader:
 
 
 # ---- denoiser ---------------------------------------------------------------------------------------------------------------------
+# atoms per chunk of the fine-tune loop (finetune._ft_step_module_surface): the training forward keeps every activation for the
+# backward (~33 MB per atom at the benchmark sizes, mirrored by the gradient arena, plus the frozen prior's workspace)
+FT_CHUNK_ATOMS = 1280
+
+
 class GBatch:
     """Graph buffers + activation arena of one batch of crystals (mi_gbatch)."""
 
@@ -349,14 +354,19 @@ class MatterGenModule(nn.Module):
         return ChemGraphBatch([ds[i] for i in range(len(ds))])
 
     def _batch_for(self, num_atoms):
+        """The batch handle (graph buffers + activation arenas) for this atom-count signature, with the current shard / chunk offsets.
+        Handles are cached by signature only -- equal-shaped chunks of a large fine-tune set share one handle and its arenas -- and the
+        cache is bounded both in entries and in atoms (an arena set is ~100 MB per atom in training)."""
         off = getattr(self, "shard_offsets", (0, 0))
-        key = (tuple(int(x) for x in num_atoms.tolist()), off)
+        key = tuple(int(x) for x in num_atoms.tolist())
         cache = self.__dict__.setdefault("_gb_cache", {})
         gb = cache.get(key)
         if gb is None:
-            if len(cache) >= 4:
+            budget = 2 * FT_CHUNK_ATOMS
+            while cache and (len(cache) >= 4 or sum(sum(k) for k in cache) + sum(key) > budget):
                 cache.pop(next(iter(cache)))
-            gb = cache[key] = self.decoder.make_batch(list(key[0]), off[0], off[1])
+            gb = cache[key] = self.decoder.make_batch(list(key), off[0], off[1])
+        _lib.check(gb._lib.mi_gbatch_set_offsets(gb._h, int(off[0]), int(off[1])), "mi_gbatch_set_offsets")
         return gb
 
     def add_noise(self, batch, timestep: int, noise=None, seed=None):

@@ -6,7 +6,7 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r2_gpu_pytest.lo
 bash scripts/profile_round.sh r2 $HEAD > gpurun_out/r2_profile_round.log 2>&1
 bash scripts/gpu_mg_prof.sh > gpurun_out/r2_mg_prof.log 2>&1
 for mode in mg-sample sample-default ft-default mg-ft; do
-  python bench.py --mode $mode 2> gpurun_out/r2_bench_$mode.err | tail -1 > gpurun_out/r2_bench_$mode.json
+  python bench.py --mode $mode $([ $mode = mg-ft ] && echo --mg-batch 256) 2> gpurun_out/r2_bench_$mode.err | tail -1 > gpurun_out/r2_bench_$mode.json
 done
 MI_DEBUG_OPTIME=1 python bench.py --mode mg-sample --steps 1 --warmup 1 --no-cpu-baseline 2> gpurun_out/r2_mg_optime.log > /dev/null
 cat gpurun_out/r2_gpu_pytest.log

@@ -280,8 +280,39 @@ def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
     assert bad <= 0.02 * tot_n, f"{bad} of {tot_n} parameters differ by more than 1e-5 after the Adam step"
 
 
-@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 0, 1)],
-                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
+def test_fine_tune_step_in_chunks_equals_the_unchunked_step(monkeypatch):
+    """A fine-tune set larger than the activation budget is walked in chunks of crystals (equal-shaped chunks share one batch handle
+    and its arenas; the noise is indexed by global ids and every chunk of a timestep draws from the same Philox step): the update
+    must be the unchunked one up to the summation order of the gradient."""
+    import matinvent_amd.mattergen as MG
+    from matinvent_amd.finetune import ft_step
+    from matinvent_amd.mattergen import ChemGraph
+    hp = M.GemNetHParams(**M.TINY)
+    g = torch.Generator().manual_seed(17)
+    P0 = M.init_params(hp, seed=5, head_scale=0.3)
+    na, frac, cell, a, _, g = _case([6, 6, 6, 6, 3, 9, 6], seed=19)
+    a = torch.randint(1, 101, a.shape, generator=g)   # (clean records: elements only, no mask state)
+    off = [0] + torch.cumsum(na, 0).tolist()
+    data = [ChemGraph(frac[off[i]:off[i + 1]], cell[i:i + 1], a[off[i]:off[i + 1]]) for i in range(len(na))]
+    rewards = torch.rand(len(na), generator=g).numpy()
+    cfg = dict(lr=1e-4, accum_steps=2, epochs=1, timesteps=3, sigma=0.025)
+    out = []
+    for limit in (10 ** 9, 12):   # one chunk; chunks of two 6-atom crystals (one shared handle), then [3, 9], then [6]
+        monkeypatch.setattr(MG, "FT_CHUNK_ATOMS", limit)
+        agent, prior = _module(M.TINY, P0), _module(M.TINY, P0)
+        prior.requires_grad_(False)
+        agent.noise_seed = prior.noise_seed = 77
+        stats = ft_step(agent, prior, data, rewards, cfg)
+        out.append((stats[0], {k: v.detach().cpu().clone() for k, v in agent.decoder.views().items()}))
+    (s0, w0), (s1, w1) = out
+    assert abs(s0["loss"] - s1["loss"]) <= 1e-5 * max(1.0, abs(s0["loss"])), (s0, s1)
+    for k in w0:
+        assert float((w0[k] - w1[k]).abs().max()) <= 2e-6, k   # (lr 1e-4: an Adam step moves a weight by at most ~1e-4)
+
+
+@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (2, 0, 1), (0, 1, 1), (0, 0, 1)],
+                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "pre-split-plane-sets-lds-dma-256-tiles", "fp32-operand-fp16-2plane",
+                              "fp32-operand-bf16-3plane"])
 def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
     (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values; inference keeps one
@@ -295,8 +326,10 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
-    _lib.check(_lib.load().mi_debug_set_mg_planes(planes))
+    _lib.check(_lib.load().mi_debug_set_mg_planes(1 if planes else 0))
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
+    if planes == 2:   # every qualifying product (epilogue extensions included) on the 256 x 256 LDS-DMA kernel, whatever its row count
+        _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))
     try:
         gb = m.decoder.make_batch(na)
         E = gb.graph(frac, cell)["src"].shape[0]
@@ -325,3 +358,4 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
         _lib.check(_lib.load().mi_debug_set_mg_f16(0))
         _lib.check(_lib.load().mi_debug_set_mg_planes(1))
         _lib.check(_lib.load().mi_debug_set_mg_lean(1))
+        _lib.check(_lib.load().mi_debug_set_planes_big(1, 65536))

@@ -160,3 +160,17 @@ def test_host_records_and_dataset_transform():
     assert torch.allclose(b.reward, torch.tensor([0.1, 0.5, 0.9])) and torch.allclose(b.cell, S, atol=1e-6)
     back = b.to_data_list()
     assert [d.num_atoms for d in back] == [3, 5, 2] and torch.equal(back[1].atomic_numbers, items[1].atomic_numbers)
+
+
+def test_scalar_heads_through_the_derived_radial_tensors_identity():
+    """The inference path evaluates the per-edge scalar heads as  F[e] = sum_k rbf[e,k] (x Q^T)[e,k],  Q[k,c] = w[c] Wr[c,k]  (derived at
+    mi_gemnet_set_params) instead of  sum_c x[e,c] (rbf Wr^T)[e,c] w[c]  (the oracle's form, oracle/mattergen_oracle.py out block):
+    the two are the same contraction in a different order."""
+    g = torch.Generator().manual_seed(5)
+    E, Ed, Rb = 37, 24, 8
+    x, rbf = torch.randn(E, Ed, generator=g, dtype=torch.float64), torch.randn(E, Rb, generator=g, dtype=torch.float64)
+    Wr, w = torch.randn(Ed, Rb, generator=g, dtype=torch.float64), torch.randn(Ed, generator=g, dtype=torch.float64)
+    ref = (x * (rbf @ Wr.t()) * w).sum(1)
+    Q = (w[:, None] * Wr).t()            # [Rb, Ed]
+    got = (rbf * (x @ Q.t())).sum(1)
+    assert torch.allclose(ref, got, rtol=1e-12, atol=1e-12)
