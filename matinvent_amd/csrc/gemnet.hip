@@ -487,18 +487,20 @@ __global__ void mg_scale_kernel(const unsigned* a, const float* rs, const unsign
         dsc[1] = exp2f(-(float)e);
     }
 }
-// max over rows of sum_k |W[row][k]|, k in [0, K)
+// max over rows of sum_k |W[row][k]|, k in [0, K): a wave per row, the blocks' maxima merged by atomicMax on the bit pattern (non-negative
+// floats order like unsigned integers; *out must be zero before the launch).  One block for the whole matrix took 200 us per weight --
+// 21 ms after every parameter update of a fine-tune run.
 __global__ __launch_bounds__(256) void rowsum_max_kernel(const float* __restrict__ W, int ldw, int rows, int K, float* __restrict__ out) {
     __shared__ float red[4];
     float m = 0.f;
-    for (int r = threadIdx.x >> 6; r < rows; r += 4) {
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += 4 * gridDim.x) {
         float sacc = 0.f;
         for (int k = threadIdx.x & 63; k < K; k += 64) sacc += fabsf(W[(size_t)r * ldw + k]);
         m = fmaxf(m, wave_sum(sacc));
     }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 __device__ __forceinline__ void store_pl_pair(const Planes& P, int64_t row, int col, float x, float y) {
     unsigned pr[3];
@@ -1134,7 +1136,8 @@ struct Ctx {
     int rc = MI_OK;
     float* take(size_t n) { return b->fwd.take(n); }
     u16* take_planes(int64_t rows, int cols) {
-        if (getenv("MI_DEBUG_ARENA")) fprintf(stderr, "[arena %s] planes %lld x %d at %zu\n", dry ? "dry" : "run", (long long)rows, cols, b->fwd.top);
+        static const bool dbg_arena = getenv("MI_DEBUG_ARENA") != nullptr;
+        if (dbg_arena) fprintf(stderr, "[arena %s] planes %lld x %d at %zu\n", dry ? "dry" : "run", (long long)rows, cols, b->fwd.top);
         return reinterpret_cast<u16*>(b->fwd.take((planes_elems(rows, cols) + 1) / 2));
     }
     bool pm() const { return b->planes_mode; }
@@ -1249,7 +1252,8 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     Planes P = make_planes(e.pl, K, e.scale);
     const int64_t nthr = (int64_t)((w.rows + 127) / 128 * 128) * P.KT * 16;
     hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, P, 0);
-    hipLaunchKernelGGL(rowsum_max_kernel, dim3(1), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
+    MI_HIP(hipMemsetAsync(e.rowsum, 0, sizeof(float), c.s));
+    hipLaunchKernelGGL(rowsum_max_kernel, dim3((unsigned)std::min(64, (w.rows + 3) / 4)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
     MI_KERNEL_CHECK();
     net->wplanes[key] = e;
     *out = e;
