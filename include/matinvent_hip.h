@@ -330,6 +330,11 @@ int mi_debug_set_planes_small_tiles(int n);
  * run on the 256 x 256-tile kernel that stages its operands by LDS-DMA (fp16 two-plane build): 1 (default) / 0 = the 128 x 128
  * kernel everywhere.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
 int mi_debug_set_planes_big(int on, int min_rows);
+/* Plane-set products whose launch is at most `max_blocks` workgroups (default 256 = one per CU; 0 = never) run the LATENCY form of the
+ * 128 x 128 kernel: three operand register sets, loads three k-tiles ahead.  Such launches (short edge lists -- the reference's default
+ * sampling and fine-tune batches, models/diffcsp/sample.py:42-62 -- and node-level products) are one round of workgroups whose k-loop
+ * is a chain of memory latencies.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
+int mi_debug_set_planes_latency(int max_blocks);
 /* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
  * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
  * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results

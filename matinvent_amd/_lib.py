@@ -66,6 +66,7 @@ SIGNATURES = {
     "mi_debug_set_tn_split_min_rows": (_I, [_I]),
     "mi_debug_set_planes_small_tiles": (_I, [_I]),
     "mi_debug_set_planes_big": (_I, [_I, _I]),
+    "mi_debug_set_planes_latency": (_I, [_I]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),
     "mi_batch_num_edges": (_L, [_P]),

@@ -340,6 +340,7 @@ extern int g_planes_db_min_tiles;
 extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
 extern int g_planes_big;          // 1: row-major-epilogue products with M >= g_planes_big_min_rows and N % 256 == 0 on the 256 x 256 LDS-DMA kernel
 extern int g_planes_big_min_rows;
+extern int g_planes_lat_max_blocks;  // plane GEMMs of at most this many workgroups run the latency form (deep operand prefetch); 0 = never
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                    hipStream_t s, const SplitK* sk = nullptr) {
@@ -864,7 +865,11 @@ __host__ __device__ __forceinline__ bool planes_epilogue_is_rows(const PlanesEpi
 // share a CU (3 x 48 KiB LDS) and cover each other's staging, barriers and epilogues; in situ this beats the 256-row
 // double-buffered kernel below (one workgroup per CU), which is kept as an option.  V = 1: PAIR mode (see PlanesEpilogue) -- a
 // second accumulator set, 196 registers, two workgroups per CU.
-template <int V, int TM, bool EXT = false>
+// PF > 1: the LATENCY form for launches of at most one round of workgroups (short edge lists, node-level products of small batches): PF
+// register sets, the loads of k-tiles kt + 1 .. kt + PF in flight while k-tile kt is multiplied.  With one workgroup per CU nothing else
+// covers the load -> stage -> barrier chain, and a k-tile then costs one memory latency (~1.5 us: a K = 768 product over 265 edges took
+// 38 us, as long as over 7.5k edges).  Same tiles, same LDS image, same accumulation order: results are bit-identical to PF = 1.
+template <int V, int TM, bool EXT = false, int PF = 1>
 __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int N, int K, const PlanesEpilogue& pe, int rt_base) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32, TN = 2, PLA = BM * 64, PLB = 128 * 64;  // bytes per plane tile in LDS (A, W)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1008,6 +1013,57 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
         }
     };
 
+    if constexpr (PF > 1) {
+        u32x4 ra[PF][3][TM], rw[PF][3][2];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load_tiles(u, ra[u], rw[u]);
+        // at_half(k): pair mode switches accumulator sets when k reaches the cosine half of K
+        auto run_pf = [&](auto&& at_half) {
+            int k0 = 0;
+            for (; k0 + PF <= KT; k0 += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    at_half(k0 + u);
+                    store_tiles(ra[u], rw[u]);
+                    __syncthreads();
+                    load_tiles(k0 + u + PF, ra[u], rw[u]);  // past the last k-tile: outside the descriptor (zeros), never staged
+                    compute();
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF - 1; ++u) {
+                if (k0 + u < KT) {
+                    at_half(k0 + u);
+                    store_tiles(ra[u], rw[u]);
+                    __syncthreads();
+                    compute();
+                    __syncthreads();
+                }
+            }
+        };
+        if constexpr (V == 1) {
+            f32x16 accS[TM][TN];
+            const int khalf = KT / 2;
+            run_pf([&](int k) {
+                if (k == khalf) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            accS[i][j] = acc[i][j];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        }
+                }
+            });
+            planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+                                          cps_local);
+            return;
+        } else {
+            run_pf([](int) {});
+        }
+    } else {
     load_tiles(0, ra0, rw0);
     int kt = 0;
     // k-tiles kt .. kend-1.  One register set, loads issued one k-tile ahead (right after the staging barrier, so they have the
@@ -1040,6 +1096,7 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
         return;
     }
     run(KT);
+    }
 
     if (planes_epilogue_is_rows(pe, N)) {  // block-uniform
         __syncthreads();                   // the staging patches overlay the operand tiles
@@ -1068,6 +1125,15 @@ template <int V, int TM = 2, bool EXT = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0, V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0)))
 void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
     gemm_planes_body<V, TM, EXT>(A, W, M, N, K, pe, rt_base);
+}
+// the latency form (see gemm_planes_body): at most two workgroups per CU, i.e. up to 256 registers for the PF operand sets
+#ifndef MI_PLANES_PF
+#define MI_PLANES_PF 3
+#endif
+template <int V, bool EXT = false>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void gemm_planes_lat_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
+    gemm_planes_body<V, 2, EXT, MI_PLANES_PF>(A, W, M, N, K, pe, rt_base);
 }
 // dynamic LDS of gemm_planes_kernel: the operand tiles, overlaid after the loop by the epilogue's per-wave staging patches
 constexpr int planes_lds_bytes(int V, int TM) {
@@ -1561,11 +1627,13 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
     } else if (pair) {
         int nblk = nct * ((cdiv(M, 128) + 7) / 8 * 8);
+        const bool lat = nblk <= g_planes_lat_max_blocks;
         if (pe.diag_C0) {  // self edges ride along as extra workgroups behind the GEMM tiles
             pe.diag_block0 = nblk;
             nblk += cdiv(pe.diag_nodes, 8);
         }
-        hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (MI_PLANES_FP16 && g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && (N & 255) == 0 && planes_epilogue_is_rows(pe, N)) {
 #if MI_PLANES_FP16
         static bool attr_set = false;
@@ -1582,6 +1650,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
+    } else if (nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) {   // at most one round: the latency form
+        if (ext) hipLaunchKernelGGL((gemm_planes_lat_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_lat_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
     } else {
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 2, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 2>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
