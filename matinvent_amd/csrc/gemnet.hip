@@ -740,81 +740,132 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
 }
 // backward: dxd[k][j] += sum_{e != k} sum_l Y_l(cos_ek) dacc_e[l][j],  dacc_e[l][j] = sum_i cbfW[e][l][i] dTm[e][i][j];
 //           dcbfW[e][l][i] += sum_j acc_e[l][j] dTm[e][i][j]   (acc recomputed).
-// Edges are processed in chunks of TCH whose dacc sits in LDS; each wave then owns target rows k and adds the chunk in a fixed order.
-constexpr int TCH = 16;
+// Same structure as the forward: edges in chunks of TBC (a wave per edge), the chunk's Y_l(cos) computed once per PAIR into LDS and used
+// twice (acc of the chunk's edges; the chunk's contribution to every row k), the chunk's weights and dTm rows staged through LDS by
+// coalesced loads.  The per-edge [S x TR] x [TR x CB] product that is dcbfW runs from LDS (acc rows and dTm rows padded to TAS floats:
+// conflict-free 16-byte reads), one output per thread -- the first version reduced every output with a wave-wide sum and added it to
+// global memory from lane 0 (112 dependent read-modify-writes per edge: 3 ms per call at 64k edges, 13x the forward).
+constexpr int TBC = 8, TAS = 68;
+static inline size_t triplet_bwd_lds_floats(int TR, int CB) {
+    return (size_t)TBC * GN_DEG * 8 + GN_DEG * 3 + (size_t)GN_DEG * TR + TBC * 8 * 64 + (size_t)TBC * CB * 8 + TBC * 8 * TAS + (size_t)TBC * CB * TAS;
+}
 template <int S>
-__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
+__global__ __launch_bounds__(512) void triplet_bwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
                                                           const int* __restrict__ rowptr, const float* __restrict__ dTm, float* __restrict__ dxd,
                                                           float* __restrict__ dcbfW, int TR, int CB) {
-    extern __shared__ float sm[];  // V [GN_DEG][3] | xd [GN_DEG][TR] | dacc [TCH][S][64]
-    float* Vs = sm;
-    float* xs = sm + GN_DEG * 3;
-    float* da = xs + GN_DEG * TR;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ys = sm;                         // [TBC][GN_DEG][8]   Y_l(cos_ek), zero for k == e and l >= S
+    float* Vs = Ys + TBC * GN_DEG * 8;      // [GN_DEG][3]
+    float* xs = Vs + GN_DEG * 3;            // [GN_DEG][TR]
+    float* da = xs + GN_DEG * TR;           // [TBC][8][64]       dacc of the chunk's edges
+    float* wT = da + TBC * 8 * 64;          // [TBC][CB][8]       the chunk's weights, (i, l) order
+    float* as = wT + TBC * CB * 8;          // [TBC][8][TAS]      acc of the chunk's edges
+    float* gs = as + TBC * 8 * TAS;         // [TBC][CB][TAS]     the chunk's dTm rows
     const int a = blockIdx.x, lo = rowptr[a], deg = rowptr[a + 1] - lo, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < deg * 3; i += 256) Vs[i] = V[(size_t)lo * 3 + i];
-    for (int i = tid; i < deg * TR; i += 256) xs[i] = xd[(size_t)lo * TR + i];
+    for (int i = tid; i < deg * 3; i += 512) Vs[i] = V[(size_t)lo * 3 + i];
+    for (int i = tid; i < deg * TR; i += 512) xs[i] = xd[(size_t)lo * TR + i];
+    float gk[GN_DEG / 8];  // this wave's rows k = wave, wave + 8, ...: accumulated gradient of feature `lane`
+#pragma unroll
+    for (int q = 0; q < GN_DEG / 8; ++q) gk[q] = 0.f;
+    const int SC = S * CB, CT = CB * TR;
     __syncthreads();
-    float gk[GN_DEG / 4];  // this wave's rows k = wave, wave + 4, ...: accumulated gradient of feature `lane`
+    for (int c0 = 0; c0 < deg; c0 += TBC) {
+        const int ne = deg - c0 < TBC ? deg - c0 : TBC;
+        for (int p = tid; p < ne * deg; p += 512) {
+            const int ee = p / deg, k = p - ee * deg, e = c0 + ee;
+            float c = Vs[e * 3] * Vs[k * 3] + Vs[e * 3 + 1] * Vs[k * 3 + 1] + Vs[e * 3 + 2] * Vs[k * 3 + 2];
+            c = fminf(fmaxf(c, -1.f), 1.f);
+            float y[S];
+            sph_l<S>(c, y);
+            float o[8];
 #pragma unroll
-    for (int q = 0; q < GN_DEG / 4; ++q) gk[q] = 0.f;
-    for (int c0 = 0; c0 < deg; c0 += TCH) {
-        // phase A: dacc (and the cbfW gradient) of the chunk's edges
-        for (int ee = wave; ee < TCH; ee += 4) {
-            const int e = c0 + ee;
-            if (e >= deg) {
+            for (int l = 0; l < 8; ++l) o[l] = (l < S && k != e) ? y[l < S ? l : 0] : 0.f;
+            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+            dst[0] = f32x4{o[0], o[1], o[2], o[3]};
+            dst[1] = f32x4{o[4], o[5], o[6], o[7]};
+        }
+        for (int i = tid; i < ne * SC; i += 512) {
+            const int ee = i / SC, r = i - ee * SC, l = r / CB, ii = r - l * CB;
+            wT[(ee * CB + ii) * 8 + l] = cbfW[(size_t)(lo + c0) * SC + i];
+        }
+        for (int i = tid; i < ne * CT; i += 512) {
+            const int ee = i / CT, r = i - ee * CT, ii = r / TR, j = r - ii * TR;
+            gs[(ee * CB + ii) * TAS + j] = dTm[(size_t)(lo + c0) * CT + i];
+        }
+        __syncthreads();
+        if (wave < ne) {   // phase A: acc and dacc of edge c0 + wave, lane = feature
+            const int ee = wave;
+            float acc[8], dacc[8];
 #pragma unroll
-                for (int l = 0; l < S; ++l) da[(ee * S + l) * 64 + lane] = 0.f;
-                continue;
-            }
-            const float vx = Vs[e * 3], vy = Vs[e * 3 + 1], vz = Vs[e * 3 + 2];
-            float acc[S], dacc[S];
-#pragma unroll
-            for (int l = 0; l < S; ++l) acc[l] = dacc[l] = 0.f;
+            for (int l = 0; l < 8; ++l) acc[l] = dacc[l] = 0.f;
+            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * GN_DEG * 8);
+#pragma unroll 4
             for (int k = 0; k < deg; ++k) {
-                if (k == e) continue;
-                float c = vx * Vs[k * 3] + vy * Vs[k * 3 + 1] + vz * Vs[k * 3 + 2];
-                c = fminf(fmaxf(c, -1.f), 1.f);
-                float y[S];
-                sph_l<S>(c, y);
+                const f32x4 y0 = yr[2 * k], y1 = yr[2 * k + 1];
                 const float x = lane < TR ? xs[k * TR + lane] : 0.f;
-#pragma unroll
-                for (int l = 0; l < S; ++l) acc[l] += y[l] * x;
+                acc[0] += y0[0] * x;
+                acc[1] += y0[1] * x;
+                acc[2] += y0[2] * x;
+                acc[3] += y0[3] * x;
+                if (S > 4) {
+                    acc[4] += y1[0] * x;
+                    acc[5] += y1[1] * x;
+                    acc[6] += y1[2] * x;
+                    acc[7] += y1[3] * x;
+                }
             }
-            const float* w = cbfW + (size_t)(lo + e) * S * CB;
             for (int i = 0; i < CB; ++i) {
-                const float g = lane < TR ? dTm[((size_t)(lo + e) * CB + i) * TR + lane] : 0.f;
-#pragma unroll
-                for (int l = 0; l < S; ++l) {
-                    dacc[l] += w[l * CB + i] * g;
-                    const float r = wave_sum(acc[l] * g);
-                    if (lane == 0) dcbfW[(size_t)(lo + e) * S * CB + l * CB + i] += r;
+                const float g = lane < TR ? gs[(ee * CB + i) * TAS + lane] : 0.f;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wT + (ee * CB + i) * 8), w1 = *reinterpret_cast<const f32x4*>(wT + (ee * CB + i) * 8 + 4);
+                dacc[0] += w0[0] * g;
+                dacc[1] += w0[1] * g;
+                dacc[2] += w0[2] * g;
+                dacc[3] += w0[3] * g;
+                if (S > 4) {
+                    dacc[4] += w1[0] * g;
+                    dacc[5] += w1[1] * g;
+                    dacc[6] += w1[2] * g;
+                    dacc[7] += w1[3] * g;
                 }
             }
 #pragma unroll
-            for (int l = 0; l < S; ++l) da[(ee * S + l) * 64 + lane] = dacc[l];
+            for (int l = 0; l < 8; ++l) {
+                da[(ee * 8 + l) * 64 + lane] = l < S ? dacc[l] : 0.f;
+                as[(ee * 8 + l) * TAS + lane] = l < S ? acc[l] : 0.f;
+            }
         }
         __syncthreads();
-        // phase B: every row k collects the chunk's contributions
-        int q = 0;
-        for (int k = wave; k < deg; k += 4, ++q) {
-            const float vx = Vs[k * 3], vy = Vs[k * 3 + 1], vz = Vs[k * 3 + 2];
-            float s = 0.f;
-            for (int ee = 0; ee < TCH && c0 + ee < deg; ++ee) {
-                const int e = c0 + ee;
-                if (e == k) continue;
-                float c = vx * Vs[e * 3] + vy * Vs[e * 3 + 1] + vz * Vs[e * 3 + 2];
-                c = fminf(fmaxf(c, -1.f), 1.f);
-                float y[S];
-                sph_l<S>(c, y);
-#pragma unroll
-                for (int l = 0; l < S; ++l) s += y[l] * da[(ee * S + l) * 64 + lane];
+        // dcbfW[e][l][i] += sum_j acc_e[l][j] dTm[e][i][j]: one output per thread, coalesced read-modify-write
+        for (int o = tid; o < ne * SC; o += 512) {
+            const int ee = o / SC, r = o - ee * SC, l = r / CB, ii = r - l * CB;
+            const float* ar = as + (ee * 8 + l) * TAS;
+            const float* gr = gs + (ee * CB + ii) * TAS;
+            float sacc = 0.f;
+            int j = 0;
+            for (; j + 4 <= TR; j += 4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ar + j), gv = *reinterpret_cast<const f32x4*>(gr + j);
+                sacc += av[0] * gv[0] + av[1] * gv[1] + av[2] * gv[2] + av[3] * gv[3];
             }
-            gk[q] += s;
+            for (; j < TR; ++j) sacc += ar[j] * gr[j];
+            dcbfW[(size_t)(lo + c0) * SC + o] += sacc;
+        }
+        // every row k collects the chunk's contributions (Y is zero where e == k)
+        int q = 0;
+        for (int k = wave; k < deg; k += 8, ++q) {
+            float sk = 0.f;
+            for (int ee = 0; ee < ne; ++ee) {
+                const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+                const f32x4 y0 = yr[0], y1 = yr[1];
+                const float* d = da + ee * 8 * 64 + lane;
+                sk += y0[0] * d[0] + y0[1] * d[64] + y0[2] * d[128] + y0[3] * d[192];
+                if (S > 4) sk += y1[0] * d[256] + y1[1] * d[320] + y1[2] * d[384] + y1[3] * d[448];
+            }
+            gk[q] += sk;
         }
         __syncthreads();
     }
     int q = 0;
-    for (int k = wave; k < deg; k += 4, ++q)
+    for (int k = wave; k < deg; k += 8, ++q)
         if (lane < TR) dxd[(size_t)(lo + k) * TR + lane] += gk[q];
 }
 
@@ -1920,10 +1971,12 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 break;
             case OP_TRIPLET: {
                 if (o.M == 0) break;
-                const size_t sh = (size_t)(GN_DEG * 3 + GN_DEG * g.emb_trip + TCH * g.num_spherical * 64) * sizeof(float);
+                const size_t sh = triplet_bwd_lds_floats(g.emb_trip, g.emb_cbf) * sizeof(float);
+                MI_CHECK(sh <= 160 * 1024 && g.emb_trip <= 64 && g.emb_trip % 4 == 0, MI_EINVAL, "triplet backward: emb_trip / emb_cbf beyond the kernel's LDS budget");
 #define TRIP_BWD(SS)                                                                                                                              \
     case SS:                                                                                                                                      \
-        hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(256), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_bwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
+        hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(512), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf); \
         break;
                 switch (g.num_spherical) {
                     TRIP_BWD(1) TRIP_BWD(2) TRIP_BWD(3) TRIP_BWD(4) TRIP_BWD(5) TRIP_BWD(6) TRIP_BWD(7) TRIP_BWD(8)
