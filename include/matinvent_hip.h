@@ -400,7 +400,9 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
  * 1 = TWO fp16 planes with power-of-two scales from the operands' exact absmax (three terms; saturation impossible by
  * construction; measured no faster: the fp32-operand kernel is bound by its operand path).  Both are fp32-class; the tests run both. */
 int mi_debug_set_mg_f16(int on);
-/* Edge-level dense layers (from 4096 edges up) on the pre-split plane-set kernel: 1 (default) / 0 = the fp32-operand kernel everywhere. */
+/* Edge-level dense layers (from 4096 edges up) on the pre-split plane-set kernel: 1 (default) / 0 = the fp32-operand kernel everywhere;
+ * 3 = the forward on the plane-set kernel, the backward's data-gradient products (dX += dZ W, dZ written as a plane set by the
+ * activation-gradient pass) on the fp32-operand kernel (ablation). */
 int mi_debug_set_mg_planes(int on);
 /* Inference forwards in plane mode keep each edge-level tensor in ONE format (the plane set where a dense layer reads it, fp32 rows
  * otherwise; other consumers reconstruct the exact value from the planes), fold the skip-connection merges into the last layer of the

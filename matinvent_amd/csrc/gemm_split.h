@@ -139,7 +139,18 @@ __device__ __forceinline__ float f16_scale_from_absmax(unsigned bits) {
 // launch of thousands of waves spreads them over a power-of-two row of sub-slots that the reader folds; 0 = one slot)
 static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out, int spread_mask = 0) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // 16-byte loads (4-byte ones ran at 2.3 TB/s on a [64k, 512] tensor)
+        const int64_t n4 = n >> 2;
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int64_t i = tid; i < n4; i += nthr) {
+            const f32x4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthr) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (int64_t i = tid; i < n; i += nthr) m = fmaxf(m, fabsf(x[i]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out + (blockIdx.x & spread_mask), __float_as_uint(m));

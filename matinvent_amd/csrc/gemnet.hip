@@ -37,6 +37,10 @@ int g_mg_f16 = 0;
 // mi_gemnet_set_params, activations in their producer's epilogue, scaled by a power of two from a rigorous one-layer bound on the exact
 // absmax of the producer's inputs): measured 2.0-2.6x the fp32-operand kernel on every shape of this network
 int g_mg_planes = 1;
+// training: the data gradients of the edge-level dense layers (dX += dZ W) on the plane-set kernel as well -- dZ written as a plane set by
+// the activation-gradient pass (scale from the exact absmax of dY: |dZ| <= |s| max|silu'| max|dY|), against plane sets of the transposed
+// weight blocks built at first use after mi_gemnet_set_params; three fp16 terms instead of the fp32-operand kernel's six bf16 terms
+int g_mg_bwd_planes = 1;
 // inference forwards in plane mode keep every edge-level tensor in ONE format -- the plane set where a dense layer reads it, fp32 rows
 // otherwise -- instead of both (elementwise consumers and residual merges reconstruct x = (h0 + h1) / scale, exact in fp32), fold the
 // skip-connection merges into the last layer of the residual stack they close and the radial weighting into the edge -> atom sum.
@@ -507,6 +511,32 @@ __device__ __forceinline__ void store_pl_pair(const Planes& P, int64_t row, int 
     pl_split_pair(x, y, P.s(), pr);
 #pragma unroll
     for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(P.base + P.elem((int)row, col, k)) = pr[k];
+}
+// act_bwd_kernel that also leaves dZ as a plane set (the A operand of the data-gradient product); a thread per column pair.
+// dz == NULL: planes only (layers without activation / merge, whose dZ is dY itself).
+__global__ void act_bwd_pl_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ z, float s, float* __restrict__ dres,
+                                  float* __restrict__ dz, Planes P, int64_t rows, int cols) {
+    const int cp = cols >> 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cp) return;
+    const int64_t r = i / cp;
+    const int c = (int)(i - r * cp) * 2;
+    const float2 g2 = *reinterpret_cast<const float2*>(dy + r * ldy + c);
+    float g0 = g2.x * s, g1 = g2.y * s;
+    if (dres) {
+        float2* d = reinterpret_cast<float2*>(dres + r * cols + c);
+        float2 v = *d;
+        v.x += g0;
+        v.y += g1;
+        *d = v;
+    }
+    if (z) {
+        const float2 zz = *reinterpret_cast<const float2*>(z + r * cols + c);
+        g0 *= ssilu_grad(zz.x);
+        g1 *= ssilu_grad(zz.y);
+    }
+    if (dz) *reinterpret_cast<float2*>(dz + r * cols + c) = make_float2(g0, g1);
+    store_pl_pair(P, r, c, g0, g1);
 }
 __device__ __forceinline__ void note_absmax(unsigned* slot, float m) {
 #pragma unroll
@@ -1116,6 +1146,11 @@ struct mi_gbatch {
     Arena fwd, grad;
     float* scratch = nullptr;  // dZ buffer [E][max N] + reduction scratch
     size_t scratch_floats = 0, dz_floats = 0;
+    mi::u16* dzpl = nullptr;   // dZ as a plane set (backward on the plane-set kernel), its absmax slot row and {scale, 1 / scale}
+    size_t dzpl_elems = 0;
+    unsigned* bwd_amax = nullptr;
+    float* bwd_dsc = nullptr;
+    std::vector<std::pair<size_t, size_t>> pl_ranges;   // (offset, bytes) of the plane sets in the activation arena of the last training forward
     std::vector<GOp> tape;
     bool tape_valid = false;
     std::map<std::string, std::pair<const float*, int64_t>> taps;
@@ -1189,7 +1224,9 @@ struct Ctx {
     u16* take_planes(int64_t rows, int cols) {
         static const bool dbg_arena = getenv("MI_DEBUG_ARENA") != nullptr;
         if (dbg_arena) fprintf(stderr, "[arena %s] planes %lld x %d at %zu\n", dry ? "dry" : "run", (long long)rows, cols, b->fwd.top);
-        return reinterpret_cast<u16*>(b->fwd.take((planes_elems(rows, cols) + 1) / 2));
+        u16* p = reinterpret_cast<u16*>(b->fwd.take((planes_elems(rows, cols) + 1) / 2));
+        if (!dry && train) b->pl_ranges.emplace_back((size_t)(reinterpret_cast<char*>(p) - b->fwd.base), b->fwd.top - (size_t)(reinterpret_cast<char*>(p) - b->fwd.base));
+        return p;
     }
     bool pm() const { return b->planes_mode; }
     // the exact absmax slot of a tensor: the producer's if it tracked one, otherwise one extra pass over the tensor (node-level tensors)
@@ -1291,7 +1328,8 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     const GParam& w = net->params[pidx];
     if (!net->warena) {
         size_t tot = 0;
-        for (const GParam& q : net->params) tot += planes_elems(q.rows, q.cols) + 3 * planes_elems(q.rows, 32);
+        // (+ the transposed blocks the backward's data-gradient products read: [cols, rows] per tensor, sliced by rows)
+        for (const GParam& q : net->params) tot += planes_elems(q.rows, q.cols) + 3 * planes_elems(q.rows, 32) + planes_elems(q.cols, q.rows) + 3 * planes_elems(128, q.rows);
         MI_HIP(hipMalloc((void**)&net->warena, tot * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&net->wrowsum, 1024 * sizeof(float)));
         net->warena_elems = tot;
@@ -1305,6 +1343,30 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, P, 0);
     MI_HIP(hipMemsetAsync(e.rowsum, 0, sizeof(float), c.s));
     hipLaunchKernelGGL(rowsum_max_kernel, dim3((unsigned)std::min(64, (w.rows + 3) / 4)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
+    MI_KERNEL_CHECK();
+    net->wplanes[key] = e;
+    *out = e;
+    return MI_OK;
+}
+
+// plane set of the TRANSPOSED weight block (W[:, wcol0 : wcol0 + K])^T = rows wcol0 .. wcol0 + K of thetaT's copy, [K, N]: the W operand of
+// dX[M, K] += dZ[M, N] W[:, wcol0 : wcol0 + K]; built on first use after mi_gemnet_set_params (the forward has allocated the arena)
+static int get_wtplanes(mi_gemnet* net, hipStream_t s, int pidx, int wcol0, int K, mi_gemnet::WPl* out) {
+    const int64_t key = ((int64_t)1 << 62) | ((int64_t)pidx << 40) | ((int64_t)wcol0 << 16) | (int64_t)K;
+    auto it = net->wplanes.find(key);
+    if (it != net->wplanes.end()) {
+        *out = it->second;
+        return MI_OK;
+    }
+    const GParam& w = net->params[pidx];
+    MI_CHECK(net->warena && net->thetaT && !w.derived, MI_ESTATE, "transposed weight planes before a plane-mode forward");
+    const size_t need = planes_elems(K, w.rows);
+    MI_CHECK(net->warena_top + need <= net->warena_elems, MI_ENOMEM, "weight plane arena exhausted");
+    mi_gemnet::WPl e{net->warena + net->warena_top, nullptr, net->wscale_h[pidx]};
+    net->warena_top += need;
+    Planes P = make_planes(e.pl, w.rows, e.scale);
+    const int64_t nthr = (int64_t)((K + 127) / 128 * 128) * P.KT * 16;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, s, net->thetaT + w.toff + (size_t)wcol0 * w.ldt, w.ldt, K, w.rows, P, 0);
     MI_KERNEL_CHECK();
     net->wplanes[key] = e;
     *out = e;
@@ -1882,12 +1944,27 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
         b->scratch_floats = dz + dz / 8 + red;
         b->dz_floats = dz + dz / 8;
     }
+    if (train && MI_PLANES_FP16 && g_mg_bwd_planes && g_mg_planes && g_gemm_mode != 0 && b->E >= MG_PLANES_MIN_ROWS) {
+        const size_t pe = planes_elems(b->E, std::max(g.emb_edge, g.emb_atom));
+        if (b->dzpl_elems < pe) {
+            if (b->dzpl) (void)hipFree(b->dzpl);
+            b->dzpl = nullptr;
+            b->dzpl_elems = 0;
+            MI_HIP(hipMalloc((void**)&b->dzpl, (pe + pe / 8) * sizeof(u16)));
+            b->dzpl_elems = pe + pe / 8;
+        }
+        if (!b->bwd_amax) {
+            MI_HIP(hipMalloc((void**)&b->bwd_amax, AMAX_W * sizeof(unsigned)));
+            MI_HIP(hipMalloc((void**)&b->bwd_dsc, 2 * sizeof(float)));
+        }
+    }
     if (train) {  // the backward re-reads the inputs the forward saw
         MI_HIP(hipMemcpyAsync(b->types_copy, types, (size_t)b->N * sizeof(int), hipMemcpyDeviceToDevice, s));
         MI_HIP(hipMemcpyAsync(b->cell_copy, cell, (size_t)b->B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
         types = b->types_copy;
     }
     Ctx run{net, b, s, false, train};
+    b->pl_ranges.clear();
     run_program(run, pos, train ? b->cell_copy : cell, types, t);
     MI_CHECK(b->fwd.top <= need, MI_ESTATE, "activation arena: the program used %zu bytes, its dry run %zu", b->fwd.top, need);
     MI_TRY(run.rc);
@@ -1901,7 +1978,14 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
     MI_CHECK(net->thetaT != nullptr, MI_ESTATE, "mi_gemnet_set_params must run before backward");
     b->tape_valid = false;
     MI_TRY(arena_ensure(b->grad, b->fwd.top));
-    MI_HIP(hipMemsetAsync(b->grad.base, 0, b->fwd.top, s));
+    {   // zero the gradient arena -- except the mirror of the forward's plane sets, which no gradient kernel touches (a third of the arena)
+        size_t pos = 0;
+        for (const auto& r : b->pl_ranges) {
+            if (r.first > pos) MI_HIP(hipMemsetAsync(b->grad.base + pos, 0, r.first - pos, s));
+            pos = std::max(pos, r.first + r.second);
+        }
+        if (pos < b->fwd.top) MI_HIP(hipMemsetAsync(b->grad.base + pos, 0, b->fwd.top - pos, s));
+    }
     auto G = [&](const float* p) -> float* {
         if (!p) return nullptr;
         const char* q = reinterpret_cast<const char*>(p);
@@ -1931,7 +2015,27 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 const GParam& w = net->params[o.pidx];
                 const float* dZ = dY;
                 int ldz = o.ldy;
-                if (o.act != ACT_NONE || o.X2 || o.s != 1.f) {
+                float* dX = o.x_grad ? G(o.X) : nullptr;
+                const bool elementwise = o.act != ACT_NONE || o.X2 || o.s != 1.f;
+                // edge-level data gradient on the plane-set kernel: dZ leaves the activation-gradient pass as a plane set as well
+                const bool bwd_pl = MI_PLANES_FP16 && g_mg_bwd_planes && b->planes_mode && b->dzpl && dX && !w.derived && o.M >= MG_PLANES_MIN_ROWS &&
+                                    o.N % 32 == 0 && (o.K & 7) == 0 && o.ldy == o.N && planes_elems(o.M, o.N) <= b->dzpl_elems;
+                Planes dzp;
+                if (bwd_pl) {
+                    MI_HIP(hipMemsetAsync(b->bwd_amax, 0, AMAX_W * sizeof(unsigned), s));
+                    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(o.M * o.N, 1024))), dim3(256), 0, s, dY, o.M * o.N, b->bwd_amax,
+                                       AMAX_W - 1);
+                    hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, s, b->bwd_amax, (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+                                       (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, o.act != ACT_NONE ? 1.1f * GN_ACT : 1.f, fabsf(o.s),
+                                       b->bwd_dsc);
+                    dzp = make_planes(b->dzpl, o.N, 1.f, b->bwd_dsc);
+                    hipLaunchKernelGGL(act_bwd_pl_kernel, dim3(nblk(o.M * (o.N / 2))), dim3(256), 0, s, dY, o.ldy, o.act != ACT_NONE ? o.Z : (const float*)nullptr, o.s,
+                                       G(o.X2), elementwise ? dz : (float*)nullptr, dzp, o.M, o.N);
+                    if (elementwise) {
+                        dZ = dz;
+                        ldz = o.N;
+                    }
+                } else if (elementwise) {
                     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.ldy, o.act != ACT_NONE ? o.Z : (const float*)nullptr, o.s,
                                        G(o.X2), dz, o.M, o.N);
                     dZ = dz;
@@ -1949,9 +2053,24 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                     else hipLaunchKernelGGL(segsum_kernel, dim3(nblk((int64_t)B * o.N)), dim3(256), 0, s, dZ, ldz, b->node_off, (const int*)nullptr, dG, B, o.N, 1);
                 }
                 // dW[:, wcol0 : wcol0 + K] += dZ^T X
-                MI_TRY(gemm_tn_auto(dZ, ldz, o.X, o.K, grad + w.off + o.wcol0, w.cols, (int)o.M, o.N, o.K, red, red_floats, s));
-                float* dX = o.x_grad ? G(o.X) : nullptr;
-                if (dX) {  // dX += dZ W[:, wcol0 : wcol0 + K]  = dZ (W^T rows wcol0..)^T
+                // (both operands with rigorous power-of-two scales -- dZ's from this pass, X's from its forward plane set: the weight-gradient
+                //  product splits them into two fp16 planes, three terms, instead of three bf16 planes, six terms)
+                const float* sx = nullptr;
+                if (bwd_pl) {
+                    auto xi = b->pl_of.find(o.X);
+                    if (xi != b->pl_of.end() && xi->second.dsc) sx = xi->second.dsc;
+                }
+                MI_TRY(gemm_tn_auto(dZ, ldz, o.X, o.K, grad + w.off + o.wcol0, w.cols, (int)o.M, o.N, o.K, red, red_floats, s, false, sx ? b->bwd_dsc : nullptr, sx));
+                if (bwd_pl) {
+                    mi_gemnet::WPl wt;
+                    MI_TRY(get_wtplanes(net, s, o.pidx, o.wcol0, o.K, &wt));
+                    PlanesEpilogue pd;
+                    pd.C = dX;
+                    pd.ldc = o.K;
+                    pd.ep.residual = dX;
+                    pd.ep.ld_res = o.K;
+                    MI_TRY(gemm_planes(dzp, make_planes(wt.pl, o.N, wt.scale), (int)o.M, o.K, o.N, pd, s));
+                } else if (dX) {  // dX += dZ W[:, wcol0 : wcol0 + K]  = dZ (W^T rows wcol0..)^T
                     GemmEpilogue ep;
                     ep.residual = dX;
                     ep.ld_res = o.K;
@@ -2260,6 +2379,9 @@ void mi_gbatch_destroy(mi_gbatch* b) {
     if (b->fwd.base) (void)hipFree(b->fwd.base);
     if (b->grad.base) (void)hipFree(b->grad.base);
     if (b->scratch) (void)hipFree(b->scratch);
+    if (b->dzpl) (void)hipFree(b->dzpl);
+    if (b->bwd_amax) (void)hipFree(b->bwd_amax);
+    if (b->bwd_dsc) (void)hipFree(b->bwd_dsc);
     if (b->ts_dev) (void)hipFree(b->ts_dev);
     delete b;
 }
@@ -2333,7 +2455,8 @@ int mi_gemnet_backward(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const f
 }
 
 int mi_debug_set_mg_planes(int on) {
-    mi::g_mg_planes = on != 0;
+    mi::g_mg_planes = (on & 1) != 0;
+    mi::g_mg_bwd_planes = on != 0 && (on & 2) == 0;   // +2: forward on the plane-set kernel, the backward's data gradients on the fp32-operand kernel
     return MI_OK;
 }
 

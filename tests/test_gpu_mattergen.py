@@ -310,15 +310,16 @@ def test_fine_tune_step_in_chunks_equals_the_unchunked_step(monkeypatch):
         assert float((w0[k] - w1[k]).abs().max()) <= 2e-6, k   # (lr 1e-4: an Adam step moves a weight by at most ~1e-4)
 
 
-@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (2, 0, 1), (0, 1, 1), (0, 0, 1)],
-                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "pre-split-plane-sets-lds-dma-256-tiles", "fp32-operand-fp16-2plane",
-                              "fp32-operand-bf16-3plane"])
+@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
+                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "pre-split-plane-sets-lds-dma-256-tiles",
+                              "pre-split-plane-sets-forward-only", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
 def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
     (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values; inference keeps one
     format per edge-level tensor and folds the skip merges into the residual stacks -- `lean`, also run switched off) or on the
     fp32-operand kernel (three bf16 planes or two fp16 planes split on the fly); all against the oracle, outputs and per-block taps,
-    the default also through the backward."""
+    the plane-set variants also through the backward (whose edge-level data gradients run on the plane-set kernel too, dZ written as a
+    plane set by the activation-gradient pass -- `planes` = 3 keeps them on the fp32-operand kernel)."""
     from matinvent_amd import _lib
     hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
     hp = M.GemNetHParams(**hpd)
@@ -326,7 +327,7 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
-    _lib.check(_lib.load().mi_debug_set_mg_planes(1 if planes else 0))
+    _lib.check(_lib.load().mi_debug_set_mg_planes(3 if planes == 3 else 1 if planes else 0))
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
     if planes == 2:   # every qualifying product (epilogue extensions included) on the 256 x 256 LDS-DMA kernel, whatever its row count
         _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))
