@@ -335,6 +335,10 @@ int mi_debug_set_planes_big(int on, int min_rows);
  * sampling and fine-tune batches, models/diffcsp/sample.py:42-62 -- and node-level products) are one round of workgroups whose k-loop
  * is a chain of memory latencies.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
 int mi_debug_set_planes_latency(int max_blocks);
+/* The 128 x 128-tile plane product with its operands staged by LDS-DMA (`buffer_load ... lds` into two 32 KiB stages, fragments
+ * software-pipelined over two register sets, one barrier per k-tile): 0 = never, 1 (default) = launches of at most the latency
+ * limit above, 2 = every launch of the 128-row kernel.  Bit-identical to the register-staged loop (tests/test_gpu_gemm.py). */
+int mi_debug_set_planes_dma(int mode);
 /* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
  * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
  * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results

@@ -351,6 +351,7 @@ extern int g_planes_db_min_tiles;
 extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
 extern int g_planes_big;          // 1: row-major-epilogue products with M >= g_planes_big_min_rows and N % 256 == 0 on the 256 x 256 LDS-DMA kernel
 extern int g_planes_big_min_rows;
+extern int g_planes_dma;             // 128 x 128 tiles fed by LDS-DMA: 0 = never, 1 = launches of at most g_planes_lat_max_blocks workgroups, 2 = every launch
 extern int g_planes_lat_max_blocks;  // plane GEMMs of at most this many workgroups run the latency form (deep operand prefetch); 0 = never
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
 inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
@@ -1024,7 +1025,110 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
         }
     };
 
-    if constexpr (PF > 1) {
+    if constexpr (PF == 0) {
+#if MI_PLANES_FP16
+        // LDS-DMA form of the 128 x 128 tile (the large-M kernel's pipeline at this tile size): operand tiles by `buffer_load ... lds`
+        // straight into two 32 KiB stages [A plane 0 | A plane 1 | W plane 0 | W plane 1] (8 KiB blocks, the XOR swizzle applied on the
+        // source side), wave w brings in block w; no staging registers and no ds_write pass; fragments software-pipelined over two
+        // register sets (F0 = first 16-deep half of a k-tile, F1 = second), ONE barrier per k-tile, DMA two k-tiles ahead.  A lone
+        // workgroup on a CU then overlaps its own LDS reads, DMA and MFMAs instead of running them in turn (0.8 us per k-tile in the
+        // register-staged loop).  Same k order and term order per output: bit-identical results.
+        static_assert(TM == 2, "the LDS-DMA form exists for 128-row tiles");
+        constexpr int STG = 4 * 8192;
+        const int KT_ = (K + 31) / 32;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int blk_op = wv >> 1, blk_pl = wv & 1;
+        const Planes& X = blk_op ? W : A;
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(X.base + X.tile(blk_op ? ct : rt, 0) + blk_pl * 4096, KT_ * 24576 - blk_pl * 8192);
+        const int voff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        auto dma_piece = [&](int kt, int stage, int sub) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STG + wv * 8192 + sub * 1024), 16, voff,
+                                                     kt * 24576 + sub * 1024, 0, 0);
+        };
+        auto dma = [&](int kt, int stage) {
+#pragma unroll
+            for (int sub = 0; sub < 8; ++sub) dma_piece(kt, stage, sub);
+        };
+        struct Frag {
+            f16x8 a[TM][2], b[TN][2];
+        };
+        auto read_a = [&](const unsigned char* st, int s2, Frag& f, int i) {
+            const int r = (wm * TM + i) * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f.a[i][pl] = *reinterpret_cast<const f16x8*>(st + pl * 8192 + r * 64 + c * 16);
+        };
+        auto read_b = [&](const unsigned char* st, int s2, Frag& f, int j) {
+            const int r = (wn * TN + j) * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f.b[j][pl] = *reinterpret_cast<const f16x8*>(st + (2 + pl) * 8192 + r * 64 + c * 16);
+        };
+        auto mma3 = [&](const Frag& f, int i, int j) {   // the three terms in the register-staged loop's order
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
+        };
+        f32x16 accS[V == 1 ? TM : 1][V == 1 ? TN : 1];
+        const int khalf = V == 1 ? KT_ / 2 : -1;
+        dma(0, 0);
+        if (KT_ > 1) {
+            dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (loads retire in order: the eight pieces of k-tile 0 are in)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        Frag F0, F1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_b(smem, 0, F0, j);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_a(smem, 0, F0, i);
+        for (int kt = 0; kt < KT_; ++kt) {
+            const unsigned char* st = smem + (kt & 1) * STG;
+            const unsigned char* stn = smem + ((kt + 1) & 1) * STG;
+            if constexpr (V == 1) {
+                if (kt == khalf) {   // pair mode: the cosine half of K goes into the second accumulator set
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            accS[i][j] = acc[i][j];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) read_b(st, 1, F1, j);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) read_a(st, 1, F1, i);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma3(F0, i, j);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool more = kt + 1 < KT_, more2 = kt + 2 < KT_;
+#pragma unroll
+            for (int q = 0; q < TM * TN; ++q) {
+                if (more2) {
+                    dma_piece(kt + 2, kt & 1, 2 * q);
+                    dma_piece(kt + 2, kt & 1, 2 * q + 1);
+                }
+                if (more) {
+                    if (q < TN) read_b(stn, 0, F0, q);
+                    else read_a(stn, 0, F0, q - TN);
+                }
+                mma3(F1, q / TN, q % TN);
+            }
+        }
+        if constexpr (V == 1) {
+            __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
+            planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+                                          cps_local);
+            return;
+        }
+#endif
+    } else if constexpr (PF > 1) {
         u32x4 ra[PF][3][TM], rw[PF][3][2];
 #pragma unroll
         for (int u = 0; u < PF; ++u) load_tiles(u, ra[u], rw[u]);
@@ -1136,6 +1240,13 @@ template <int V, int TM = 2, bool EXT = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0, V == 1 ? MI_PLANES_OCC1 : MI_PLANES_OCC0)))
 void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
     gemm_planes_body<V, TM, EXT>(A, W, M, N, K, pe, rt_base);
+}
+// the LDS-DMA form of the 128 x 128 tile (see gemm_planes_body, PF = 0): two 32 KiB stages, two workgroups per CU
+constexpr int PLANES_DMA_LDS = 2 * 4 * 8192;
+template <int V, bool EXT = false>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_planes_dma_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
+    gemm_planes_body<V, 2, EXT, 0>(A, W, M, N, K, pe, rt_base);
 }
 // the latency form (see gemm_planes_body): at most two workgroups per CU, i.e. up to 256 registers for the PF operand sets
 #ifndef MI_PLANES_PF
@@ -1621,6 +1732,17 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
     const int nct = cdiv(N, 128);
+#if MI_PLANES_FP16
+    {
+        static bool dma_attr_set = false;
+        if (!dma_attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
+            dma_attr_set = true;
+        }
+    }
+#endif
     // pair mode has twice the epilogue per row of MFMA work: two workgroups per CU (128-row kernel) hide it behind each other's main
     // loop, which measured faster than the one-workgroup-per-CU kernel at every size tried
     // (the 256-row double-buffered kernel only exists for the three-plane bf16 format)
@@ -1639,11 +1761,13 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     } else if (pair) {
         int nblk = nct * ((cdiv(M, 128) + 7) / 8 * 8);
         const bool lat = nblk <= g_planes_lat_max_blocks;
+        const bool dma = MI_PLANES_FP16 && (g_planes_dma > 1 || (g_planes_dma == 1 && lat));
         if (pe.diag_C0) {  // self edges ride along as extra workgroups behind the GEMM tiles
             pe.diag_block0 = nblk;
             nblk += cdiv(pe.diag_nodes, 8);
         }
-        if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
+        else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (MI_PLANES_FP16 && g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && (N & 255) == 0 && planes_epilogue_is_rows(pe, N)) {
 #if MI_PLANES_FP16
@@ -1661,6 +1785,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
+    } else if (MI_PLANES_FP16 && (g_planes_dma > 1 || (g_planes_dma == 1 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks))) {
+        if (ext) hipLaunchKernelGGL((gemm_planes_dma_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_dma_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
     } else if (nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) {   // at most one round: the latency form
         if (ext) hipLaunchKernelGGL((gemm_planes_lat_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_lat_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);

@@ -125,11 +125,14 @@ def test_plane_gemm_lds_dma_256_tiles_bit_identical(M, N, K):
     assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(265, 512, 768), (31, 1536, 512), (300, 256, 96), (128, 128, 16), (1000, 384, 64), (700, 512, 128), (513, 512, 160)])
-def test_plane_gemm_latency_form_bit_identical(M, N, K):
-    """Launches of at most one workgroup per CU run the latency form (three operand register sets, loads three k-tiles ahead); the k
-    order and the order of the product terms per output are unchanged, so it agrees bit for bit with the one-set loop -- k-tile counts
-    below, at and above the prefetch depth, and counts that leave a remainder of one or two."""
+@pytest.mark.parametrize("M,N,K", [(265, 512, 768), (31, 1536, 512), (300, 256, 96), (128, 128, 16), (1000, 384, 64), (700, 512, 128), (513, 512, 160),
+                                   (3000, 512, 512), (70000, 512, 512)])
+def test_plane_gemm_latency_and_lds_dma_forms_bit_identical(M, N, K):
+    """Launches of at most one workgroup per CU run a latency-tolerant form of the 128 x 128 kernel: by default the LDS-DMA form
+    (operand tiles by `buffer_load ... lds` into two stages, fragments software-pipelined over two register sets, one barrier per
+    k-tile), optionally the register form (three operand register sets, loads three k-tiles ahead); mode 2 runs the LDS-DMA form for
+    every launch.  The k order and the order of the product terms per output are unchanged, so all agree bit for bit with the
+    one-set loop -- k-tile counts of 1, 2, 3 and more, odd and even, ragged M and N, single- and multi-round launches."""
     from matinvent_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + N + K)
@@ -137,43 +140,52 @@ def test_plane_gemm_latency_form_bit_identical(M, N, K):
     W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     outs = []
     try:
-        for lat in (0, 256):
+        _lib.check(lib.mi_debug_set_planes_big(0, 1))
+        for dma, lat in ((0, 0), (0, 256), (1, 256), (2, 0)):
+            _lib.check(lib.mi_debug_set_planes_dma(dma))
             _lib.check(lib.mi_debug_set_planes_latency(lat))
-            for _ in range(3 if lat else 1):
+            for _ in range(3 if dma else 1):   # (repeated: a DMA / barrier ordering slip would show as run-to-run differences)
                 out = torch.full((M, N), float("nan"), device="cuda")
                 _lib.check(lib.mi_debug_gemm(2, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
                 torch.cuda.synchronize()
                 outs.append(out)
     finally:
         _lib.check(lib.mi_debug_set_planes_latency(256))
+        _lib.check(lib.mi_debug_set_planes_dma(1))
+        _lib.check(lib.mi_debug_set_planes_big(1, 65536))
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
     ref = A.double() @ W.double().t()
     assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
 
 
-def test_latency_form_in_the_network_bit_identical():
-    """A short chain of a small batch at the benchmark network (pair-mode Fourier GEMM with its folded self edges and scales, the
-    second linear with the fused segmented sum, the node-level products): every plane product is one round of workgroups, i.e. the
-    latency form; the final state must equal the one-set kernels' bit for bit."""
+@pytest.mark.parametrize("na", [[10, 7, 4, 10, 20, 1], [20] * 40], ids=["one-round-launches", "multi-round-launches"])
+def test_latency_forms_in_the_network_bit_identical(na):
+    """A short chain at the benchmark network (pair-mode Fourier GEMM with its folded self edges and scales, the second linear with
+    the fused segmented sum, the node-level products) with the plane products on the one-set loop, the register latency form, the
+    LDS-DMA form for one-round launches (default) and the LDS-DMA form everywhere: the final states must be equal bit for bit."""
     from matinvent_amd import _lib
     from tests.gpu_util import Box, make_module
     lib = _lib.load()
     torch.manual_seed(0)
     m = make_module(512, 6, 128, 1000)
     with torch.no_grad():
-        for n, p in m.decoder.named_parameters():
-            if n.startswith(("coord_out", "type_out", "lattice_out")):
-                p.mul_(1e-2)
+        v = m.decoder.views()
+        for k in ("coord_out.weight", "lattice_out.weight", "type_out.weight", "type_out.bias"):
+            v[k].mul_(1e-2)
+    m.decoder.mark_dirty()
     finals = []
     try:
-        for lat in (0, 256):
+        for dma, lat in ((0, 0), (0, 256), (1, 256), (2, 0)):
+            _lib.check(lib.mi_debug_set_planes_dma(dma))
             _lib.check(lib.mi_debug_set_planes_latency(lat))
-            final, _ = m.sample(Box([10, 7, 4, 10, 20, 1]), seed=5, step_lr=5e-6, t_start=1000, t_stop=997, streams=1)
+            final, _ = m.sample(Box(na), seed=5, step_lr=5e-6, t_start=1000, t_stop=997, streams=1)
             torch.cuda.synchronize()
             finals.append({k: v.clone() for k, v in final.items() if torch.is_tensor(v)})
     finally:
         _lib.check(lib.mi_debug_set_planes_latency(256))
-    for k in ("frac_coords", "atom_types", "lattices"):
-        assert torch.isfinite(finals[0][k]).all()
-        assert torch.equal(finals[0][k], finals[1][k]), k
+        _lib.check(lib.mi_debug_set_planes_dma(1))
+    for f in finals[1:]:
+        for k in ("frac_coords", "atom_types", "lattices"):
+            assert torch.isfinite(finals[0][k]).all()
+            assert torch.equal(finals[0][k], f[k]), k
