@@ -335,6 +335,9 @@ int mi_debug_set_planes_big(int on, int min_rows);
  * sampling and fine-tune batches, models/diffcsp/sample.py:42-62 -- and node-level products) are one round of workgroups whose k-loop
  * is a chain of memory latencies.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
 int mi_debug_set_planes_latency(int max_blocks);
+/* The second edge GEMM of an inference forward (SiLU + fused segmented sum epilogue, cspnet.py:79) with at least `min_rows` edges on
+ * the 256 x 256 LDS-DMA kernel as well; 0 (default) = never.  Bit-identical partial sums (same accumulation order). */
+int mi_debug_set_planes_big_seg(int min_rows);
 /* The 128 x 128-tile plane product with its operands staged by LDS-DMA (`buffer_load ... lds` into two 32 KiB stages, fragments
  * software-pipelined over two register sets, one barrier per k-tile): 0 = never, 1 (default) = launches of at most the latency
  * limit above, 2 = every launch of the 128-row kernel.  Bit-identical to the register-staged loop (tests/test_gpu_gemm.py). */

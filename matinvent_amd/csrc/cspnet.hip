@@ -18,6 +18,7 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
+int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
@@ -1304,6 +1305,11 @@ int mi_debug_set_planes_big(int on, int min_rows) {
 
 int mi_debug_set_planes_latency(int max_blocks) {
     g_planes_lat_max_blocks = max_blocks;   // 0 = the latency form is never used
+    return MI_OK;
+}
+
+int mi_debug_set_planes_big_seg(int min_rows) {
+    g_planes_big_seg_min_rows = min_rows;
     return MI_OK;
 }
 

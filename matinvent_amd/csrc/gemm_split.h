@@ -351,6 +351,7 @@ extern int g_planes_db_min_tiles;
 extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
 extern int g_planes_big;          // 1: row-major-epilogue products with M >= g_planes_big_min_rows and N % 256 == 0 on the 256 x 256 LDS-DMA kernel
 extern int g_planes_big_min_rows;
+extern int g_planes_big_seg_min_rows;  // > 0: products with the fused segmented sum (second edge GEMM, inference) from this many rows up on the 256 x 256 kernel too
 extern int g_planes_dma;             // 128 x 128 tiles fed by LDS-DMA: 0 = never, 1 = launches of at most g_planes_lat_max_blocks workgroups, 2 = every launch
 extern int g_planes_lat_max_blocks;  // plane GEMMs of at most this many workgroups run the latency form (deep operand prefetch); 0 = never
 extern int g_pair_kernel;  // 0 = 128-row kernel for pair mode (default), 1 = size-based choice
@@ -1384,7 +1385,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    if (EXT || planes_epilogue_is_rows(pe, N))   // block-uniform
+        planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    else   // MFMA-layout epilogue: the second edge GEMM's SiLU + fused segmented sum (inference: no pre-activation rows)
+        planes_epilogue<TM, TN>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, l31, kg);
 }
 #endif
 
@@ -1769,7 +1773,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
         else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
-    } else if (MI_PLANES_FP16 && g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && (N & 255) == 0 && planes_epilogue_is_rows(pe, N)) {
+    } else if (MI_PLANES_FP16 && (N & 255) == 0 &&
+               ((g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && planes_epilogue_is_rows(pe, N)) ||
+                (g_planes_big_seg_min_rows > 0 && M >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act && !planes_epilogue_is_rows(pe, N)))) {
 #if MI_PLANES_FP16
         static bool attr_set = false;
         if (!attr_set) {
