@@ -391,6 +391,18 @@ def measure_mg(args, K, W):
     sat = _lib.saturation_events(reset=True)
     nparams = int(m.decoder.theta.numel())
     del m
+    # north_star: "achieved HBM GB/s against the chip's peak" for this sampler -- from the committed rocprofv3 passes of this command
+    # (kernel trace + FETCH_SIZE + WRITE_SIZE, scripts/gpu_mg_prof.sh; bench.py cannot read hardware counters itself)
+    hbm = None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_mattergen_sampler_traffic.json")))
+    if cands:
+        tr = json.load(open(cands[-1]))
+        if "whole_trace" in tr:
+            w = tr["whole_trace"]
+            hbm = {"bound": "hbm", "achieved": w["GBps"], "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s", "frac": w["frac_of_8TBps"],
+                   "source": os.path.relpath(cands[-1], ROOT), "profiled_head": tr.get("head"),
+                   "note": f"all kernels of the profiled run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; {100 * w['share_of_trace_time_covered']:.0f} % of the trace's kernel time)"}
     return {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": Bm * K / (T * elapsed), "unit": "structures/s",
             "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32: edge-level layers on pre-split two-plane fp16 operands (3 MFMA terms), " if terms == 3 else "f32: edge-level layers on pre-split three-plane bf16 operands (6 MFMA terms), ")
@@ -405,7 +417,8 @@ def measure_mg(args, K, W):
                          "achieved": terms * flops_eval * 2 * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": terms * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                          "achieved_fp32_equivalent": flops_eval * 2 * K / elapsed / 1e12, "flops_per_evaluation": flops_eval,
-                         "note": "end-to-end rate of the dense-layer flops (whole step time, all kernels); per-kernel durations and HBM GB/s: profiles/"}}
+                         "note": "end-to-end rate of the dense-layer flops (whole step time, all kernels); per-kernel durations and HBM GB/s: profiles/"},
+            "hbm_roofline": hbm}
 
 
 def main_mg(args):

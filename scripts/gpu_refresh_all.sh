@@ -4,7 +4,7 @@ HEAD=${1:-unknown}
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r2_gpu_pytest.log
 bash scripts/profile_round.sh r2 $HEAD > gpurun_out/r2_profile_round.log 2>&1
-bash scripts/gpu_mg_prof.sh > gpurun_out/r2_mg_prof.log 2>&1
+bash scripts/gpu_mg_prof.sh $HEAD > gpurun_out/r2_mg_prof.log 2>&1
 for mode in mg-sample sample-default ft-default mg-ft; do
   python bench.py --mode $mode $([ $mode = mg-ft ] && echo --mg-batch 256) 2> gpurun_out/r2_bench_$mode.err | tail -1 > gpurun_out/r2_bench_$mode.json
 done

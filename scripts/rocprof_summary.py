@@ -50,6 +50,16 @@ def main():
                   "| kernel | avg us | fetch MB | write MB | GB/s | % of peak |", "|---|---|---|---|---|---|"]
         for _, k, us, f, w, gbs in sorted(rows, reverse=True)[:14]:
             lines.append(f"| `{k[:70]}` | {us:.1f} | {f / 1e6:.1f} | {w / 1e6:.1f} | {gbs:.0f} | {gbs / 80:.1f} |")
+        # the whole trace: every kernel that appears in all three passes, weighted by its calls (north_star: the sampler's
+        # achieved HBM GB/s against the chip's peak)
+        tot_b = sum((f + w) * dur[k][1] for _, k, us, f, w, gbs in rows)
+        tot_us = sum(us * dur[k][1] for _, k, us, f, w, gbs in rows)
+        all_us = sum(a * c for a, c in dur.values())
+        whole = {"bytes": tot_b, "kernel_time_us": tot_us, "GBps": tot_b / (tot_us * 1e-6) / 1e9, "frac_of_8TBps": tot_b / (tot_us * 1e-6) / 8e12,
+                 "share_of_trace_time_covered": tot_us / all_us}
+        lines += ["", f"Whole trace (kernels present in all passes, {100 * whole['share_of_trace_time_covered']:.1f} % of the kernel time): "
+                      f"{tot_b / 1e9:.2f} GB in {tot_us / 1e3:.1f} ms of kernel time = {whole['GBps']:.0f} GB/s = {100 * whole['frac_of_8TBps']:.1f} % of the 8 TB/s peak"]
+    whole = locals().get("whole")
     traffic = {}
     for p in pmcs:
         cur = sqlite3.connect(p).cursor()
@@ -65,6 +75,8 @@ def main():
         rec = {"kernel": "gemm_planes_kernel<1> (pair mode) + gemm_planes_kernel<0> (edge stage; the FETCH/WRITE passes run with the node-level products on the fp32-operand kernel so that every plane-GEMM dispatch is an edge-stage one)", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
                "write_bytes_per_dispatch": write, "dispatches_per_bench_launch": 2, "counters": traffic,
                "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
+        if whole:
+            rec["whole_trace"] = whole
         json.dump(rec, open(out.rsplit(".", 1)[0] + "_traffic.json", "w"), indent=1)
         lines += ["", f"HBM-side traffic of the edge-stage `gemm_planes_kernel` dispatches, per dispatch (corrected): fetch {fetch / 1e6:.1f} MB + write {write / 1e6:.1f} MB"]
     open(out, "w").write("\n".join(lines) + "\n")
