@@ -461,7 +461,9 @@ def main_mg_ft(args):
     elapsed = time.perf_counter() - t0
     out = {"metric": "fine-tune crystal-timesteps/sec, MatterGen-shaped network", "value": Bm * K / elapsed, "unit": "crystal-timesteps/s", "n_gpus": 1,
            "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 via 3-plane bf16 split (6 MFMA terms)", "data": "synthetic",
+           "dtype": ("f32: edge-level layers, their data gradients and weight gradients on two fp16 planes (3 MFMA terms); node-level products on three "
+                     "bf16 planes split on the fly (6 terms); f32 accumulate") if _lib.load().mi_plane_format() == 2 else "f32 via 3-plane bf16 split (6 MFMA terms)",
+           "data": "synthetic",
            "config": {"workload": f"MatterGen-labelled form of BASELINE configs[2]: fine-tune timesteps (noise, agent fwd, frozen-prior fwd, backward; Adam every 50), "
                                   f"{Bm} crystals x 20 atoms, synthetic reward; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
                       "batch_per_gpu": Bm, "parameters": int(agent.decoder.theta.numel()),
