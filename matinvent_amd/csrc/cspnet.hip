@@ -20,6 +20,7 @@ int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS
 int g_planes_big_min_rows = 65536;
 int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
+int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16;
@@ -713,6 +714,29 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
     }
+    // Node-level kernels on a helper stream of the highest priority (experiment, `g_node_hi`): with four chains in flight a chain's short
+    // node-level launches queue behind the other chains' edge GEMM workgroups (18 us of work take ~55 us), and a denoising step is the
+    // SUM of one chain's kernel durations -- the chains run side by side, each at the pace of its own serial sequence.
+    const bool use_hi = g_node_hi && !train;
+    hipStream_t ns = s, cur = s;
+    int evi = 0;
+    if (use_hi) {
+        if (!b->hi_stream) {
+            int lo = 0, hi = 0;
+            MI_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MI_HIP(hipStreamCreateWithPriority(&b->hi_stream, hipStreamNonBlocking, hi));
+            for (hipEvent_t& e : b->hi_ev) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        ns = b->hi_stream;
+    }
+    auto to = [&](hipStream_t x) -> int {   // the work that follows goes to stream x: join it behind the stream used so far
+        if (cur == x) return MI_OK;
+        MI_HIP(hipEventRecord(b->hi_ev[evi], cur));
+        MI_HIP(hipStreamWaitEvent(x, b->hi_ev[evi], 0));
+        evi ^= 1;
+        cur = x;
+        return MI_OK;
+    };
     // ---- message-passing layers (cspnet.py:84-91) ----
     const bool node_planes = g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && H % 32 == 0 && N >= g_node_planes_min_rows;
     for (int l = 0; l < L; ++l) {
@@ -727,11 +751,12 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const Planes lnp = node_planes ? make_planes(b->lnpl, H, PL_S_LN) : Planes();
         const Planes aggp = node_planes ? make_planes(b->aggpl, H, PL_S_ACT, b->dsc + 2) : Planes();
         const int ldpq = node_planes ? 3 * H : 2 * H;
+        MI_TRY(to(ns));
         if (net->cfg.ln) {
-            hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_in, net->p(p + "layer_norm.weight"),
+            hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, ns, h_in, net->p(p + "layer_norm.weight"),
                                net->p(p + "layer_norm.bias"), cat, 2 * H, train ? tp.lnstat + (size_t)l * N * 2 : (float*)nullptr, N, H, lnp);
         } else {
-            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_in, cat, 2 * H, N, H, lnp);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, h_in, cat, 2 * H, N, H, lnp);
         }
         MI_KERNEL_CHECK();
         if (node_planes) {
@@ -739,15 +764,16 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             pq.C = b->PQ;
             pq.ldc = ldpq;
             pq.absmax = MI_PLANES_FP16 ? b->absmax + 2 * l : nullptr;
-            MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, s));
+            MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, ns));
         } else {
-            MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+            MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), ns, &b->sk));
             if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && b->E > 0) {
-                hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, s, b->PQ, (int64_t)N * 2 * H,
+                hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, ns, b->PQ, (int64_t)N * 2 * H,
                                    b->absmax + 2 * l);
                 MI_KERNEL_CHECK();
             }
         }
+        MI_TRY(to(s));
         // pair mode folds the activation scales and the self edges into the launch of its Fourier-block GEMM
         const bool pair_path = net->edge_mode != 0 && b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0;
         const bool fold = pair_path && g_fold_pair_extras && b->Np > 0;
@@ -758,7 +784,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         }
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
             MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
-            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
+            MI_TRY(to(ns));
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         } else if (b->E > 0) {      // two tiled GEMMs over the edge list with gather / SiLU epilogues
             const int E = (int)b->E, F6 = 6 * net->F;
@@ -835,17 +862,20 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_nodes = N;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
                 MI_TRY(prof_end(net, s, ps));
-                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
+                MI_TRY(to(ns));
+                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
                 MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
                 MI_TRY(gemm_nt(b->M1, H, net->p(p + "edge_mlp.2.weight"), H, b->M2, H, E, H, H, g2e, s));
                 MI_TRY(prof_end(net, s, ps));
-                hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->M2, b->rowptr, cat, N, H);
+                MI_TRY(to(ns));
+                hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->M2, b->rowptr, cat, N, H);
                 MI_KERNEL_CHECK();
             }
         } else {
-            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, b->part, b->rowptr, cat, N, H, aggp);
+            MI_TRY(to(ns));
+            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         }
         GemmEpilogue e1;
@@ -861,9 +891,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             p1.ep.pre_add = b->PQ + 2 * H;  // LayerNorm(h) x W[:, :H], computed with P_i / P_j
             p1.ep.ld_pre_add = ldpq;
             p1.Cp = make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4);
-            MI_TRY(gemm_planes(aggp, make_planes(net->Waggpl + (size_t)l * planes_elems(H, H), H), N, H, H, p1, s));
+            MI_TRY(gemm_planes(aggp, make_planes(net->Waggpl + (size_t)l * planes_elems(H, H), H), N, H, H, p1, ns));
         } else {
-            MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, s, &b->sk));
+            MI_TRY(gemm_nt(cat, 2 * H, net->p(p + "node_mlp.0.weight"), 2 * H, b->X, H, N, H, 2 * H, e1, ns, &b->sk));
         }
         GemmEpilogue e2;
         e2.bias = net->p(p + "node_mlp.2.bias");
@@ -879,11 +909,12 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             p2.ep = e2;
             p2.C = h_out;
             p2.ldc = H;
-            MI_TRY(gemm_planes(make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4), make_planes(net->Wn2pl + (size_t)l * planes_elems(H, H), H), N, H, H, p2, s));
+            MI_TRY(gemm_planes(make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4), make_planes(net->Wn2pl + (size_t)l * planes_elems(H, H), H), N, H, H, p2, ns));
         } else {
-            MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, s, &b->sk));
+            MI_TRY(gemm_nt(b->X, H, net->p(p + "node_mlp.2.weight"), H, h_out, H, N, H, H, e2, ns, &b->sk));
         }
     }
+    MI_TRY(to(s));
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
     if (net->cfg.ln) {
@@ -1247,6 +1278,9 @@ void mi_batch_destroy(mi_batch* b) {
     if (!b) return;
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+    if (b->hi_stream) (void)hipStreamDestroy(b->hi_stream);
+    for (hipEvent_t e : b->hi_ev)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : b->allocs) (void)hipFree(p);
     delete b;
 }
@@ -1305,6 +1339,11 @@ int mi_debug_set_planes_big(int on, int min_rows) {
 
 int mi_debug_set_planes_latency(int max_blocks) {
     g_planes_lat_max_blocks = max_blocks;   // 0 = the latency form is never used
+    return MI_OK;
+}
+
+int mi_debug_set_node_priority(int on) {
+    g_node_hi = on;
     return MI_OK;
 }
 

@@ -1251,6 +1251,13 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V ==
 void gemm_planes_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
     gemm_planes_body<V, TM, EXT>(A, W, M, N, K, pe, rt_base);
 }
+// the register-staged loop compiled for FOUR waves per SIMD (<= 128 registers): a node-level launch of this form fits beside two resident
+// pair-mode workgroups (2 x 190 registers) or two LDS-DMA workgroups (2 x 64 KiB LDS + 32 KiB), instead of waiting for one of them to retire
+template <bool EXT = false>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_planes_slim_kernel(Planes A, Planes W, int M, int N, int K, PlanesEpilogue pe, int rt_base) {
+    gemm_planes_body<0, 2, EXT, 1>(A, W, M, N, K, pe, rt_base);
+}
 // the LDS-DMA form of the 128 x 128 tile (see gemm_planes_body, PF = 0): two 32 KiB stages, two workgroups per CU
 constexpr int PLANES_DMA_LDS = 2 * 4 * 8192;
 template <int V, bool EXT = false>
@@ -1774,7 +1781,7 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     } else if (pair) {
         int nblk = nct * ((cdiv(M, 128) + 7) / 8 * 8);
         const bool lat = nblk <= g_planes_lat_max_blocks;
-        const bool dma = MI_PLANES_FP16 && (g_planes_dma > 1 || (g_planes_dma == 1 && lat));
+        const bool dma = MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && lat));
         if (pe.diag_C0) {  // self edges ride along as extra workgroups behind the GEMM tiles
             pe.diag_block0 = nblk;
             nblk += cdiv(pe.diag_nodes, 8);
@@ -1800,7 +1807,11 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
-    } else if (MI_PLANES_FP16 && (g_planes_dma > 1 || (g_planes_dma == 1 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks))) {
+    } else if (g_planes_dma >= 4 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= 256) {   // mode 4: one-round launches on the four-waves-per-SIMD build
+        if (ext) hipLaunchKernelGGL((gemm_planes_slim_kernel<true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+        else hipLaunchKernelGGL((gemm_planes_slim_kernel<false>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+    } else if (MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) ||
+                                  (g_planes_dma >= 3 && nct * ((cdiv(M, 128) + 7) / 8 * 8) > 256))) {   // (modes 3 / 4: the LDS-DMA form for the LARGE launches only)
         if (ext) hipLaunchKernelGGL((gemm_planes_dma_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_dma_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
     } else if (nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) {   // at most one round: the latency form

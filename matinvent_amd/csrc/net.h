@@ -131,6 +131,9 @@ struct mi_batch {
     std::vector<float> coef_h;  // host copy of what `coef` holds (re-uploaded only when the caller's table differs)
     int keep_lattice = 0, keep_coords = 0;  // CSP mode of the sampler (mi_sampler_set_keep)
     mi::SplitK sk;  // split-K scratch of the node-level products (small batches only)
+    // optional helper stream of higher priority for the node-level kernels of an inference forward (see net_forward) + its join events
+    hipStream_t hi_stream = nullptr;
+    hipEvent_t hi_ev[2] = {nullptr, nullptr};
     Tape tape;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // fork / join of work put on an auxiliary stream (mi_ft_micro_step)
     std::vector<void*> allocs;

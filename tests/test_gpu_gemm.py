@@ -176,10 +176,11 @@ def test_latency_forms_in_the_network_bit_identical(na):
     m.decoder.mark_dirty()
     finals = []
     try:
-        for dma, lat, bigseg in ((0, 0, 0), (0, 256, 0), (1, 256, 0), (2, 0, 0), (1, 256, 1)):
+        for dma, lat, bigseg, hi in ((0, 0, 0, 0), (0, 256, 0, 0), (1, 256, 0, 0), (2, 0, 0, 0), (1, 256, 1, 0), (1, 256, 0, 1)):
             _lib.check(lib.mi_debug_set_planes_dma(dma))
             _lib.check(lib.mi_debug_set_planes_latency(lat))
             _lib.check(lib.mi_debug_set_planes_big_seg(bigseg))   # (1: the second edge GEMM on the 256 x 256 LDS-DMA kernel, whatever its row count)
+            _lib.check(lib.mi_debug_set_node_priority(hi))        # (1: node-level kernels on the batch's high-priority helper stream, joined by events)
             final, _ = m.sample(Box(na), seed=5, step_lr=5e-6, t_start=1000, t_stop=997, streams=1)
             torch.cuda.synchronize()
             finals.append({k: v.clone() for k, v in final.items() if torch.is_tensor(v)})
@@ -187,6 +188,7 @@ def test_latency_forms_in_the_network_bit_identical(na):
         _lib.check(lib.mi_debug_set_planes_latency(256))
         _lib.check(lib.mi_debug_set_planes_dma(1))
         _lib.check(lib.mi_debug_set_planes_big_seg(0))
+        _lib.check(lib.mi_debug_set_node_priority(0))
     for f in finals[1:]:
         for k in ("frac_coords", "atom_types", "lattices"):
             assert torch.isfinite(finals[0][k]).all()
