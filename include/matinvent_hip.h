@@ -320,7 +320,7 @@ int mi_debug_set_node_planes_min_rows(int n);
  * dZ1-consumer kernels instead of the fused fc pair-mode backward pass, +16 = a separate silu(Z1) pass instead of forming M1 inside
  * the weight-gradient product's operand load, +32 = the dM1 data gradient on the on-the-fly three-plane bf16 split instead of the
  * pre-split fp16 plane GEMM, +64 = the edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes /
- * three (ablations). */
+ * three, +128 = the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form (ablations). */
 int mi_debug_set_tn128(int on);
 /* Tuning knob: shortest row list (contraction length) for which the bf16-pipe weight-gradient kernel is used (default 4096). */
 int mi_debug_set_tn_split_min_rows(int n);

@@ -14,6 +14,7 @@
 namespace mi {
 extern int g_edge_pairs;
 int g_tn_xsilu = 1;          // M1 = silu(Z1) inside the weight-gradient product's operand load (0: separate pass, ablation)
+int g_bwd_pairs_tile = 1;   // crystals of at most 24 atoms: the LDS-tile form of the fused pass (0: the thread-per-column form, ablation)
 int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
 int g_bwd_dz2_planes = 1;   // fp16 plane format: dZ2 also as a plane set, its data gradient on the pre-split plane GEMM (0: on-the-fly bf16 split)
 int g_bwd_wgrad_f16 = 1;    // fp16 plane format: edge-level weight gradients on two fp16 planes / three terms (0: three bf16 planes / six)
@@ -234,6 +235,78 @@ __global__ __launch_bounds__(128) void edge_bwd_pairs_kernel(const float* __rest
     }
     dG[(size_t)g * H + c] = gs;
     dsum_part[(size_t)g * H + c] = ds;
+}
+
+// The same pass for crystals of at most PAIRS_NMAX atoms, restructured for parallelism: the kernel above walks a crystal's 190 pairs
+// serially in each thread with (B x H / 128) two-wave blocks -- 340 blocks on 256 CUs at the benchmark set, a chain of load latencies
+// (137 us per layer).  Here a block owns a (crystal, 32-column) slice: its dZ1 = dM1 silu'(Z1) tile [n x n][32] goes through LDS once
+// (eight row workers x 32 columns, coalesced 128-byte pieces), then every output is formed from LDS in a fixed order: pairs round-robin
+// over the workers, row / column sums per node, the per-crystal sums by one worker each.  4x the blocks, 4 waves each.
+constexpr int PAIRS_NMAX = 24, PAIRS_W = 32, PAIRS_WORKERS = 8;
+__global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* __restrict__ dM1, const float* __restrict__ Z1,
+                                                                  const int* __restrict__ node_off, const int* __restrict__ rowptr,
+                                                                  const int* __restrict__ pair_off, float* __restrict__ Dm, float* __restrict__ Dp,
+                                                                  float* __restrict__ dPQ, float* __restrict__ dG, float* __restrict__ dsum_part,
+                                                                  int H, const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
+    extern __shared__ float tile[];  // dZ1 [n * n][32] | row sums [n][32]
+    __shared__ unsigned short pij[PAIRS_NMAX * (PAIRS_NMAX - 1) / 2];   // pair k -> (i << 8) | j
+    if (dsc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (scales of the weight-gradient operands: see the kernel above)
+        const float bnd = 2.2f * __uint_as_float(amax[0]);
+        int ex = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
+        if (!(bnd == bnd) || bnd > 3e38f) ex = -100;
+        ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+        dsc_out[0] = exp2f((float)ex);
+        dsc_out[1] = exp2f(-(float)ex);
+        dsc_out[2] = 16384.f;
+        dsc_out[3] = 1.f / 16384.f;
+    }
+    const int g = blockIdx.x, tid = threadIdx.x, lc = tid & (PAIRS_W - 1), w = tid >> 5, c = blockIdx.y * PAIRS_W + lc;
+    const int o = node_off[g], n = node_off[g + 1] - o;
+    if (n == 0) return;
+    const bool cok = c < H;
+    const int64_t e0 = rowptr[o];
+    const int nn = n * n, np = n * (n - 1) / 2;
+    float* rs = tile + (size_t)nn * PAIRS_W;
+    for (int e = w; e < nn; e += PAIRS_WORKERS) {
+        const size_t a = (size_t)(e0 + e) * H + c;
+        tile[e * PAIRS_W + lc] = cok ? dM1[a] * silu_grad(Z1[a]) : 0.f;
+    }
+    for (int i = tid; i < n; i += 256) {   // pair table in the order of the pair list (i < j, row-major)
+        int k = i * n - i * (i + 1) / 2;
+        for (int j = i + 1; j < n; ++j, ++k) pij[k] = (unsigned short)((i << 8) | j);
+    }
+    __syncthreads();
+    const int64_t p0 = pair_off[g];
+    if (cok) {
+        for (int k = w; k < np; k += PAIRS_WORKERS) {
+            const int i = pij[k] >> 8, j = pij[k] & 255;
+            const float v1 = tile[(i * n + j) * PAIRS_W + lc], v2 = tile[(j * n + i) * PAIRS_W + lc];
+            Dm[(size_t)(p0 + k) * H + c] = v1 - v2;
+            Dp[(size_t)(p0 + k) * H + c] = v1 + v2;
+        }
+    }
+    for (int i = w; i < n; i += PAIRS_WORKERS) {   // dPQ[i][0:H] = sum_j dZ1[(i,j)],  dPQ[i][H:2H] = sum_i' dZ1[(i',i)]
+        float r = 0.f, cs = 0.f;
+        for (int j = 0; j < n; ++j) {
+            r += tile[(i * n + j) * PAIRS_W + lc];
+            cs += tile[(j * n + i) * PAIRS_W + lc];
+        }
+        rs[i * PAIRS_W + lc] = r;
+        if (cok) {
+            dPQ[(size_t)(o + i) * (2 * H) + c] = r;
+            dPQ[(size_t)(o + i) * (2 * H) + H + c] = cs;
+        }
+    }
+    __syncthreads();
+    if (cok && w == 0) {
+        float gs = 0.f;
+        for (int i = 0; i < n; ++i) gs += rs[i * PAIRS_W + lc];
+        dG[(size_t)g * H + c] = gs;
+    } else if (cok && w == 1) {
+        float ds = 0.f;
+        for (int i = 0; i < n; ++i) ds += tile[(i * n + i) * PAIRS_W + lc];
+        dsum_part[(size_t)g * H + c] = ds;
+    }
 }
 
 // gW[f][c] += v[f] for c < ncols   (self edges: every cosine feature is 1)
@@ -586,7 +659,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
                 MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
                 const bool wff_f16 = dz2_planes && fused_pairs && g_bwd_wgrad_f16;  // two-plane fp16 operands for the Fourier-block weight gradient
-                if (fused_pairs) {
+                if (fused_pairs && b->nmax_fc <= PAIRS_NMAX && g_bwd_pairs_tile) {
+                    const size_t sh = ((size_t)b->nmax_fc * b->nmax_fc + b->nmax_fc) * PAIRS_W * sizeof(float);
+                    hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
+                                       Dp, t.dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
+                    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
+                    MI_KERNEL_CHECK();
+                } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
                                        Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, t.dPQ, t.dG, sc, H,
                                        wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);

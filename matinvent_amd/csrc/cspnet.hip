@@ -23,7 +23,7 @@ int g_planes_dma = 1;
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
-extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16;
+extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile;
 int g_tn128 = 1;
 int g_tn_split = 1;
 int g_tn_split_min_rows = 4096;  // (at 5120 rows: 43 -> 39 us for 512 x 512, 71 -> 56 us for 512 x 1024; no gain below)
@@ -1365,6 +1365,7 @@ int mi_debug_set_tn128(int on) {
     g_tn_xsilu = (on & 16) == 0;         // +16: separate silu(Z1) pass instead of forming M1 inside the weight-gradient product
     g_bwd_pairs_fused = (on & 8) == 0;  // +8: the separate dZ1 consumers instead of the fused pair-mode backward pass  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
     g_bwd_dz2_planes = (on & 32) == 0;  // +32: dM1 data gradient on the on-the-fly three-plane bf16 split instead of the fp16 plane GEMM
+    g_bwd_pairs_tile = (on & 128) == 0;  // +128: the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
 }

@@ -17,7 +17,7 @@ def main():
     rows = [r for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels")
             if "spin_kernel" not in r[0]]   # (the stream-concurrency probe runs once at start-up, outside the timed region)
     tot_all = sum(r[2] for r in rows) or 1.0
-    for name, calls, tot, avg, pct in rows[:16]:
+    for name, calls, tot, avg, pct in rows[:int(__import__("os").environ.get("MI_SUMMARY_ROWS", "16"))]:
         lines.append(f"| `{name[:110]}` | {calls} | {tot:.1f} | {avg:.2f} | {100.0 * tot / tot_all:.2f} |")
     for p in pmcs:
         cur = sqlite3.connect(p).cursor()

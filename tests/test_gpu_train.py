@@ -178,10 +178,22 @@ def test_gradients_vs_oracle_autograd_mid_size():
         _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, 2e-5, f"grad {k}")  # measured <= 4e-6 of max|grad|
 
 
-def test_gradients_vs_oracle_autograd_ragged_large():
+@pytest.mark.parametrize("pairs_form", [3, 3 + 128], ids=["lds-tile-pair-pass", "thread-per-column-pair-pass"])
+def test_gradients_vs_oracle_autograd_ragged_large(pairs_form):
     """Ragged crystals (1..20 atoms, single-atom cells included) at a size where the edge-level backward products take their
     large-list forms: E > 8192 edges, so dZ2 is also written as an fp16 plane set, its data gradient runs on the plane GEMM and
-    both edge-level weight gradients split into two fp16 planes with device-side scales."""
+    both edge-level weight gradients split into two fp16 planes with device-side scales.  The fused
+    pair-mode pass over dZ1 runs in its LDS-tile form (a block per crystal and 32-column slice; default) and in the
+    thread-per-column form."""
+    from matinvent_amd import _lib
+    _lib.check(_lib.load().mi_debug_set_tn128(pairs_form))
+    try:
+        _ragged_large_case()
+    finally:
+        _lib.check(_lib.load().mi_debug_set_tn128(3))
+
+
+def _ragged_large_case():
     H, L, F = 256, 2, 32
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P = O.init_params(hp, seed=9)
