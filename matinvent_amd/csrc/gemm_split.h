@@ -518,18 +518,29 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
                                                 int kg) {
     const GemmEpilogue& ep = pe.ep;
     const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
+    // segment structure of every row block of this wave, requested together (one chain of two dependent loads instead of one per block)
+    int h_srcv[TM], h_rpv[TM], h_nvalid[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        h_srcv[i] = h_rpv[i] = h_nvalid[i] = 0;
+        if (pe.seg_part) {
+            const int rb = row_w + i * 32;
+            h_nvalid[i] = M - rb < 32 ? (M - rb > 0 ? M - rb : 0) : 32;
+            h_srcv[i] = h_nvalid[i] > 0 ? pe.seg_src[rb + (l31 < h_nvalid[i] ? l31 : h_nvalid[i] - 1)] : 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        if (pe.seg_part) h_rpv[i] = h_nvalid[i] > 0 ? pe.seg_rowptr[h_srcv[i]] : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rb = row_w + i * 32;  // first row of this 32-row block
         // segment structure of the block (runs of equal seg_src), wave-uniform
         uint32_t starts = 0;
-        int srcv = 0, rpv = 0, nvalid = 0;
+        const int srcv = h_srcv[i], rpv = h_rpv[i], nvalid = h_nvalid[i];
         if (pe.seg_part) {
-            nvalid = M - rb < 32 ? (M - rb > 0 ? M - rb : 0) : 32;
-            srcv = nvalid > 0 ? pe.seg_src[rb + (l31 < nvalid ? l31 : nvalid - 1)] : 0;
-            // the run's first edge, per lane and up front: looked up inside the segment loop it was one dependent global load per
-            // segment and column tile (a serial chain of ~12 load latencies = a quarter of this kernel's time)
-            rpv = nvalid > 0 ? pe.seg_rowptr[srcv] : 0;
+            // (rpv = the run's first edge, per lane and up front: looked up inside the segment loop it was one dependent global load per
+            // segment and column tile -- a serial chain of ~12 load latencies, a quarter of this kernel's time)
             const int prev = __shfl_up(srcv, 1, 64);
             starts = (uint32_t)__ballot(kg == 0 && l31 < nvalid && (l31 == 0 || srcv != prev));
         }
@@ -745,6 +756,22 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
     const int l31 = lane & 31, kg = lane >> 5;
     float* stS = stage;
     float* stC = stage + 1152;
+    // the index rows of this lane's pairs (they depend on the row block and the half only, not on the column tile), all requested up
+    // front: inside the tile loop each tile paid an index-load latency ahead of its gathers -- eight times per wave in a launch of one
+    // workgroup per CU, where nothing else covers it (a third of a 33 us product at 265 edges)
+    int h_ni[TM][2], h_nj[TM][2], h_gr[TM][2], h_e1[TM][2], h_e2[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row_w + i * 32 + ((lane + 64 * u) >> 2);
+            const bool ok = row < M;
+            h_ni[i][u] = ok ? pe.pair_i[row] : 0;
+            h_nj[i][u] = ok ? pe.pair_j[row] : 0;
+            h_gr[i][u] = ok ? pe.pair_graph[row] : 0;
+            h_e1[i][u] = ok ? pe.pair_e1[row] : 0;
+            h_e2[i][u] = ok ? pe.pair_e2[row] : 0;
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -774,7 +801,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                             cv[4 + k] = d[k];
                         }
                     }
-                    const int ni = pe.pair_i[row], nj = pe.pair_j[row], gr = pe.pair_graph[row];
+                    const int ni = h_ni[i][u], nj = h_nj[i][u], gr = h_gr[i][u];
                     auto ld8 = [&](float (&dst)[8], const float* src) {
                         const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
@@ -792,7 +819,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                     if (ep.bias) ld8(bb, ep.bias + col);
 #pragma unroll
                     for (int dir = 0; dir < 2; ++dir) {
-                        const int erow = dir == 0 ? pe.pair_e1[row] : pe.pair_e2[row];
+                        const int erow = dir == 0 ? h_e1[i][u] : h_e2[i][u];
                         float v[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
