@@ -1324,7 +1324,9 @@ constexpr int planes_lds_bytes(int V, int TM) {
 // ------------------------------------------------------------------------------------------------------------------------
 #if MI_PLANES_FP16
 constexpr int GEMM_BIG_STAGE = 8 * 8192, GEMM_BIG_LDS = 2 * GEMM_BIG_STAGE;
-template <bool EXT>
+// SEG: the MFMA-layout epilogue with the fused segmented sum instead of the row-major one -- its own instantiation (an ablation, DESIGN
+// 15.3): as a run-time branch inside the default instantiation it cost that one 20-30 % (197 -> 258 us on [102 400, 512] x [512, 512])
+template <bool EXT, bool SEG = false>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_big_kernel(Planes A, Planes W, int M, int N, int K,
                                                                                                                PlanesEpilogue pe) {
     constexpr int TM = 4, TN = 2;
@@ -1428,10 +1430,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    if (EXT || planes_epilogue_is_rows(pe, N))   // block-uniform
-        planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
-    else   // MFMA-layout epilogue: the second edge GEMM's SiLU + fused segmented sum (inference: no pre-activation rows)
+    if constexpr (SEG)   // MFMA-layout epilogue: the second edge GEMM's SiLU + fused segmented sum (inference: no pre-activation rows)
         planes_epilogue<TM, TN>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, l31, kg);
+    else
+        planes_epilogue_rows<TM, TN, EXT>(pe, acc, row0 + wm * 128, col0 + wn * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
 }
 #endif
 
@@ -1824,10 +1826,12 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
             attr_set = true;
         }
         const dim3 grid((N >> 8) * ((cdiv(M, 256) + 7) / 8 * 8));
-        if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
+        if (!planes_epilogue_is_rows(pe, N)) hipLaunchKernelGGL((gemm_planes_big_kernel<false, true>), grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
+        else if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
         else hipLaunchKernelGGL(gemm_planes_big_kernel<false>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
 #endif
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {

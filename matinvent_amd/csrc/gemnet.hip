@@ -657,12 +657,14 @@ __device__ __forceinline__ void sph_l(float c, float (&y)[S]) {
 constexpr int TFC = 8;
 template <int S>
 __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
-                                                          const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB, Planes P, unsigned* amax) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // Y [TFC][GN_DEG][8] | V [GN_DEG][3] | xd [GN_DEG][TR] | cbfW [TFC][S * CB]
+                                                          const int* __restrict__ rowptr, float* __restrict__ Tm, int TR, int CB, Planes P, unsigned* amax, int DG) {
+    // DG = in-degree capacity of THIS graph (its largest in-degree rounded up to a multiple of 4; at most GN_DEG): the LDS image is sized
+    // by it, so that three or four workgroups share a CU at the usual 50-70 in-edges instead of two at the 128-edge worst case
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // Y [TFC][DG][8] | V [DG][3] | xd [DG][TR] | cbfW [TFC][S * CB]
     float* Ys = sm;
-    float* Vs = sm + TFC * GN_DEG * 8;
-    float* xs = Vs + GN_DEG * 3;
-    float* ws = xs + GN_DEG * TR;
+    float* Vs = sm + TFC * DG * 8;
+    float* xs = Vs + DG * 3;
+    float* ws = xs + DG * TR;
     const int a = blockIdx.x, lo = rowptr[a], deg = rowptr[a + 1] - lo, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < deg * 3; i += 512) Vs[i] = V[(size_t)lo * 3 + i];
     for (int i = tid; i < deg * TR; i += 512) xs[i] = xd[(size_t)lo * TR + i];
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
             float o[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) o[l] = (l < S && k != e) ? y[l < S ? l : 0] : 0.f;
-            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * DG + k) * 8);
             dst[0] = f32x4{o[0], o[1], o[2], o[3]};
             dst[1] = f32x4{o[4], o[5], o[6], o[7]};
         }
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
             float acc[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) acc[l] = 0.f;
-            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * GN_DEG * 8);
+            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * DG * 8);
 #pragma unroll 4
             for (int k = 0; k < deg; ++k) {
                 const f32x4 y0 = yr[2 * k], y1 = yr[2 * k + 1];
@@ -776,18 +778,18 @@ __global__ __launch_bounds__(512) void triplet_fwd_kernel(const float* __restric
 // conflict-free 16-byte reads), one output per thread -- the first version reduced every output with a wave-wide sum and added it to
 // global memory from lane 0 (112 dependent read-modify-writes per edge: 3 ms per call at 64k edges, 13x the forward).
 constexpr int TBC = 8, TAS = 68;
-static inline size_t triplet_bwd_lds_floats(int TR, int CB) {
-    return (size_t)TBC * GN_DEG * 8 + GN_DEG * 3 + (size_t)GN_DEG * TR + TBC * 8 * 64 + (size_t)TBC * CB * 8 + TBC * 8 * TAS + (size_t)TBC * CB * TAS;
+static inline size_t triplet_bwd_lds_floats(int TR, int CB, int DG) {
+    return (size_t)TBC * DG * 8 + DG * 3 + (size_t)DG * TR + TBC * 8 * 64 + (size_t)TBC * CB * 8 + TBC * 8 * TAS + (size_t)TBC * CB * TAS;
 }
 template <int S>
 __global__ __launch_bounds__(512) void triplet_bwd_kernel(const float* __restrict__ xd, const float* __restrict__ V, const float* __restrict__ cbfW,
                                                           const int* __restrict__ rowptr, const float* __restrict__ dTm, float* __restrict__ dxd,
-                                                          float* __restrict__ dcbfW, int TR, int CB) {
+                                                          float* __restrict__ dcbfW, int TR, int CB, int DG) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ys = sm;                         // [TBC][GN_DEG][8]   Y_l(cos_ek), zero for k == e and l >= S
-    float* Vs = Ys + TBC * GN_DEG * 8;      // [GN_DEG][3]
-    float* xs = Vs + GN_DEG * 3;            // [GN_DEG][TR]
-    float* da = xs + GN_DEG * TR;           // [TBC][8][64]       dacc of the chunk's edges
+    float* Ys = sm;                         // [TBC][DG][8]       Y_l(cos_ek), zero for k == e and l >= S   (DG: see the forward)
+    float* Vs = Ys + TBC * DG * 8;          // [DG][3]
+    float* xs = Vs + DG * 3;                // [DG][TR]
+    float* da = xs + DG * TR;               // [TBC][8][64]       dacc of the chunk's edges
     float* wT = da + TBC * 8 * 64;          // [TBC][CB][8]       the chunk's weights, (i, l) order
     float* as = wT + TBC * CB * 8;          // [TBC][8][TAS]      acc of the chunk's edges
     float* gs = as + TBC * 8 * TAS;         // [TBC][CB][TAS]     the chunk's dTm rows
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(512) void triplet_bwd_kernel(const float* __restric
             float o[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) o[l] = (l < S && k != e) ? y[l < S ? l : 0] : 0.f;
-            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+            f32x4* dst = reinterpret_cast<f32x4*>(Ys + ((size_t)ee * DG + k) * 8);
             dst[0] = f32x4{o[0], o[1], o[2], o[3]};
             dst[1] = f32x4{o[4], o[5], o[6], o[7]};
         }
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(512) void triplet_bwd_kernel(const float* __restric
             float acc[8], dacc[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) acc[l] = dacc[l] = 0.f;
-            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * GN_DEG * 8);
+            const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + (size_t)ee * DG * 8);
 #pragma unroll 4
             for (int k = 0; k < deg; ++k) {
                 const f32x4 y0 = yr[2 * k], y1 = yr[2 * k + 1];
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(512) void triplet_bwd_kernel(const float* __restric
         for (int k = wave; k < deg; k += 8, ++q) {
             float sk = 0.f;
             for (int ee = 0; ee < ne; ++ee) {
-                const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + ((size_t)ee * GN_DEG + k) * 8);
+                const f32x4* yr = reinterpret_cast<const f32x4*>(Ys + ((size_t)ee * DG + k) * 8);
                 const f32x4 y0 = yr[0], y1 = yr[1];
                 const float* d = da + ee * 8 * 64 + lane;
                 sk += y0[0] * d[0] + y0[1] * d[64] + y0[2] * d[128] + y0[3] * d[192];
@@ -1134,6 +1136,7 @@ struct Arena {
 struct mi_gbatch {
     int B = 0, N = 0;
     int64_t E = 0, E_cap = 0;
+    int deg_max = mi::GN_DEG;   // largest in-degree of the current graph (host copy: sizes the triplet kernels' LDS)
     int64_t node_offset = 0, graph_offset = 0;
     std::vector<int> num_atoms_h, node_off_h;
     int *num_atoms = nullptr, *node_off = nullptr, *node2graph = nullptr;
@@ -1684,11 +1687,12 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
         ymax = c.new_amax(Y);
         c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
     }
-    const size_t sh = (size_t)(TFC * GN_DEG * 8 + GN_DEG * 3 + GN_DEG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
+    const int DG = std::min(GN_DEG, (c.b->deg_max + 3) / 4 * 4);
+    const size_t sh = (size_t)(TFC * DG * 8 + DG * 3 + DG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
 #define TRIP_FWD(SS)                                                                                                                       \
     case SS:                                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_fwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, (pl && !c.train) ? (float*)nullptr : Y, g.emb_trip, g.emb_cbf, P, ymax); \
+        hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, (pl && !c.train) ? (float*)nullptr : Y, g.emb_trip, g.emb_cbf, P, ymax, DG); \
         break;
     switch (g.num_spherical) {
         TRIP_FWD(1) TRIP_FWD(2) TRIP_FWD(3) TRIP_FWD(4) TRIP_FWD(5) TRIP_FWD(6) TRIP_FWD(7) TRIP_FWD(8)
@@ -1920,6 +1924,7 @@ static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const flo
              "inside the cutoff even after shrinking it, 4 = in-degree above %d)", meta[2], GN_CAND, GN_DEG);
     MI_CHECK((int64_t)meta[0] <= b->E_cap, MI_ENOMEM, "periodic graph: %d edges exceed the capacity %lld", meta[0], (long long)b->E_cap);
     b->E = meta[0];
+    b->deg_max = std::max(1, std::min(meta[1], GN_DEG));
     return MI_OK;
 }
 
@@ -2090,12 +2095,13 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 break;
             case OP_TRIPLET: {
                 if (o.M == 0) break;
-                const size_t sh = triplet_bwd_lds_floats(g.emb_trip, g.emb_cbf) * sizeof(float);
+                const int DG = std::min(GN_DEG, (b->deg_max + 3) / 4 * 4);
+                const size_t sh = triplet_bwd_lds_floats(g.emb_trip, g.emb_cbf, DG) * sizeof(float);
                 MI_CHECK(sh <= 160 * 1024 && g.emb_trip <= 64 && g.emb_trip % 4 == 0, MI_EINVAL, "triplet backward: emb_trip / emb_cbf beyond the kernel's LDS budget");
 #define TRIP_BWD(SS)                                                                                                                              \
     case SS:                                                                                                                                      \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_bwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
-        hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(512), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf); \
+        hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(512), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf, DG); \
         break;
                 switch (g.num_spherical) {
                     TRIP_BWD(1) TRIP_BWD(2) TRIP_BWD(3) TRIP_BWD(4) TRIP_BWD(5) TRIP_BWD(6) TRIP_BWD(7) TRIP_BWD(8)
