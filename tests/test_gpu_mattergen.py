@@ -70,17 +70,23 @@ def test_periodic_graph_matches_the_oracle_exactly(na, scale, hpk):
     assert E > 0 and torch.equal(og["swap"][og["swap"]], torch.arange(E))
 
 
-def test_forward_matches_the_oracle_layer_by_layer():
-    hp = M.GemNetHParams(**M.TINY)
+# the benchmark network's basis sizes (7 spherical orders, 16-wide circular basis, 64-wide triplet embedding: the branches of the triplet
+# kernels that the four-order TINY network does not reach) at widths the CPU oracle finishes in seconds
+BASIS7 = dict(M.TINY, emb_trip=64, emb_cbf=16, emb_rbf=16, emb_bil=64, num_spherical=7, num_radial=32)
+
+
+@pytest.mark.parametrize("hpd", [M.TINY, BASIS7], ids=["tiny", "benchmark-basis-sizes"])
+def test_forward_matches_the_oracle_layer_by_layer(hpd):
+    hp = M.GemNetHParams(**hpd)
     P = M.init_params(hp, seed=0, head_scale=0.3)
-    m = _module(M.TINY, P)
+    m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([4, 7, 1, 10, 20])
     taps = {}
     ref = M.gemnet_forward(P, hp, frac, cell, a, na, t, taps=taps)
     gb = m.decoder.make_batch(na)
     with torch.no_grad():
         out = m.decoder(frac, cell, a, t, gb)
-    _rel(gb.tap("rbf"), taps["rbf"].reshape(-1), 2e-6, "rbf")
+    _rel(gb.tap("rbf"), taps["rbf"].reshape(-1), 5e-6, "rbf")   # (device expf vs libm on Gaussians up to exp(-60): 2.3e-6 measured at 32 radial functions)
     _rel(gb.tap("h0"), taps["h0"].reshape(-1), 1e-5, "h0")
     _rel(gb.tap("m0"), taps["m0"].reshape(-1), 1e-5, "m0")
     for i in range(hp.num_blocks):
@@ -96,10 +102,11 @@ def test_forward_matches_the_oracle_layer_by_layer():
         assert torch.equal(out[k], out2[k]), k
 
 
-def test_parameter_gradients_match_the_oracle_autograd():
-    hp = M.GemNetHParams(**M.TINY)
+@pytest.mark.parametrize("hpd", [M.TINY, BASIS7], ids=["tiny", "benchmark-basis-sizes"])
+def test_parameter_gradients_match_the_oracle_autograd(hpd):
+    hp = M.GemNetHParams(**hpd)
     P = M.init_params(hp, seed=2, head_scale=0.5)
-    m = _module(M.TINY, P)
+    m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([5, 1, 12, 20, 3], seed=7)
     N, B = int(na.sum()), len(na)
     up, uc, ul = torch.randn(N, 3, generator=g), M.symmetric_noise(torch.randn(B, 3, 3, generator=g)), torch.randn(N, 101, generator=g)
