@@ -367,11 +367,12 @@ def measure_mg(args, K, W):
     state["cell"] = 0.5 * (state["cell"] + state["cell"].transpose(1, 2))
     i0 = 500
     E0 = int(m._batch_for(torch.tensor(na)).graph(state["pos"], state["cell"])["src"].shape[0])
-    s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state)
+    chains = max(1, int(getattr(args, "mg_chains", 4)))
+    s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state, chains=chains)
     st = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st)
+    s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gr = m._batch_for(torch.tensor(na)).graph(s["pos"], s["cell"])
@@ -411,7 +412,7 @@ def measure_mg(args, K, W):
             "config": {"workload": f"MatterGen-labelled form of BASELINE configs[1]: predictor-corrector sampler of the MatterGen-shaped network, batch={Bm} "
                                    "crystals x 20 atoms, 2 denoiser evals/step, mid-chain state (the random-init chain's cells drift, so the edge count "
                                    "moves during the run: compare lines of equal steps / warmup); SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
-                       "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "edges_first_step": E0, "edges_last_step": E,
+                       "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "concurrent_chains": chains, "edges_first_step": E0, "edges_last_step": E,
                        "parameters": nparams, "final_state_finite": finite, "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers of the interaction / output blocks)",
                          "achieved": terms * flops_eval * 2 * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -499,6 +500,7 @@ def main():
                     help="arithmetic path: split-gemm (default) = bf16 three-plane split GEMMs, fp32-class accuracy; "
                          "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage")
     ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
+    ap.add_argument("--mg-chains", type=int, default=4, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams")
     ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "mg-ft", "sample-default", "ft-default"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
