@@ -235,6 +235,9 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     return stats
 
 
+PRIOR_ON_AUX_STREAM = True   # module-surface loop: the frozen prior's forward concurrently with the agent's
+
+
 def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, lr, accum_steps, epochs, timesteps, sigma, device, noise_fn, log, rank):
     """pipeline/mat_invent.py:136-189 literally, over the module surface (add_noise / calc_sample_loss / calc_kl_reg; the network is
     one differentiable op with a hand-written backward), with the fused Adam on the flat parameter vector, device-side loss
@@ -261,6 +264,12 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
         chunks.append((cb, (sum(d.num_atoms for d in data_list[:a_]), a_)))
     optimizer = FusedAdam([theta], lr=lr)
     stats = []
+    aux = None
+    if PRIOR_ON_AUX_STREAM and torch.device(device).type == "cuda":
+        from .streams import concurrent_streams
+        aux = concurrent_streams(2, device)[1]
+        if aux == torch.cuda.current_stream():
+            aux = concurrent_streams(2, device)[0]
     for epoch in range(epochs):
         agent.train()
         if theta.grad is not None:
@@ -274,9 +283,19 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
                 agent.shard_offsets = prior.shard_offsets = offs
                 agent._noise_calls = calls                                            # (every chunk of a timestep draws from the same Philox step)
                 noised = agent.add_noise(batch, t, noise=noise)                       # :152
-                sample_loss, agent_pred = agent.calc_sample_loss(noised)              # :153
-                with torch.no_grad():
-                    _, prior_pred = prior.calc_sample_loss(noised)                    # :154
+                if aux is not None:   # the frozen prior's forward on a second stream, under the agent's (separate network and batch handle)
+                    aux.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(aux), torch.no_grad():
+                        _, prior_pred = prior.calc_sample_loss(noised)                # :154
+                    sample_loss, agent_pred = agent.calc_sample_loss(noised)          # :153
+                    torch.cuda.current_stream().wait_stream(aux)
+                    for v in prior_pred.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(torch.cuda.current_stream())
+                else:
+                    sample_loss, agent_pred = agent.calc_sample_loss(noised)          # :153
+                    with torch.no_grad():
+                        _, prior_pred = prior.calc_sample_loss(noised)                # :154
                 loss_diff = batch.reward * sample_loss                                # :158
                 loss_kl = agent.calc_kl_reg(agent_pred, prior_pred, batch) * (1.1 - batch.reward)   # :160-161
                 loss = (loss_diff + loss_kl * sigma).sum() / (n_global * accum_steps)  # == .mean() / accum_steps (:163)
