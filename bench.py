@@ -403,7 +403,8 @@ def measure_mg(args, K, W):
             w = tr["whole_trace"]
             hbm = {"bound": "hbm", "achieved": w["GBps"], "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s", "frac": w["frac_of_8TBps"],
                    "source": os.path.relpath(cands[-1], ROOT), "profiled_head": tr.get("head"),
-                   "note": f"all kernels of the profiled run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; {100 * w['share_of_trace_time_covered']:.0f} % of the trace's kernel time)"}
+                   "note": f"all kernels of the profiled SINGLE-CHAIN run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; {100 * w['share_of_trace_time_covered']:.0f} % of the "
+                           "trace's kernel time; with concurrent chains kernel durations overlap and are no measure of a kernel's own rate)"}
     return {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": Bm * K / (T * elapsed), "unit": "structures/s",
             "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32: edge-level layers on pre-split two-plane fp16 operands (3 MFMA terms), " if terms == 3 else "f32: edge-level layers on pre-split three-plane bf16 operands (6 MFMA terms), ")
