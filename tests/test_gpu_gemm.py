@@ -141,7 +141,9 @@ def test_plane_gemm_latency_and_lds_dma_forms_bit_identical(M, N, K):
     outs = []
     try:
         _lib.check(lib.mi_debug_set_planes_big(0, 1))
-        for dma, lat in ((0, 0), (0, 256), (1, 256), (2, 0)):
+        # (modes 3 / 4 -- recorded ablations: the LDS-DMA form for the LARGE launches only, one-round launches register-staged / on the
+        #  four-waves-per-SIMD build)
+        for dma, lat in ((0, 0), (0, 256), (1, 256), (2, 0), (3, 256), (4, 256)):
             _lib.check(lib.mi_debug_set_planes_dma(dma))
             _lib.check(lib.mi_debug_set_planes_latency(lat))
             for _ in range(3 if dma else 1):   # (repeated: a DMA / barrier ordering slip would show as run-to-run differences)
@@ -176,7 +178,7 @@ def test_latency_forms_in_the_network_bit_identical(na):
     m.decoder.mark_dirty()
     finals = []
     try:
-        for dma, lat, bigseg, hi in ((0, 0, 0, 0), (0, 256, 0, 0), (1, 256, 0, 0), (2, 0, 0, 0), (1, 256, 1, 0), (1, 256, 0, 1)):
+        for dma, lat, bigseg, hi in ((0, 0, 0, 0), (0, 256, 0, 0), (1, 256, 0, 0), (2, 0, 0, 0), (1, 256, 1, 0), (1, 256, 0, 1), (3, 256, 0, 0), (4, 256, 0, 0)):
             _lib.check(lib.mi_debug_set_planes_dma(dma))
             _lib.check(lib.mi_debug_set_planes_latency(lat))
             _lib.check(lib.mi_debug_set_planes_big_seg(bigseg))   # (1: the second edge GEMM on the 256 x 256 LDS-DMA kernel, whatever its row count)
