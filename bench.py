@@ -371,8 +371,18 @@ def measure_mg(args, K, W):
     s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state, chains=chains)
     st = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
     torch.cuda.synchronize()
+    # A random-init denoiser cannot hold a crystal together: left to itself the chain inflates the cells within a few steps and the edge
+    # count falls (256k -> 60k over ten steps, nothing left after a few hundred), so a free-running chain measures an emptying graph.  A
+    # trained model keeps cells near physical densities, where every atom has its 50 neighbours inside the cutoff -- the 256k-edge regime
+    # of the starting state.  Default: every timed step starts from that state (one-step calls; all kernels of a step run, only the
+    # hand-over of the state to the next step is replaced); --mg-free-chain times the free-running chain instead.
+    hold = not getattr(args, "mg_free_chain", False)
     t0 = time.perf_counter()
-    s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains)
+    if hold:
+        for k in range(K):
+            s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE + k, i_start=i0 + W + k, i_stop=i0 + W + k + 1, state=st, chains=chains)
+    else:
+        s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gr = m._batch_for(torch.tensor(na)).graph(s["pos"], s["cell"])
@@ -411,8 +421,12 @@ def measure_mg(args, K, W):
                      + "node-level layers on three bf16 planes split on the fly (6 terms); f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"MatterGen-labelled form of BASELINE configs[1]: predictor-corrector sampler of the MatterGen-shaped network, batch={Bm} "
-                                   "crystals x 20 atoms, 2 denoiser evals/step, mid-chain state (the random-init chain's cells drift, so the edge count "
-                                   "moves during the run: compare lines of equal steps / warmup); SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
+                                   "crystals x 20 atoms, 2 denoiser evals/step, "
+                                   + ("every timed step from the same mid-chain state at physical density (50 neighbours per atom: the regime a trained "
+                                      "model keeps; a random-init chain left to itself inflates its cells and empties its graph)" if hold else
+                                      "free-running random-init chain (its cells drift, so the edge count falls during the run: compare lines of equal steps / warmup)")
+                                   + "; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
+                       "state": "held" if hold else "free-running",
                        "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "concurrent_chains": chains, "edges_first_step": E0, "edges_last_step": E,
                        "parameters": nparams, "final_state_finite": finite, "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers of the interaction / output blocks)",
@@ -501,6 +515,8 @@ def main():
                     help="arithmetic path: split-gemm (default) = bf16 three-plane split GEMMs, fp32-class accuracy; "
                          "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage")
     ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
+    ap.add_argument("--mg-free-chain", action="store_true", help="--mode mg-sample: time the free-running random-init chain (emptying graph) instead of "
+                    "steps that each start from the physical-density state")
     ap.add_argument("--mg-chains", type=int, default=4, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams")
     ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "mg-ft", "sample-default", "ft-default"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")

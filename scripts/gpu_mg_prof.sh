@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace + FETCH_SIZE / WRITE_SIZE passes of the MatterGen-shaped sampler line, summarised on the box
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --mode mg-sample --steps 2 --warmup 1 --mg-chains 1 --no-cpu-baseline"   # (one chain: kernels run one after the other, so a kernel's bytes / its duration is ITS rate; with concurrent chains the durations overlap)
+CMD="python bench.py --mode mg-sample --steps 3 --warmup 1 --mg-chains 1 --no-cpu-baseline"   # (one chain: kernels run one after the other, so a kernel's bytes / its duration is ITS rate; with concurrent chains the durations overlap)
 rocprofv3 --kernel-trace --stats -d gpurun_out/pm_t -o mg -- $CMD > gpurun_out/pm_t.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pm_f -o mg -- $CMD > gpurun_out/pm_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pm_w -o mg -- $CMD > gpurun_out/pm_w.log 2>&1
