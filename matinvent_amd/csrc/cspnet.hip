@@ -327,6 +327,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const float* xr = x + (size_t)row * H;
+    // H = 8 x 64 or less, 16-byte aligned operands: a lane owns eight CONSECUTIVE columns -- two 16-byte loads, two 16-byte stores and one
+    // 16-byte store per plane instead of eight 4-byte loads / stores and sixteen 2-byte plane stores (the kernel sits on every chain's
+    // serial path 14 times per evaluation, beside the other chains' GEMM workgroups)
+    if (H <= 512 && (H & 7) == 0 && (ldy & 3) == 0 &&
+        (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bsh | (uintptr_t)y) & 15) == 0) {
+        const int c0 = lane * 8;
+        const bool act = c0 < H;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            a = *reinterpret_cast<const f32x4*>(xr + c0);
+            b = *reinterpret_cast<const f32x4*>(xr + c0 + 4);
+        }
+        const float mean = wave_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]))) / (float)H;
+        float q = 0.f;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float da = a[k] - mean, db = b[k] - mean;
+                q += da * da + db * db;
+            }
+        }
+        const float var = wave_sum(q) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (act) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0), w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsh + c0), b1 = *reinterpret_cast<const f32x4*>(bsh + c0 + 4);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o0[k] = (a[k] - mean) * rstd * w0[k] + b0[k];
+                o1[k] = (b[k] - mean) * rstd * w1[k] + b1[k];
+            }
+            float* yr = y + (size_t)row * ldy + c0;
+            *reinterpret_cast<f32x4*>(yr) = o0;
+            *reinterpret_cast<f32x4*>(yr + 4) = o1;
+            if (ypl.base) {
+                const float ps = ypl.s();
+                u32x4 pk[3];
+                unsigned pr[3];
+                pl_split_pair(o0[0], o0[1], ps, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1]; pk[2][0] = pr[2];
+                pl_split_pair(o0[2], o0[3], ps, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1]; pk[2][1] = pr[2];
+                pl_split_pair(o1[0], o1[1], ps, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1]; pk[2][2] = pr[2];
+                pl_split_pair(o1[2], o1[3], ps, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1]; pk[2][3] = pr[2];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(ypl.base + ypl.elem(row, c0, pl)) = pk[pl];
+            }
+        }
+        if (stats && lane == 0) {
+            stats[2 * row] = mean;
+            stats[2 * row + 1] = rstd;
+        }
+        return;
+    }
     float v[8];
     float s = 0.f;
     int cnt = 0;
