@@ -532,6 +532,42 @@ __global__ void act_scales_kernel(const unsigned* __restrict__ pq, const unsigne
 __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* __restrict__ rowptr,
                                     float* __restrict__ cat, int N, int H, Planes aggpl = Planes()) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((H & 7) == 0 && (((uintptr_t)part | (uintptr_t)cat) & 15) == 0) {   // eight consecutive columns per thread: 16-byte accesses throughout
+        const int h8 = H >> 3;
+        if (idx >= (int64_t)N * h8) return;
+        const int i = (int)(idx / h8), f = (int)(idx % h8) * 8;
+        const int e0 = rowptr[i], e1 = rowptr[i + 1];
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (e1 > e0) {
+            const int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
+            for (int sl = 0; sl <= t1 - t0; ++sl) {
+                const float* p = part + ((size_t)sl * N + i) * H + f;
+                a += *reinterpret_cast<const f32x4*>(p);
+                b += *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            const float d = (float)(e1 - e0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = a[k] / d;
+                b[k] = b[k] / d;
+            }
+        }
+        float* o = cat + (size_t)i * (2 * H) + H + f;
+        *reinterpret_cast<f32x4*>(o) = a;
+        *reinterpret_cast<f32x4*>(o + 4) = b;
+        if (aggpl.base) {
+            const float ps = aggpl.s();
+            u32x4 pk[3];
+            unsigned pr[3];
+            pl_split_pair(a[0], a[1], ps, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1]; pk[2][0] = pr[2];
+            pl_split_pair(a[2], a[3], ps, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1]; pk[2][1] = pr[2];
+            pl_split_pair(b[0], b[1], ps, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1]; pk[2][2] = pr[2];
+            pl_split_pair(b[2], b[3], ps, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1]; pk[2][3] = pr[2];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(aggpl.base + aggpl.elem(i, f, pl)) = pk[pl];
+        }
+        return;
+    }
     if (idx >= (int64_t)N * H) return;
     int i = (int)(idx / H), f = (int)(idx % H);
     int e0 = rowptr[i], e1 = rowptr[i + 1];
