@@ -340,7 +340,8 @@ int mi_debug_set_planes_latency(int max_blocks);
 int mi_debug_set_planes_big_seg(int min_rows);
 /* Experiment: 1 = the node-level kernels of an inference forward (LayerNorm, the node-level products, the aggregation's last pass) run on
  * a helper stream of the highest priority owned by the batch handle, joined to the caller's stream by events at every hand-over;
- * 0 (default) = everything on the caller's stream.  Same kernels, same order of dependent work: identical results. */
+ * 0 (default) = everything on the caller's stream.  Same kernels, same order of dependent work: identical results.
+ * +2 = the coordinate / type heads of an inference forward as two fp32-operand GEMM launches instead of the fused heads kernel (ablation). */
 int mi_debug_set_node_priority(int on);
 /* The 128 x 128-tile plane product with its operands staged by LDS-DMA (`buffer_load ... lds` into two 32 KiB stages, fragments
  * software-pipelined over two register sets, one barrier per k-tile): 0 = never, 1 (default) = launches of at most the latency

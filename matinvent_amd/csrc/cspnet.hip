@@ -20,6 +20,7 @@ int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS
 int g_planes_big_min_rows = 65536;
 int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
+int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0: two fp32-operand GEMM launches; mi_debug_set_node_priority(2))
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
@@ -587,6 +588,68 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
     }
 }
 
+// Coordinate and type heads of an inference forward in ONE launch (cspnet.py:276-279: coord_out (no bias) and type_out on the final
+// LayerNorm's rows): the two [N, 3] / [N, 100] products were two fp32-operand GEMM launches plus their split-K reductions on every chain's
+// serial path (~60 us per evaluation for 67 MFLOP).  Four rows per block in LDS, a thread per output column, the 103 weight rows read
+// transposed ([H][104]: coalesced), plain fp32 FMA chains over k.
+constexpr int HEADS_LD = 104, HEADS_ROWS = 4;
+__global__ void pack_heads_kernel(const float* __restrict__ Wc, const float* __restrict__ Wt, float* __restrict__ WT, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * HEADS_LD) return;
+    const int k = idx / HEADS_LD, c = idx % HEADS_LD;
+    WT[idx] = c < 3 ? Wc[(size_t)c * H + k] : c < 3 + MI_NUM_TYPES ? Wt[(size_t)(c - 3) * H + k] : 0.f;
+}
+__global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf, const float* __restrict__ WT, const float* __restrict__ type_bias,
+                                                    float* __restrict__ coord_out, float* __restrict__ type_out, int N, int H) {
+    // 512 threads = 4 k-groups x 128 output columns (103 used): a k-group walks a quarter of H with eight weight loads in flight per
+    // step (a single group with four was a chain of 128 load latencies: slower than the two GEMM launches it replaced); the four partial
+    // sums of an output are added in a fixed order through LDS.
+    extern __shared__ __attribute__((aligned(16))) float hs[];   // [HEADS_ROWS][H] | partial sums [4][HEADS_ROWS][128]
+    float* red = hs + HEADS_ROWS * H;
+    const int r0 = blockIdx.x * HEADS_ROWS, tid = threadIdx.x, t = tid & 127, kgp = tid >> 7;
+    for (int i = tid; i < HEADS_ROWS * H; i += 512) {
+        const int r = r0 + i / H;
+        hs[i] = r < N ? hf[(size_t)r * H + i % H] : 0.f;
+    }
+    __syncthreads();
+    float acc[HEADS_ROWS];
+#pragma unroll
+    for (int r = 0; r < HEADS_ROWS; ++r) acc[r] = 0.f;
+    const int kq = H >> 2, k0 = kgp * kq, k1 = k0 + kq;
+    if (t < 3 + MI_NUM_TYPES) {
+        for (int k = k0; k < k1; k += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = WT[(size_t)(k + u) * HEADS_LD + t];
+#pragma unroll
+            for (int r = 0; r < HEADS_ROWS; ++r) {
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(hs + r * H + k), h1 = *reinterpret_cast<const f32x4*>(hs + r * H + k + 4);
+                acc[r] = fmaf(w[0], h0[0], acc[r]);
+                acc[r] = fmaf(w[1], h0[1], acc[r]);
+                acc[r] = fmaf(w[2], h0[2], acc[r]);
+                acc[r] = fmaf(w[3], h0[3], acc[r]);
+                acc[r] = fmaf(w[4], h1[0], acc[r]);
+                acc[r] = fmaf(w[5], h1[1], acc[r]);
+                acc[r] = fmaf(w[6], h1[2], acc[r]);
+                acc[r] = fmaf(w[7], h1[3], acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < HEADS_ROWS; ++r) red[(kgp * HEADS_ROWS + r) * 128 + t] = acc[r];
+    __syncthreads();
+    if (kgp != 0 || t >= 3 + MI_NUM_TYPES) return;
+#pragma unroll
+    for (int r = 0; r < HEADS_ROWS; ++r) {
+        const int row = r0 + r;
+        if (row >= N) break;
+        const float v = ((red[(0 * HEADS_ROWS + r) * 128 + t] + red[(1 * HEADS_ROWS + r) * 128 + t]) + red[(2 * HEADS_ROWS + r) * 128 + t]) +
+                        red[(3 * HEADS_ROWS + r) * 128 + t];
+        if (t < 3) coord_out[(size_t)row * 3 + t] = v;
+        else type_out[(size_t)row * MI_NUM_TYPES + (t - 3)] = v + type_bias[t - 3];
+    }
+}
+
 // graph mean-pool + lattice head:  out[b] = reshape(Wl * mean_i hf_i, 3, 3) @ L_b  (cspnet.py:281-289)
 __global__ __launch_bounds__(256) void lattice_head_kernel(const float* __restrict__ hf, const int* __restrict__ node_off,
                                                            const float* __restrict__ Wl, const float* __restrict__ lattices,
@@ -1013,10 +1076,16 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
     }
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s, &b->sk));
-    GemmEpilogue et;
-    et.bias = net->p("type_out.bias");
-    MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
+    if (!train && net->WheadT && g_fused_heads && H % 32 == 0) {
+        hipLaunchKernelGGL(heads_kernel, dim3(cdiv(N, HEADS_ROWS)), dim3(512), (size_t)(HEADS_ROWS * H + 4 * HEADS_ROWS * 128) * sizeof(float), s, b->hf, net->WheadT,
+                           net->p("type_out.bias"), coord_out, type_out, N, H);
+        MI_KERNEL_CHECK();
+    } else {
+        MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s, &b->sk));
+        GemmEpilogue et;
+        et.bias = net->p("type_out.bias");
+        MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
+    }
     hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (H + 9) * sizeof(float), s, b->hf, b->node_off,
                        net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
     MI_KERNEL_CHECK();
@@ -1094,7 +1163,7 @@ int mi_net_create(const mi_net_config* cfg, mi_net** out) {
 
 void mi_net_destroy(mi_net* n) {
     if (!n) return;
-    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->Wff, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT})
+    for (float* p : {n->freqs, n->Whh, n->Wff_p, n->W2_p, n->Wff, n->W2T, n->Wn2T, n->Wn1T, n->WhhT, n->WaT, n->WheadT})
         if (p) (void)hipFree(p);
     if (n->Wffpl) (void)hipFree(n->Wffpl);
     if (n->Wffpl_pair) (void)hipFree(n->Wffpl_pair);
@@ -1192,6 +1261,8 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
                            n->p("csp_layer_0.edge_mlp.2.bias"), n->p("csp_layer_0.node_mlp.0.weight"), n->p("csp_layer_0.node_mlp.0.bias"), lstride,
                            n->edge_in, H, 6 * n->F, reinterpret_cast<unsigned*>(n->wbounds));
     }
+    if (!n->WheadT) MI_HIP(hipMalloc((void**)&n->WheadT, (size_t)H * HEADS_LD * sizeof(float)));
+    hipLaunchKernelGGL(pack_heads_kernel, dim3(cdiv(H * HEADS_LD, 256)), dim3(256), 0, s, n->p("coord_out.weight"), n->p("type_out.weight"), n->WheadT, H);
     MI_KERNEL_CHECK();
     MI_TRY(net_pack_transposes(n, s));
     return MI_OK;
@@ -1432,7 +1503,8 @@ int mi_debug_set_planes_latency(int max_blocks) {
 }
 
 int mi_debug_set_node_priority(int on) {
-    g_node_hi = on;
+    g_fused_heads = (on & 2) == 0;   // +2: the two-GEMM heads (ablation)
+    g_node_hi = on & 1;
     return MI_OK;
 }
 

@@ -45,6 +45,7 @@ struct mi_net {
     float* Wn1T = nullptr;   // [L][2H][H]
     float* WhhT = nullptr;   // [L][H][2H]
     float* WaT = nullptr;    // [H][H]   (atom_latent_emb.weight[:, :H])^T
+    float* WheadT = nullptr; // [H][104] coord_out.weight (3 rows) and type_out.weight (100 rows) transposed side by side (inference heads)
     // profiling of the dominant kernel (event pairs; launches may come from several host threads / streams)
     bool prof = false;
     std::vector<hipEvent_t> ev;  // pairs

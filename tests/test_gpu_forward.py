@@ -239,3 +239,29 @@ def test_forward_random_ragged_batches_vs_oracle(seed):
     out = net(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), None, batch=net.make_batch(na))
     for a, b, w in zip(out, ref, ("pred_l", "pred_x", "pred_t")):
         _close(a, b, 2e-5, f"{w} seed {seed} atoms {na}")
+
+
+def test_inference_heads_kernel_vs_golden_and_vs_the_two_gemm_heads(golden):
+    """The inference forward forms the coordinate and type heads in one launch (plain fp32 FMA chains over the final LayerNorm's rows);
+    the training forward keeps the two fp32-operand GEMM launches.  Both against the reference-generated outputs at the benchmark
+    hyper-parameters, and against each other."""
+    from matinvent_amd import _lib
+    g = golden("g5b_cspnet_ns")
+    torch.manual_seed(0)
+    net = _net(512, 6, 128)
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    outs = []
+    try:
+        for knob in (0, 2):
+            _lib.check(_lib.load().mi_debug_set_node_priority(knob))
+            with torch.no_grad():
+                outs.append(net(T("t_emb"), T("atom_types"), T("frac"), T("lattices"), g["num_atoms"]))
+    finally:
+        _lib.check(_lib.load().mi_debug_set_node_priority(0))
+    for pl, px, pt in outs:
+        _close(pl, g["pred_l"], 5e-5, "pred_l")
+        _close(px, g["pred_x"], 5e-5, "pred_x")
+        _close(pt, g["pred_t"], 5e-5, "pred_t")
+    assert torch.equal(outs[0][0], outs[1][0])   # (the lattice head is the same kernel)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
