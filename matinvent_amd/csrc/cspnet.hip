@@ -617,21 +617,20 @@ __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf
     for (int r = 0; r < HEADS_ROWS; ++r) acc[r] = 0.f;
     const int kq = H >> 2, k0 = kgp * kq, k1 = k0 + kq;
     if (t < 3 + MI_NUM_TYPES) {
-        for (int k = k0; k < k1; k += 8) {
-            float w[8];
+        for (int k = k0; k < k1; k += 16) {   // (H % 64 == 0: a k-group's quarter is a multiple of 16)
+            float w[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = WT[(size_t)(k + u) * HEADS_LD + t];
+            for (int u = 0; u < 16; ++u) w[u] = WT[(size_t)(k + u) * HEADS_LD + t];
 #pragma unroll
             for (int r = 0; r < HEADS_ROWS; ++r) {
-                const f32x4 h0 = *reinterpret_cast<const f32x4*>(hs + r * H + k), h1 = *reinterpret_cast<const f32x4*>(hs + r * H + k + 4);
-                acc[r] = fmaf(w[0], h0[0], acc[r]);
-                acc[r] = fmaf(w[1], h0[1], acc[r]);
-                acc[r] = fmaf(w[2], h0[2], acc[r]);
-                acc[r] = fmaf(w[3], h0[3], acc[r]);
-                acc[r] = fmaf(w[4], h1[0], acc[r]);
-                acc[r] = fmaf(w[5], h1[1], acc[r]);
-                acc[r] = fmaf(w[6], h1[2], acc[r]);
-                acc[r] = fmaf(w[7], h1[3], acc[r]);
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 h = *reinterpret_cast<const f32x4*>(hs + r * H + k + 4 * v4);
+                    acc[r] = fmaf(w[4 * v4], h[0], acc[r]);
+                    acc[r] = fmaf(w[4 * v4 + 1], h[1], acc[r]);
+                    acc[r] = fmaf(w[4 * v4 + 2], h[2], acc[r]);
+                    acc[r] = fmaf(w[4 * v4 + 3], h[3], acc[r]);
+                }
             }
         }
     }
@@ -654,11 +653,73 @@ __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf
 __global__ __launch_bounds__(256) void lattice_head_kernel(const float* __restrict__ hf, const int* __restrict__ node_off,
                                                            const float* __restrict__ Wl, const float* __restrict__ lattices,
                                                            float* __restrict__ out, float* __restrict__ gf_out, int H) {
+    // One block per crystal, on every chain's serial path twice per step.  Everything that does not depend on the pooled features is
+    // requested first (the head's weight rows of this wave, the lattice), the pooling runs as two independent half-sums of 16-byte
+    // loads per thread instead of one serial walk over the atoms, and the nine dot products follow from registers.
     int b = blockIdx.x;
-    extern __shared__ float sm[];  // H + 9
+    extern __shared__ float sm[];  // gf [H] | lo [9] | second half-sums [H]
     float* gf = sm;
     float* lo = sm + H;
-    int n0 = node_off[b], n1 = node_off[b + 1];
+    float* half2 = sm + H + 12;
+    const int n0 = node_off[b], n1 = node_off[b + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool fast = H <= 512 && (H & 7) == 0 && ((uintptr_t)hf & 15) == 0;
+    float wreg[3][8];
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int m = wave + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = lane + 64 * j;
+                wreg[q][j] = (m < 9 && f < H) ? Wl[(size_t)m * H + f] : 0.f;
+            }
+        }
+        float lm[3] = {0.f, 0.f, 0.f};
+        if (threadIdx.x < 9) {
+            const float* Lm = lattices + (size_t)b * 9;
+            const int c = threadIdx.x % 3;
+            lm[0] = Lm[c];
+            lm[1] = Lm[3 + c];
+            lm[2] = Lm[6 + c];
+        }
+        const int h4 = H >> 2, grp = threadIdx.x >= 128 ? 1 : 0, f4 = threadIdx.x & 127;
+        const int mid = n0 + (n1 - n0 + 1) / 2, ia = grp ? mid : n0, ib = grp ? n1 : mid;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        if (f4 < h4)
+            for (int i = ia; i < ib; ++i) s4 += *reinterpret_cast<const f32x4*>(hf + (size_t)i * H + 4 * f4);
+        if (grp == 1 && f4 < h4) *reinterpret_cast<f32x4*>(half2 + 4 * f4) = s4;
+        __syncthreads();
+        if (grp == 0 && f4 < h4) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(half2 + 4 * f4);
+            const float cnt = (float)(n1 - n0), d = cnt < 1.f ? 1.f : cnt;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = (s4[k] + o[k]) / d;
+                gf[4 * f4 + k] = v;
+                if (gf_out) gf_out[(size_t)b * H + 4 * f4 + k] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int m = wave + 4 * q;
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = lane + 64 * j;
+                if (f < H) sacc += wreg[q][j] * gf[f];
+            }
+            sacc = wave_sum(sacc);
+            if (lane == 0 && m < 9) lo[m] = sacc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            const int r = threadIdx.x / 3;
+            out[(size_t)b * 9 + threadIdx.x] = lo[r * 3] * lm[0] + lo[r * 3 + 1] * lm[1] + lo[r * 3 + 2] * lm[2];
+        }
+        return;
+    }
     for (int f = threadIdx.x; f < H; f += blockDim.x) {
         float s = 0.f;
         for (int i = n0; i < n1; ++i) s += hf[(size_t)i * H + f];
@@ -667,7 +728,6 @@ __global__ __launch_bounds__(256) void lattice_head_kernel(const float* __restri
         if (gf_out) gf_out[(size_t)b * H + f] = gf[f];
     }
     __syncthreads();
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int m = wave; m < 9; m += 4) {
         float s = 0.f;
         for (int f = lane; f < H; f += 64) s += Wl[(size_t)m * H + f] * gf[f];
@@ -1076,7 +1136,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
     }
     MI_KERNEL_CHECK();
-    if (!train && net->WheadT && g_fused_heads && H % 32 == 0) {
+    if (!train && net->WheadT && g_fused_heads && H % 64 == 0) {
         hipLaunchKernelGGL(heads_kernel, dim3(cdiv(N, HEADS_ROWS)), dim3(512), (size_t)(HEADS_ROWS * H + 4 * HEADS_ROWS * 128) * sizeof(float), s, b->hf, net->WheadT,
                            net->p("type_out.bias"), coord_out, type_out, N, H);
         MI_KERNEL_CHECK();
@@ -1086,7 +1146,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         et.bias = net->p("type_out.bias");
         MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
     }
-    hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (H + 9) * sizeof(float), s, b->hf, b->node_off,
+    hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (2 * H + 12) * sizeof(float), s, b->hf, b->node_off,
                        net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
     MI_KERNEL_CHECK();
     tp.valid = train;
