@@ -347,6 +347,10 @@ int mi_debug_set_node_priority(int on);
  * software-pipelined over two register sets, one barrier per k-tile): 0 = never, 1 (default) = launches of at most the latency
  * limit above, 2 = every launch of the 128-row kernel.  Bit-identical to the register-staged loop (tests/test_gpu_gemm.py). */
 int mi_debug_set_planes_dma(int mode);
+/* The node-level chain between two edge stages of an inference forward (segmented mean, node MLP with residual, LayerNorm, the
+ * projections LayerNorm(h) feeds: models/diffcsp/cspnet.py:79-91,61) as ONE launch per layer boundary (csrc/node_chain.hip):
+ * 1 (default) = on for hidden_dim 128 / 256 / 512 with LayerNorm, 0 = the seven-launch form.  Returns the previous setting. */
+int mi_debug_set_node_fused(int on);
 /* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
  * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
  * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results

@@ -1,17 +1,26 @@
 """Build the gfx950 shared library in-tree:  python -m matinvent_amd.build
 
 hipcc cross-compiles without a GPU; the resulting matinvent_amd/lib/libmatinvent_hip.so is
-git-ignored but travels to the GPU box with the repo snapshot.
+git-ignored but travels to the GPU box with the repo snapshot.  Every translation unit is compiled
+to its own object file (in parallel, only when it or a header changed) and the objects are linked:
+a cold build takes about as long as the slowest unit (~50 s) instead of the sum.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmatinvent_hip.so")
-SOURCES = ["cspnet.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wno-unused-result"]
+OBJ = os.path.join(HERE, "lib", "obj")
+SOURCES = ["cspnet.hip", "node_chain.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
+ARCH = ["--offload-arch=gfx950"]
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), __file__]
 
 
 def _stale() -> bool:
@@ -22,14 +31,24 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_stale(src: str, obj: str, flags_tag: str) -> bool:
+    if not os.path.exists(obj) or not os.path.exists(obj + ".flags"):
+        return True
+    with open(obj + ".flags") as f:
+        if f.read() != flags_tag:
+            return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + _headers())
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile the library if it is missing or older than its sources.  Safe to call from several processes at once (one rank
-    per GPU): an exclusive file lock serialises them, the compiler writes to a temporary file that is renamed into place, and a
+    per GPU): an exclusive file lock serialises them, the linker writes to a temporary file that is renamed into place, and a
     process that waited for the lock re-checks before compiling again."""
     if not force and not _stale():
         return LIB
     import fcntl
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
     with open(LIB + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
@@ -37,8 +56,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 return LIB
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
+            tag = " ".join(ARCH + CFLAGS + extra)
+
+            def compile_one(name: str) -> str:
+                src, obj = os.path.join(CSRC, name), os.path.join(OBJ, name.replace(".hip", ".o"))
+                if force or _obj_stale(src, obj, tag):
+                    cmd = [hipcc] + ARCH + CFLAGS + extra + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    subprocess.run(cmd, check=True)
+                    with open(obj + ".flags", "w") as f:
+                        f.write(tag)
+                return obj
+
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(compile_one, SOURCES))
             tmp = f"{LIB}.tmp{os.getpid()}"
-            cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            cmd = [hipcc] + ARCH + ["-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd), flush=True)
             try:

@@ -918,7 +918,6 @@ __global__ void fill_stack_times_kernel(int* __restrict__ times, StackTimes st, 
     if (b < B) times[b] = st.t[b / B0];
 }
 
-int sat_fetch_backward(unsigned* out, bool reset) { return sat_fetch(out, reset); }
 
 }  // namespace mi
 

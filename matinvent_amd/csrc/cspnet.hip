@@ -31,6 +31,16 @@ int g_tn_split_min_rows = 4096;  // (at 5120 rows: 43 -> 39 us for 512 x 512, 71
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
 int g_node_planes_min_rows = 512;  // node-level products: plane-set kernel from this many nodes up, fp32-operand split-K kernel below
 
+// readers of the per-translation-unit saturation counters (gemm_split.h); a function-local static, because the registrars run
+// during static initialisation of several units in unspecified order
+std::vector<int (*)(unsigned*, bool)>& sat_readers() {
+    static std::vector<int (*)(unsigned*, bool)> v;
+    return v;
+}
+void sat_register(int (*fetch)(unsigned*, bool)) { sat_readers().push_back(fetch); }
+
+static bool cfg_ln_and_wide(const mi_net* n) { return n->cfg.ln && (n->H == 128 || n->H == 256 || n->H == 512); }
+
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -951,6 +961,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     };
     // ---- message-passing layers (cspnet.py:84-91) ----
     const bool node_planes = g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && H % 32 == 0 && N >= g_node_planes_min_rows;
+    // inference: everything between two edge stages -- aggregation, node MLP, residual, LayerNorm, the projections LayerNorm(h) feeds --
+    // is ONE launch per layer boundary (node_chain.hip), for any batch size
+    const bool fused = !train && !use_hi && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 && node_chain_supported(net);
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
@@ -962,8 +975,11 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         // before the edge stage, so only agg x W[:, H:] (K = H instead of 2H) is left on the path after it.
         const Planes lnp = node_planes ? make_planes(b->lnpl, H, PL_S_LN) : Planes();
         const Planes aggp = node_planes ? make_planes(b->aggpl, H, PL_S_ACT, b->dsc + 2) : Planes();
-        const int ldpq = node_planes ? 3 * H : 2 * H;
+        const int ldpq = (node_planes || fused) ? 3 * H : 2 * H;
         MI_TRY(to(ns));
+        if (fused) {
+            MI_TRY(node_chain(net, b, l, s));
+        } else {
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, ns, h_in, net->p(p + "layer_norm.weight"),
                                net->p(p + "layer_norm.bias"), cat, 2 * H, train ? tp.lnstat + (size_t)l * N * 2 : (float*)nullptr, N, H, lnp);
@@ -985,6 +1001,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 MI_KERNEL_CHECK();
             }
         }
+        }
         MI_TRY(to(s));
         // pair mode folds the activation scales and the self edges into the launch of its Fourier-block GEMM
         const bool pair_path = net->edge_mode != 0 && b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0;
@@ -997,7 +1014,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         if (net->edge_mode == 0) {  // fused register-chained f32-MFMA kernel
             MI_TRY(launch_edge(net, b, l, frac, train ? tp.Z1 + (size_t)l * b->E * H : nullptr, train ? tp.Z2 + (size_t)l * b->E * H : nullptr, s));
             MI_TRY(to(ns));
-            hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
+            if (!fused) hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         } else if (b->E > 0) {      // two tiled GEMMs over the edge list with gather / SiLU epilogues
             const int E = (int)b->E, F6 = 6 * net->F;
@@ -1075,7 +1092,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
                 MI_TRY(prof_end(net, s, ps));
                 MI_TRY(to(ns));
-                hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
+                if (!fused) hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
                 MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
@@ -1090,6 +1107,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
             MI_KERNEL_CHECK();
         }
+        if (fused) continue;  // the rest of this layer runs in front of the next layer's edge stage (node_chain(l + 1))
         GemmEpilogue e1;
         e1.bias = net->p(p + "node_mlp.0.bias");
         e1.act = ACT_SILU;
@@ -1129,7 +1147,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     MI_TRY(to(s));
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
-    if (net->cfg.ln) {
+    if (fused) {
+        MI_TRY(node_chain(net, b, L, s));   // the last layer's node MLP + residual and the final LayerNorm -> b->hf
+    } else if (net->cfg.ln) {
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_last, net->p("final_layer_norm.weight"),
                            net->p("final_layer_norm.bias"), b->hf, H, train ? tp.lnstat + (size_t)L * N * 2 : (float*)nullptr, N, H);
     } else {
@@ -1233,6 +1253,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->Wlnpl) (void)hipFree(n->Wlnpl);
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
+    if (n->Wnc) (void)hipFree(n->Wnc);
     if (n->wbounds) (void)hipFree(n->wbounds);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
@@ -1269,6 +1290,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Waggpl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->Wn2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->wbounds, (size_t)n->L * 8 * sizeof(float)));
+        if (node_chain_pack_elems(H) && cfg_ln_and_wide(n)) MI_HIP(hipMalloc((void**)&n->Wnc, (size_t)n->L * node_chain_pack_elems(H) * sizeof(u16)));
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
@@ -1311,6 +1333,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
             Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
+            if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), s));  // the same weights in fragment order (node_chain.hip)
         }
     }
     if (n->L > 0) {  // weight bounds behind the activation scales of the fp16 plane format (see act_scales_kernel)
@@ -1615,10 +1638,13 @@ int mi_net_set_edge_mode(mi_net* net, int mode) {
 int mi_saturation_events(int64_t* count, int reset) {
     MI_CHECK(count, MI_EINVAL, "null argument");
     MI_HIP(hipDeviceSynchronize());
-    unsigned a = 0, b = 0;
-    MI_TRY(mi::sat_fetch(&a, reset != 0));
-    MI_TRY(mi::sat_fetch_backward(&b, reset != 0));
-    *count = (int64_t)a + (int64_t)b;
+    int64_t total = 0;
+    for (auto fetch : mi::sat_readers()) {   // one reader per translation unit that converts to the plane format
+        unsigned v = 0;
+        MI_TRY(fetch(&v, reset != 0));
+        total += v;
+    }
+    *count = total;
     return MI_OK;
 }
 

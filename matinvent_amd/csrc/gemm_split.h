@@ -94,6 +94,15 @@ static inline int sat_fetch(unsigned* out, bool reset) {
     *out = v;
     return MI_OK;
 }
+// Every translation unit that includes this header owns a copy of the counter (no relocatable device code) and registers its
+// reader at library load, so that mi_saturation_events() (cspnet.hip) sums ALL of them -- a unit cannot be forgotten.
+void sat_register(int (*fetch)(unsigned*, bool));
+namespace {
+struct SatRegistrar {
+    SatRegistrar() { sat_register(&sat_fetch); }
+};
+static SatRegistrar g_sat_registrar;
+}  // namespace
 // plane words of the element pair (x, y): p[k] = plane k of x | plane k of y << 16; `scale` = the destination plane set's scale
 __device__ __forceinline__ void pl_split_pair(float x, float y, float scale, unsigned (&p)[3]) {
 #if MI_PLANES_FP16

@@ -32,6 +32,7 @@ struct mi_net {
     unsigned short* Wlnpl = nullptr;   // (3H x H): [P_i block; P_j block; node_mlp.0.weight[:, :H]] -- everything LayerNorm(h) feeds
     unsigned short* Waggpl = nullptr;  // (H x H):  node_mlp.0.weight[:, H:]  (multiplies the aggregated messages)
     unsigned short* Wn2pl = nullptr;   // (H x H):  node_mlp.2.weight
+    unsigned short* Wnc = nullptr;     // [L] the three operands above in MFMA fragment order: [Wagg | Wn2 | Wln] (node_chain.hip; H = 128 / 256 / 512 with LayerNorm)
     float* wbounds = nullptr;          // [L][8] row-sum / bias bounds of the layer's weights (fp16 plane format: activation scales)
     // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],
     // Kh = 3F rounded up to 32, so that each block is a whole number of k-tiles
@@ -150,6 +151,10 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
 int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);
+// node_chain.hip: the node-level chain between two edge stages of an inference forward as one launch
+bool node_chain_supported(const mi_net* net);
+size_t node_chain_pack_elems(int H);
+int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s);
+int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
-int sat_fetch_backward(unsigned* out, bool reset);  // backward.hip's copy of the saturation counter (gemm_split.h)
 }  // namespace mi

@@ -1,0 +1,439 @@
+// The node-level chain between two edge stages of an inference forward as ONE launch (cspnet.py:80-91 of layer l-1, :87-88 and the
+// h_i / h_j projections of :61 for layer l):
+//
+//   phase A (finishes layer l-1)   agg = segmented mean of the edge stage's partial sums          (cspnet.py:79)
+//                                  X   = SiLU(agg W0b^T + X_part + b0)                            (node_mlp.0, the agg half; :80-82)
+//                                  h'  = h + SiLU(X W2^T + b2)                                    (node_mlp.2 + residual, :91)
+//   LayerNorm                      y   = LN_l(h')                                                 (:87-88; the final LayerNorm after layer L)
+//   phase B (begins layer l)       [P_i | P_j | X_part] = y [W1[:, :H]; W1[:, H:2H]; W0[:, :H]]^T (everything LayerNorm(h) feeds)
+//
+// Every step is row-local (a node's row never meets another node's), so a workgroup that owns 32 nodes runs the whole chain with the
+// activations in LDS and only h', the projections and the absmax leave the chip.  This replaces seven launches on every chain's
+// serial path (finalize_agg, two node-MLP products, LayerNorm, the 3H-wide projection product) by one: a denoising step is the SUM of one
+// chain's kernel durations, and those launches were 38 % of the kernel time for 5 % of the flops.
+//
+// Arithmetic: the fp16 two-plane format of gemm_split.h (three MFMA terms, f32 accumulate, the same scales as the plane GEMMs: the
+// rigorous per-layer activation scales published by the pair-mode edge GEMM for agg and X, 2^3 for LayerNorm outputs, 2^6 for weights).
+// Weights come pre-split in MFMA FRAGMENT ORDER and go from L2 straight into registers through a D-deep ring (a weight element is used by
+// exactly one wave of the workgroup, so staging it in LDS would only add traffic); the activation planes sit in LDS (32 rows x H).
+// Products whose result feeds the next product are computed TRANSPOSED (weights as the first MFMA operand): a lane then owns four
+// consecutive columns of one row, i.e. whole 8-byte pieces of the next operand's LDS rows.
+#include <mutex>
+
+#include "net.h"
+#include "gemm_split.h"
+
+namespace mi {
+
+int g_node_fused = 1;  // inference forwards: the node-level chain as one launch per layer boundary (0: the seven-launch form)
+
+#if MI_PLANES_FP16
+
+// fragment-order pack of W[rows][K] (row stride ld) into dst: out-column tile ct (32 rows of W), k-step ks (16 k):
+//   [ct][ks][plane][lane = kg * 32 + l31][8 halfs] = plane(W[32 ct + l31][16 ks + 8 kg + 0..7] * PL_SW);  rows >= `rows` are zero
+// (row0: first destination row, so that several matrices stack into one packed operand)
+__global__ void pack_frag_kernel(const float* __restrict__ W, int ld, int rows, int K, u16* __restrict__ dst, int row0) {
+    const int KS = K / 16;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (row, 8-k chunk) per thread
+    if (idx >= (int64_t)rows * (K / 8)) return;
+    const int r = (int)(idx / (K / 8)), ch = (int)(idx % (K / 8));
+    const int R = row0 + r, ct = R >> 5, l31 = R & 31, ks = ch >> 1, kg = ch & 1;
+    u32x4 pk[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned p[3];
+        pl_split_pair(W[(size_t)r * ld + ch * 8 + 2 * i], W[(size_t)r * ld + ch * 8 + 2 * i + 1], PL_SW, p);
+        pk[0][i] = p[0];
+        pk[1][i] = p[1];
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+        *reinterpret_cast<u32x4*>(dst + ((((size_t)ct * KS + ks) * 2 + pl) * 64 + kg * 32 + l31) * 8) = pk[pl];
+}
+
+struct NodeChainArgs {
+    int N = 0;
+    // phase A (nullptr part: skipped -- the chain starts at h_in, the embedding's output)
+    const float* part = nullptr;    // [nslots][N][H] partial sums of the edge -> node reduction
+    const int* rowptr = nullptr;    // [N + 1] CSR rows (degree, slots)
+    const float* xpart = nullptr;   // LayerNorm(h) W0[:, :H]^T of layer l-1 (computed with its P_i / P_j), row stride ld_xpart
+    int ld_xpart = 0;
+    const u16* Wagg = nullptr;      // fragment-order packs (H x H)
+    const u16* Wn2 = nullptr;
+    const float* b0 = nullptr;
+    const float* b2 = nullptr;
+    const float* dsc = nullptr;     // this layer's activation scales {M1, 1/M1, agg, 1/agg, X, 1/X} (act_scales_eval)
+    const float* h_in = nullptr;    // [N][H]
+    float* h_out = nullptr;         // [N][H] (phase A only)
+    // LayerNorm
+    const float* ln_w = nullptr;
+    const float* ln_b = nullptr;
+    float* hf = nullptr;            // final LayerNorm: fp32 rows out, no phase B
+    // phase B (nullptr Wln: skipped)
+    const u16* Wln = nullptr;       // fragment-order pack (3H x H)
+    float* PQ = nullptr;            // [N][3H]
+    unsigned* absmax = nullptr;     // atomicMax of the bit pattern of max |PQ|
+};
+
+template <int H>
+struct NodeChainCfg {
+    static constexpr int KS = H / 16, ROWB = 2 * H + 16, PLB = 32 * ROWB, HLD = H + 4;
+    static constexpr int LDS = 2 * PLB + 32 * HLD * 4;
+};
+
+// NW waves (4 or 8) share the H output columns of a product: wave w owns columns [w CW, (w + 1) CW), CW = H / NW = TW tiles of 32.
+// D = depth of the weight ring in 16-deep k-steps.
+template <int H, int NW, int D>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void node_chain_kernel(NodeChainArgs a) {
+    using C = NodeChainCfg<H>;
+    constexpr int KS = C::KS, ROWB = C::ROWB, PLB = C::PLB, HLD = C::HLD, CW = H / NW, TW = CW / 32, RPW = 32 / NW;
+    static_assert(KS % D == 0 && KS >= 2 * D && CW % 32 == 0, "ring depth / column split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* P = smem;                                    // activation planes [2][32][ROWB]
+    float* Hs = reinterpret_cast<float*>(smem + 2 * PLB);       // h' rows [32][HLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int row0 = blockIdx.x * 32, N = a.N;
+
+    u32x4 ring[D][TW][2];
+    f32x16 acc[TW];
+    // ---- weight ring: k-steps ks .. ks + D - 1 of the wave's TW column tiles (first tile ct0) in flight ----
+    // (per-tile offsets live in the vector offset, the plane in the instruction's immediate: one scalar offset per k-step)
+    int voff[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) voff[t] = lane * 16 + t * KS * 2048;
+    auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, int ct0, int ks, u32x4 (&w)[TW][2]) {
+        const int so = (ct0 * KS + ks) * 2048;
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[t] + pl * 1024, so, 0);
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rs, int ct0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ring_load(rs, ct0, d, ring[d]);
+    };
+    auto read_act = [&](int ks, f16x8 (&af)[2]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[pl] = *reinterpret_cast<const f16x8*>(P + pl * PLB + l31 * ROWB + (2 * ks + kg) * 16);
+    };
+    // one product over K = H: acc[t] (+)= the wave's TW tiles.  TR: weights as the first operand (lane = row, registers = columns).
+    // Term order of the plane GEMMs: (a1, b0), (a0, b1), (a0, b0) with a = activation, b = weight.
+    auto mma_step = [&](auto tr, const u32x4 (&w)[TW][2], const f16x8 (&af)[2]) {
+        constexpr bool TR = decltype(tr)::value;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const f16x8 wv = __builtin_bit_cast(f16x8, w[t][term == 1 ? 1 : 0]);
+                const f16x8 av = af[term == 0 ? 1 : 0];
+                if constexpr (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, av, acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc[t], 0, 0, 0);
+            }
+    };
+    auto run = [&](auto tr, const __amdgpu_buffer_rsrc_t& rs, int ct0) {   // the ring holds k-steps 0 .. D-1 on entry, nothing on exit
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        f16x8 af[2][2];
+        read_act(0, af[0]);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS - D; ks0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                read_act(ks0 + d + 1, af[(d + 1) & 1]);
+                mma_step(tr, ring[d], af[d & 1]);
+                ring_load(rs, ct0, ks0 + d + D, ring[d]);
+                // (pin the order: left alone, the scheduler moves every refill to the end of the unrolled body, which empties the ring)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d + 1 < D) read_act(KS - D + d + 1, af[(d + 1) & 1]);
+            mma_step(tr, ring[d], af[d & 1]);
+        }
+    };
+    using TRt = std::true_type;
+    using TRf = std::false_type;
+    static_assert(D % 2 == 0, "the activation fragments alternate between two register sets");
+
+    const bool phaseA = a.part != nullptr, phaseB = a.Wln != nullptr;
+    const int wsz = H * H * 4;  // bytes of one packed H x H operand
+    if (phaseA) {
+        const __amdgpu_buffer_rsrc_t rs_agg = uniform_rsrc(a.Wagg, wsz);
+        ring_fill(rs_agg, wave * TW);   // in flight under the aggregation
+        // ---- A1: agg = (sum of the node's slots) / degree -> planes (finalize_agg_kernel's arithmetic) ----
+        const float s_agg = a.dsc[2];
+#pragma unroll 2
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r, i = row0 + row, c0 = lane * 8;
+            if (c0 < H) {
+                f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+                if (i < N) {
+                    const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
+                    if (e1 > e0) {
+                        const int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
+                        for (int sl = 0; sl <= t1 - t0; ++sl) {
+                            const float* p = a.part + ((size_t)sl * N + i) * H + c0;
+                            x += *reinterpret_cast<const f32x4*>(p);
+                            y += *reinterpret_cast<const f32x4*>(p + 4);
+                        }
+                        const float d = (float)(e1 - e0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            x[k] = x[k] / d;
+                            y[k] = y[k] / d;
+                        }
+                    }
+                }
+                u32x4 pk[2];
+                unsigned pr[3];
+                pl_split_pair(x[0], x[1], s_agg, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                pl_split_pair(x[2], x[3], s_agg, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                pl_split_pair(y[0], y[1], s_agg, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                pl_split_pair(y[2], y[3], s_agg, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
+            }
+        }
+        __syncthreads();
+        // ---- A2: Z = agg W0b^T (transposed) ----
+        run(TRt{}, rs_agg, wave * TW);
+        const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
+        ring_fill(rs_n2, wave * TW);    // in flight under the epilogue
+        __syncthreads();                // every wave has read the agg planes
+        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes ----
+        {
+            const float os = a.dsc[3] * (1.f / PL_SW), s_x = a.dsc[4];
+            const int i = row0 + l31;
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.b0 + c4);
+                    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+                    if (i < N) xp = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + c4);
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = silu_fast((acc[t][4 * q + k] * os + b[k]) + xp[k]);
+                    if (i >= N) v[0] = v[1] = v[2] = v[3] = 0.f;
+                    unsigned p01[3], p23[3];
+                    pl_split_pair(v[0], v[1], s_x, p01);
+                    pl_split_pair(v[2], v[3], s_x, p23);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const uint2 wv = make_uint2(p01[pl], p23[pl]);
+                        *reinterpret_cast<uint2*>(P + pl * PLB + l31 * ROWB + c4 * 2) = wv;
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- A4: Y = X W2^T (transposed) ----
+        run(TRt{}, rs_n2, wave * TW);
+        if (phaseB) ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);   // pass 0 of phase B, in flight under the epilogue and the LayerNorm
+        // ---- A5: h' = h + SiLU(Y + b2) -> Hs ----
+        {
+            const float os = a.dsc[5] * (1.f / PL_SW);
+            const int i = row0 + l31;
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + c4);
+                    f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+                    if (i < N) hv = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c4);
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = silu_fast(acc[t][4 * q + k] * os + b[k]) + hv[k];
+                    *reinterpret_cast<f32x4*>(Hs + l31 * HLD + c4) = o;
+                }
+        }
+        __syncthreads();
+    } else if (phaseB) {
+        ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);
+    }
+    // ---- LayerNorm (layernorm_kernel's arithmetic: a wave per row, a lane owns eight consecutive columns) ----
+    {
+        const int c0 = lane * 8;
+        const bool act = c0 < H;
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, b0 = w0, b1 = w0;
+        if (act) {
+            w0 = *reinterpret_cast<const f32x4*>(a.ln_w + c0);
+            w1 = *reinterpret_cast<const f32x4*>(a.ln_w + c0 + 4);
+            b0 = *reinterpret_cast<const f32x4*>(a.ln_b + c0);
+            b1 = *reinterpret_cast<const f32x4*>(a.ln_b + c0 + 4);
+        }
+#pragma unroll 2
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r, i = row0 + row;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+            if (act && i < N) {
+                if (phaseA) {
+                    x = *reinterpret_cast<const f32x4*>(Hs + row * HLD + c0);
+                    y = *reinterpret_cast<const f32x4*>(Hs + row * HLD + c0 + 4);
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)i * H + c0) = x;
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)i * H + c0 + 4) = y;
+                } else {
+                    x = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c0);
+                    y = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c0 + 4);
+                }
+            }
+            const float mean = wave_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3]))) / (float)H;
+            float q = 0.f;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float da = x[k] - mean, db = y[k] - mean;
+                    q += da * da + db * db;
+                }
+            }
+            const float var = wave_sum(q) / (float)H;
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            if (act && i < N) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o0[k] = (x[k] - mean) * rstd * w0[k] + b0[k];
+                    o1[k] = (y[k] - mean) * rstd * w1[k] + b1[k];
+                }
+                if (a.hf) {
+                    *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0) = o0;
+                    *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0 + 4) = o1;
+                }
+            }
+            if (act && phaseB) {
+                u32x4 pk[2];
+                unsigned pr[3];
+                pl_split_pair(o0[0], o0[1], PL_S_LN, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                pl_split_pair(o0[2], o0[3], PL_S_LN, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                pl_split_pair(o1[0], o1[1], PL_S_LN, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                pl_split_pair(o1[2], o1[3], PL_S_LN, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
+            }
+        }
+    }
+    if (!phaseB) return;
+    __syncthreads();
+    // ---- phase B: [P_i | P_j | X_part] = y Wln^T, three passes of H columns (lane = column, registers = rows) ----
+    {
+        const __amdgpu_buffer_rsrc_t rs_ln = uniform_rsrc(a.Wln, 3 * wsz);
+        constexpr float os = 1.f / (PL_S_LN * PL_SW);
+        float m = 0.f;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int ct0 = (pass * H + wave * CW) / 32;
+            run(TRf{}, rs_ln, ct0);
+            if (pass < 2) ring_fill(rs_ln, ((pass + 1) * H + wave * CW) / 32);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const int col = pass * H + wave * CW + t * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    const float v = acc[t][r] * os;
+                    if (i < N) {
+                        a.PQ[(size_t)i * (3 * H) + col] = v;
+                        m = fmaxf(m, fabsf(v));
+                    }
+                }
+            }
+        }
+        if (a.absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) atomicMax(a.absmax, __float_as_uint(m));
+        }
+    }
+}
+
+template <int H, int NW, int D>
+static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_chain_kernel<H, NW, D>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeChainCfg<H>::LDS); });
+    MI_HIP(attr_err);
+    hipLaunchKernelGGL((node_chain_kernel<H, NW, D>), dim3(cdiv(a.N, 32)), dim3(64 * NW), NodeChainCfg<H>::LDS, s, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+bool node_chain_supported(const mi_net* net) { return g_node_fused && net->cfg.ln && (net->H == 128 || net->H == 256 || net->H == 512) && net->Wnc != nullptr; }
+
+size_t node_chain_pack_elems(int H) { return (size_t)5 * H * H * 2; }  // per layer: [Wagg | Wn2 | Wln] x two planes (u16 elements)
+
+// packs of layer l (called by mi_net_set_params): Wagg = node_mlp.0.weight[:, H:], Wn2 = node_mlp.2.weight, Wln = [W1[:, :H]; W1[:, H:2H]; node_mlp.0.weight[:, :H]]
+int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s) {
+    const int H = net->H;
+    u16* base = net->Wnc + (size_t)l * node_chain_pack_elems(H);
+    const int nb = cdiv((int64_t)H * (H / 8), 256);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, base, 0);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, Wn2, H, H, H, base + (size_t)H * H * 2, 0);
+    u16* wln = base + (size_t)2 * H * H * 2;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, W1, net->edge_in, H, H, wln, 0);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, W1 + H, net->edge_in, H, H, wln, H);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, Wn0, 2 * H, H, H, wln, 2 * H);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+// The chain in front of layer l's edge stage (l = 0 .. L; l = L: finishes the last layer and applies the final LayerNorm into b->hf).
+int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
+    const int H = net->H, L = net->L, N = b->N;
+    const size_t NH = (size_t)N * H;
+    NodeChainArgs a;
+    a.N = N;
+    if (l > 0) {
+        const std::string p = "csp_layer_" + std::to_string(l - 1) + ".";
+        const u16* base = net->Wnc + (size_t)(l - 1) * node_chain_pack_elems(H);
+        a.part = b->part;
+        a.rowptr = b->rowptr;
+        a.xpart = b->PQ + 2 * H;
+        a.ld_xpart = 3 * H;
+        a.Wagg = base;
+        a.Wn2 = base + (size_t)H * H * 2;
+        a.b0 = net->p(p + "node_mlp.0.bias");
+        a.b2 = net->p(p + "node_mlp.2.bias");
+        a.dsc = b->dsc;
+        a.h_in = b->h + (size_t)(l - 1) * NH;
+        a.h_out = b->h + (size_t)l * NH;
+    } else {
+        a.h_in = b->h;
+    }
+    if (l < L) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        a.ln_w = net->p(p + "layer_norm.weight");
+        a.ln_b = net->p(p + "layer_norm.bias");
+        a.Wln = net->Wnc + (size_t)l * node_chain_pack_elems(H) + (size_t)2 * H * H * 2;
+        a.PQ = b->PQ;
+        a.absmax = b->absmax + 2 * l;
+    } else {
+        a.ln_w = net->p("final_layer_norm.weight");
+        a.ln_b = net->p("final_layer_norm.bias");
+        a.hf = b->hf;
+    }
+    if (H == 512) return g_node_fused == 2 ? node_chain_launch<512, 4, 4>(a, s) : node_chain_launch<512, 8, 8>(a, s);
+    if (H == 256) return node_chain_launch<256, 8, 4>(a, s);
+    return node_chain_launch<128, 4, 4>(a, s);
+}
+
+#else  // three-plane bf16 build: the chain stays on the plane GEMMs
+
+bool node_chain_supported(const mi_net*) { return false; }
+size_t node_chain_pack_elems(int) { return 0; }
+int node_chain_pack(mi_net*, int, const float*, const float*, const float*, hipStream_t) { return MI_OK; }
+int node_chain(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
+
+#endif
+
+}  // namespace mi
+
+extern "C" int mi_debug_set_node_fused(int on) {
+    const int was = mi::g_node_fused;
+    mi::g_node_fused = on;  // (2: the four-wave form at hidden_dim 512 -- ablation)
+    return was;
+}

@@ -265,3 +265,55 @@ def test_inference_heads_kernel_vs_golden_and_vs_the_two_gemm_heads(golden):
     assert torch.equal(outs[0][0], outs[1][0])   # (the lattice head is the same kernel)
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("H,L,F,num_atoms,style", [
+    (128, 3, 10, [5, 0, 9, 20, 20, 4, 1], "fc"),          # 59 nodes: a partial last 32-row block
+    (256, 2, 16, [20] * 9 + [3], "fc"),
+    (512, 2, 16, [20, 7, 1, 33, 12, 20, 20, 2], "fc"),   # both wave forms of the 512-wide kernel
+    (512, 2, 16, [20] * 40, "fc"),                        # 800 nodes: the seven-launch form runs its node products on the plane GEMMs
+    (256, 2, 16, [12, 20, 8, 16], "knn"),
+])
+def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
+    """Inference forwards run everything between two edge stages (segmented mean, node MLP + residual, LayerNorm, the projections
+    LayerNorm(h) feeds: cspnet.py:79-91,61) as one launch per layer boundary (csrc/node_chain.hip).  Same plane format, same scales, same
+    k order as the plane GEMMs it replaces: outputs and every layer's node features agree to a few ulp of the accumulations -- and both
+    forms agree with the oracle at the forward tests' tolerance."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=21)
+    g = torch.Generator().manual_seed(23)
+    for k in P:
+        if "layer_norm" in k:
+            P[k] = P[k] + 0.1 * torch.randn(P[k].shape, generator=g)
+    from matinvent_amd.cspnet import CSPNet
+    net = CSPNet(hidden_dim=H, num_layers=L, num_freqs=F, latent_dim=256, ln=True, smooth=True, pred_type=True, device="cuda", edge_style=style)
+    load_decoder(net, P)
+    na = torch.tensor(num_atoms)
+    B, N = len(num_atoms), int(na.sum())
+    t_emb = O.time_embedding(torch.full((B,), 77), 256).cuda()
+    at = torch.randn(N, 100, generator=g).cuda()
+    fr = torch.rand(N, 3, generator=g).cuda()
+    lat = (5 * torch.eye(3) + 0.5 * torch.randn(B, 3, 3, generator=g)).cuda()
+    bt = net.make_batch(num_atoms)
+    res = {}
+    try:
+        for knob in (0, 1, 2):
+            lib.mi_debug_set_node_fused(knob)
+            with torch.no_grad():
+                outs = [x.clone() for x in net(t_emb, at, fr, lat, None, batch=bt)]
+            res[knob] = outs + [net.tap(bt, l + 1).clone() for l in range(L)]
+            assert all(torch.isfinite(x).all() for x in res[knob])
+    finally:
+        lib.mi_debug_set_node_fused(1)
+    names = ["pred_l", "pred_x", "pred_t"] + [f"h after layer {l}" for l in range(L)]
+    for knob in (1, 2):
+        for a, b, w in zip(res[knob], res[0], names):
+            _close(a, b, 2e-6, f"{w}: one launch (form {knob}) vs seven")
+    if style == "fc":
+        n2g = torch.repeat_interleave(torch.arange(B), na)
+        with torch.no_grad():
+            ref = O.cspnet_forward(P, hp, t_emb.cpu(), at.cpu(), fr.cpu(), lat.cpu(), na, n2g)
+        for a, b, w in zip(res[1][:3], ref, names):
+            _close(a, b, 3e-5, w + " vs oracle")
