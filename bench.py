@@ -57,6 +57,79 @@ def bytes_per_crystal_eval(n):
     return 4 * (n * (103 + 103) + 265 + n * H * (1 + 5 * L + 1)) + 4 * P / B
 
 
+def dist_setup(gpus=None):
+    """One process per GPU (torch.distributed over RCCL = backend "nccl"; rendezvous from the launcher's environment).  Returns
+    (world, rank, local_rank, share, dist).  MI_BENCH_SHARE_GPU (tests only): the N ranks share device 0 and talk over gloo, which
+    exercises the control flow on a one-GPU box.  Fails with a clear message -- not a hang inside the collective -- when the box has
+    fewer GPUs than ranks."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = bool(os.environ.get("MI_BENCH_SHARE_GPU"))
+    dist = None
+    if gpus is not None and world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (or from a bare shell, which self-launches)")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if share:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            n_dev = torch.cuda.device_count()
+            if n_dev < world or local_rank >= n_dev:
+                raise SystemExit(f"bench.py: {world} ranks (one process per GPU over RCCL) but this node shows {n_dev} GPU(s): "
+                                 f"rank {rank} has no device {local_rank}.  Run with --gpus <= {n_dev}.")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(torch.device("cuda", local_rank))
+    return world, rank, local_rank, share, dist
+
+
+def dist_barrier(ctx):
+    world, rank, local_rank, share, dist = ctx
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier() if share else dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+
+
+def dist_max_time(ctx, elapsed):
+    world, rank, local_rank, share, dist = ctx
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cpu" if share else torch.device("cuda", local_rank), dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def mg_flops_eval(hp, N, E):
+    """F_eval_mg: dense-layer flops (fp32 multiply-adds x 2) of ONE evaluation of the MatterGen-shaped network over N atoms and E directed
+    edges (oracle/mattergen_oracle.py op by op): per edge the interaction blocks' 512-wide layers (concat, residual stacks, the
+    triplet down / up projections and the bilinear layer) and the output blocks' layers, per atom the atom-update stacks and heads."""
+    Ed, A = hp["emb_edge"], hp["emb_atom"]
+    per_edge_block = 2 * Ed * (Ed * (2 + 2 * hp["num_before_skip"] + 2 * hp["num_after_skip"] + 1 + 2 * hp["num_concat"]) + hp["emb_rbf"] * 2
+                               + hp["emb_trip"] + 2 * hp["emb_bil"]) + 2 * hp["emb_cbf"] * hp["emb_trip"] * hp["emb_bil"]
+    per_edge_out = 2 * Ed * (Ed * 4 + 2 * hp["emb_rbf"])
+    per_node_block = 2 * A * (Ed + A * 2 * hp["num_atom"] + 2 * Ed)
+    return E * (hp["num_blocks"] * (per_edge_block + per_edge_out) + per_edge_out + 2 * hp["num_radial"] * (Ed + 3 * hp["emb_rbf"] + hp["num_spherical"] * hp["emb_cbf"])) \
+        + N * (hp["num_blocks"] * per_node_block + 2 * A * (A + 2 * Ed + 101))
+
+
+def mg_bytes_per_crystal_eval(hp, n, e, nparams, batch):
+    """Y_eval_mg(n, e): stage-boundary MINIMUM HBM bytes (fp32) of one crystal-evaluation of the MatterGen-shaped network with n atoms and
+    e directed edges -- the rules of SURVEY 8(d): weights once per evaluation amortised over the batch, every array that has to be
+    globally visible at a message-passing boundary round-trips once, nothing else is written.  Unlike CSPNet the EDGE state is such an
+    array: a triplet interaction gathers the down-projected messages of neighbouring edges, so the edge embedding m [e, emb_edge] is
+    written by the embedding block and read + written once per interaction block, and the down-projection [e, emb_trip] is written and
+    gathered once per block; node features round-trip once per block (+ embedding, + final read); the graph (src, dst, image code) is
+    written once and read once; the two per-edge scalar heads of every output block are written and read once.  DESIGN 11."""
+    nb, Ed, A, Tr = hp["num_blocks"], hp["emb_edge"], hp["emb_atom"], hp["emb_trip"]
+    floats = n * (4 + 3 + 101) + 19 + 6 * e + e * Ed * (1 + 2 * nb) + 2 * nb * e * Tr + (2 * nb + 2) * n * A + 4 * (nb + 1) * e
+    return 4 * floats + 4 * nparams / batch
+
+
 def build_module(device):
     from matinvent_amd.diffcsp import DiffCSPModule
     torch.manual_seed(SEED_W)
@@ -72,7 +145,7 @@ def build_module(device):
     return m
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=15.0, na=None, what=None):
     """The CPU oracle (port of the reference's PyTorch path, pinned by tests/golden) on this
     host's cores: a bounded slice of the same workload (B=32 of the 256 crystals, a few
     denoising steps of the 1000), scaled linearly -- per-step cost is t-independent."""
@@ -80,8 +153,8 @@ def cpu_baseline(budget_s=15.0):
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P = O.init_params(hp, seed=SEED_W, head_scale=HEAD_SCALE)
     sch = O.Schedules.make(T, sigmas_norm=torch.from_numpy(np.load(SIGMAS_NORM)))
-    Bc = 32
-    na = torch.full((Bc,), NATOM, dtype=torch.long)
+    Bc = 32 if na is None else len(na)
+    na = torch.full((Bc,), NATOM, dtype=torch.long) if na is None else torch.tensor(na, dtype=torch.long)
     cores = torch.get_num_threads()
     steps_done, t_total = 0, 0.0
     n_steps = 1
@@ -105,27 +178,29 @@ def cpu_baseline(budget_s=15.0):
             break
     value = Bc * steps_done / (T * t_total)
     return {"value": value, "unit": "structures/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/diffcsp_oracle.py (plain torch fp32 CPU), B={Bc} crystals x {NATOM} atoms, {steps_done} of {T} "
-                      f"denoising steps in {t_total:.1f} s, scaled linearly (per-step cost is t-independent)"}
+            "sample": f"oracle/diffcsp_oracle.py (plain torch fp32 CPU), " + (f"B={Bc} crystals x {NATOM} atoms" if what is None else f"{what} ({int(na.sum())} atoms)")
+                      + f", {steps_done} of {T} denoising steps in {t_total:.1f} s, scaled linearly (per-step cost is t-independent)"}
 
 
-def cpu_baseline_ft(budget_s=15.0):
+def cpu_baseline_ft(budget_s=15.0, na=None, what=None):
     """The CPU oracle's ft_step (restatement of pipeline/mat_invent.py:150-177: noise, agent forward, frozen-prior forward,
     autograd backward) on this host's cores: a bounded slice of the same workload (16 of the 256 crystals, a few timesteps)."""
     from oracle import diffcsp_oracle as O
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     agent, prior = O.init_params(hp, seed=SEED_W, head_scale=HEAD_SCALE), O.init_params(hp, seed=SEED_W, head_scale=HEAD_SCALE)
     sch = O.Schedules.make(T, sigmas_norm=torch.from_numpy(np.load(SIGMAS_NORM)))
-    Bc = 16
+    Bc = 16 if na is None else len(na)
+    nat = torch.full((Bc,), NATOM, dtype=torch.long) if na is None else torch.tensor(na, dtype=torch.long)
+    Nc = int(nat.sum())
     g = torch.Generator().manual_seed(7)
-    batch = dict(num_atoms=torch.full((Bc,), NATOM, dtype=torch.long), frac_coords=torch.rand(Bc * NATOM, 3, generator=g),
-                 atom_types=torch.randint(1, 95, (Bc * NATOM,), generator=g), lengths=4 + 6 * torch.rand(Bc, 3, generator=g),
+    batch = dict(num_atoms=nat, frac_coords=torch.rand(Nc, 3, generator=g),
+                 atom_types=torch.randint(1, 95, (Nc,), generator=g), lengths=4 + 6 * torch.rand(Bc, 3, generator=g),
                  angles=70 + 40 * torch.rand(Bc, 3, generator=g))
     rewards = torch.rand(Bc, generator=g)
 
     def noise_fn(epoch, t):
-        return dict(rand_l=torch.randn(Bc, 3, 3, generator=g), rand_x=torch.randn(Bc * NATOM, 3, generator=g),
-                    rand_t=torch.randn(Bc * NATOM, 100, generator=g))
+        return dict(rand_l=torch.randn(Bc, 3, 3, generator=g), rand_x=torch.randn(Nc, 3, generator=g),
+                    rand_t=torch.randn(Nc, 100, generator=g))
     done, t_total, n = 0, 0.0, 1
     while t_total < budget_s and done < 24:
         t0 = time.perf_counter()
@@ -134,8 +209,8 @@ def cpu_baseline_ft(budget_s=15.0):
         done += n
         n = max(1, min(24 - done, int((budget_s - t_total) / (t_total / done))))
     return {"value": Bc * done / t_total, "unit": "crystal-timesteps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/diffcsp_oracle.py ft_step (plain torch fp32 CPU, autograd), {Bc} crystals x {NATOM} atoms, {done} timesteps "
-                      f"(+ one Adam step per call) in {t_total:.1f} s"}
+            "sample": f"oracle/diffcsp_oracle.py ft_step (plain torch fp32 CPU, autograd), " + (f"{Bc} crystals x {NATOM} atoms" if what is None else f"{what} ({Nc} atoms)")
+                      + f", {done} timesteps (+ one Adam step per call) in {t_total:.1f} s"}
 
 
 def _oracle_steps(O, P, hp, sch, na, noise, t_from, t_to):
@@ -152,31 +227,18 @@ def _apply_env_knobs(lib):
     """Experiment knobs (A/B runs of kernel choices); the defaults are what the library ships with."""
     for env, fn in (("MI_DB_MIN_TILES", lib.mi_debug_set_db_min_tiles), ("MI_NODE_PLANES_MIN_ROWS", lib.mi_debug_set_node_planes_min_rows),
                     ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128), ("MI_TN_SPLIT_MIN_ROWS", lib.mi_debug_set_tn_split_min_rows),
-                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused)):
+                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused)):
         if os.environ.get(env) is not None and os.environ[env] != "":
             fn(int(os.environ[env]))
 
 
-def main_ft(args):
+def measure_ft(args, K, W, ctx, cpu_budget_s=15.0):
     """Secondary metric (BASELINE configs[2]/[3]): crystal-timesteps / second of the fine-tune loop
-    (noise + agent fwd + frozen-prior fwd + agent bwd per timestep, fused Adam every 50), ft set =
-    256 synthetic crystals x 20 atoms per GPU, reward ~ U[0,1] (stands in for reward=hhi)."""
-    K, W = (args.steps if args.steps != 1000 else 100), args.warmup
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    share = bool(os.environ.get("MI_BENCH_SHARE_GPU"))  # test-only: N ranks on ONE GPU over gloo
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            local_rank = 0
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    (noise + agent fwd + frozen-prior fwd + agent bwd per timestep, fused Adam every 50 -- and after the last timestep of a call, as
+    pipeline/mat_invent.py:176-177 does), ft set = 256 synthetic crystals x 20 atoms per GPU, reward ~ U[0,1] (stands in for reward=hhi).
+    Returns the bench line (rank 0) or None."""
+    world, rank, local_rank, share, dist = ctx
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import ft_step
     from matinvent_amd import _lib
@@ -191,10 +253,8 @@ def main_ft(args):
     cfg = dict(lr=1e-4, accum_steps=50, epochs=1, sigma=0.025)
 
     def run(n):
-        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None, groups=args.ft_groups)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier() if share else dist.barrier(device_ids=[local_rank])
+        ft_step(agent, prior, data, rewards, dict(cfg, timesteps=n), log=lambda *_: None, groups=getattr(args, "ft_groups", None))
+        dist_barrier(ctx)
 
     import ctypes as C
     lib = _lib.load()
@@ -202,47 +262,75 @@ def main_ft(args):
     _lib.check(lib.mi_profile_enable(agent.decoder._h, 1))
     t0 = time.perf_counter()
     run(K)
-    elapsed = time.perf_counter() - t0
+    elapsed = dist_max_time(ctx, time.perf_counter() - t0)
     n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.mi_profile_read(agent.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
     _lib.check(lib.mi_profile_enable(agent.decoder._h, 0))
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if rank == 0:
-        flops = 4 * 5.893e9 * nglob * K  # agent fwd + prior fwd + 2x for backward
-        # dominant kernel pair of the micro-step (profiles/*_finetune.md): the agent's forward edge stage -- the same two plane GEMMs
-        # as the sampler's, bracketed by HIP events on their launch stream; one launch = one layer over one crystal group
-        groups = max(1, n_launch.value // max(1, K * L))
-        E = B * NATOM * NATOM / groups
-        f_exec, f_alg = edge_flops_per_edge(pairs=True)
-        terms = 3 if lib.mi_plane_format() == 2 else 6
-        busy_ms = union_ms.value if groups > 1 else tot_ms.value
-        issued = terms * n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12
-        out = {"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
-               "data": "synthetic",
-               "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps (noise + agent fwd + frozen-prior fwd + agent bwd per "
-                                      "timestep), 256 crystals x 20 atoms per GPU, synthetic reward, accum_steps=50, fused Adam, one flat-gradient "
-                                      "all-reduce (RCCL) per optimizer step when N>1; a bench step = one timestep over the batch",
-                          "batch_per_gpu": B, "atoms_per_cell": NATOM, "accum_steps": 50, "concurrent_groups": groups,
-                          "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world},
-               "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (agent forward, edge MLP of one layer; the "
-                                                          "largest single kernel of the micro-step)",
-                            "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS,
-                            "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": tot_ms.value / max(1, n_launch.value),
-                            "concurrent_streams": groups, "stage_busy_ms": busy_ms,
-                            "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg},
-               "end_to_end": {"tflops_section8d": flops / elapsed / 1e12,
-                              "frac_of_f32_mfma_peak_section8d": flops / elapsed / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_ft()
+    del agent, prior
+    if rank != 0:
+        return None
+    flops = 4 * 5.893e9 * nglob * K  # agent fwd + prior fwd + 2x for backward
+    # dominant kernel pair of the micro-step (profiles/*_finetune.md): the agent's forward edge stage -- the same two plane GEMMs
+    # as the sampler's, bracketed by HIP events on their launch stream; one launch = one layer over one crystal group
+    groups = max(1, n_launch.value // max(1, K * L))
+    E = B * NATOM * NATOM / groups
+    f_exec, f_alg = edge_flops_per_edge(pairs=True)
+    terms = 3 if lib.mi_plane_format() == 2 else 6
+    busy_ms = union_ms.value if groups > 1 else tot_ms.value
+    issued = terms * n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12
+    out = {"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
+           "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps (noise + agent fwd + frozen-prior fwd + agent bwd per "
+                                  "timestep), 256 crystals x 20 atoms per GPU, synthetic reward, accum_steps=50, fused Adam, one flat-gradient "
+                                  "all-reduce (RCCL) per optimizer step when N>1; a bench step = one timestep over the batch",
+                      "batch_per_gpu": B, "atoms_per_cell": NATOM, "accum_steps": 50, "concurrent_groups": groups,
+                      "adam_steps_in_timed_region": K // 50 + (1 if K % 50 else 0),
+                      "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world},
+           "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (agent forward, edge MLP of one layer; the "
+                                                      "largest single kernel of the micro-step)",
+                        "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS,
+                        "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": tot_ms.value / max(1, n_launch.value),
+                        "concurrent_streams": groups, "stage_busy_ms": busy_ms,
+                        "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg},
+           "end_to_end": {"tflops_section8d": flops / elapsed / 1e12,
+                          "frac_of_f32_mfma_peak_section8d": flops / elapsed / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_ft(cpu_budget_s)
+    return out
+
+
+def main_ft(args):
+    K, W = (args.steps if args.steps != 1000 else 100), args.warmup
+    ctx = dist_setup(args.gpus)
+    out = measure_ft(args, K, W, ctx)
+    if out is not None:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if ctx[0] > 1:
+        dist_barrier(ctx)
+        ctx[4].destroy_process_group()
+
+
+def _edge_stage_roofline(lib, module, edges_total, pairs_total, evals):
+    """Event-bracketed edge stage (the two plane GEMMs of a layer, mi_profile_*) of a run over a RAGGED set: matrix-pipe flops issued by all
+    bracketed launches / the union of their execution intervals.  edges_total / pairs_total: directed edges (self edges included) and
+    unordered atom pairs of the whole set; evals: network evaluations of the profiled module in the timed region."""
+    import ctypes as C
+    from matinvent_amd import _lib
+    n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(lib.mi_profile_read(module.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
+    _lib.check(lib.mi_profile_enable(module.decoder._h, 0))
+    terms = 3 if lib.mi_plane_format() == 2 else 6
+    fp32_flops = evals * L * (pairs_total * 2 * (6 * F) * H + edges_total * 2 * H * H)   # Fourier block over pairs + second linear over edges
+    busy_ms = max(union_ms.value, 1e-9)
+    issued = terms * fp32_flops / (busy_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer over one crystal group)", "achieved": issued,
+            "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "launches": int(n_launch.value),
+            "avg_launch_ms": tot_ms.value / max(1, n_launch.value), "stage_busy_ms": busy_ms, "achieved_fp32_equivalent": issued / terms,
+            "note": "flops of all bracketed launches / union of their execution intervals (concurrent groups overlap); small ragged sets are "
+                    "latency-bound launches of at most one workgroup per CU, so the fraction is low by construction"}
 
 
 def main_reference_defaults(args):
@@ -255,7 +343,8 @@ def main_reference_defaults(args):
     torch.cuda.set_device(dev)
     from matinvent_amd import _lib
     from matinvent_amd.sampling import ATOM_DIST
-    _apply_env_knobs(_lib.load())
+    lib = _lib.load()
+    _apply_env_knobs(lib)
     np.random.seed(0)
     p = ATOM_DIST["mp_20"]
     if args.mode == "sample-default":
@@ -271,15 +360,20 @@ def main_reference_defaults(args):
         final, _ = m.sample(cb, seed=SEED_NOISE, step_lr=STEP_LR, t_start=T, t_stop=T)
         state = (final["frac_coords"], final["lattices"], final["atom_types"])
         torch.cuda.synchronize()
+        _lib.check(lib.mi_profile_enable(m.decoder._h, 1))
         t0 = time.perf_counter()
         m.sample(cb, seed=SEED_NOISE, step_lr=STEP_LR, init=state, t_start=T, t_stop=T - K)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        roof = _edge_stage_roofline(lib, m, int((na.astype(np.int64) ** 2).sum()), int((na.astype(np.int64) * (na - 1) // 2).sum()), 2 * K)
         out = {"metric": "crystal structures/sec (1000-step reverse diffusion), reference default sampling batch", "value": Bd * K / (T * elapsed),
                "unit": "structures/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32 via 2-plane fp16 split", "data": "synthetic",
                "config": {"workload": "reference default: 192 crystals with mp_20 atom counts (1..20, numpy seed 0), T=1000, DiffCSP CSPNet H=512 L=6 F=128",
-                          "batch_per_gpu": Bd, "atoms_total": int(na.sum()), "edges_total": int((na.astype(np.int64) ** 2).sum())}}
+                          "batch_per_gpu": Bd, "atoms_total": int(na.sum()), "edges_total": int((na.astype(np.int64) ** 2).sum())},
+               "roofline": roof}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(na=[int(v) for v in na[:48]], what="the first 48 of the 192 ragged crystals")
     else:
         from matinvent_amd.data import CrystalData
         from matinvent_amd.finetune import ft_step
@@ -295,17 +389,23 @@ def main_reference_defaults(args):
         cfg = dict(lr=1e-4, accum_steps=50, epochs=1, sigma=0.025)
         ft_step(agent, prior, data, rewards, dict(cfg, timesteps=max(W, 50)), log=lambda *_: None)
         torch.cuda.synchronize()
+        _lib.check(lib.mi_profile_enable(agent.decoder._h, 1))
         t0 = time.perf_counter()
         ft_step(agent, prior, data, rewards, dict(cfg, timesteps=K), log=lambda *_: None)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        roof = _edge_stage_roofline(lib, agent, int((na.astype(np.int64) ** 2).sum()), int((na.astype(np.int64) * (na - 1) // 2).sum()), K)
+        roof["kernel"] += " -- the agent's training forward"
         out = {"metric": "fine-tune crystal-timesteps/sec, reference default fine-tune set", "value": nset * K / elapsed, "unit": "crystal-timesteps/s",
                "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32 via 2-plane fp16 / 3-plane bf16 splits", "data": "synthetic",
                "config": {"workload": "reference default fine-tune set: 18 crystals with mp_20 atom counts (top-k 8 + replay 10), accum_steps 50, stacked "
                                       "timesteps (automatic), fused Adam; an RL step runs 3 x 1000 such timesteps",
                           "set_size": nset, "atoms_total": int(na.sum()), "edges_total": int((na.astype(np.int64) ** 2).sum()),
-                          "seconds_per_rl_step_finetune": 3000 * elapsed / K}}
+                          "seconds_per_rl_step_finetune": 3000 * elapsed / K},
+               "roofline": roof}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_ft(na=[int(v) for v in na], what="the same 18 ragged crystals")
     print(json.dumps(out), flush=True)
 
 
@@ -339,12 +439,48 @@ def cpu_baseline_mg(budget_s=20.0):
                       f"predictor-corrector steps in {t_total:.1f} s, scaled linearly"}
 
 
-def measure_mg(args, K, W):
+def cpu_baseline_mg_ft(budget_s=20.0):
+    """oracle/mattergen_oracle.py fine-tune timesteps (noising, agent forward, frozen-prior forward, torch autograd backward) on this host's
+    cores: a bounded slice of the same workload (4 of the crystals, one or two timesteps)."""
+    from oracle import mattergen_oracle as MO
+    hp = MO.GemNetHParams()
+    A = {k: v.requires_grad_(True) for k, v in MO.init_params(hp, seed=SEED_W, head_scale=20.0).items()}
+    Q = MO.init_params(hp, seed=SEED_W, head_scale=20.0)
+    Bc = 4
+    g = torch.Generator().manual_seed(7)
+    mu = (NATOM / 0.05771451654022283) ** (1 / 3)
+    na = torch.full((Bc,), NATOM, dtype=torch.long)
+    cell = mu * torch.eye(3)[None].repeat(Bc, 1, 1) + 0.3 * MO.symmetric_noise(torch.randn(Bc, 3, 3, generator=g))
+    ob = dict(pos=torch.rand(Bc * NATOM, 3, generator=g), cell=cell, atomic_numbers=torch.randint(1, 95, (Bc * NATOM,), generator=g), num_atoms=na)
+    rw = torch.rand(Bc, generator=g)
+    corr = MO.Corruption()
+    done, t_total = 0, 0.0
+    while t_total < budget_s and done < 4:
+        nz = dict(pos=torch.randn(Bc * NATOM, 3, generator=g), cell=torch.randn(Bc, 3, 3, generator=g), types=torch.rand(Bc * NATOM, generator=g))
+        t0 = time.perf_counter()
+        t = torch.full((Bc,), MO.time_grid(corr, 500 + done))
+        noisy, aux = MO.sample_marginal(corr, ob, t, nz)
+        pa = MO.gemnet_forward(A, hp, noisy["pos"], noisy["cell"], noisy["atomic_numbers"], na, t)
+        with torch.no_grad():
+            pp = MO.gemnet_forward(Q, hp, noisy["pos"], noisy["cell"], noisy["atomic_numbers"], na, t)
+        sl, _ = MO.sample_loss(corr, ob, aux, pa)
+        kl = MO.calc_kl_reg(pa, pp, aux["node2graph"], Bc)
+        torch.autograd.grad((rw * sl + 0.025 * kl * (1.1 - rw)).mean(), list(A.values()))
+        t_total += time.perf_counter() - t0
+        done += 1
+    return {"value": Bc * done / t_total, "unit": "crystal-timesteps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/mattergen_oracle.py fine-tune timesteps (plain torch fp32 CPU, autograd; graph and triplet sums are Python loops), {Bc} crystals x "
+                      f"{NATOM} atoms, {done} timesteps in {t_total:.1f} s"}
+
+
+def measure_mg(args, K, W, ctx=None):
     """The MatterGen-LABELLED form of BASELINE configs[1]: the predictor-corrector reverse sampler of the MatterGen-shaped network
     (GemNet-T shape: 4 blocks at 512 / 512 / 64 / 16 / 16, cutoff 7 A, <= 50 neighbours, triplet basis; 28.3 M parameters), batch 256 x
     20 atoms, 1000-point grid, two denoiser evaluations per step.  SELF-CONSISTENT, PARITY-UNPINNED vs upstream (the reference's
     MatterGen arithmetic is an un-vendored dependency).  Returns the fields of a bench line."""
-    dev = torch.device("cuda", 0)
+    ctx = ctx or (1, 0, torch.cuda.current_device(), False, None)
+    world, rank, local_rank, share, dist = ctx
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     from matinvent_amd import _lib
     from matinvent_amd.mattergen import MatterGenModule
@@ -368,9 +504,10 @@ def measure_mg(args, K, W):
     i0 = 500
     E0 = int(m._batch_for(torch.tensor(na)).graph(state["pos"], state["cell"])["src"].shape[0])
     chains = max(1, int(getattr(args, "mg_chains", 4)))
-    s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state, chains=chains)
+    okw = dict(node_offset=rank * N, graph_offset=rank * Bm)   # global ids: every rank samples its own crystals of one global batch (weak scaling)
+    s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state, chains=chains, **okw)
     st = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
-    torch.cuda.synchronize()
+    dist_barrier(ctx)
     # A random-init denoiser cannot hold a crystal together: left to itself the chain inflates the cells within a few steps and the edge
     # count falls (256k -> 60k over ten steps, nothing left after a few hundred), so a free-running chain measures an emptying graph.  A
     # trained model keeps cells near physical densities, where every atom has its 50 neighbours inside the cutoff -- the 256k-edge regime
@@ -380,43 +517,46 @@ def measure_mg(args, K, W):
     t0 = time.perf_counter()
     if hold:
         for k in range(K):
-            s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE + k, i_start=i0 + W + k, i_stop=i0 + W + k + 1, state=st, chains=chains)
+            s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE + k, i_start=i0 + W + k, i_stop=i0 + W + k + 1, state=st, chains=chains, **okw)
     else:
-        s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains, **okw)
+    dist_barrier(ctx)
+    elapsed = dist_max_time(ctx, time.perf_counter() - t0)
     gr = m._batch_for(torch.tensor(na)).graph(s["pos"], s["cell"])
     E = int(gr["src"].shape[0])
     finite = bool(torch.isfinite(mean["pos"]).all()) and bool(torch.isfinite(mean["cell"]).all())
     hp = m.decoder.hp
-    Ed, A = hp["emb_edge"], hp["emb_atom"]
-    # dense-layer flops of one evaluation at this edge count (the matrix-pipe work; oracle/mattergen_oracle.py op by op)
-    per_edge_block = 2 * Ed * (Ed * (2 + 2 * hp["num_before_skip"] + 2 * hp["num_after_skip"] + 1 + 2 * hp["num_concat"]) + hp["emb_rbf"] * 2
-                               + hp["emb_trip"] + 2 * hp["emb_bil"]) + 2 * hp["emb_cbf"] * hp["emb_trip"] * hp["emb_bil"]
-    per_edge_out = 2 * Ed * (Ed * 4 + 2 * hp["emb_rbf"])
-    per_node_block = 2 * A * (Ed + A * 2 * hp["num_atom"] + 2 * Ed)
     Em = 0.5 * (E0 + E)
-    flops_eval = Em * (hp["num_blocks"] * (per_edge_block + per_edge_out) + per_edge_out + 2 * hp["num_radial"] * (Ed + 3 * hp["emb_rbf"] + hp["num_spherical"] * hp["emb_cbf"])) \
-        + N * (hp["num_blocks"] * per_node_block + 2 * A * (A + 2 * Ed + 101))
+    flops_eval = mg_flops_eval(hp, N, Em)
     terms = 3 if lib.mi_plane_format() == 2 else 6
     sat = _lib.saturation_events(reset=True)
     nparams = int(m.decoder.theta.numel())
     del m
-    # north_star: "achieved HBM GB/s against the chip's peak" for this sampler -- from the committed rocprofv3 passes of this command
-    # (kernel trace + FETCH_SIZE + WRITE_SIZE, scripts/gpu_mg_prof.sh; bench.py cannot read hardware counters itself)
-    hbm = None
+    # north_star: "achieved HBM GB/s against the chip's peak" for this sampler.  `frac` prices the ALGORITHMIC bytes (Y_eval_mg above: what
+    # a perfectly fused implementation has to move) against the 8 TB/s peak over the measured time; beside it the bytes the kernels
+    # actually moved (FETCH_SIZE x2 + WRITE_SIZE of the committed rocprofv3 passes of this command, scripts/gpu_mg_prof.sh -- bench.py cannot
+    # read hardware counters itself) as a ratio to the algorithmic ones.  The network is matrix-pipe-bound by nature (F / Y >> the chip's
+    # balance point), so a low algorithmic fraction is a property of the workload; the ratio is what measures wasted traffic.
+    y_eval = mg_bytes_per_crystal_eval(hp, NATOM, Em / Bm, nparams, Bm)
+    alg_gbps = y_eval * 2 * Bm * K * world / elapsed / 1e9
+    hbm = {"bound": "hbm", "achieved": alg_gbps, "peak": PEAK_HBM_TBPS * 1e3 * world, "unit": "GB/s", "frac": alg_gbps / (PEAK_HBM_TBPS * 1e3 * world),
+           "algorithmic_bytes_per_crystal_evaluation": y_eval, "flops_per_byte": flops_eval / Bm / y_eval,
+           "counter_over_algorithmic": None, "counter_GBps_single_chain": None}
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_mattergen_sampler_traffic.json")))
     if cands:
         tr = json.load(open(cands[-1]))
         if "whole_trace" in tr:
             w = tr["whole_trace"]
-            hbm = {"bound": "hbm", "achieved": w["GBps"], "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s", "frac": w["frac_of_8TBps"],
-                   "source": os.path.relpath(cands[-1], ROOT), "profiled_head": tr.get("head"),
-                   "note": f"all kernels of the profiled SINGLE-CHAIN run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; {100 * w['share_of_trace_time_covered']:.0f} % of the "
-                           "trace's kernel time; with concurrent chains kernel durations overlap and are no measure of a kernel's own rate)"}
-    return {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": Bm * K / (T * elapsed), "unit": "structures/s",
-            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            steps_in_trace = tr.get("steps_in_trace", 4)   # (the profiled command: 1 warm-up + 3 timed steps, two evaluations each)
+            hbm.update(counter_over_algorithmic=w["bytes"] / (steps_in_trace * 2 * Bm * y_eval), counter_GBps_single_chain=w["GBps"],
+                       counter_frac_of_peak_single_chain=w["frac_of_8TBps"], source=os.path.relpath(cands[-1], ROOT), profiled_head=tr.get("head"),
+                       note=f"counter figures: all kernels of the profiled SINGLE-CHAIN run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; "
+                            f"{100 * w['share_of_trace_time_covered']:.0f} % of the trace's kernel time covered)")
+    if rank != 0:
+        return None
+    return {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": world * Bm * K / (T * elapsed), "unit": "structures/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32: edge-level layers on pre-split two-plane fp16 operands (3 MFMA terms), " if terms == 3 else "f32: edge-level layers on pre-split three-plane bf16 operands (6 MFMA terms), ")
                      + "node-level layers on three bf16 planes split on the fly (6 terms); f32 accumulate",
             "data": "synthetic",
@@ -428,10 +568,11 @@ def measure_mg(args, K, W):
                                    + "; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
                        "state": "held" if hold else "free-running",
                        "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "concurrent_chains": chains, "edges_first_step": E0, "edges_last_step": E,
+                       "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
                        "parameters": nparams, "final_state_finite": finite, "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers of the interaction / output blocks)",
                          "achieved": terms * flops_eval * 2 * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": terms * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                         "frac": terms * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "per_gpu": True,
                          "achieved_fp32_equivalent": flops_eval * 2 * K / elapsed / 1e12, "flops_per_evaluation": flops_eval,
                          "note": "end-to-end rate of the dense-layer flops (whole step time, all kernels); per-kernel durations and HBM GB/s: profiles/"},
             "hbm_roofline": hbm}
@@ -440,10 +581,16 @@ def measure_mg(args, K, W):
 def main_mg(args):
     """Secondary line: the MatterGen-shaped sampler (see measure_mg); the headline `value` stays on the pinned DiffCSP network."""
     K, W = (args.steps if args.steps != 1000 else 10), max(1, min(args.warmup, 2))
-    out = measure_mg(args, K, W)
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_mg()
-    print(json.dumps(out), flush=True)
+    ctx = dist_setup(args.gpus)
+    _apply_env_knobs(__import__("matinvent_amd._lib", fromlist=["load"]).load())
+    out = measure_mg(args, K, W, ctx)
+    if out is not None:
+        if not args.no_cpu_baseline and ctx[0] == 1:
+            out["cpu_baseline"] = cpu_baseline_mg()
+        print(json.dumps(out), flush=True)
+    if ctx[0] > 1:
+        dist_barrier(ctx)
+        ctx[4].destroy_process_group()
 
 
 def main_mg_ft(args):
@@ -484,6 +631,23 @@ def main_mg_ft(args):
                                   f"{Bm} crystals x 20 atoms, synthetic reward; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
                       "batch_per_gpu": Bm, "parameters": int(agent.decoder.theta.numel()),
                       "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}}
+    # dense-layer flops of a timestep = agent forward + frozen-prior forward + backward (data and weight gradients: 2x a forward), at the
+    # set's edge count; the forward's products issue 3 fp16 MFMA terms each, the backward's 3 (edge level) or 6 (node level): priced at 3
+    # (a lower bound on the matrix-pipe work actually issued)
+    gb = agent._batch_for(torch.tensor([NATOM] * min(Bm, 64)))
+    d0 = data[:min(Bm, 64)]
+    c64 = torch.cat([d.cell for d in d0])
+    E64 = int(gb.graph(torch.cat([d.pos for d in d0]), 0.5 * (c64 + c64.transpose(1, 2)))["src"].shape[0])   # (the dataset transform symmetrises the cells)
+    Eset = E64 * Bm / min(Bm, 64)
+    f_eval = mg_flops_eval(agent.decoder.hp, Bm * NATOM, Eset)
+    terms = 3 if _lib.load().mi_plane_format() == 2 else 6
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers: forward, data gradients) + gemm_tn_split_kernel (weight gradients)",
+                       "achieved": terms * 4 * f_eval * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": terms * 4 * f_eval * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                       "achieved_fp32_equivalent": 4 * f_eval * K / elapsed / 1e12, "flops_per_evaluation": f_eval, "edges": Eset,
+                       "note": "end-to-end rate of the dense-layer flops of a timestep (2 forwards + backward = 4 x F_eval_mg) over the whole step time"}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_mg_ft()
     print(json.dumps(out), flush=True)
 
 
@@ -512,7 +676,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="crystal groups of the batch sampled concurrently on separate HIP "
                     "streams (same samples: the noise is indexed by global ids)")
     ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused"], default="split-gemm",
-                    help="arithmetic path: split-gemm (default) = bf16 three-plane split GEMMs, fp32-class accuracy; "
+                    help="arithmetic path: split-gemm (default) = fp32 products on the fp16 matrix pipe from two pre-split fp16 planes per operand "
+                         "(three MFMA terms, f32 accumulate; a -DMI_PLANES_FP16=0 build uses three bf16 planes / six terms), fp32-class accuracy; "
                          "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage")
     ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
     ap.add_argument("--mg-free-chain", action="store_true", help="--mode mg-sample: time the free-running random-init chain (emptying graph) instead of "
@@ -522,6 +687,8 @@ def main():
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not os.environ.get("MI_BENCH_SHARE_GPU") and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} starts one process per GPU over RCCL, but this node shows {torch.cuda.device_count()} GPU(s)")
         sys.exit(_self_launch(args.gpus))
     if args.mode == "ft":
         return main_ft(args)
@@ -534,22 +701,9 @@ def main():
     K, W = args.steps, args.warmup
     assert 1 <= K <= T and 0 <= W <= T, f"steps and warmup must be <= T = {T}"
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("MI_BENCH_SHARE_GPU"):   # test-only: N ranks on ONE GPU over gloo, to exercise the control flow
-            local_rank = 0
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    ctx = dist_setup(args.gpus)
+    world, rank, local_rank, share, dist = ctx
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     from matinvent_amd import _lib, build as _build
     _build.build(verbose=False)
@@ -569,10 +723,7 @@ def main():
     skw = dict(step_lr=STEP_LR, node_offset=rank * N, graph_offset=rank * B, streams=S)  # global ids: shard-invariant noise
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier() if os.environ.get("MI_BENCH_SHARE_GPU") else dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+        dist_barrier(ctx)
 
     # W untimed denoising steps on a throwaway state, then exactly K timed steps of the chain that
     # starts at t = T (its Philox initial state is generated outside the timed region: inputs resident)
@@ -594,10 +745,7 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for v in (final["frac_coords"], final["lattices"], final["atom_types"]))
     sat = _lib.saturation_events(reset=True)   # fp16-plane conversions that clamped during the run (0 = the format held)
 
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if os.environ.get("MI_BENCH_SHARE_GPU") else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = dist_max_time(ctx, elapsed)
 
     if rank == 0:
         value = world * B * K / (T * elapsed)
@@ -677,12 +825,23 @@ def main():
                 # the MatterGen-LABELLED form of the same config (self-consistent, parity-unpinned vs upstream): a short run of its own
                 # sampler, outside the timed region, so that every driver-run record carries it next to the pinned headline
                 try:
-                    mg = measure_mg(args, 6, 1)
-                    out["extra"]["mattergen_shaped_sampler"] = {k: mg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
+                    mg = measure_mg(args, 6, 1, ctx)
+                    out["extra"]["mattergen_shaped_sampler"] = {k: mg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "hbm_roofline")}
                     out["extra"]["mattergen_shaped_sampler"].update(edges_first_step=mg["config"]["edges_first_step"], edges_last_step=mg["config"]["edges_last_step"],
                                                                     parity="self-consistent, PARITY-UNPINNED vs upstream", dense_layer_frac_of_mfma_peak=mg["roofline"]["frac"])
                 except Exception as e:   # (never let the secondary figure take the headline down)
                     out["extra"]["mattergen_shaped_sampler"] = {"error": repr(e)}
+                # BASELINE configs[2] in every driver-run record: a short fine-tune leg (B = 256, 20 timesteps + 3 warm-up, the Adam step
+                # that closes the window -- pipeline/mat_invent.py:150-177), with its own roofline and CPU baseline
+                try:
+                    del m
+                    torch.cuda.empty_cache()
+                    ftl = measure_ft(args, 20, 3, ctx, cpu_budget_s=8.0)
+                    out["extra"]["fine_tune"] = {k: ftl[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline") if k in ftl}
+                    out["extra"]["fine_tune"]["workload"] = ftl["config"]["workload"]
+                    out["extra"]["fine_tune"]["adam_steps_in_timed_region"] = ftl["config"]["adam_steps_in_timed_region"]
+                except Exception as e:
+                    out["extra"]["fine_tune"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -351,6 +351,13 @@ int mi_debug_set_planes_dma(int mode);
  * projections LayerNorm(h) feeds: models/diffcsp/cspnet.py:79-91,61) as ONE launch per layer boundary (csrc/node_chain.hip):
  * 1 (default) = on for hidden_dim 128 / 256 / 512 with LayerNorm, 0 = the seven-launch form.  Returns the previous setting. */
 int mi_debug_set_node_fused(int on);
+/* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
+ * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
+ * 1 (default) = on (needs the node-chain launch above), 0 = the 128 x 128-tile plane GEMM.  Returns the previous setting. */
+int mi_debug_set_edge2_fused(int on);
+/* Phase clock of that launch (measurement only): a device buffer of [workgroups][16] 64-bit words that every workgroup fills with
+ * s_memtime stamps at its phase boundaries; nullptr (default) = off. */
+int mi_debug_node_chain_clock(void* dev_buffer);
 /* Saturation guard of the two-plane fp16 operand format: every fp32 -> plane conversion that had to clamp to the fp16 range (or
  * met a NaN / inf) increments a device-side counter.  Synchronises the device, returns the number of such conversions since the
  * last reset (all networks, all streams of the current device) and clears it when `reset` != 0.  A non-zero count means results

@@ -71,6 +71,8 @@ SIGNATURES = {
     "mi_debug_set_planes_big_seg": (_I, [_I]),
     "mi_debug_set_node_priority": (_I, [_I]),
     "mi_debug_set_node_fused": (_I, [_I]),
+    "mi_debug_node_chain_clock": (_I, [_P]),
+    "mi_debug_set_edge2_fused": (_I, [_I]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),
     "mi_batch_num_edges": (_L, [_P]),

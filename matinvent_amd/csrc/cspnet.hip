@@ -1083,6 +1083,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 } else {
                     MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
                 }
+                if (fused && edge_gemm2_supported(net)) {   // 128-row x H-column register tiles, segmented sum on the matrix pipe (edge_stage.hip)
+                    MI_TRY(edge_gemm2(net, b, l, s));
+                    b->seg_shift = 7;
+                } else {
                 PlanesEpilogue pe2;   // M2 never reaches HBM: the edge -> node sum happens in the epilogue
                 pe2.ep = g2e;
                 pe2.seg_part = b->part;
@@ -1090,6 +1094,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_rowptr = b->rowptr;
                 pe2.seg_nodes = N;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
+                b->seg_shift = 5;
+                }
                 MI_TRY(prof_end(net, s, ps));
                 MI_TRY(to(ns));
                 if (!fused) hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
@@ -1333,7 +1339,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
             Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
-            if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), s));  // the same weights in fragment order (node_chain.hip)
+            if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), W2, s));  // the same weights in fragment order (node_chain.hip)
         }
     }
     if (n->L > 0) {  // weight bounds behind the activation scales of the fp16 plane format (see act_scales_kernel)
@@ -1592,11 +1598,15 @@ int mi_debug_set_node_priority(int on) {
 }
 
 int mi_debug_set_planes_big_seg(int min_rows) {
+    MI_CHECK(min_rows <= 0 || MI_HAVE_ABLATION_KERNELS, MI_EINVAL, "the segmented-sum epilogue on the 256 x 256 kernel is an ablation instantiation: rebuild with "
+             "MI_EXTRA_FLAGS=-DMI_ABLATION_KERNELS");
     g_planes_big_seg_min_rows = min_rows;
     return MI_OK;
 }
 
 int mi_debug_set_planes_dma(int mode) {
+    MI_CHECK(mode < 4 || MI_HAVE_ABLATION_KERNELS, MI_EINVAL, "mode 4 (the four-waves-per-SIMD build of the 128-row loop) is an ablation instantiation: rebuild with "
+             "MI_EXTRA_FLAGS=-DMI_ABLATION_KERNELS");
     g_planes_dma = mode;
     return MI_OK;
 }

@@ -67,6 +67,15 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) 
 #ifndef MI_PLANES_FP16
 #define MI_PLANES_FP16 1
 #endif
+// Ablation-only instantiations that SPILL registers (the segmented-sum epilogue on the 256 x 256 LDS-DMA kernel: 576 B of scratch; the
+// four-waves-per-SIMD build of the 128-row loop: 15-16 spilled registers) are compiled only with -DMI_ABLATION_KERNELS: the default library
+// ships no kernel with scratch on any path, and the switches that select them (mi_debug_set_planes_big_seg, mi_debug_set_planes_dma(4))
+// return MI_EINVAL without it.
+#ifdef MI_ABLATION_KERNELS
+#define MI_HAVE_ABLATION_KERNELS 1
+#else
+#define MI_HAVE_ABLATION_KERNELS 0
+#endif
 constexpr int NPL = MI_PLANES_FP16 ? 2 : 3;
 // scales by operand class (a plane set carries its scale in Planes::scale; the GEMM multiplies the accumulator by 1 / (sA sW)):
 constexpr float PL_SW = MI_PLANES_FP16 ? 64.f : 1.f;      // weights: exact up to |w| = 1023, residual plane normal down to |w| ~ 2e-3
@@ -118,6 +127,26 @@ __device__ __forceinline__ void pl_split_pair(float x, float y, float scale, uns
     (void)scale;
     split3_pair(x, y, p);
 #endif
+}
+// The same with the saturation test ACCUMULATED into `sat` (non-zero = some conversion clamped or met a NaN) instead of a branch with an
+// atomic per conversion: lets the compiler schedule a whole epilogue as straight-line code; the caller reports once with sat_report().
+__device__ __forceinline__ void pl_split_pair_acc(float x, float y, float scale, unsigned (&p)[3], unsigned& sat) {
+#if MI_PLANES_FP16
+    const float xr = x * scale, yr = y * scale;
+    sat |= (unsigned)(!(fabsf(xr) <= 65504.f)) | (unsigned)(!(fabsf(yr) <= 65504.f));
+    const float xs = fminf(fmaxf(xr, -65504.f), 65504.f), ys = fminf(fmaxf(yr, -65504.f), 65504.f);
+    const f16x2 h0 = {(_Float16)xs, (_Float16)ys};
+    p[0] = __builtin_bit_cast(unsigned, h0);
+    p[1] = pack_f16(xs - (float)h0[0], ys - (float)h0[1]);
+    p[2] = 0u;
+#else
+    (void)scale;
+    (void)sat;
+    split3_pair(x, y, p);
+#endif
+}
+__device__ __forceinline__ void sat_report(unsigned sat) {
+    if (sat) atomicAdd(&g_sat_events, 1u);
 }
 __device__ __forceinline__ void pl_split(float x, float scale, u16& p0, u16& p1, u16& p2) {
 #if MI_PLANES_FP16
@@ -1804,7 +1833,8 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     // pair mode has twice the epilogue per row of MFMA work: two workgroups per CU (128-row kernel) hide it behind each other's main
     // loop, which measured faster than the one-workgroup-per-CU kernel at every size tried
     // (the 256-row double-buffered kernel only exists for the three-plane bf16 format)
-    if (!MI_PLANES_FP16 && g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= g_planes_db_min_tiles && !(pair && g_pair_kernel == 0)) {
+#if !MI_PLANES_FP16   // (the two-plane fp16 build never takes this branch: its instantiations -- one of which spills -- are not compiled there)
+    if (g_planes_variant == 1 && (int64_t)cdiv(M, 256) * nct >= g_planes_db_min_tiles && !(pair && g_pair_kernel == 0)) {
         static bool attr_set = false;
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_db_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DB_LDS));
@@ -1816,7 +1846,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         const dim3 grid(nct * ((cdiv(M, 256) + 7) / 8 * 8));
         if (pair) hipLaunchKernelGGL(gemm_planes_db_kernel<true>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
         else hipLaunchKernelGGL(gemm_planes_db_kernel<false>, grid, dim3(512), GEMM_DB_LDS, s, A, W, M, N, K, pe, M);
-    } else if (pair) {
+    } else
+#endif
+    if (pair) {
         int nblk = nct * ((cdiv(M, 128) + 7) / 8 * 8);
         const bool lat = nblk <= g_planes_lat_max_blocks;
         const bool dma = MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && lat));
@@ -1829,27 +1861,35 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
     } else if (MI_PLANES_FP16 && (N & 255) == 0 &&
                ((g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && planes_epilogue_is_rows(pe, N)) ||
-                (g_planes_big_seg_min_rows > 0 && M >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act && !planes_epilogue_is_rows(pe, N)))) {
+                (MI_HAVE_ABLATION_KERNELS && g_planes_big_seg_min_rows > 0 && M >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act &&
+                 !planes_epilogue_is_rows(pe, N)))) {
 #if MI_PLANES_FP16
         static bool attr_set = false;
         if (!attr_set) {
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
+#if MI_HAVE_ABLATION_KERNELS
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_LDS));
+#endif
             attr_set = true;
         }
         const dim3 grid((N >> 8) * ((cdiv(M, 256) + 7) / 8 * 8));
+#if MI_HAVE_ABLATION_KERNELS
         if (!planes_epilogue_is_rows(pe, N)) hipLaunchKernelGGL((gemm_planes_big_kernel<false, true>), grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
-        else if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
+        else
+#endif
+        if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
         else hipLaunchKernelGGL(gemm_planes_big_kernel<false>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
 #endif
     } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
+#if MI_HAVE_ABLATION_KERNELS
     } else if (g_planes_dma >= 4 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= 256) {   // mode 4: one-round launches on the four-waves-per-SIMD build
         if (ext) hipLaunchKernelGGL((gemm_planes_slim_kernel<true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_slim_kernel<false>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
+#endif
     } else if (MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) ||
                                   (g_planes_dma >= 3 && nct * ((cdiv(M, 128) + 7) / 8 * 8) > 256))) {   // (modes 3 / 4: the LDS-DMA form for the LARGE launches only)
         if (ext) hipLaunchKernelGGL((gemm_planes_dma_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);

@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "gemm_split.h"
 
 namespace mi {
@@ -1085,8 +1087,17 @@ struct mi_gemnet {
         mi::u16* pl;
         float* rowsum;   // device: largest row sum of |W| of the block (output bounds)
         float scale;     // host: power-of-two scale of the block's plane set
+        // the build is enqueued on the stream of the first use: a use on ANOTHER stream waits for `ready` until it has been seen complete
+        hipEvent_t ready = nullptr;
+        hipStream_t built_on = nullptr;
+        bool done = false;
     };
     std::map<int64_t, WPl> wplanes;
+    // Forwards of one network run from several host threads (MatterGenModule.sample(chains > 1): a chain per thread and stream), and plane
+    // mode is decided per batch (E >= 4096, E rebuilt by every forward), so any forward may be the first use of a block: the map and the
+    // two bump allocators below are guarded by this mutex, and cross-stream readers by the blocks' events.
+    std::mutex wmu;
+    std::vector<hipEvent_t> wevents;   // owned: destroyed when the plane sets are dropped
     mi::u16* warena = nullptr;
     size_t warena_elems = 0, warena_top = 0;
     float* wrowsum = nullptr;          // [1024] device floats handed out with the blocks
@@ -1319,12 +1330,29 @@ struct OpTimer {
 
 static inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
+// (both under net->wmu)  publish: the block's build has just been enqueued on `s`.  join: a later use on stream `s`.
+static int wpl_publish(mi_gemnet* net, mi_gemnet::WPl& e, hipStream_t s) {
+    MI_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+    net->wevents.push_back(e.ready);
+    MI_HIP(hipEventRecord(e.ready, s));
+    e.built_on = s;
+    return MI_OK;
+}
+static int wpl_join(mi_gemnet::WPl& e, hipStream_t s) {
+    if (e.done || e.built_on == s) return MI_OK;   // (same stream: ordered behind the build anyway)
+    if (hipEventQuery(e.ready) == hipSuccess) e.done = true;
+    else MI_HIP(hipStreamWaitEvent(s, e.ready, 0));
+    return MI_OK;
+}
+
 // plane set (+ largest |row| sum) of the weight block W[:, wcol0 : wcol0 + K], built on first use after mi_gemnet_set_params
 static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) {
     mi_gemnet* net = c.net;
     const int64_t key = ((int64_t)pidx << 40) | ((int64_t)wcol0 << 16) | (int64_t)K;
+    std::lock_guard<std::mutex> guard(net->wmu);
     auto it = net->wplanes.find(key);
     if (it != net->wplanes.end()) {
+        MI_TRY(wpl_join(it->second, c.s));
         *out = it->second;
         return MI_OK;
     }
@@ -1347,6 +1375,7 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     MI_HIP(hipMemsetAsync(e.rowsum, 0, sizeof(float), c.s));
     hipLaunchKernelGGL(rowsum_max_kernel, dim3((unsigned)std::min(64, (w.rows + 3) / 4)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
     MI_KERNEL_CHECK();
+    MI_TRY(wpl_publish(net, e, c.s));
     net->wplanes[key] = e;
     *out = e;
     return MI_OK;
@@ -1356,8 +1385,10 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
 // dX[M, K] += dZ[M, N] W[:, wcol0 : wcol0 + K]; built on first use after mi_gemnet_set_params (the forward has allocated the arena)
 static int get_wtplanes(mi_gemnet* net, hipStream_t s, int pidx, int wcol0, int K, mi_gemnet::WPl* out) {
     const int64_t key = ((int64_t)1 << 62) | ((int64_t)pidx << 40) | ((int64_t)wcol0 << 16) | (int64_t)K;
+    std::lock_guard<std::mutex> guard(net->wmu);
     auto it = net->wplanes.find(key);
     if (it != net->wplanes.end()) {
+        MI_TRY(wpl_join(it->second, s));
         *out = it->second;
         return MI_OK;
     }
@@ -1371,6 +1402,7 @@ static int get_wtplanes(mi_gemnet* net, hipStream_t s, int pidx, int wcol0, int 
     const int64_t nthr = (int64_t)((K + 127) / 128 * 128) * P.KT * 16;
     hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, s, net->thetaT + w.toff + (size_t)wcol0 * w.ldt, w.ldt, K, w.rows, P, 0);
     MI_KERNEL_CHECK();
+    MI_TRY(wpl_publish(net, e, s));
     net->wplanes[key] = e;
     *out = e;
     return MI_OK;
@@ -2244,6 +2276,7 @@ void mi_gemnet_destroy(mi_gemnet* net) {
     if (net->dtheta) (void)hipFree(net->dtheta);
     if (net->warena) (void)hipFree(net->warena);
     if (net->wrowsum) (void)hipFree(net->wrowsum);
+    for (hipEvent_t e : net->wevents) (void)hipEventDestroy(e);
     delete net;
 }
 int64_t mi_gemnet_num_params(const mi_gemnet* net) { return net ? net->nparams : 0; }
@@ -2290,7 +2323,10 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
             memcpy(&m, &bits[i], 4);
             if (m > 0.f && m < 3e38f) net->wscale_h[i] = exp2f((float)std::min(30, 14 - (int)ceilf(log2f(m))));
         }
+        std::lock_guard<std::mutex> guard(net->wmu);
         net->wplanes.clear();
+        for (hipEvent_t e : net->wevents) (void)hipEventDestroy(e);
+        net->wevents.clear();
         net->warena_top = 0;
         net->wrowsum_used = 0;
     }

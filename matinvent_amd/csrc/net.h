@@ -81,6 +81,7 @@ struct mi_batch {
     int64_t E = 0;      // edges of the current graph (fixed for fc; rewritten by every forward for knn)
     int64_t E_cap = 0;  // edge capacity every per-edge buffer is sized for (= E for fc)
     int nslots = 1;
+    int seg_shift = 5;  // log2 of the row-block size behind the partial sums currently in `part` (5: plane GEMM epilogue; 7: edge_stage.hip)
     // knn edge style (CSPNet.gen_edges knn branch, graph.hip)
     int knn = 0, max_neighbors = 0, cap_per_node = 0, deg_cap = 0, nmax = 0;
     // pair tables of the fc edge list (unordered node pairs i < j of each crystal): the first edge GEMM runs over pairs
@@ -154,7 +155,10 @@ int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);
 // node_chain.hip: the node-level chain between two edge stages of an inference forward as one launch
 bool node_chain_supported(const mi_net* net);
 size_t node_chain_pack_elems(int H);
-int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s);
+int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, const float* W2, hipStream_t s);
+// edge_stage.hip: the second edge GEMM + edge -> node reduction on 128-row x H-column register tiles (inference, hidden_dim 512)
+bool edge_gemm2_supported(const mi_net* net);
+int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s);
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
 }  // namespace mi

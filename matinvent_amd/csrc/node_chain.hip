@@ -25,6 +25,7 @@
 
 namespace mi {
 
+unsigned long long* g_node_clk = nullptr;
 int g_node_fused = 1;  // inference forwards: the node-level chain as one launch per layer boundary (0: the seven-launch form)
 
 #if MI_PLANES_FP16
@@ -56,6 +57,7 @@ struct NodeChainArgs {
     // phase A (nullptr part: skipped -- the chain starts at h_in, the embedding's output)
     const float* part = nullptr;    // [nslots][N][H] partial sums of the edge -> node reduction
     const int* rowptr = nullptr;    // [N + 1] CSR rows (degree, slots)
+    int seg_shift = 5;              // log2 of the row-block size the partial sums were formed over (32 rows: plane GEMM; 128: edge_stage.hip)
     const float* xpart = nullptr;   // LayerNorm(h) W0[:, :H]^T of layer l-1 (computed with its P_i / P_j), row stride ld_xpart
     int ld_xpart = 0;
     const u16* Wagg = nullptr;      // fragment-order packs (H x H)
@@ -73,6 +75,7 @@ struct NodeChainArgs {
     const u16* Wln = nullptr;       // fragment-order pack (3H x H)
     float* PQ = nullptr;            // [N][3H]
     unsigned* absmax = nullptr;     // atomicMax of the bit pattern of max |PQ|
+    unsigned long long* clk = nullptr;  // optional phase clock: [workgroup][16] s_memtime stamps (mi_debug_node_chain_clock)
 };
 
 template <int H>
@@ -95,6 +98,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const int l31 = lane & 31, kg = lane >> 5;
     const int row0 = blockIdx.x * 32, N = a.N;
 
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.clk && tid == 0) a.clk[(size_t)blockIdx.x * 16 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
     u32x4 ring[D][TW][2];
     f32x16 acc[TW];
     // ---- weight ring: k-steps ks .. ks + D - 1 of the wave's TW column tiles (first tile ct0) in flight ----
@@ -163,100 +172,152 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const int wsz = H * H * 4;  // bytes of one packed H x H operand
     if (phaseA) {
         const __amdgpu_buffer_rsrc_t rs_agg = uniform_rsrc(a.Wagg, wsz);
-        ring_fill(rs_agg, wave * TW);   // in flight under the aggregation
         // ---- A1: agg = (sum of the node's slots) / degree -> planes (finalize_agg_kernel's arithmetic) ----
         const float s_agg = a.dsc[2];
-#pragma unroll 2
-        for (int r = 0; r < RPW; ++r) {
-            const int row = wave * RPW + r, i = row0 + row, c0 = lane * 8;
-            if (c0 < H) {
-                f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
-                if (i < N) {
-                    const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
-                    if (e1 > e0) {
-                        const int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
-                        for (int sl = 0; sl <= t1 - t0; ++sl) {
-                            const float* p = a.part + ((size_t)sl * N + i) * H + c0;
-                            x += *reinterpret_cast<const f32x4*>(p);
-                            y += *reinterpret_cast<const f32x4*>(p + 4);
-                        }
-                        const float d = (float)(e1 - e0);
+        unsigned sat = 0;
+        {
+            // all of the wave's rows at once: the row pointers, then the first two slots of every row (the common case: a node's edges
+            // span at most two 32-row blocks), then the arithmetic -- one chain of two dependent load latencies instead of one per row
+            const int c0 = lane * 8;
+            const bool act = c0 < H;
+            int e0[RPW], e1[RPW];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            x[k] = x[k] / d;
-                            y[k] = y[k] / d;
-                        }
+            for (int r = 0; r < RPW; ++r) {
+                const int i = row0 + wave * RPW + r;
+                e0[r] = i < N ? a.rowptr[i] : 0;
+                e1[r] = i < N ? a.rowptr[i + 1] : 0;
+            }
+            f32x4 x[RPW], y[RPW], x1[RPW], y1[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int i = row0 + wave * RPW + r;
+                const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
+                x[r] = y[r] = x1[r] = y1[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (act && ns > 0) {
+                    const float* p = a.part + (size_t)i * H + c0;
+                    x[r] = *reinterpret_cast<const f32x4*>(p);
+                    y[r] = *reinterpret_cast<const f32x4*>(p + 4);
+                    if (ns > 1) {
+                        x1[r] = *reinterpret_cast<const f32x4*>(p + (size_t)N * H);
+                        y1[r] = *reinterpret_cast<const f32x4*>(p + (size_t)N * H + 4);
+                    }
+                }
+            }
+            // (vector loads return in order: the ring fill goes BEHIND the gathers, so that the arithmetic waits for the gathers only and
+            // the weights land while it runs)
+            ring_fill(rs_agg, wave * TW);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, i = row0 + row;
+                const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
+                if (!act) continue;
+                f32x4 xs = x[r], ys = y[r];
+                if (ns > 1) {
+                    xs += x1[r];
+                    ys += y1[r];
+                    for (int sl = 2; sl < ns; ++sl) {
+                        const float* p = a.part + ((size_t)sl * N + i) * H + c0;
+                        xs += *reinterpret_cast<const f32x4*>(p);
+                        ys += *reinterpret_cast<const f32x4*>(p + 4);
+                    }
+                }
+                if (ns > 0) {
+                    const float d = (float)(e1[r] - e0[r]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xs[k] = xs[k] / d;
+                        ys[k] = ys[k] / d;
                     }
                 }
                 u32x4 pk[2];
                 unsigned pr[3];
-                pl_split_pair(x[0], x[1], s_agg, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1];
-                pl_split_pair(x[2], x[3], s_agg, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1];
-                pl_split_pair(y[0], y[1], s_agg, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1];
-                pl_split_pair(y[2], y[3], s_agg, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+                pl_split_pair_acc(xs[0], xs[1], s_agg, pr, sat); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                pl_split_pair_acc(xs[2], xs[3], s_agg, pr, sat); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                pl_split_pair_acc(ys[0], ys[1], s_agg, pr, sat); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                pl_split_pair_acc(ys[2], ys[3], s_agg, pr, sat); pk[0][3] = pr[0]; pk[1][3] = pr[1];
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
             }
         }
         __syncthreads();
+        stamp();
         // ---- A2: Z = agg W0b^T (transposed) ----
         run(TRt{}, rs_agg, wave * TW);
+        stamp();
         const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
-        ring_fill(rs_n2, wave * TW);    // in flight under the epilogue
         __syncthreads();                // every wave has read the agg planes
-        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes ----
+        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes (every gather requested before the arithmetic) ----
         {
             const float os = a.dsc[3] * (1.f / PL_SW), s_x = a.dsc[4];
             const int i = row0 + l31;
+            f32x4 bq[TW][4], xq[TW][4];
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.b0 + c4);
-                    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
-                    if (i < N) xp = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + c4);
+                    bq[t][q] = *reinterpret_cast<const f32x4*>(a.b0 + c4);
+                    xq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < N) xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + c4);
+                }
+            ring_fill(rs_n2, wave * TW);    // behind the gathers, in flight under the arithmetic
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
                     float v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = silu_fast((acc[t][4 * q + k] * os + b[k]) + xp[k]);
-                    if (i >= N) v[0] = v[1] = v[2] = v[3] = 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = i < N ? silu_fast((acc[t][4 * q + k] * os + bq[t][q][k]) + xq[t][q][k]) : 0.f;
                     unsigned p01[3], p23[3];
-                    pl_split_pair(v[0], v[1], s_x, p01);
-                    pl_split_pair(v[2], v[3], s_x, p23);
+                    pl_split_pair_acc(v[0], v[1], s_x, p01, sat);
+                    pl_split_pair_acc(v[2], v[3], s_x, p23, sat);
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
                         const uint2 wv = make_uint2(p01[pl], p23[pl]);
                         *reinterpret_cast<uint2*>(P + pl * PLB + l31 * ROWB + c4 * 2) = wv;
                     }
                 }
+            sat_report(sat);
         }
         __syncthreads();
+        stamp();
         // ---- A4: Y = X W2^T (transposed) ----
         run(TRt{}, rs_n2, wave * TW);
-        if (phaseB) ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);   // pass 0 of phase B, in flight under the epilogue and the LayerNorm
+        stamp();
         // ---- A5: h' = h + SiLU(Y + b2) -> Hs ----
         {
             const float os = a.dsc[5] * (1.f / PL_SW);
             const int i = row0 + l31;
+            f32x4 bq[TW][4], hq[TW][4];
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + c4);
-                    f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-                    if (i < N) hv = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c4);
+                    bq[t][q] = *reinterpret_cast<const f32x4*>(a.b2 + c4);
+                    hq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < N) hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c4);
+                }
+            if (phaseB) ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);   // pass 0 of phase B, in flight under the epilogue and the LayerNorm
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
                     f32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = silu_fast(acc[t][4 * q + k] * os + b[k]) + hv[k];
+                    for (int k = 0; k < 4; ++k) o[k] = silu_fast(acc[t][4 * q + k] * os + bq[t][q][k]) + hq[t][q][k];
                     *reinterpret_cast<f32x4*>(Hs + l31 * HLD + c4) = o;
                 }
         }
         __syncthreads();
+        stamp();
     } else if (phaseB) {
         ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);
     }
     // ---- LayerNorm (layernorm_kernel's arithmetic: a wave per row, a lane owns eight consecutive columns) ----
+    unsigned sat_ln = 0;
     {
         const int c0 = lane * 8;
         const bool act = c0 < H;
@@ -308,17 +369,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             if (act && phaseB) {
                 u32x4 pk[2];
                 unsigned pr[3];
-                pl_split_pair(o0[0], o0[1], PL_S_LN, pr); pk[0][0] = pr[0]; pk[1][0] = pr[1];
-                pl_split_pair(o0[2], o0[3], PL_S_LN, pr); pk[0][1] = pr[0]; pk[1][1] = pr[1];
-                pl_split_pair(o1[0], o1[1], PL_S_LN, pr); pk[0][2] = pr[0]; pk[1][2] = pr[1];
-                pl_split_pair(o1[2], o1[3], PL_S_LN, pr); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+                pl_split_pair_acc(o0[0], o0[1], PL_S_LN, pr, sat_ln); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                pl_split_pair_acc(o0[2], o0[3], PL_S_LN, pr, sat_ln); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                pl_split_pair_acc(o1[0], o1[1], PL_S_LN, pr, sat_ln); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                pl_split_pair_acc(o1[2], o1[3], PL_S_LN, pr, sat_ln); pk[0][3] = pr[0]; pk[1][3] = pr[1];
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
             }
         }
     }
+    sat_report(sat_ln);
     if (!phaseB) return;
     __syncthreads();
+    stamp();
     // ---- phase B: [P_i | P_j | X_part] = y Wln^T, three passes of H columns (lane = column, registers = rows) ----
     {
         const __amdgpu_buffer_rsrc_t rs_ln = uniform_rsrc(a.Wln, 3 * wsz);
@@ -328,6 +391,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         for (int pass = 0; pass < 3; ++pass) {
             const int ct0 = (pass * H + wave * CW) / 32;
             run(TRf{}, rs_ln, ct0);
+            stamp();
             if (pass < 2) ring_fill(rs_ln, ((pass + 1) * H + wave * CW) / 32);
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
@@ -348,6 +412,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             if (lane == 0) atomicMax(a.absmax, __float_as_uint(m));
         }
+        stamp();
     }
 }
 
@@ -364,10 +429,10 @@ static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
 
 bool node_chain_supported(const mi_net* net) { return g_node_fused && net->cfg.ln && (net->H == 128 || net->H == 256 || net->H == 512) && net->Wnc != nullptr; }
 
-size_t node_chain_pack_elems(int H) { return (size_t)5 * H * H * 2; }  // per layer: [Wagg | Wn2 | Wln] x two planes (u16 elements)
+size_t node_chain_pack_elems(int H) { return (size_t)6 * H * H * 2; }  // per layer: [Wagg | Wn2 | Wln (3H rows) | W2 (edge_mlp.2, edge_stage.hip)] x two planes (u16 elements)
 
 // packs of layer l (called by mi_net_set_params): Wagg = node_mlp.0.weight[:, H:], Wn2 = node_mlp.2.weight, Wln = [W1[:, :H]; W1[:, H:2H]; node_mlp.0.weight[:, :H]]
-int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s) {
+int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, const float* W2, hipStream_t s) {
     const int H = net->H;
     u16* base = net->Wnc + (size_t)l * node_chain_pack_elems(H);
     const int nb = cdiv((int64_t)H * (H / 8), 256);
@@ -377,6 +442,7 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
     hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, W1, net->edge_in, H, H, wln, 0);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, W1 + H, net->edge_in, H, H, wln, H);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, Wn0, 2 * H, H, H, wln, 2 * H);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(nb), dim3(256), 0, s, W2, H, H, H, base + (size_t)5 * H * H * 2, 0);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -387,11 +453,13 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
     const size_t NH = (size_t)N * H;
     NodeChainArgs a;
     a.N = N;
+    a.clk = g_node_clk;
     if (l > 0) {
         const std::string p = "csp_layer_" + std::to_string(l - 1) + ".";
         const u16* base = net->Wnc + (size_t)(l - 1) * node_chain_pack_elems(H);
         a.part = b->part;
         a.rowptr = b->rowptr;
+        a.seg_shift = b->seg_shift;
         a.xpart = b->PQ + 2 * H;
         a.ld_xpart = 3 * H;
         a.Wagg = base;
@@ -416,7 +484,7 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
         a.ln_b = net->p("final_layer_norm.bias");
         a.hf = b->hf;
     }
-    if (H == 512) return g_node_fused == 2 ? node_chain_launch<512, 4, 4>(a, s) : node_chain_launch<512, 8, 8>(a, s);
+    if (H == 512) return g_node_fused == 2 ? node_chain_launch<512, 8, 8>(a, s) : node_chain_launch<512, 8, 4>(a, s);
     if (H == 256) return node_chain_launch<256, 8, 4>(a, s);
     return node_chain_launch<128, 4, 4>(a, s);
 }
@@ -425,15 +493,20 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
 
 bool node_chain_supported(const mi_net*) { return false; }
 size_t node_chain_pack_elems(int) { return 0; }
-int node_chain_pack(mi_net*, int, const float*, const float*, const float*, hipStream_t) { return MI_OK; }
+int node_chain_pack(mi_net*, int, const float*, const float*, const float*, const float*, hipStream_t) { return MI_OK; }
 int node_chain(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
 
 #endif
 
 }  // namespace mi
 
+extern "C" int mi_debug_node_chain_clock(void* dev_buffer) {
+    mi::g_node_clk = (unsigned long long*)dev_buffer;
+    return MI_OK;
+}
+
 extern "C" int mi_debug_set_node_fused(int on) {
     const int was = mi::g_node_fused;
-    mi::g_node_fused = on;  // (2: the four-wave form at hidden_dim 512 -- ablation)
+    mi::g_node_fused = on;  // (2: the deeper weight ring at hidden_dim 512 -- ablation)
     return was;
 }

@@ -224,15 +224,29 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
             allreduce_flat_(theta.grad)
             optimizer.step()
             optimizer.zero_grad(set_to_none=False)
-        allreduce_flat_(acc)
-        a = acc.tolist()  # the only host sync of the epoch
-        from . import _lib
-        _lib.check_saturation("ft_step")
+        a = _epoch_reduce(acc, "ft_step")
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:
             log(f"Epoch {epoch}: " + ", ".join(f"{k}: {v:.4f}" for k, v in d.items()))
     return stats
+
+
+def _epoch_reduce(acc, where):
+    """End of an epoch on every rank: sum the loss accumulators over the ranks and, in the same collective, the ranks' saturation counts
+    of the two-plane fp16 format -- a rank-local check would raise on one rank while its peers go on to the next epoch's all-reduces
+    (a hang instead of an error).  Returns the accumulators as a list; raises FloatingPointError on EVERY rank when any rank saturated."""
+    from . import _lib
+    n_local = _lib.saturation_events(reset=True)   # (synchronises the device: the epoch's kernels have finished)
+    buf = torch.cat([acc.to(torch.float32), torch.tensor([float(min(n_local, 1 << 24))], device=acc.device)])
+    allreduce_flat_(buf)
+    a = buf.tolist()  # the only host read of the epoch
+    if a[-1] > 0:
+        raise FloatingPointError(
+            f"{where}: {int(a[-1])} operand conversions (summed over the ranks; {n_local} on this one) saturated the two-plane fp16 format "
+            "(values beyond 65504 / scale, or NaN / inf upstream): the results are outside the stated fp32-class tolerance.  Rebuild with "
+            "MI_EXTRA_FLAGS=-DMI_PLANES_FP16=0 (three bf16 planes, no range limit) or use --path f32-gemm")
+    return a[:-1]
 
 
 PRIOR_ON_AUX_STREAM = True   # module-surface loop: the frozen prior's forward concurrently with the agent's
@@ -310,8 +324,7 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
             allreduce_flat_(theta.grad)
             optimizer.step()
             optimizer.zero_grad(set_to_none=False)
-        allreduce_flat_(acc)
-        a = acc.tolist()
+        a = _epoch_reduce(acc, "ft_step")
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:
@@ -328,14 +341,16 @@ def _ft_step_empty_shard(agent, n_global, lr, accum_steps, epochs, timesteps, lo
     stats = []
     for epoch in range(epochs):
         theta.grad.zero_()
+        # the Philox call id advances once per timestep on the ranks that hold data: keep this rank's counter in step, so that the noise of
+        # later ft_steps does not depend on which ranks had empty shards before (world-size invariance of the global-id noise)
+        agent._noise_calls = getattr(agent, "_noise_calls", 0) + timesteps
         n_steps = timesteps // accum_steps + (1 if timesteps % accum_steps else 0)
         for _ in range(n_steps):
             allreduce_flat_(theta.grad)
             optimizer.step()
             optimizer.zero_grad(set_to_none=False)
         acc = torch.zeros(3, device=theta.device)
-        allreduce_flat_(acc)
-        a = acc.tolist()
+        a = _epoch_reduce(acc, "ft_step")
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:
@@ -404,10 +419,7 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
         for k in range(groups):
             main.wait_event(streams[k].record_event())
         acc = torch.stack(accs).sum(0)
-        allreduce_flat_(acc)
-        a = acc.tolist()  # the only host sync of the epoch
-        from . import _lib
-        _lib.check_saturation("ft_step")
+        a = _epoch_reduce(acc, "ft_step")
         d = dict(loss=a[0] / timesteps, loss_diff=a[1] / timesteps / n_global, loss_kl=a[2] / timesteps / n_global)
         stats.append(d)
         if rank == 0:

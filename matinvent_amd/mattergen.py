@@ -463,14 +463,9 @@ class MatterGenModule(nn.Module):
             n0 = [sum(na_all[:c]) for c in cuts]
             self.decoder.sync()
             cur = torch.cuda.current_stream()
-            if getattr(self.decoder, "_planes_gen", -1) != getattr(self.decoder, "_sync_gen", 0):
-                # the library builds a weight block's plane set at its first use after a parameter upload, on the stream of that use: one
-                # step of the first chain on the caller's stream builds them all before several streams read them
-                st0 = None if state is None else dict(pos=state["pos"][n0[0]:n0[1]], cell=state["cell"][g0[0]:g0[1]],
-                                                     atomic_numbers=state["atomic_numbers"][n0[0]:n0[1]])
-                self._sample_chain(na_all[g0[0]:g0[1]], n_steps, eps_t, seed, None, min(n_steps, i_start + 1), node_offset + n0[0], graph_offset + g0[0],
-                                   i_start, st0, slot=1)
-                self.decoder._planes_gen = getattr(self.decoder, "_sync_gen", 0)
+            # (the library builds a weight block's plane set at its first use after a parameter upload, on the stream of that use; the lazy
+            # build is guarded by a mutex and later uses on other streams wait for the block's event -- csrc/gemnet.hip get_wplanes --
+            # so the chains can start at once, whichever of them meets a block first)
             ready = cur.record_event()
             pool = concurrent_streams(chains, self.device)
             out, err = [None] * chains, [None] * chains
@@ -571,8 +566,20 @@ class MatterGenSampler:
             na = counts[bi * batch_size:(bi + 1) * batch_size]
             lo, hi = shard_range(len(na), rank, world)
             self.seed += 1
-            _, mean = model.sample(na[lo:hi], n_steps=self.n_steps, eps_t=self.eps_t, seed=self.seed, node_offset=int(np.sum(na[:lo])), graph_offset=lo,
-                                   chains=kwargs.get("chains"))
+            try:
+                _, mean = model.sample(na[lo:hi], n_steps=self.n_steps, eps_t=self.eps_t, seed=self.seed, node_offset=int(np.sum(na[:lo])), graph_offset=lo,
+                                       chains=kwargs.get("chains"))
+            except RuntimeError as e:
+                # A crystal whose cell collapses mid-chain (plausible with an untrained or diverging denoiser and the Langevin cell
+                # corrector) overflows the periodic graph's per-atom capacities; the library refuses to truncate the neighbour list
+                # (MI_ENOMEM "periodic graph: capacity exceeded").  Such a batch is DISCARDED -- the RL step goes on with the other
+                # batches' crystals, as the reference's invalid_filter would have dropped the collapsed ones (opt_filter.py:49-61).
+                if "periodic graph" not in str(e):
+                    raise
+                import logging
+                logging.getLogger(__name__).warning("MatterGenSampler.generate: batch %d discarded (%s)", bi, e)
+                _lib.saturation_events(reset=True)
+                continue
             _lib.check_saturation("MatterGenSampler.generate")
             from .structure import check_structures_counts   # geometric validity quantities where the final state lives (K18)
             geom = check_structures_counts(mean["num_atoms"], mean["pos"], mean["cell"]).cpu()

@@ -179,9 +179,12 @@ def test_latency_forms_in_the_network_bit_identical(na):
     finals = []
     try:
         for dma, lat, bigseg, hi in ((0, 0, 0, 0), (0, 256, 0, 0), (1, 256, 0, 0), (2, 0, 0, 0), (1, 256, 1, 0), (1, 256, 0, 1), (3, 256, 0, 0), (4, 256, 0, 0)):
-            _lib.check(lib.mi_debug_set_planes_dma(dma))
+            # (the instantiations that spill registers -- dma mode 4, the big-tile segmented-sum epilogue -- exist only in a
+            #  -DMI_ABLATION_KERNELS build: their switches refuse otherwise, and the configuration is skipped)
+            if lib.mi_debug_set_planes_dma(dma) != 0 or lib.mi_debug_set_planes_big_seg(bigseg) != 0:
+                lib.mi_debug_set_planes_dma(1)
+                continue
             _lib.check(lib.mi_debug_set_planes_latency(lat))
-            _lib.check(lib.mi_debug_set_planes_big_seg(bigseg))   # (1: the second edge GEMM on the 256 x 256 LDS-DMA kernel, whatever its row count)
             _lib.check(lib.mi_debug_set_node_priority(hi))        # (1: node-level kernels on the batch's high-priority helper stream, joined by events)
             final, _ = m.sample(Box(na), seed=5, step_lr=5e-6, t_start=1000, t_stop=997, streams=1)
             torch.cuda.synchronize()

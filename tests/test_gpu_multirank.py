@@ -201,6 +201,22 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
     f = _bench(["--mode", "ft", "--gpus", "2", "--steps", "2", "--warmup", "1"], {"MI_BENCH_SHARE_GPU": "1"})
     assert f["n_gpus"] == 2 and f["unit"] == "crystal-timesteps/s" and f["value"] > 0 and f["config"]["comm_backend"] == "gloo"
     assert "roofline" in f and f["roofline"]["launches"] > 0
+    g = _bench(["--mode", "mg-sample", "--gpus", "2", "--steps", "1", "--warmup", "1", "--mg-batch", "16", "--mg-chains", "1", "--no-cpu-baseline"],
+               {"MI_BENCH_SHARE_GPU": "1"})
+    assert g["n_gpus"] == 2 and g["value"] > 0 and g["config"]["comm_backend"] == "gloo" and g["config"]["world_size"] == 2
+    assert g["hbm_roofline"]["frac"] > 0 and g["hbm_roofline"]["algorithmic_bytes_per_crystal_evaluation"] > 1e6
+
+
+def test_bench_refuses_more_ranks_than_gpus_with_a_message():
+    """`--gpus N` on a node with fewer GPUs must fail at once with a clear message (one process per GPU over RCCL), not hang in a collective."""
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MI_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "one process per GPU" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-500:]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
