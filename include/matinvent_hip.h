@@ -355,6 +355,16 @@ int mi_debug_set_node_fused(int on);
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
  * 1 (default) = on (needs the node-chain launch above), 0 = the 128 x 128-tile plane GEMM.  Returns the previous setting. */
 int mi_debug_set_edge2_fused(int on);
+/* The pair-mode first edge GEMM (Fourier block over unordered atom pairs, models/diffcsp/cspnet.py:59-74) on the same form -- 128 x 128
+ * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 1 = on for hidden_dim
+ * multiples of 128, 0 (default: the two measure equal, this product is bound by its epilogue) = the plane GEMM.  Same epilogue:
+ * bit-identical M1.  Returns the previous setting. */
+int mi_debug_set_edge1_fused(int on);
+/* Phase clock of that kernel (measurement only): device buffer of [row tiles][8] 64-bit s_memtime stamps (start, first operand chunk
+ * landed, main loop done, epilogue done); nullptr = off.  `on` = 2 above selects the variant with a two-deep weight ring and
+ * double-buffered activation fragments (ablation). */
+int mi_debug_edge2_clock(void* dev_buffer);
+int mi_debug_edge1_clock(void* dev_buffer);   /* the same for the first edge GEMM: [row tiles x column quarters][8] stamps */
 /* Phase clock of that launch (measurement only): a device buffer of [workgroups][16] 64-bit words that every workgroup fills with
  * s_memtime stamps at its phase boundaries; nullptr (default) = off. */
 int mi_debug_node_chain_clock(void* dev_buffer);

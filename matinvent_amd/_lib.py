@@ -73,6 +73,9 @@ SIGNATURES = {
     "mi_debug_set_node_fused": (_I, [_I]),
     "mi_debug_node_chain_clock": (_I, [_P]),
     "mi_debug_set_edge2_fused": (_I, [_I]),
+    "mi_debug_edge2_clock": (_I, [_P]),
+    "mi_debug_set_edge1_fused": (_I, [_I]),
+    "mi_debug_edge1_clock": (_I, [_P]),
     "mi_batch_destroy": (None, [_P]),
     "mi_batch_num_nodes": (_I, [_P]),
     "mi_batch_num_edges": (_L, [_P]),

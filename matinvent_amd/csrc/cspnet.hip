@@ -39,6 +39,8 @@ std::vector<int (*)(unsigned*, bool)>& sat_readers() {
 }
 void sat_register(int (*fetch)(unsigned*, bool)) { sat_readers().push_back(fetch); }
 
+int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s);   // edge_stage.hip
+
 static bool cfg_ln_and_wide(const mi_net* n) { return n->cfg.ln && (n->H == 128 || n->H == 256 || n->H == 512); }
 
 static thread_local char g_err[512] = "";
@@ -1072,7 +1074,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         pe1.diag_e = b->e_diag;
                         pe1.diag_nodes = N;
                     }
-                    if (b->Np > 0)
+                    if (b->Np > 0 && fold && edge_gemm1_supported(net))   // 128 x 128 tiles, weights straight from L2 in fragment order (edge_stage.hip)
+                        MI_TRY(edge_gemm1(net, make_planes(b->FFpl, Kp, PL_S_UNIT), l, (int)b->Np, pe1, s));
+                    else if (b->Np > 0)
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp, PL_S_UNIT), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
                     if (!fold) {
@@ -1260,6 +1264,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
     if (n->Wnc) (void)hipFree(n->Wnc);
+    if (n->Wffc) (void)hipFree(n->Wffc);
     if (n->wbounds) (void)hipFree(n->wbounds);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
@@ -1297,6 +1302,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->Wn2pl, (size_t)n->L * planes_elems(H, H) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->wbounds, (size_t)n->L * 8 * sizeof(float)));
         if (node_chain_pack_elems(H) && cfg_ln_and_wide(n)) MI_HIP(hipMalloc((void**)&n->Wnc, (size_t)n->L * node_chain_pack_elems(H) * sizeof(u16)));
+        if (MI_PLANES_FP16 && H % 128 == 0) MI_HIP(hipMalloc((void**)&n->Wffc, (size_t)n->L * H * 2 * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
@@ -1339,7 +1345,8 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
             Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
-            if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), W2, s));  // the same weights in fragment order (node_chain.hip)
+            if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), W2, s));
+            if (n->Wffc) MI_TRY(edge_gemm1_pack(n, l, W1, s));  // the same weights in fragment order (node_chain.hip)
         }
     }
     if (n->L > 0) {  // weight bounds behind the activation scales of the fp16 plane format (see act_scales_kernel)

@@ -38,12 +38,14 @@ struct EdgeGemm2Args {
     const int* rowptr;        // [N + 1]
     float* part;              // [nslots][N][H], slot = tile - (first row of the node >> 7)
     int E, N;
+    unsigned long long* clk;  // optional phase clock: [tile][8] s_memtime stamps (mi_debug_edge2_clock)
 };
 
 constexpr int EG2_CHUNK = 2 * 128 * 256;            // bytes of one k-chunk in LDS: [plane][row 128][k 128 halfs], 16-byte pieces XOR-swizzled by row
 constexpr int EG2_LDS = 2 * EG2_CHUNK + 128 * 4 + 128 * 4;   // two chunks + per-row local source + per-local-node slot base
 
-template <int D>
+// D: depth of the weight ring in k-steps; AFB: 2 = the activation fragments of k-step s + 1 are read while k-step s multiplies
+template <int D, int AFB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm2_kernel(EdgeGemm2Args a) {
     constexpr int H = 512, KS = H / 16;   // 32 k-steps of 16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -53,6 +55,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int l31 = lane & 31, kg = lane >> 5;
     const int tile = blockIdx.x, row0 = tile * 128;
     const int nrows = a.E - row0 < 128 ? a.E - row0 : 128;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.clk && tid == 0) a.clk[(size_t)tile * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
 
     // ---- A operand by LDS-DMA: chunk kc = k-tiles 4 kc .. 4 kc + 3 of this row tile, 64 pieces of 1 KiB, eight per wave ----
     // LDS image: [plane][row][16 pieces of 16 B], piece c of row r stored at position c ^ (r & 15)  (conflict-free ds_read_b128 fragments)
@@ -122,45 +130,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(8 % D == 0, "the ring index is static inside a chunk");
 #pragma unroll 1
     for (int kc = 0; kc < 4; ++kc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's pieces have landed (and the ring's first sets with them)
+        // this chunk's pieces have landed: vector loads retire in order and the pieces were issued BEFORE the chunk's ring loads, so leaving
+        // the youngest 4 D ring loads in flight is enough (a full drain exposed one L2 latency per chunk)
+        if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();                                    // ... for every wave; and every wave has finished reading the other buffer
+        if (kc == 0) stamp();
         if (kc + 1 < 4) dma_chunk(kc + 1, (kc + 1) & 1);
-        f16x8 af[4][2];
+        f16x8 af[AFB][4][2];
+        if constexpr (AFB == 2) read_a(kc & 1, 0, af[0]);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            read_a(kc & 1, s, af);
-            mma(ring[s % D], af);
+            if constexpr (AFB == 2) {
+                if (s + 1 < 8) read_a(kc & 1, s + 1, af[(s + 1) & 1]);
+                mma(ring[s % D], af[s & 1]);
+            } else {
+                read_a(kc & 1, s, af[0]);
+                mma(ring[s % D], af[0]);
+            }
             if (kc * 8 + s + D < KS) ring_load(kc * 8 + s + D, ring[s % D]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    stamp();
 
     // ---- epilogue: M2 = SiLU(acc / (s_A s_W) + b2) -> two fp16 planes in registers -> part = S x M2 on the matrix pipe ----
     // k order of a 32-row block's two k-steps (u = 0, 1): lane group kg holds rows 4 kg + 8 (2 u + (idx >> 2)) + (idx & 3), idx = 0 .. 7.
-    // slk[kg][rb][u] = the local sources of those eight rows as bytes (255: no row), read back as one broadcast 8-byte load per fragment.
+    // The S fragments -- S[32 lb + l31][those rows] = 1 iff the row's local source is that node -- are the same for every wave and both
+    // column tiles: built once into LDS in fragment order, [block][rb][u][lane][8 halfs] (8 KiB per 32-node block, overlays the chunk
+    // buffers), and read back with one ds_read_b128 each.
     const int cnt = (nrows > 0 ? a.src[row0 + nrows - 1] - node_first + 1 : 0);   // local nodes of this tile (<= 128)
-    __syncthreads();   // (srcl / slotb written above; every wave is out of the main loop, so the chunk buffers are free)
-    unsigned char* slk = smem;   // 16 x 8 bytes, overlays the first chunk buffer
-    if (tid < 128) {
-        const int kg_ = tid >> 6, rb_ = (tid >> 4) & 3, u_ = (tid >> 3) & 1, idx = tid & 7;
-        const int v = srcl[rb_ * 32 + 4 * kg_ + 8 * (2 * u_ + (idx >> 2)) + (idx & 3)];
-        slk[tid] = (unsigned char)(v < 0 || v > 254 ? 255 : v);
+    u16* sfr = reinterpret_cast<u16*>(smem);
+    unsigned sat = 0;
+    const int nlb = (cnt + 31) >> 5;   // 32-node blocks of partial sums (1 for all but degenerate tiles; <= 4)
+    __syncthreads();   // every wave is out of the main loop: the overlay is free; srcl / slotb are visible
+    for (int f = tid; f < nlb * 8 * 64; f += 512) {   // one (fragment, lane) per iteration: 16 bytes
+        const int ln = f & 63, fu = (f >> 6) & 1, frb = (f >> 7) & 3, fq = f >> 9;
+        const int me = fq * 32 + (ln & 31), fkg = ln >> 5;
+        u32x4 w;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int ia = 2 * i2, ib = 2 * i2 + 1;
+            const int ra = frb * 32 + 4 * fkg + 8 * (2 * fu + (ia >> 2)) + (ia & 3), rbb = frb * 32 + 4 * fkg + 8 * (2 * fu + (ib >> 2)) + (ib & 3);
+            w[i2] = (srcl[ra] == me ? 0x3C00u : 0u) | (srcl[rbb] == me ? 0x3C000000u : 0u);   // fp16 1.0 = 0x3C00
+        }
+        *reinterpret_cast<u32x4*>(sfr + (size_t)f * 8) = w;
     }
     __syncthreads();
-    unsigned sat = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         __builtin_amdgcn_sched_barrier(0);
         const int col = wave * 64 + j * 32 + l31;
         const float bcol = a.b2[col];
 #pragma unroll 1
-        for (int lb0 = 0; lb0 * 32 < cnt; lb0 += 2) {   // two 32-node blocks of partial sums at a time (one pass for all but degenerate tiles)
+        for (int lb0 = 0; lb0 < nlb; lb0 += 2) {   // two blocks at a time (one pass for all but degenerate tiles)
+            const bool two = lb0 + 1 < nlb;
             f32x16 ps[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ps[q][r] = 0.f;
-            const bool two = (lb0 + 1) * 32 < cnt;
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
                 const f32x16 av = acc[rb][j];
@@ -176,17 +206,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         mh[idx] = h[0]; mh[idx + 1] = h[1];
                         ml[idx] = lo[0]; ml[idx + 1] = lo[1];
                     }
-                    const uint2 sb = *reinterpret_cast<const uint2*>(slk + ((kg * 4 + rb) * 2 + u) * 8);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         if (q == 1 && !two) break;
-                        const unsigned me = (unsigned)((lb0 + q) * 32 + l31);
-                        f16x8 sf;
-#pragma unroll
-                        for (int idx = 0; idx < 8; ++idx) {
-                            const unsigned byte = ((idx < 4 ? sb.x : sb.y) >> (8 * (idx & 3))) & 255u;
-                            sf[idx] = byte == me ? (_Float16)1.0f : (_Float16)0.0f;
-                        }
+                        const f16x8 sf = *reinterpret_cast<const f16x8*>(sfr + (size_t)((((lb0 + q) * 4 + rb) * 2 + u) * 64 + lane) * 8);
                         ps[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, ml, ps[q], 0, 0, 0);
                         ps[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, mh, ps[q], 0, 0, 0);
                     }
@@ -202,14 +225,407 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
         }
     }
+    stamp();
     sat_report(sat);
 }
 
-int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
-    constexpr int D = 4;
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Form B (default): 128 rows x 256 columns per FOUR-wave workgroup, TWO workgroups per CU.  A wave does the same work as in the form
+// above (4 x 2 MFMA tiles per fragment set, 128 accumulator registers, its weights straight from L2), but the two workgroups of a CU are
+// independent, so they drift apart and one's epilogue -- SiLU and the plane split are ~11k VALU cycles per wave, a quarter of a tile's
+// time in the eight-wave form, where both waves of a SIMD reach it together -- runs under the other's MFMA loop; so do the operand fills
+// at a tile's start.  The A operand goes through four 16 KiB LDS stages of one 32-deep k-tile each (the plane GEMM's LDS image and
+// source-side swizzle), three k-tiles ahead; the two column halves of a row tile run on the same XCD (its second read of A hits L2).
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int EG2B_STAGE = 2 * 128 * 64, EG2B_NST = 4;                   // [plane][row 128][32 k halfs]
+constexpr int EG2B_LDS = EG2B_NST * EG2B_STAGE + 128 * 4 + 128 * 4;      // stages (overlaid by the S fragments in the epilogue) + srcl + slotb
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm2b_kernel(EdgeGemm2Args a) {
+    constexpr int H = 512, KS = H / 16, KT = H / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* srcl = reinterpret_cast<int*>(smem + EG2B_NST * EG2B_STAGE);
+    int* slotb = srcl + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    // XCD-aware mapping (workgroups go round-robin to the 8 XCDs): both column halves of a row tile on the same XCD
+    const int id = blockIdx.x, slot = id >> 3, half = slot & 1, tile = (slot >> 1) * 8 + (id & 7);
+    const int row0 = tile * 128;
+    if (row0 >= a.E) return;
+    const int nrows = a.E - row0 < 128 ? a.E - row0 : 128;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.clk && tid == 0) a.clk[(size_t)(tile * 2 + half) * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+
+    // ---- A operand: k-tile kt = one 16 KiB block [plane][128 rows][64 B] of the plane set, 16 pieces of 1 KiB, four per wave ----
+    // LDS image of a stage = the plane GEMM's: 64-byte rows, 16-byte piece c of row r at position c ^ ((r >> 2) & 3)
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(a.A.base + a.A.tile(tile, 0), a.A.KT * 24576);
+    const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;   // plane = piece >> 3, rows 16 (piece & 7) .. + 15
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+    dma_tile(1, 1);
+    dma_tile(2, 2);
+
+    // ---- W operand: register ring over the k-steps, the wave's two column tiles: columns 256 half + 64 wave .. + 63 ----
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(a.W2f, H * H * 4);
+    int voffw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * half + 2 * wave + t) * KS) * 2048;
+    u32x4 ring[D][2][2];
+    auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
+
+    const int node_first = a.src[row0];
+    if (tid < 128) {
+        const int r = row0 + tid;
+        srcl[tid] = r < a.E ? a.src[r] - node_first : -1;
+        const int node = node_first + tid;
+        slotb[tid] = node < a.N ? tile - (a.rowptr[node] >> 7) : 0;
+    }
+    const float os = a.dsc[1] * (1.f / PL_SW), s_m2 = a.dsc[2], inv_m2 = a.dsc[3];
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+    };
+    static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
+    // vector loads retire in order.  Per k-tile this wave issues 4 DMA pieces (k-tile kt + 3) and then 8 ring loads; k-tile kt's pieces were
+    // issued three iterations ago, i.e. at least 8 + 12 + 12 operations ago: vmcnt(24) leaves the younger ones in flight.
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int k = kt + h2;
+            // (the last three k-tiles have fewer loads behind them -- no further DMA, the ring runs dry: drain)
+            if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            __syncthreads();   // k-tile k has landed for every wave; every wave is done with the stage k-tile k + 3 goes to (= that of k - 1)
+            if (k == 0) stamp();
+            if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
+            f16x8 af[4][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                read_a(k & 3, s2, af);
+                mma(ring[2 * h2 + s2], af);
+                if (2 * k + s2 + D < KS) ring_load(2 * k + s2 + D, ring[2 * h2 + s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    stamp();
+
+    // ---- epilogue (as in the eight-wave form): SiLU -> two fp16 planes -> part = S x M2 on the matrix pipe ----
+    const int cnt = (nrows > 0 ? a.src[row0 + nrows - 1] - node_first + 1 : 0);
+    u16* sfr = reinterpret_cast<u16*>(smem);
+    unsigned sat = 0;
+    const int nlb = (cnt + 31) >> 5;
+    __syncthreads();
+    for (int f = tid; f < nlb * 8 * 64; f += 256) {
+        const int ln = f & 63, fu = (f >> 6) & 1, frb = (f >> 7) & 3, fq = f >> 9;
+        const int me = fq * 32 + (ln & 31), fkg = ln >> 5;
+        u32x4 w;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int ia = 2 * i2, ib = 2 * i2 + 1;
+            const int ra = frb * 32 + 4 * fkg + 8 * (2 * fu + (ia >> 2)) + (ia & 3), rbb = frb * 32 + 4 * fkg + 8 * (2 * fu + (ib >> 2)) + (ib & 3);
+            w[i2] = (srcl[ra] == me ? 0x3C00u : 0u) | (srcl[rbb] == me ? 0x3C000000u : 0u);
+        }
+        *reinterpret_cast<u32x4*>(sfr + (size_t)f * 8) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int col = half * 256 + wave * 64 + j * 32 + l31;
+        const float bcol = a.b2[col];
+#pragma unroll 1
+        for (int lb0 = 0; lb0 < nlb; lb0 += 2) {
+            const bool two = lb0 + 1 < nlb;
+            f32x16 ps[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps[q][r] = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const f32x16 av = acc[rb][j];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f16x8 mh, ml;
+#pragma unroll
+                    for (int idx = 0; idx < 8; idx += 2) {
+                        const float v0 = silu_fast(av[8 * u + idx] * os + bcol), v1 = silu_fast(av[8 * u + idx + 1] * os + bcol);
+                        unsigned p[3];
+                        pl_split_pair_acc(v0, v1, s_m2, p, sat);
+                        const f16x2 h = __builtin_bit_cast(f16x2, p[0]), lo = __builtin_bit_cast(f16x2, p[1]);
+                        mh[idx] = h[0]; mh[idx + 1] = h[1];
+                        ml[idx] = lo[0]; ml[idx + 1] = lo[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q == 1 && !two) break;
+                        const f16x8 sf = *reinterpret_cast<const f16x8*>(sfr + (size_t)((((lb0 + q) * 4 + rb) * 2 + u) * 64 + lane) * 8);
+                        ps[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, ml, ps[q], 0, 0, 0);
+                        ps[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, mh, ps[q], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int loc = (lb0 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (loc < cnt) a.part[((size_t)slotb[loc] * a.N + node_first + loc) * H + col] = ps[q][r] * inv_m2;
+                }
+        }
+    }
+    stamp();
+    sat_report(sat);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// First edge GEMM, pair mode (see PlanesEpilogue: one operand row per unordered atom pair, the sine half of K into one accumulator set,
+// the cosine half into another, both directed edges emitted by the epilogue), in the same form: 128 pairs x 128 columns per four-wave
+// workgroup, a wave owns 128 pairs x 32 columns (4 x 1 MFMA tiles x two accumulator sets = 128 registers), the Fourier operand through
+// four LDS stages by LDS-DMA, the weights in fragment order straight from L2 into a register ring, two workgroups per CU.  The plane
+// GEMM's form of this product staged BOTH operands through registers into LDS (48 KiB of ds_write_b128 and 64 fragment reads per
+// k-tile for 96 MFMAs): its main loop ran at 42 % of the matrix pipe's floor.  Epilogue, folded-in activation scales and self-edge
+// workgroups are the plane GEMM's (planes_epilogue_pairs / act_scales_eval), so M1 is bit-identical to its output.
+// ------------------------------------------------------------------------------------------------------------------------------------
+int g_edge1_fused = 0;   // off: measured equal to the plane GEMM (191.8 vs 186.6 us at B = 256) -- this product is bound by its epilogue, not by its loop
+
+// fragment-order pack of the Fourier block of edge_mlp.0 in the pair-mode column layout [sin block | pad | cos block | pad] (2 Kh columns)
+__global__ void pack_frag_wff_pair_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int Kh, u16* __restrict__ dst) {
+    const int K = 2 * Kh, KS = K / 16, F3 = 3 * F;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (row, 8-k chunk) per thread
+    if (idx >= (int64_t)H * (K / 8)) return;
+    const int r = (int)(idx / (K / 8)), ch = (int)(idx % (K / 8));
+    const int ct = r >> 5, l31 = r & 31, ks = ch >> 1, kg = ch & 1;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i, blk = c >= Kh, cc = blk ? c - Kh : c;
+        v[i] = cc < F3 ? W1[(size_t)r * edge_in + 2 * H + 9 + blk * F3 + cc] : 0.f;
+    }
+    u32x4 pk[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned p[3];
+        pl_split_pair(v[2 * i], v[2 * i + 1], PL_SW, p);
+        pk[0][i] = p[0];
+        pk[1][i] = p[1];
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dst + ((((size_t)ct * KS + ks) * 2 + pl) * 64 + kg * 32 + l31) * 8) = pk[pl];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1b_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                     PlanesEpilogue pe, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int KT = K / 32, KS = K / 16, nq = N / 128;   // k-tiles, k-steps, column quarters
+    const int id = blockIdx.x;
+    // this layer's M1 scale from the absmax slots and the weight bounds; workgroup 0 publishes all six scales (as the plane GEMM does)
+    float cps_local = 0.f;
+    if (pe.sc_pq) {
+        float dsc[6];
+        act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
+        cps_local = dsc[0];
+        if (id == 0 && tid < 6) {
+            pe.sc_dsc[tid] = dsc[tid];
+            if (pe.sc_dsc2) pe.sc_dsc2[tid] = dsc[tid];
+        }
+    }
+    if (pe.diag_C0 && id >= pe.diag_block0) {  // self edges: eight nodes per workgroup, a thread per column pair (d = 0: the Fourier term is C0)
+        const float cps = cps_local != 0.f ? cps_local : pe.Cp.s();
+        const int n0 = (id - pe.diag_block0) * 8, n1 = n0 + 8 < pe.diag_nodes ? n0 + 8 : pe.diag_nodes;
+        const float* PQ = pe.ep.row_bias;
+        const int ldpq = pe.ep.ld_row_bias;
+        for (int f = 2 * tid; f < N; f += 512) {
+            const float c0 = pe.diag_C0[f], c1 = pe.diag_C0[f + 1];
+            for (int i = n0; i < n1; ++i) {
+                const int e = pe.diag_e[i], g = pe.diag_node2graph[i];
+                const float* G = pe.ep.row_bias3 + (size_t)g * pe.ep.ld_row_bias3;
+                const float v0 = c0 + ((PQ[(size_t)i * ldpq + f] + PQ[(size_t)i * ldpq + N + f]) + G[f]);
+                const float v1 = c1 + ((PQ[(size_t)i * ldpq + f + 1] + PQ[(size_t)i * ldpq + N + f + 1]) + G[f + 1]);
+                unsigned p[3];
+                pl_split_pair(silu_fast(v0), silu_fast(v1), cps, p);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(pe.Cp.base + pe.Cp.elem(e, f, k)) = p[k];
+            }
+        }
+        return;
+    }
+    // XCD-aware mapping: the column quarters of a row tile run on the same XCD
+    const int slot = id >> 3, qt = slot % nq, tile = (slot / nq) * 8 + (id & 7);
+    const int row0 = tile * 128;
+    if (row0 >= M) return;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (clk && tid == 0) clk[(size_t)(tile * nq + qt) * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(tile, 0), A.KT * 24576);
+    const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+    dma_tile(1, 1);
+    dma_tile(2, 2);
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wf, N * K * 4);
+    const int voffw = lane * 16 + ((4 * qt + wave) * KS) * 2048;   // the wave's column tile: columns 128 qt + 32 wave .. + 31
+    u32x4 ring[D][2];
+    auto ring_load = [&](int ks, u32x4 (&w)[2]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw + pl * 1024, ks * 2048, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
+
+    f32x16 acc[4][1], accS[4][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&w)[2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
+    };
+    static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
+    const int khalf = KT / 2;
+    // (vmcnt: per k-tile this wave issues 4 DMA pieces and then 4 ring loads; k-tile kt's pieces were issued three iterations ago, i.e. at
+    //  least 4 + 8 + 8 operations ago: vmcnt(16) leaves the younger ones in flight; the last three k-tiles drain)
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int k = kt + h2;
+            if (k == khalf) {   // the cosine half of K goes into the second accumulator set
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    accS[i][0] = acc[i][0];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+                }
+            }
+            if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __syncthreads();
+            if (k == 0) stamp();
+            if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
+            f16x8 af[4][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                read_a(k & 3, s2, af);
+                mma(ring[2 * h2 + s2], af);
+                if (2 * k + s2 + D < KS) ring_load(2 * k + s2 + D, ring[2 * h2 + s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    stamp();
+    __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
+    planes_epilogue_pairs<4, 1>(pe, accS, acc, row0, qt * 128 + wave * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
+    stamp();
+}
+
+unsigned long long* g_edge1_clk = nullptr;
+
+int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS); });
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS); });
+    MI_HIP(attr_err);
+    const int H = net->H, K = 2 * net->Kh;
+    pe.out_scale = 1.f / (A.scale * PL_SW);
+    int nblk = (H / 128) * ((cdiv(M, 128) + 7) / 8 * 8);
+    if (pe.diag_C0) {
+        pe.diag_block0 = nblk;
+        nblk += cdiv(pe.diag_nodes, 8);
+    }
+    hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, net->Wffc + (size_t)layer * ((size_t)H * K * 2), M, H, K, pe, g_edge1_clk);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+bool edge_gemm1_supported(const mi_net* net) { return g_edge1_fused && net->H % 128 == 0 && net->Wffc != nullptr && (2 * net->Kh) % 64 == 0; }
+
+int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s) {
+    const int H = net->H, K = 2 * net->Kh;
+    hipLaunchKernelGGL(pack_frag_wff_pair_kernel, dim3(cdiv((int64_t)H * (K / 8), 256)), dim3(256), 0, s, W1, net->edge_in, H, net->F, net->Kh,
+                       net->Wffc + (size_t)l * ((size_t)H * K * 2));
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+unsigned long long* g_edge2_clk = nullptr;
+
+int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+    });
     MI_HIP(attr_err);
     const int H = net->H;
     EdgeGemm2Args a;
@@ -222,7 +638,11 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
     a.part = b->part;
     a.E = (int)b->E;
     a.N = b->N;
-    hipLaunchKernelGGL(edge_gemm2_kernel<D>, dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
+    a.clk = g_edge2_clk;
+    // 1 (default): form B -- 128 x 256 tiles, four waves, two workgroups per CU; 2 / 3: the eight-wave 128 x 512 form (ablations)
+    if (g_edge2_fused == 2) hipLaunchKernelGGL((edge_gemm2_kernel<2, 2>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
+    else if (g_edge2_fused == 3) hipLaunchKernelGGL((edge_gemm2_kernel<4, 1>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
+    else hipLaunchKernelGGL((edge_gemm2b_kernel<4>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -233,13 +653,37 @@ bool edge_gemm2_supported(const mi_net* net) { return g_edge2_fused && net->H ==
 
 int edge_gemm2(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
 bool edge_gemm2_supported(const mi_net*) { return false; }
+int edge_gemm1(mi_net*, const Planes&, int, int, PlanesEpilogue, hipStream_t) { return MI_ESTATE; }
+bool edge_gemm1_supported(const mi_net*) { return false; }
+int edge_gemm1_pack(mi_net*, int, const float*, hipStream_t) { return MI_OK; }
+int g_edge1_fused = 0;
 
 #endif
 
 }  // namespace mi
 
+extern "C" int mi_debug_edge2_clock(void* dev_buffer) {
+#if MI_PLANES_FP16
+    mi::g_edge2_clk = (unsigned long long*)dev_buffer;
+#endif
+    return MI_OK;
+}
+
+extern "C" int mi_debug_edge1_clock(void* dev_buffer) {
+#if MI_PLANES_FP16
+    mi::g_edge1_clk = (unsigned long long*)dev_buffer;
+#endif
+    return MI_OK;
+}
+
 extern "C" int mi_debug_set_edge2_fused(int on) {
     const int was = mi::g_edge2_fused;
     mi::g_edge2_fused = on;
+    return was;
+}
+
+extern "C" int mi_debug_set_edge1_fused(int on) {
+    const int was = mi::g_edge1_fused;
+    mi::g_edge1_fused = on;
     return was;
 }

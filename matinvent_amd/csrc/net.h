@@ -32,6 +32,7 @@ struct mi_net {
     unsigned short* Wlnpl = nullptr;   // (3H x H): [P_i block; P_j block; node_mlp.0.weight[:, :H]] -- everything LayerNorm(h) feeds
     unsigned short* Waggpl = nullptr;  // (H x H):  node_mlp.0.weight[:, H:]  (multiplies the aggregated messages)
     unsigned short* Wn2pl = nullptr;   // (H x H):  node_mlp.2.weight
+    unsigned short* Wffc = nullptr;    // [L] the pair-layout Fourier block of edge_mlp.0 in MFMA fragment order (edge_stage.hip: first edge GEMM)
     unsigned short* Wnc = nullptr;     // [L] the three operands above in MFMA fragment order: [Wagg | Wn2 | Wln] (node_chain.hip; H = 128 / 256 / 512 with LayerNorm)
     float* wbounds = nullptr;          // [L][8] row-sum / bias bounds of the layer's weights (fp16 plane format: activation scales)
     // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],
@@ -157,6 +158,8 @@ bool node_chain_supported(const mi_net* net);
 size_t node_chain_pack_elems(int H);
 int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, const float* W2, hipStream_t s);
 // edge_stage.hip: the second edge GEMM + edge -> node reduction on 128-row x H-column register tiles (inference, hidden_dim 512)
+bool edge_gemm1_supported(const mi_net* net);
+int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s);
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
