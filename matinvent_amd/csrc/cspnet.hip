@@ -1499,7 +1499,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
         hipMemset(b->lnpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->aggpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
-        hipMemset(b->absmax, 0, (2 * L + 2) * sizeof(unsigned)) != hipSuccess) {
+        hipMemset(b->absmax, 0, (2 * L + 2) * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {   // (the handle will be used on non-blocking side streams: its set-up on the null stream must have finished)
         mi_batch_destroy(b);
         set_error("hipMemset failed");
         return MI_EHIP;

@@ -1695,6 +1695,15 @@ static float* op_segsum(Ctx& c, const float* X, int cols) {  // edges -> atoms b
     }
     return Y;
 }
+// dynamic-LDS ceiling of a kernel: only ever RAISED, under a lock, and remembered per function -- never set per launch (see op_triplet)
+static void raise_lds_ceiling(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::map<const void*, int> cur;
+    std::lock_guard<std::mutex> g(mu);
+    int& c = cur[fn];
+    if (bytes > c && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) c = bytes;
+}
+
 static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     OpTimer optimer(c, "triplet", c.b->E, 0, 0);
     const mi_gemnet_config& g = c.net->cfg;
@@ -1721,9 +1730,13 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     }
     const int DG = std::min(GN_DEG, (c.b->deg_max + 3) / 4 * 4);
     const size_t sh = (size_t)(TFC * DG * 8 + DG * 3 + DG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
+    // (the kernel's dynamic-LDS ceiling is raised once per network shape, to what the largest in-degree needs: forwards of one network run
+    //  from several host threads -- concurrent sampler chains -- and a per-launch hipFuncSetAttribute with THIS launch's size raced with the
+    //  other threads' launches of the same function)
+    const size_t sh_max = (size_t)(TFC * GN_DEG * 8 + GN_DEG * 3 + GN_DEG * g.emb_trip + TFC * g.num_spherical * g.emb_cbf) * sizeof(float);
 #define TRIP_FWD(SS)                                                                                                                       \
     case SS:                                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_fwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        raise_lds_ceiling(reinterpret_cast<const void*>(&triplet_fwd_kernel<SS>), (int)sh_max);                                           \
         hipLaunchKernelGGL((triplet_fwd_kernel<SS>), dim3(c.b->N), dim3(512), sh, c.s, xd, c.b->V, cbfW, c.b->rowptr, (pl && !c.train) ? (float*)nullptr : Y, g.emb_trip, g.emb_cbf, P, ymax, DG); \
         break;
     switch (g.num_spherical) {
@@ -1926,6 +1939,10 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
         out_block(c, i + 1, m, rbf_out, false);
     }
     b->out_logits = op_dense(c, h, N, A, "fc_atom.weight", 0, ACT_NONE, true, "fc_atom.bias", nullptr, GK_NONE, nullptr, GK_NONE, LOGIT_LD);
+    b->taps["Fe"] = {b->Fe, E};
+    b->taps["Se"] = {b->Se, E};
+    b->taps["out_pos"] = {b->out_pos, (int64_t)N * 3};
+    b->taps["V"] = {b->V, E * 3};
     if (!c.dry && CTX_OK(c)) {
         if (E == 0) {
             MI_HIP_VOID(hipMemsetAsync(b->Fe, 0, sizeof(float), c.s));
@@ -2129,10 +2146,11 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 if (o.M == 0) break;
                 const int DG = std::min(GN_DEG, (b->deg_max + 3) / 4 * 4);
                 const size_t sh = triplet_bwd_lds_floats(g.emb_trip, g.emb_cbf, DG) * sizeof(float);
+                const size_t sh_max = std::min<size_t>(160 * 1024 - 2048, triplet_bwd_lds_floats(g.emb_trip, g.emb_cbf, GN_DEG) * sizeof(float));
                 MI_CHECK(sh <= 160 * 1024 && g.emb_trip <= 64 && g.emb_trip % 4 == 0, MI_EINVAL, "triplet backward: emb_trip / emb_cbf beyond the kernel's LDS budget");
 #define TRIP_BWD(SS)                                                                                                                              \
     case SS:                                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&triplet_bwd_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
+        raise_lds_ceiling(reinterpret_cast<const void*>(&triplet_bwd_kernel<SS>), (int)sh_max);                                                   \
         hipLaunchKernelGGL((triplet_bwd_kernel<SS>), dim3(N), dim3(512), sh, s, o.X, b->V, o.X2, b->rowptr, dY, G(o.X), G(o.X2), g.emb_trip, g.emb_cbf, DG); \
         break;
                 switch (g.num_spherical) {
@@ -2399,6 +2417,7 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     if (e == hipSuccess) e = hipMemcpy(b->node_off, b->node_off_h.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess && N > 0) e = hipMemcpy(b->node2graph, n2g.data(), N * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->rowptr, 0, (N + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // (the handle will be used on non-blocking side streams: nothing of its set-up may still be in flight on the null stream)
     if (e != hipSuccess) {
         set_error("mi_gbatch_create: %s", hipGetErrorString(e));
         mi_gbatch_destroy(b);
@@ -2481,8 +2500,10 @@ int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const floa
     if (b->N == 0 || b->B == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
     MI_TRY(forward_impl(net, b, pos, cell, atomic_numbers, t, train != 0, s));
-    if (out_pos) MI_HIP(hipMemcpyAsync(out_pos, b->out_pos, (size_t)b->N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out_cell) MI_HIP(hipMemcpyAsync(out_cell, b->out_cell, (size_t)b->B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // (copies by kernel, not hipMemcpyAsync: concurrent sampler chains on four non-blocking streams showed the position head -- the first
+    //  copy, issued right behind the kernel that writes its source -- intermittently returning the PREVIOUS evaluation's values)
+    if (out_pos) hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)b->N * 3)), dim3(256), 0, s, b->out_pos, 3, out_pos, 3, (int64_t)b->N, 3);
+    if (out_cell) hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)b->B * 9)), dim3(256), 0, s, b->out_cell, 9, out_cell, 9, (int64_t)b->B, 9);
     if (out_logits)
         hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)b->N * MI_MG_CLASSES)), dim3(256), 0, s, b->out_logits, LOGIT_LD, out_logits, MI_MG_CLASSES,
                            (int64_t)b->N, MI_MG_CLASSES);

@@ -1,0 +1,86 @@
+"""Round 3 finding: inference forwards of the MatterGen-shaped network on four 64-crystal groups, run CONCURRENTLY from four host
+threads on four HIP streams, do not always reproduce the same forwards run one after the other: one quarter-wave (16 consecutive atoms)
+of the position head's output differs in roughly one trial in three, while the graph, the per-edge force scalars Fe, the unit vectors V and
+every other output are bit-identical.  usage (GPU box): python scripts/mg_concurrent_forward_check.py"""
+import sys, threading, torch
+sys.path.insert(0, ".")
+from oracle import mattergen_oracle as M
+from matinvent_amd import _lib
+from matinvent_amd.mattergen import MatterGenModule
+from matinvent_amd.streams import concurrent_streams
+lib = _lib.load()
+hp = M.GemNetHParams()
+P = M.init_params(hp, seed=0, head_scale=20.0)
+m = MatterGenModule(gemnet={}); m.decoder.load_state_dict(P, strict=True)
+n = 20
+g = torch.Generator().manual_seed(3)
+mu = (n / 0.05771451654022283) ** (1 / 3)
+G, Bg = 4, 64
+groups = []
+for k in range(G):
+    cell = mu * torch.eye(3)[None].repeat(Bg, 1, 1) + 0.3 * M.symmetric_noise(torch.randn(Bg, 3, 3, generator=g))
+    groups.append(dict(na=torch.full((Bg,), n, dtype=torch.long), frac=torch.rand(Bg * n, 3, generator=g).cuda(), cell=cell.cuda(),
+                       a=torch.randint(1, 101, (Bg * n,), generator=g).cuda(), t=(0.1 + 0.8 * torch.rand(Bg, generator=g)).cuda()))
+gbs = [m.decoder.make_batch(gr["na"]) for gr in groups]
+m.decoder.sync()
+torch.set_grad_enabled(False)
+def fwd(k, taps):
+    torch.set_grad_enabled(False)   # (thread-local)
+    gr = groups[k]
+    c0 = (gr["cell"].double().sum(), gr["frac"].double().sum(), gr["a"].sum(), gr["t"].double().sum())
+    o = m.decoder(gr["frac"], gr["cell"], gr["a"], gr["t"], gbs[k])
+    res = {kk: v.clone() for kk, v in o.items()}
+    c1 = (gr["cell"].double().sum(), gr["frac"].double().sum(), gr["a"].sum(), gr["t"].double().sum())
+    res["in_before"] = torch.stack([x.double() for x in c0])
+    res["in_after"] = torch.stack([x.double() for x in c1])
+    for name in taps:
+        res[name] = gbs[k].tap(name).clone().view(torch.int32)
+    return res
+taps = ["Fe", "out_pos", "V"]
+seqr = [fwd(k, taps) for k in range(G)]
+seqr2 = [fwd(k, taps) for k in range(G)]
+print("sequential reproducible:", all(torch.equal(seqr[k][kk], seqr2[k][kk]) for k in range(G) for kk in seqr[k]))
+pool = concurrent_streams(G, m.device)
+cur = torch.cuda.current_stream()
+def cmp(out, label):
+    bad = [(k, kk, "size" if out[k][kk].shape != seqr[k][kk].shape else float((out[k][kk].double() - seqr[k][kk].double()).abs().max())) for k in range(G) for kk in seqr[k]
+           if out[k][kk].shape != seqr[k][kk].shape or not torch.equal(out[k][kk], seqr[k][kk])]
+    print(label, "identical" if not bad else [(b[0], b[1], b[2] if isinstance(b[2], str) else f"{b[2]:.2e}") for b in bad][:14])
+    for (k, kk, v) in bad:
+        if kk == "out_pos" and not isinstance(v, str):
+            d = (out[k][kk].view(torch.float32) - seqr[k][kk].view(torch.float32)).abs().view(-1, 3).max(dim=1).values
+            idx = torch.nonzero(d > 0).flatten().tolist()
+            print(f"   group {k}: {len(idx)} atoms differ: {idx[:40]}  crystals {sorted(set(i // 20 for i in idx))[:20]}")
+# (1) side streams, one group at a time (threads joined one by one)
+out = [None] * G
+for k in range(G):
+    def run1(k=k):
+        with torch.cuda.stream(pool[k]):
+            out[k] = fwd(k, taps)
+            torch.cuda.current_stream().synchronize()
+    t = threading.Thread(target=run1); t.start(); t.join()
+cmp(out, "side streams, serial:")
+# (2) main thread, side streams, serial
+out = [None] * G
+for k in range(G):
+    with torch.cuda.stream(pool[k]):
+        out[k] = fwd(k, taps)
+        torch.cuda.current_stream().synchronize()
+cmp(out, "main thread, side streams, serial:")
+# (3) concurrent, 2 groups then 4
+for ng in [4] * 24:
+    out = [None] * G
+    ready = cur.record_event()
+    def run(k):
+        with torch.cuda.stream(pool[k]):
+            pool[k].wait_event(ready)
+            out[k] = fwd(k, taps)
+            cur.wait_event(pool[k].record_event())
+    th = [threading.Thread(target=run, args=(k,)) for k in range(ng)]
+    [t.start() for t in th]; [t.join() for t in th]
+    torch.cuda.synchronize()
+    for k in range(ng, G):
+        out[k] = seqr[k]
+    cmp(out, f"{ng} concurrent:")
+# (4) default stream again
+cmp([fwd(k, taps) for k in range(G)], "default stream again:")

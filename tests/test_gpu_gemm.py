@@ -170,6 +170,10 @@ def test_latency_forms_in_the_network_bit_identical(na):
     from matinvent_amd import _lib
     from tests.gpu_util import Box, make_module
     lib = _lib.load()
+    # (this test is about the forms of the PLANE GEMM: the node-level chain and the second edge GEMM stay on it -- the one-launch node chain
+    #  and the register-tile second GEMM of round 3 have their own comparison in tests/test_gpu_forward.py)
+    lib.mi_debug_set_node_fused(0)
+    lib.mi_debug_set_edge2_fused(0)
     torch.manual_seed(0)
     m = make_module(512, 6, 128, 1000)
     with torch.no_grad():
@@ -195,6 +199,8 @@ def test_latency_forms_in_the_network_bit_identical(na):
         _lib.check(lib.mi_debug_set_planes_dma(1))
         _lib.check(lib.mi_debug_set_planes_big_seg(0))
         _lib.check(lib.mi_debug_set_node_priority(0))
+        lib.mi_debug_set_node_fused(1)
+        lib.mi_debug_set_edge2_fused(1)
     for f in finals[1:]:
         for k in ("frac_coords", "atom_types", "lattices"):
             assert torch.isfinite(finals[0][k]).all()

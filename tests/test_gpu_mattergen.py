@@ -462,19 +462,20 @@ def _drop_handles(m):
     torch.cuda.synchronize()
 
 
-def test_benchmark_size_four_chains_vs_the_unsplit_batch_after_one_step(bench_net):
-    """(iii) The bench's default (four concurrent chains of 64 crystals) against the unsplit batch of 256.  Same Philox draws (global ids),
-    same per-crystal step sizes; what differs is the batch-wide maxima behind the plane-set scales, i.e. the rounding of the 22-bit format.
+def test_benchmark_size_crystal_groups_vs_the_unsplit_batch(bench_net):
+    """(iii) Four groups of 64 crystals against the unsplit batch of 256 (the split `chains` makes; same Philox draws through global ids, same
+    per-crystal step sizes).  What differs is the batch-wide maxima behind the plane-set scales, i.e. the rounding of the 22-bit format.
       (a) ONE EVALUATION: a 64-crystal group alone vs the same crystals inside the unsplit batch -- 2e-5 of max|output| per head (the
           composition dependence of the network itself; measured ~1e-6);
-      (b) ONE PREDICTOR-CORRECTOR STEP (two evaluations + updates) at a late grid point: types identical, cells within 5e-3 of max|cell|,
-          the MEDIAN atom within 1e-4 (wrapped).  The maximum over the 5120 atoms is NOT bounded: with random-init weights (heads scaled so that
-          score x std is of order one) the Langevin step size 2 (snr |z| / |score|)^2 and the 50-nearest selection amplify a 1e-6
-          difference to O(1) for a few atoms (measured: 0.48 for the worst atom, 2.7e-3 of max|cell|) -- DESIGN 11 records the same for
-          the oracle against itself under a 1e-6 perturbation."""
+      (b) ONE PREDICTOR-CORRECTOR STEP (two evaluations + updates) at a late grid point, the groups sampled ONE AFTER THE OTHER (bit-
+          reproducible): types identical, cells within 5e-3 of max|cell|, the MEDIAN atom within 1e-4 (wrapped).  The maximum over the 5120
+          atoms is NOT bounded: with random-init weights (heads scaled so that score x std is of order one) the Langevin step size
+          2 (snr |z| / |score|)^2 and the 50-nearest selection amplify a 1e-6 difference to O(0.1) for a few atoms (measured: 0.16 for the worst
+          atom, 9e-4 of max|cell|) -- DESIGN 11 records the same for the oracle against itself under a 1e-6 perturbation;
+      (c) CONCURRENT chains (`chains=4`) are reported, not asserted: at this size two runs of the same concurrent sample do not reproduce each
+          other -- which is why `chains` defaults to 1 for this sampler."""
     hp, P, m = bench_net
     s = _bench_state(BENCH_B)
-    # (a) one evaluation
     with torch.no_grad():
         full = {k: v.clone() for k, v in m.decoder(s["frac"], s["cell"], s["a"], s["t"], m.decoder.make_batch(s["na"])).items()}
         for g0 in (0, 128):
@@ -483,22 +484,40 @@ def test_benchmark_size_four_chains_vs_the_unsplit_batch_after_one_step(bench_ne
             _rel(part["pos"], full["pos"][n0:n1], 2e-5, f"pos, group {g0}..{g1} alone vs inside the batch")
             _rel(part["cell"], full["cell"][g0:g1], 2e-5, f"cell, group {g0}..{g1} alone vs inside the batch")
             _rel(part["atomic_numbers"], full["atomic_numbers"][n0:n1], 2e-5, f"logits, group {g0}..{g1} alone vs inside the batch")
-    # (b) one predictor-corrector step
     state = dict(pos=s["frac"].cuda(), cell=s["cell"].cuda(), atomic_numbers=s["a"].cuda())
     i0 = 900   # t ~ 0.1: late in the chain
-    outs = {}
-    for chains in (1, 4):
-        st = {k: v.clone() for k, v in state.items()}
-        outs[chains] = m.sample(s["na"], n_steps=1000, seed=5, i_start=i0, i_stop=i0 + 1, state=st, chains=chains)[1]
-    a, b = outs[1], outs[4]
-    dc = float((a["cell"] - b["cell"]).abs().max()) / float(a["cell"].abs().max())
-    d = (a["pos"] - b["pos"]).abs()
-    d = torch.minimum(d, 1 - d).max(dim=1).values
-    nt = int((a["atomic_numbers"] != b["atomic_numbers"]).sum())
-    _drop_handles(m)
-    print(f"MEASURED four chains vs unsplit after one step: cell {dc:.3e} of max|cell|; positions (wrapped) median {float(d.median()):.3e}, "
-          f"99th percentile {float(d.quantile(0.99)):.3e}, max {float(d.max()):.3e}; {nt} types differ")
+    kw = dict(n_steps=1000, seed=5, i_start=i0, i_stop=i0 + 1)
+    whole = m.sample(s["na"], state={k: v.clone() for k, v in state.items()}, chains=1, **kw)[1]
+    cuts = [BENCH_B * k // 4 for k in range(5)]
+
+    def groups():
+        outs = []
+        for k in range(4):
+            n0, n1 = cuts[k] * BENCH_N, cuts[k + 1] * BENCH_N
+            st = dict(pos=state["pos"][n0:n1].clone(), cell=state["cell"][cuts[k]:cuts[k + 1]].clone(), atomic_numbers=state["atomic_numbers"][n0:n1].clone())
+            outs.append(m.sample(s["na"][cuts[k]:cuts[k + 1]], state=st, node_offset=n0, graph_offset=cuts[k], chains=1, **kw)[1])
+        return {k: torch.cat([o[k] for o in outs]) for k in ("pos", "cell", "atomic_numbers")}
+
+    def dist(a, b):
+        d = (a["pos"] - b["pos"]).abs()
+        d = torch.minimum(d, 1 - d).max(dim=1).values
+        return float((a["cell"] - b["cell"]).abs().max()) / float(a["cell"].abs().max()), d, int((a["atomic_numbers"] != b["atomic_numbers"]).sum())
+
+    g1, g2 = groups(), groups()
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"{k}: the groups sampled one after the other are not reproducible"
+    dc, d, nt = dist(whole, g1)
+    print(f"MEASURED four groups (one after the other) vs unsplit after one step: cell {dc:.3e} of max|cell|; positions (wrapped) median "
+          f"{float(d.median()):.3e}, 99th percentile {float(d.quantile(0.99)):.3e}, max {float(d.max()):.3e}; {nt} types differ")
     assert nt == 0 and dc <= 5e-3 and float(d.median()) <= 1e-4, (dc, float(d.median()), nt)
+    c1 = m.sample(s["na"], state={k: v.clone() for k, v in state.items()}, chains=4, **kw)[1]
+    c2 = m.sample(s["na"], state={k: v.clone() for k, v in state.items()}, chains=4, **kw)[1]
+    _drop_handles(m)
+    dcc, dd, ntc = dist(c1, c2)
+    dcs, ds, nts = dist(c1, g1)
+    print(f"MEASURED four CONCURRENT chains: run vs run cell {dcc:.3e}, worst atom {float(dd.max()):.3e}, atoms that differ {int((dd > 0).sum())}; "
+          f"vs the groups one after the other cell {dcs:.3e}, worst atom {float(ds.max()):.3e}, atoms that differ {int((ds > 0).sum())}")
+    assert all(bool(torch.isfinite(c1[k].float()).all()) for k in c1) and ntc == 0
 
 
 def test_benchmark_size_fine_tune_window_vs_the_oracle(bench_net):
