@@ -24,7 +24,7 @@ def main():
         lines += ["", f"## PMC pass `{p}` (per-dispatch averages)", "", "| kernel | counter | dispatches | avg value |", "|---|---|---|---|"]
         q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
              "group by kernel_name, counter_name order by sum(value) desc")
-        rows = [r for r in cur.execute(q) if any(t in r[0] for t in ("edge_mlp", "gemm_nt", "gemm_planes"))]
+        rows = [r for r in cur.execute(q) if any(t in r[0] for t in ("edge_mlp", "gemm_nt", "gemm_planes", "edge_gemm", "node_chain"))]
         for k, c, n, v in rows:
             lines.append(f"| `{k[:60]}` | {c} | {n} | {v:.6g} |")
     # HBM-side traffic and achieved bandwidth of every kernel (north_star: "achieved HBM GB/s against the chip's peak")
@@ -65,14 +65,20 @@ def main():
         cur = sqlite3.connect(p).cursor()
         # the two kernels of one bench 'launch' (pair-mode Fourier GEMM + second-linear GEMM): equally many dispatches each,
         # so the average over both x 2 = bytes per launch
-        q = ("select counter_name, count(*), avg(value) from counters_collection where (kernel_name like '%gemm_planes_db%' "
-             "or kernel_name like '%gemm_planes_kernel%') and counter_name in ('FETCH_SIZE', 'WRITE_SIZE') group by counter_name")
+        # round 3: the edge stage of an inference forward = gemm_planes_kernel<1, ...> (pair mode) + edge_gemm2b_kernel (edge_stage.hip), one
+        # dispatch of each per layer; the node-level products run inside node_chain_kernel.  Older traces: both on gemm_planes kernels.
+        has_e2 = cur.execute("select count(*) from counters_collection where kernel_name like '%edge_gemm2%'").fetchone()[0] > 0
+        where = ("(kernel_name like '%gemm_planes_kernel<1%' or kernel_name like '%edge_gemm2%' or kernel_name like '%edge_gemm1%')" if has_e2 else
+                 "(kernel_name like '%gemm_planes_db%' or kernel_name like '%gemm_planes_kernel%')")
+        q = f"select counter_name, count(*), avg(value) from counters_collection where {where} and counter_name in ('FETCH_SIZE', 'WRITE_SIZE') group by counter_name"
         for c, n, v in cur.execute(q):
             traffic[c] = {"dispatches": n, "avg_reported_KiB": v}
+        kernel_desc = ("gemm_planes_kernel<1> (pair mode) + edge_gemm2b_kernel (128-row register tiles, segmented sum on the matrix pipe): the edge stage of one layer"
+                       if has_e2 else None)
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         fetch = 2.0 * traffic["FETCH_SIZE"]["avg_reported_KiB"] * 1024.0
         write = traffic["WRITE_SIZE"]["avg_reported_KiB"] * 1024.0
-        rec = {"kernel": "gemm_planes_kernel<1> (pair mode) + gemm_planes_kernel<0> (edge stage; the FETCH/WRITE passes run with the node-level products on the fp32-operand kernel so that every plane-GEMM dispatch is an edge-stage one)", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
+        rec = {"kernel": locals().get("kernel_desc") or "gemm_planes_kernel<1> (pair mode) + gemm_planes_kernel<0> (edge stage; the FETCH/WRITE passes run with the node-level products on the fp32-operand kernel so that every plane-GEMM dispatch is an edge-stage one)", "bytes_per_dispatch": fetch + write, "fetch_bytes_per_dispatch": fetch,
                "write_bytes_per_dispatch": write, "dispatches_per_bench_launch": 2, "counters": traffic,
                "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
         if whole:
