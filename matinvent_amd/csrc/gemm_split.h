@@ -794,6 +794,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
     const int l31 = lane & 31, kg = lane >> 5;
     float* stS = stage;
     float* stC = stage + 1152;
+    unsigned sat = 0;   // saturation flag, accumulated: a branch with an atomic per conversion kept the gathers of the next piece from being scheduled under this one's arithmetic
     // the index rows of this lane's pairs (they depend on the row block and the half only, not on the column tile), all requested up
     // front: inside the tile loop each tile paid an index-load latency ahead of its gathers -- eight times per wave in a launch of one
     // workgroup per CU, where nothing else covers it (a third of a 33 us product at 265 edges)
@@ -878,7 +879,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned pr[3];
-                            pl_split_pair(v[2 * k], v[2 * k + 1], cps, pr);
+                            pl_split_pair_acc(v[2 * k], v[2 * k + 1], cps, pr, sat);
                             o[0][k] = pr[0];
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
@@ -890,6 +891,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
             }
             __builtin_amdgcn_wave_barrier();
         }
+    sat_report(sat);
 }
 
 // Pre-activation save of the result-layout epilogue (training forward of the second edge linear: Z2 = acc + bias is kept for the

@@ -241,25 +241,44 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
         __syncthreads();
         stamp();
-        // ---- A2: Z = agg W0b^T (transposed) ----
-        run(TRt{}, rs_agg, wave * TW);
-        stamp();
-        const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
-        __syncthreads();                // every wave has read the agg planes
-        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes (every gather requested before the arithmetic) ----
+        // (the epilogue's row gathers do not depend on the product: requested BEFORE it, they land under its MFMAs instead of costing one
+        //  exposed memory latency per phase -- the phase clock put A3 at 18k cycles against 12k for the product itself)
+        f32x4 xq[TW][4];
         {
-            const float os = a.dsc[3] * (1.f / PL_SW), s_x = a.dsc[4];
             const int i = row0 + l31;
-            f32x4 bq[TW][4], xq[TW][4];
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
-                    bq[t][q] = *reinterpret_cast<const f32x4*>(a.b0 + c4);
                     xq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (i < N) xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + c4);
+                    if (i < N) xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + wave * CW + t * 32 + 8 * q + 4 * kg);
                 }
+        }
+        // ---- A2: Z = agg W0b^T (transposed) ----
+        run(TRt{}, rs_agg, wave * TW);
+        stamp();
+        const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
+        f32x4 hq[TW][4];   // the residual rows of A5, requested here for the same reason
+        {
+            const int i = row0 + l31;
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < N) hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + wave * CW + t * 32 + 8 * q + 4 * kg);
+                }
+        }
+        __syncthreads();                // every wave has read the agg planes
+        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes ----
+        {
+            const float os = a.dsc[3] * (1.f / PL_SW), s_x = a.dsc[4];
+            const int i = row0 + l31;
+            f32x4 bq[TW][4];
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[t][q] = *reinterpret_cast<const f32x4*>(a.b0 + wave * CW + t * 32 + 8 * q + 4 * kg);
             ring_fill(rs_n2, wave * TW);    // behind the gathers, in flight under the arithmetic
 #pragma unroll
             for (int t = 0; t < TW; ++t)
@@ -289,16 +308,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         {
             const float os = a.dsc[5] * (1.f / PL_SW);
             const int i = row0 + l31;
-            f32x4 bq[TW][4], hq[TW][4];
+            f32x4 bq[TW][4];
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
-                    bq[t][q] = *reinterpret_cast<const f32x4*>(a.b2 + c4);
-                    hq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (i < N) hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + c4);
-                }
+                for (int q = 0; q < 4; ++q) bq[t][q] = *reinterpret_cast<const f32x4*>(a.b2 + wave * CW + t * 32 + 8 * q + 4 * kg);
             if (phaseB) ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);   // pass 0 of phase B, in flight under the epilogue and the LayerNorm
 #pragma unroll
             for (int t = 0; t < TW; ++t)
@@ -484,7 +498,10 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
         a.ln_b = net->p("final_layer_norm.bias");
         a.hf = b->hf;
     }
-    if (H == 512) return g_node_fused == 2 ? node_chain_launch<512, 8, 8>(a, s) : node_chain_launch<512, 8, 4>(a, s);
+#if MI_HAVE_ABLATION_KERNELS   // (the deeper weight ring spills registers: an ablation instantiation, see gemm_split.h)
+    if (H == 512 && g_node_fused == 2) return node_chain_launch<512, 8, 8>(a, s);
+#endif
+    if (H == 512) return node_chain_launch<512, 8, 4>(a, s);
     if (H == 256) return node_chain_launch<256, 8, 4>(a, s);
     return node_chain_launch<128, 4, 4>(a, s);
 }
