@@ -89,6 +89,9 @@ SIGNATURES = {
     "mi_philox_fill": (_I, [_U64, _U32, _U32, _L, _L, _I, _P, _P]),
     "mi_cspnet_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi_cspnet_backward": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "mi_batch_set_wgrad_window": (_I, [_P, _P, _I]),
+    "mi_cspnet_wgrad_flush": (_I, [_P, _P, _P, _P]),
+    "mi_batch_wgrad_pending": (_I, [_P]),
     "mi_adam_step": (_I, [_P, _P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "mi_add_noise": (_I, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _U64, _U32, _P, _P, _P, _P, _P, _P, _P,
                           _P, _P, _P]),

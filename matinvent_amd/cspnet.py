@@ -86,6 +86,18 @@ class CrystalBatch:
         _lib.check(self._lib.mi_knn_graph_read(self._h, _ptr(ei), _ptr(ev), {"reference": 0, "csr": 1}[order], _stream()), "mi_knn_graph_read")
         return ei.long(), ev
 
+    # ---- node-level weight gradients over a window of micro-steps (mi_batch_set_wgrad_window) ----
+    def set_wgrad_window(self, net: "CSPNet", micro_steps: int):
+        """Keep the node-level linears' operand rows of `micro_steps` backward passes and contract them together (0: each backward
+        contracts its own).  `wgrad_flush` must run before the gradient buffer is read."""
+        if getattr(self, "_wgrad_window", 0) != int(micro_steps):
+            _lib.check(self._lib.mi_batch_set_wgrad_window(net._h, self._h, int(micro_steps)), "mi_batch_set_wgrad_window")
+            self._wgrad_window = int(micro_steps)
+
+    def wgrad_flush(self, net: "CSPNet", grad):
+        """grad (flat, the network's theta layout) += the pending micro-steps' node-level weight gradients, on the current stream."""
+        _lib.check(self._lib.mi_cspnet_wgrad_flush(net._h, self._h, _ptr(grad), _stream()), "mi_cspnet_wgrad_flush")
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h is not None and getattr(self, "_lib", None) is not None:

@@ -526,6 +526,63 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
 
 int net_tape_prepare(mi_net* net, mi_batch* b) { return alloc_tape(net, b); }
 
+// Deferred node-level weight gradients (see Tape): `slots` micro-steps per contraction, 0 = every backward contracts its own rows.
+int net_wgrad_window(mi_net* net, mi_batch* b, int slots) {
+    MI_CHECK(slots >= 0 && slots <= 64, MI_EINVAL, "wgrad window: 0 .. 64 micro-steps");
+    Tape& t = b->tape;
+    MI_CHECK(t.wcur == 0, MI_ESTATE, "wgrad window changed while micro-steps are pending: mi_cspnet_wgrad_flush first");
+    if (slots == 0 || b->N == 0) {
+        t.wslots = 0;
+        return MI_OK;
+    }
+    MI_TRY(alloc_tape(net, b));
+    if (slots > t.wcap) {
+        for (float** q : {&t.w_dY, &t.w_Xa, &t.w_dXa, &t.w_cat, &t.w_dPQ})
+            if (*q) {
+                b->allocs.erase(std::remove(b->allocs.begin(), b->allocs.end(), (void*)*q), b->allocs.end());
+                (void)hipFree(*q);
+                *q = nullptr;
+            }
+        t.wcap = 0;
+        const size_t rows = (size_t)net->L * slots * b->N, H = net->H;
+        int rc = MI_OK;
+        if (rc == MI_OK) rc = dev_alloc(b, &t.w_dY, rows * H);
+        if (rc == MI_OK) rc = dev_alloc(b, &t.w_Xa, rows * H);
+        if (rc == MI_OK) rc = dev_alloc(b, &t.w_dXa, rows * H);
+        if (rc == MI_OK) rc = dev_alloc(b, &t.w_cat, rows * 2 * H);
+        if (rc == MI_OK) rc = dev_alloc(b, &t.w_dPQ, rows * 2 * H);
+        if (rc != MI_OK) {
+            t.wslots = 0;
+            return rc;
+        }
+        t.wcap = slots;
+    }
+    t.wslots = slots;
+    return MI_OK;
+}
+
+int net_wgrad_flush(mi_net* net, mi_batch* b, float* grad, hipStream_t s) {
+    Tape& t = b->tape;
+    if (t.wslots == 0 || t.wcur == 0) return MI_OK;
+    const int H = net->H, L = net->L, M = t.wcur * b->N;
+    auto G = [&](const std::string& name) { return grad + net->off(name); };
+    float* sc = t.scratch;
+    const size_t scf = t.scratch_floats;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "csp_layer_" + std::to_string(l) + ".";
+        const size_t r0 = (size_t)l * t.wslots * b->N;
+        const float *dY = t.w_dY + r0 * H, *Xa = t.w_Xa + r0 * H, *dXa = t.w_dXa + r0 * H, *cat = t.w_cat + r0 * 2 * H, *dPQ = t.w_dPQ + r0 * 2 * H;
+        MI_TRY(gemm_tn_auto(dY, H, Xa, H, G(p + "node_mlp.2.weight"), H, M, H, H, sc, scf, s));
+        MI_TRY(colsum_acc(dY, H, G(p + "node_mlp.2.bias"), M, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, M, H, 2 * H, sc, scf, s));
+        MI_TRY(colsum_acc(dXa, H, G(p + "node_mlp.0.bias"), M, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, M, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, M, H, H, sc, scf, s));
+    }
+    t.wcur = 0;
+    return MI_OK;
+}
+
 static inline dim3 g1(int64_t n) { return dim3((unsigned)cdiv(n, 256)); }
 
 int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s) {
@@ -538,6 +595,8 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     auto G = [&](const std::string& name) { return grad + net->off(name); };
     float* sc = t.scratch;
     const size_t scf = t.scratch_floats;
+    const bool defer = t.wslots > 0;
+    MI_CHECK(!defer || t.wcur < t.wslots, MI_ESTATE, "wgrad window overrun");
 
     // ---------------- heads ----------------
     hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.lattices, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
@@ -581,25 +640,35 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     // ---------------- layers, last to first ----------------
     for (int l = L - 1; l >= 0; --l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
-        const float* cat = t.cat + (size_t)l * N * 2 * H;
+        // (deferred node-level weight gradients: this micro-step's operand rows live in slot t.wcur of the window)
+        const size_t wr = defer ? (size_t)l * t.wslots * N + (size_t)t.wcur * N : 0;
+        const float* cat = defer ? t.w_cat + wr * 2 * H : t.cat + (size_t)l * N * 2 * H;
+        float* dYl = defer ? t.w_dY + wr * H : t.dY;
+        float* Xa = defer ? t.w_Xa + wr * H : t.Xa;
+        float* dXa = defer ? t.w_dXa + wr * H : t.dXa;
+        float* dPQ = defer ? t.w_dPQ + wr * 2 * H : t.dPQ;
         float* Z1 = t.Z1 + (size_t)l * E * H;
         float* Z2 = t.Z2 + (size_t)l * E * H;
         const float* Xpre = t.Xpre + (size_t)l * NH;
         const float* Ypre = t.Ypre + (size_t)l * NH;
         // node MLP (cspnet.py:80-82)
-        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, t.dY, (int64_t)NH);
-        hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, t.Xa, (int64_t)NH);
+        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, dYl, (int64_t)NH);
+        hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, Xa, (int64_t)NH);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_auto(t.dY, H, t.Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
-        MI_TRY(colsum_acc(t.dY, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
-        MI_TRY(gemm_nt(t.dY, H, net->Wn2T + l * (size_t)H * H, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
+        if (!defer) {
+            MI_TRY(gemm_tn_auto(dYl, H, Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
+            MI_TRY(colsum_acc(dYl, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
+        }
+        MI_TRY(gemm_nt(dYl, H, net->Wn2T + l * (size_t)H * H, H, dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
         // (silu' as this product's epilogue measured 2.5 % slower end to end than the separate vectorised pass: in the MFMA result
         // layout a lane owns one column of 16 rows, so the pre-activation comes in as 16 four-byte loads per tile)
-        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dXa, Xpre, t.dXa, (int64_t)NH);
+        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, dXa, Xpre, dXa, (int64_t)NH);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_auto(t.dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
-        MI_TRY(colsum_acc(t.dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
-        MI_TRY(gemm_nt(t.dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+        if (!defer) {
+            MI_TRY(gemm_tn_auto(dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
+            MI_TRY(colsum_acc(dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
+        }
+        MI_TRY(gemm_nt(dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
         // edge stage (cspnet.py:59-79)
         bool edge_sums_done = false;  // dPQ and dG already produced by the fused pair-mode kernel
         if (E > 0) {
@@ -662,12 +731,12 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 if (fused_pairs && b->nmax_fc <= PAIRS_NMAX && g_bwd_pairs_tile) {
                     const size_t sh = ((size_t)b->nmax_fc * b->nmax_fc + b->nmax_fc) * PAIRS_W * sizeof(float);
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
-                                       Dp, t.dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
+                                       Dp, dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
                 } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
-                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, t.dPQ, t.dG, sc, H,
+                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, dPQ, t.dG, sc, H,
                                        wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
@@ -690,25 +759,27 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 MI_TRY(gemm_tn_auto(t.dM1, H, t.FF, 6 * F, G(p + "edge_mlp.0.weight") + 2 * H + 9, net->edge_in, (int)E, H, 6 * F, sc, scf, s));
             }
             if (!fused_pairs) {
-                if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, t.dPQ, N, H);
-                else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, t.dPQ, N, H);
+                if (b->knn) hipLaunchKernelGGL(edge_dpq_csr_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->inedge, dPQ, N, H);
+                else hipLaunchKernelGGL(edge_dpq_kernel, g1(NH), dim3(256), 0, s, t.dM1, b->rowptr, b->node2graph, b->node_off, dPQ, N, H);
                 MI_KERNEL_CHECK();
             }
             edge_sums_done = fused_pairs;
         } else {
-            MI_HIP(hipMemsetAsync(t.dPQ, 0, NH * 2 * 4, s));
+            MI_HIP(hipMemsetAsync(dPQ, 0, NH * 2 * 4, s));
         }
-        if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dPQ, 2 * H, b->node_off, t.dG, B, H);
+        if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dPQ, 2 * H, b->node_off, t.dG, B, H);
         hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
                            G(p + "edge_mlp.0.bias"), B, H);
         MI_KERNEL_CHECK();
-        MI_TRY(gemm_tn_auto(t.dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
-        MI_TRY(gemm_tn_auto(t.dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
+        if (!defer) {
+            MI_TRY(gemm_tn_auto(dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
+            MI_TRY(gemm_tn_auto(dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
+        }
         // d hn = dcat[:, :H] + dPQ * Whh   -> dY (reuse)
         GemmEpilogue er;
         er.residual = t.dcat;
         er.ld_res = 2 * H;
-        MI_TRY(gemm_nt(t.dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s, &b->sk));
+        MI_TRY(gemm_nt(dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s, &b->sk));
         // LayerNorm + residual stream: dh_l = dh_{l+1} + LN'(d hn)
         if (net->cfg.ln) {
             MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)l * NH, t.lnstat + (size_t)l * N * 2, p + "layer_norm", t.dh, 1));
@@ -728,6 +799,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
     MI_TRY(gemm_tn_auto(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
+    if (defer && ++t.wcur == t.wslots) MI_TRY(net_wgrad_flush(net, b, grad, s));
     return MI_OK;
 }
 
@@ -939,6 +1011,19 @@ int mi_cspnet_backward(mi_net* net, mi_batch* b, const float* d_lattice_out, con
     MI_CHECK(net->W2T != nullptr, MI_ESTATE, "mi_net_set_params must run before backward");
     return net_backward(net, b, d_lattice_out, d_coord_out, d_type_out, grad_theta, (hipStream_t)stream);
 }
+
+int mi_batch_set_wgrad_window(mi_net* net, mi_batch* b, int micro_steps) {
+    MI_CHECK(net && b, MI_EINVAL, "null handle");
+    MI_CHECK(b->H == net->H && b->L == net->L, MI_EINVAL, "batch was created for a different network");
+    return net_wgrad_window(net, b, micro_steps);
+}
+
+int mi_cspnet_wgrad_flush(mi_net* net, mi_batch* b, float* grad_theta, void* stream) {
+    MI_CHECK(net && b && grad_theta, MI_EINVAL, "null argument");
+    return net_wgrad_flush(net, b, grad_theta, (hipStream_t)stream);
+}
+
+int mi_batch_wgrad_pending(const mi_batch* b) { return b ? b->tape.wcur : 0; }
 
 int mi_adam_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
                  float beta2, float eps, float grad_scale, void* stream) {

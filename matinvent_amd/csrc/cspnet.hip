@@ -970,7 +970,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
         float* h_out = b->h + (l + 1) * NH;
-        float* cat = train ? tp.cat + (size_t)l * N * 2 * H : b->cat;
+        // (training: kept for the backward pass -- in this micro-step's slot of the weight-gradient window when one is set, see Tape)
+        float* cat = !train ? b->cat : tp.wslots > 0 ? tp.w_cat + ((size_t)l * tp.wslots * N + (size_t)tp.wcur * N) * 2 * H : tp.cat + (size_t)l * N * 2 * H;
         // node-level products on the plane-set kernel too (weights pre-split once per parameter update, the activations' planes
         // written by their producers; the fp32-operand kernel re-splits every operand tile in every workgroup).  Grouped by
         // operand: everything LayerNorm(h) feeds -- P_i, P_j and its half of the node MLP's first product -- is ONE product

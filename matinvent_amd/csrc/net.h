@@ -75,6 +75,15 @@ struct Tape {
     float* dsc_layers = nullptr;  // [L][8] each layer's activation scales of the training forward (fp16 plane format, folded launch)
     bool dsc_layers_valid = false;
     size_t scratch_floats = 0;
+    // Deferred node-level weight gradients (mi_batch_set_wgrad_window).  Between two optimizer steps the weights do not change, so the
+    // weight gradient of a node-level linear over `wslots` micro-steps is ONE contraction over wslots x N rows instead of wslots
+    // contractions over N rows (N = 1.7k atoms per crystal group: 24 launches of ~20 us plus as many partial reductions per evaluation,
+    // each leaving most of the chip idle).  The operand pairs of every layer are kept per micro-step, slot after slot, rows contiguous:
+    //   w_dY | w_Xa  -> node_mlp.2.weight / bias      w_dXa | w_cat -> node_mlp.0.weight / bias      w_dPQ | w_cat[:, :H] -> edge_mlp.0.weight[:, :2H]
+    // layout [L][wslots x N][width]; the training forward writes its `cat` rows straight into slot `wcur`, the backward its dY / Xa / dXa /
+    // dPQ; net_wgrad_flush contracts rows 0 .. wcur x N and resets wcur (automatically when the window is full).
+    int wslots = 0, wcap = 0, wcur = 0;
+    float *w_dY = nullptr, *w_Xa = nullptr, *w_dXa = nullptr, *w_cat = nullptr, *w_dPQ = nullptr;
 };
 
 struct mi_batch {
@@ -150,6 +159,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
 int net_tape_prepare(mi_net* net, mi_batch* b);
 int net_pack_transposes(mi_net* net, hipStream_t s);
 int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s);
+int net_wgrad_window(mi_net* net, mi_batch* b, int slots);                   // 0: every backward contracts its own rows (default)
+int net_wgrad_flush(mi_net* net, mi_batch* b, float* grad, hipStream_t s);   // grad += the pending micro-steps' node-level weight gradients
 template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
 int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);

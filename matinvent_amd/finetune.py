@@ -109,6 +109,7 @@ def _stacked_micro_steps(agent, prior, batch, time_idxs, noises, sigma, n_global
 
 
 MAX_STACK = 16  # MI_MAX_STACK of the C ABI
+WGRAD_WINDOW = 16  # micro-steps whose node-level weight gradients are contracted together (mi_batch_set_wgrad_window); 0 = off
 
 
 def auto_groups(e_total: int) -> int:
@@ -376,8 +377,24 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     grads = [theta.grad] + [torch.zeros_like(theta) for _ in range(groups - 1)]
     optimizer = FusedAdam([theta], lr=lr)  # fresh every call (:136)
     stats = []
+    # The weights only change at the optimizer step, so the node-level linears' weight gradients of a run of micro-steps are ONE
+    # contraction over all their rows instead of one short contraction (1.7k rows per group at 256 x 20 atoms) per micro-step: the
+    # agent's batch handles keep the operand rows of up to WGRAD_WINDOW micro-steps (see include/matinvent_hip.h).
+    window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 4 else 0   # (_batch_for caches four handles per module)
+    handles = []
+    for k in range(groups):
+        agent.shard_offsets = offs[k]
+        ab = agent._batch_for(batches[k].__dict__.setdefault("_mi_na", batches[k].num_atoms.cpu()))
+        ab.set_wgrad_window(agent.decoder, window if window > 1 else 0)
+        handles.append(ab)
+
+    def flush_wgrads():
+        for k in range(groups):
+            with torch.cuda.stream(streams[k]):
+                handles[k].wgrad_flush(agent.decoder, grads[k])
 
     def optimizer_step():
+        flush_wgrads()
         for k in range(groups):  # the optimizer consumes every group's gradient
             main.wait_event(streams[k].record_event())
         for g in grads[1:]:
@@ -391,6 +408,17 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
         for st in streams:
             st.wait_event(ready)
 
+    try:
+        return _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma,
+                                       device, noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats)
+    finally:
+        flush_wgrads()   # (nothing pending unless an exception cut a window short)
+        for ab in handles:
+            ab.set_wgrad_window(agent.decoder, 0)
+
+
+def _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma, device,
+                            noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats):
     for epoch in range(epochs):
         agent.train()
         theta.grad.zero_()
