@@ -184,7 +184,7 @@ class DiffCSPModule(nn.Module):
         cache = self.__dict__.setdefault("_nb_cache", {})
         cb = cache.get(key)
         if cb is None:
-            if len(cache) >= 4:
+            if len(cache) >= 8:
                 cache.pop(next(iter(cache)))
             cb = self.decoder.make_batch(list(key[0]), off[0], off[1])
             cache[key] = cb

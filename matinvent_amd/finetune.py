@@ -113,9 +113,9 @@ WGRAD_WINDOW = 16  # micro-steps whose node-level weight gradients are contracte
 
 
 def auto_groups(e_total: int) -> int:
-    """Concurrent crystal groups ft_step picks for a local set with `e_total` directed edges (measured at 256 x 20 atoms:
-    7.5k -> 9.0k / 9.3k / 8.9k crystal-timesteps/s with 2 / 3 / 4 groups)."""
-    return 3 if e_total >= 90000 else 2 if e_total >= 40000 else 1
+    """Concurrent crystal groups ft_step picks for a local set with `e_total` directed edges (measured at 256 x 20 atoms, round 3:
+    16.1k / 16.7k / 17.3k / 13.9k / 11.7k crystal-timesteps/s with 2 / 3 / 4 / 6 / 8 groups)."""
+    return 4 if e_total >= 90000 else 2 if e_total >= 40000 else 1
 
 
 def _stack_plan(e_one, accum_steps, timesteps, stack):
@@ -145,7 +145,7 @@ def ft_step(agent, prior, data_list, rewards, cfg, device=None, noise_fn=None, l
     enqueued on separate HIP streams and run concurrently, each accumulating into its own gradient buffer (summed before
     the optimizer step) -- the same arithmetic as data-parallel ranks, inside one GPU: one group's node-level and
     reduction kernels overlap the other's large GEMMs.  None = automatic (2-3 for large sets; measured at 256 x 20 atoms:
-    7.5k -> 9.0k / 9.3k / 8.9k crystal-timesteps/s with 2 / 3 / 4 groups).
+    16.1k / 16.7k / 17.3k / 13.9k crystal-timesteps/s with 2 / 3 / 4 / 6 groups, round 3).
     `stack` (fused path, single group): up to that many consecutive timesteps of an accumulation window run as ONE stacked
     micro-step (the weights only change at the optimizer step, so they are independent; same noise, same gradient up to fp32
     summation order).  None = automatic (small sets, which are bound by the host's launch rate); 1 = off."""
@@ -380,7 +380,7 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     # The weights only change at the optimizer step, so the node-level linears' weight gradients of a run of micro-steps are ONE
     # contraction over all their rows instead of one short contraction (1.7k rows per group at 256 x 20 atoms) per micro-step: the
     # agent's batch handles keep the operand rows of up to WGRAD_WINDOW micro-steps (see include/matinvent_hip.h).
-    window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 4 else 0   # (_batch_for caches four handles per module)
+    window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
     handles = []
     for k in range(groups):
         agent.shard_offsets = offs[k]

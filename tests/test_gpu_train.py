@@ -371,14 +371,15 @@ def test_stacked_timesteps_reproduce_the_sequential_update_with_device_noise():
         assert abs(sa[0][key] - sb[0][key]) <= 1e-5 * max(1.0, abs(sa[0][key])), key
 
 
-def test_ft_step_benchmark_hparams_three_concurrent_groups_vs_oracle():
-    """The route `bench.py --mode ft` takes at B = 256 (three concurrent crystal groups on separate streams with separate gradient
-    buffers, summed before the optimizer step) at the BENCHMARK network H=512, L=6, F=128: 192 crystals x 20 atoms = 76 800 edges in
-    three groups of 64 (each group's kernels are the large-list ones), one accumulation window of two timesteps with injected noise,
-    against the oracle's restatement of pipeline/mat_invent.py:125-189."""
+def test_ft_step_benchmark_hparams_concurrent_groups_vs_oracle():
+    """The route `bench.py --mode ft` takes at B = 256 (four concurrent crystal groups on separate streams with separate gradient
+    buffers, summed before the optimizer step; the node-level weight gradients of the window's micro-steps contracted together) at the
+    BENCHMARK network H=512, L=6, F=128: 192 crystals x 20 atoms = 76 800 edges in four groups of 48 (each group's kernels are the
+    large-list ones), one accumulation window of two timesteps with injected noise, against the oracle's restatement of
+    pipeline/mat_invent.py:125-189."""
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import auto_groups, ft_step
-    assert auto_groups(256 * 400) == 3 and auto_groups(192 * 400) == 2 and auto_groups(18 * 150) == 1  # what the bench's B = 256 gets
+    assert auto_groups(256 * 400) == 4 and auto_groups(192 * 400) == 2 and auto_groups(18 * 150) == 1  # what the bench's B = 256 gets
     H, L, F = 512, 6, 128
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P0, Q0 = O.init_params(hp, seed=3, head_scale=0.1), O.init_params(hp, seed=3, head_scale=0.1)
@@ -396,7 +397,7 @@ def test_ft_step_benchmark_hparams_three_concurrent_groups_vs_oracle():
     noises = {(0, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen))
               for t in range(TS)}
     cfg = dict(lr=1e-4, accum_steps=TS, epochs=1, timesteps=TS, sigma=0.025)
-    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=True, groups=3)
+    stats = ft_step(agent, prior, data, rewards, cfg, noise_fn=lambda e, t: noises[(e, t)], fused=True, groups=4)
     sch = O.Schedules.make(1000, sigmas_norm=sn)
     sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
     batch = dict(num_atoms=torch.tensor(na), lengths=torch.cat([d.lengths for d in data]), angles=torch.cat([d.angles for d in data]),
