@@ -230,6 +230,8 @@ def _apply_env_knobs(lib):
                     ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused)):
         if os.environ.get(env) is not None and os.environ[env] != "":
             fn(int(os.environ[env]))
+    if os.environ.get("MI_PLANES_RT", "") != "":   # register-tile form of the large plane products: 0 off, 1 those with epilogue extensions (default), 2 all
+        lib.mi_debug_set_planes_rt(int(os.environ["MI_PLANES_RT"]), 0)
     if os.environ.get("MI_WGRAD_WINDOW", "") != "":   # micro-steps per node-level weight-gradient contraction of the fine-tune loop (0: off)
         from matinvent_amd import finetune
         finetune.WGRAD_WINDOW = int(os.environ["MI_WGRAD_WINDOW"])

@@ -341,6 +341,12 @@ int mi_debug_set_planes_small_tiles(int n);
  * run on the 256 x 256-tile kernel that stages its operands by LDS-DMA (fp16 two-plane build): 1 (default) / 0 = the 128 x 128
  * kernel everywhere.  Same accumulation order per output: bit-identical results (tests/test_gpu_gemm.py). */
 int mi_debug_set_planes_big(int on, int min_rows);
+/* Plane-set products with a row-major epilogue whose W operand carries a fragment-order copy (the MatterGen-shaped network's
+ * edge-level dense layers), N % 256 == 0, K % 64 == 0, at least `min_rows` rows (default 16384; <= 0 keeps the limit), on the
+ * 128-row x 256-column register-tile kernel of csrc/edge_stage.hip (W straight from L2 into registers, A by LDS-DMA):
+ * 0 = never, 1 = the products with epilogue extensions (plane-set residuals, second merge, multiplicand), 2 (default) = all of
+ * them (MatterGen-shaped sampler at the benchmark size: 2.53 / 2.56 / 2.58 structures/s with 0 / 1 / 2).  Same products in the same k order, same epilogue function: bit-identical to the 128 x 128 kernel. */
+int mi_debug_set_planes_rt(int mode, int min_rows);
 /* Plane-set products whose launch is at most `max_blocks` workgroups (default 256 = one per CU; 0 = never) run the LATENCY form of the
  * 128 x 128 kernel: three operand register sets, loads three k-tiles ahead.  Such launches (short edge lists -- the reference's default
  * sampling and fine-tune batches, models/diffcsp/sample.py:42-62 -- and node-level products) are one round of workgroups whose k-loop

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mi_debug_set_tn_split_min_rows": (_I, [_I]),
     "mi_debug_set_planes_small_tiles": (_I, [_I]),
     "mi_debug_set_planes_big": (_I, [_I, _I]),
+    "mi_debug_set_planes_rt": (_I, [_I, _I]),
     "mi_debug_set_planes_latency": (_I, [_I]),
     "mi_debug_set_planes_dma": (_I, [_I]),
     "mi_debug_set_planes_big_seg": (_I, [_I]),

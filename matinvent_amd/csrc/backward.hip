@@ -1169,6 +1169,13 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((M + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, M, K, PA);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((N + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, N, K, PW);
         }
+        if (MI_PLANES_FP16 && (N & 255) == 0 && (K & 63) == 0 && K >= 128) {   // + the fragment-order copy the register-tile form reads (mi_debug_set_planes_rt)
+            static u16* pf = nullptr;
+            static size_t nf = 0;
+            if (frag_elems(N, K) > nf) { if (pf) (void)hipFree(pf); nf = frag_elems(N, K); MI_HIP(hipMalloc((void**)&pf, nf * 2)); }
+            MI_TRY(pack_frag_from_planes(PW, N, K, pf, s));
+            PW.frag = pf;
+        }
         PlanesEpilogue pe;
         pe.C = C;
         pe.ldc = ldc < 0 ? -ldc : ldc;

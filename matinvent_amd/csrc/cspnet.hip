@@ -18,6 +18,8 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
+int g_planes_rt = 2;              // register-tile kernel for every qualifying product (gemm_split.h / edge_stage.hip); 1 = only those with epilogue extensions
+int g_planes_rt_min_rows = 16384;
 int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
 int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0: two fp32-operand GEMM launches; mi_debug_set_node_priority(2))
@@ -1592,6 +1594,12 @@ int mi_debug_set_planes_small_tiles(int n) {
 int mi_debug_set_planes_big(int on, int min_rows) {
     g_planes_big = on;   // 0 = off, 1 = products without epilogue extensions, 2 = every qualifying product
     if (min_rows > 0) g_planes_big_min_rows = min_rows;
+    return MI_OK;
+}
+
+int mi_debug_set_planes_rt(int mode, int min_rows) {
+    g_planes_rt = mode;   // 0 = off, 1 = products with epilogue extensions, 2 = every qualifying product
+    if (min_rows > 0) g_planes_rt_min_rows = min_rows;
     return MI_OK;
 }
 

@@ -421,6 +421,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
+// The same main loop as a general product  C = epilogue(A W^T)  with the plane GEMM's row-major epilogue (gemm_rt, picked by
+// gemm_planes for operands that carry a fragment-order W): 128 rows x 256 columns per four-wave workgroup, any K % 64 == 0, any
+// N % 256 == 0; the column blocks of a row tile run on the same XCD.  Same products, same k order, same epilogue function as the
+// 128 x 128 plane kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool EXT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                 PlanesEpilogue pe) {
+    const int KS = K >> 4, KT = K >> 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int ncb = N >> 8;
+    const int id = blockIdx.x, slot = id >> 3, cb = slot % ncb, tile = (slot / ncb) * 8 + (id & 7);
+    const int row0 = tile * 128;
+    if (row0 >= M) return;
+
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(tile, 0), A.KT * 24576);
+    const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+    dma_tile(1, 1);
+    dma_tile(2, 2);
+
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wf, N * K * 4);
+    int voffw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * cb + 2 * wave + t) * KS) * 2048;
+    u32x4 ring[4][2][2];
+    auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ring_load(d, ring[d]);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+    };
+    // (waits as in edge_gemm2b_kernel: k-tile k's DMA pieces were issued at least 8 + 12 + 12 vector-memory operations ago)
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int k = kt + h2;
+            if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            __syncthreads();
+            if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
+            f16x8 af[4][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                read_a(k & 3, s2, af);
+                mma(ring[2 * h2 + s2], af);
+                if (2 * k + s2 + 4 < KS) ring_load(2 * k + s2 + 4, ring[2 * h2 + s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the stages: they become the epilogue's per-wave patches
+    planes_epilogue_rows<4, 2, EXT>(pe, acc, row0, cb * 256 + wave * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+}
+
+// plane set [N x K] -> fragment order (exact copy): one thread per (row, 8-k chunk)
+__global__ void pack_frag_from_planes_kernel(Planes W, int N, int K, u16* __restrict__ dst) {
+    const int KS = K / 16;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * (K / 8)) return;
+    const int r = (int)(idx / (K / 8)), ch = (int)(idx % (K / 8));
+    const int ct = r >> 5, l31 = r & 31, ks = ch >> 1, kg = ch & 1;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+        *reinterpret_cast<u32x4*>(dst + ((((size_t)ct * KS + ks) * 2 + pl) * 64 + kg * 32 + l31) * 8) = *reinterpret_cast<const u32x4*>(W.base + W.elem(r, ch * 8, pl));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
 // First edge GEMM, pair mode (see PlanesEpilogue: one operand row per unordered atom pair, the sine half of K into one accumulator set,
 // the cosine half into another, both directed edges emitted by the epilogue), in the same form: 128 pairs x 128 columns per four-wave
 // workgroup, a wave owns 128 pairs x 32 columns (4 x 1 MFMA tiles x two accumulator sets = 128 registers), the Fourier operand through
@@ -649,7 +755,37 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
 
 bool edge_gemm2_supported(const mi_net* net) { return g_edge2_fused && net->H == 512 && net->Wnc != nullptr; }
 
+int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const PlanesEpilogue& pe, bool ext, hipStream_t s) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+    });
+    MI_HIP(attr_err);
+    MI_CHECK(Wfrag && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && A.KT >= K / 32, MI_EINVAL, "gemm_rt: N % 256, K % 64, K >= 128 and a fragment-order W operand");
+    if (M <= 0) return MI_OK;
+    const dim3 grid((N >> 8) * ((cdiv(M, 128) + 7) / 8 * 8));
+    if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe);
+    else hipLaunchKernelGGL(gemm_rt_kernel<false>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
+size_t frag_elems(int N, int K) { return (size_t)N * K * 2; }
+
+int pack_frag_from_planes(const Planes& W, int N, int K, u16* dst, hipStream_t s) {
+    MI_CHECK((N & 31) == 0 && (K & 15) == 0, MI_EINVAL, "pack_frag_from_planes: N % 32, K % 16");
+    hipLaunchKernelGGL(pack_frag_from_planes_kernel, dim3((unsigned)cdiv((int64_t)N * (K / 8), 256)), dim3(256), 0, s, W, N, K, dst);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
 #else
+
+int gemm_rt(const Planes&, const u16*, int, int, int, const PlanesEpilogue&, bool, hipStream_t) { return MI_ESTATE; }
+size_t frag_elems(int N, int K) { return (size_t)N * K * 2; }
+int pack_frag_from_planes(const Planes&, int, int, u16*, hipStream_t) { return MI_ESTATE; }
 
 int edge_gemm2(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
 bool edge_gemm2_supported(const mi_net*) { return false; }

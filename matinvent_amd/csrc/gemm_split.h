@@ -398,6 +398,8 @@ extern int g_planes_db_min_tiles;
 extern int g_planes_small_tiles;  // plain plane GEMMs with fewer 128-row tiles than this use 64-row tiles
 extern int g_planes_big;          // 1: row-major-epilogue products with M >= g_planes_big_min_rows and N % 256 == 0 on the 256 x 256 LDS-DMA kernel
 extern int g_planes_big_min_rows;
+extern int g_planes_rt;           // row-major-epilogue products with a fragment-order W, N % 256 == 0, K % 64 == 0 on the 128 x 256 register-tile kernel: 0 off, 1 = those with epilogue extensions, 2 = all
+extern int g_planes_rt_min_rows;
 extern int g_planes_big_seg_min_rows;  // > 0: products with the fused segmented sum (second edge GEMM, inference) from this many rows up on the 256 x 256 kernel too
 extern int g_planes_dma;             // 128 x 128 tiles fed by LDS-DMA: 0 = never, 1 = launches of at most g_planes_lat_max_blocks workgroups, 2 = every launch
 extern int g_planes_lat_max_blocks;  // plane GEMMs of at most this many workgroups run the latency form (deep operand prefetch); 0 = never
@@ -428,6 +430,9 @@ struct Planes {
     int KT = 0;  // column tiles per row tile
     float scale = 1.f;  // power-of-two scale of the stored values (fp16 two-plane format; 1 for the bf16 format)
     const float* dscale = nullptr;  // optional DEVICE-side {scale, 1 / scale}: per-evaluation scale of an unbounded activation class
+    // optional, W operands only: the same [N x K] values in MFMA FRAGMENT order [N / 32][K / 16][plane][lane][8] (pack_frag_from_planes),
+    // which the register-tile GEMM (gemm_rt, edge_stage.hip) streams from L2 straight into registers
+    const u16* frag = nullptr;
     __device__ __forceinline__ float s() const { return dscale ? dscale[0] : scale; }
     // +2048 elements (4 KiB) per row tile: without the skew every row tile starts a multiple of 64 KiB apart,
     // i.e. on the same memory channel, and workgroups marching through k in lockstep hammer a few channels
@@ -1807,6 +1812,11 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
     return gemm_tn_acc(A, lda, X, ldx, C, ldc, M, Na, Kx, scratch, scratch_floats, s);
 }
 
+// edge_stage.hip: C = A W^T on 128-row x 256-column register tiles (four waves, W in fragment order from L2, A by LDS-DMA), row-major epilogue
+int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const PlanesEpilogue& pe, bool ext, hipStream_t s);
+size_t frag_elems(int N, int K);
+int pack_frag_from_planes(const Planes& W, int N, int K, u16* dst, hipStream_t s);
+
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s) {
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
@@ -1861,6 +1871,9 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
         if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
         else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+    } else if (MI_PLANES_FP16 && W.frag && g_planes_rt && (g_planes_rt > 1 || ext) && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && M >= g_planes_rt_min_rows &&
+               planes_epilogue_is_rows(pe, N)) {
+        return gemm_rt(A, W.frag, M, N, K, pe, ext, s);
     } else if (MI_PLANES_FP16 && (N & 255) == 0 &&
                ((g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && planes_epilogue_is_rows(pe, N)) ||
                 (MI_HAVE_ABLATION_KERNELS && g_planes_big_seg_min_rows > 0 && M >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act &&

@@ -1087,6 +1087,7 @@ struct mi_gemnet {
         mi::u16* pl;
         float* rowsum;   // device: largest row sum of |W| of the block (output bounds)
         float scale;     // host: power-of-two scale of the block's plane set
+        const mi::u16* frag = nullptr;   // the same block in MFMA fragment order (Planes::frag) where the register-tile GEMM can use it
         // the build is enqueued on the stream of the first use: a use on ANOTHER stream waits for `ready` until it has been seen complete
         hipEvent_t ready = nullptr;
         hipStream_t built_on = nullptr;
@@ -1360,7 +1361,9 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     if (!net->warena) {
         size_t tot = 0;
         // (+ the transposed blocks the backward's data-gradient products read: [cols, rows] per tensor, sliced by rows)
-        for (const GParam& q : net->params) tot += planes_elems(q.rows, q.cols) + 3 * planes_elems(q.rows, 32) + planes_elems(q.cols, q.rows) + 3 * planes_elems(128, q.rows);
+        // (+ the fragment-order copies of both for the register-tile GEMM: 2 N K elements each, + slack for the 16-byte alignment)
+        for (const GParam& q : net->params)
+            tot += planes_elems(q.rows, q.cols) + 3 * planes_elems(q.rows, 32) + planes_elems(q.cols, q.rows) + 3 * planes_elems(128, q.rows) + 2 * frag_elems(q.rows, q.cols) + 64;
         MI_HIP(hipMalloc((void**)&net->warena, tot * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&net->wrowsum, 1024 * sizeof(float)));
         net->warena_elems = tot;
@@ -1375,6 +1378,14 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     MI_HIP(hipMemsetAsync(e.rowsum, 0, sizeof(float), c.s));
     hipLaunchKernelGGL(rowsum_max_kernel, dim3((unsigned)std::min(64, (w.rows + 3) / 4)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
     MI_KERNEL_CHECK();
+    if (MI_PLANES_FP16 && (w.rows & 255) == 0 && (K & 63) == 0 && K >= 128) {
+        net->warena_top = (net->warena_top + 7) & ~(size_t)7;
+        MI_CHECK(net->warena_top + frag_elems(w.rows, K) <= net->warena_elems, MI_ENOMEM, "weight plane arena exhausted");
+        u16* f = net->warena + net->warena_top;
+        net->warena_top += frag_elems(w.rows, K);
+        MI_TRY(pack_frag_from_planes(P, w.rows, K, f, c.s));
+        e.frag = f;
+    }
     MI_TRY(wpl_publish(net, e, c.s));
     net->wplanes[key] = e;
     *out = e;
@@ -1402,6 +1413,14 @@ static int get_wtplanes(mi_gemnet* net, hipStream_t s, int pidx, int wcol0, int 
     const int64_t nthr = (int64_t)((K + 127) / 128 * 128) * P.KT * 16;
     hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, s, net->thetaT + w.toff + (size_t)wcol0 * w.ldt, w.ldt, K, w.rows, P, 0);
     MI_KERNEL_CHECK();
+    if (MI_PLANES_FP16 && (K & 255) == 0 && (w.rows & 63) == 0 && w.rows >= 128) {   // (this product's N is K, its contraction length w.rows)
+        net->warena_top = (net->warena_top + 7) & ~(size_t)7;
+        MI_CHECK(net->warena_top + frag_elems(K, w.rows) <= net->warena_elems, MI_ENOMEM, "weight plane arena exhausted");
+        u16* f = net->warena + net->warena_top;
+        net->warena_top += frag_elems(K, w.rows);
+        MI_TRY(pack_frag_from_planes(P, K, w.rows, f, s));
+        e.frag = f;
+    }
     MI_TRY(wpl_publish(net, e, s));
     net->wplanes[key] = e;
     *out = e;
@@ -1502,7 +1521,9 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             pe.Cp = make_planes(Ypl, N, 1.f, dsc);
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
         }
-        CTX_TRY(c, gemm_planes(make_planes(xi.pl, K, xi.scale, xi.dsc), make_planes(wp.pl, K, wp.scale), (int)M, N, K, pe, c.s));
+        Planes Wp = make_planes(wp.pl, K, wp.scale);
+        Wp.frag = wp.frag;
+        CTX_TRY(c, gemm_planes(make_planes(xi.pl, K, xi.scale, xi.dsc), Wp, (int)M, N, K, pe, c.s));
         if (c.train) {
             GOp o;
             o.type = OP_DENSE;
@@ -2123,7 +2144,9 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                     pd.ldc = o.K;
                     pd.ep.residual = dX;
                     pd.ep.ld_res = o.K;
-                    MI_TRY(gemm_planes(dzp, make_planes(wt.pl, o.N, wt.scale), (int)o.M, o.K, o.N, pd, s));
+                    Planes Wtp = make_planes(wt.pl, o.N, wt.scale);
+                    Wtp.frag = wt.frag;
+                    MI_TRY(gemm_planes(dzp, Wtp, (int)o.M, o.K, o.N, pd, s));
                 } else if (dX) {  // dX += dZ W[:, wcol0 : wcol0 + K]  = dZ (W^T rows wcol0..)^T
                     GemmEpilogue ep;
                     ep.residual = dX;

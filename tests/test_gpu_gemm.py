@@ -110,6 +110,7 @@ def test_plane_gemm_lds_dma_256_tiles_bit_identical(M, N, K):
     W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     outs = []
     try:
+        _lib.check(lib.mi_debug_set_planes_rt(0, 0))   # (the register-tile form would take these shapes first)
         for big in (0, 1):
             _lib.check(lib.mi_debug_set_planes_big(big, 1))
             out = torch.full((M, N), float("nan"), device="cuda")
@@ -118,6 +119,38 @@ def test_plane_gemm_lds_dma_256_tiles_bit_identical(M, N, K):
                 torch.cuda.synchronize()
                 outs.append(out.clone())
     finally:
+        _lib.check(lib.mi_debug_set_planes_big(1, 65536))
+        _lib.check(lib.mi_debug_set_planes_rt(2, 0))
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    ref = A.double() @ W.double().t()
+    assert (outs[1].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 512, 512), (129, 512, 512), (1031, 768, 128), (300, 256, 192), (70000, 512, 512)])
+def test_plane_gemm_register_tile_form_bit_identical(M, N, K):
+    """gemm_rt (csrc/edge_stage.hip): 128 rows x 256 columns per four-wave workgroup, W in MFMA fragment order from L2 into a register
+    ring, A through four LDS stages by LDS-DMA, the plane GEMM's own row-major epilogue.  Same product terms in the same k order per
+    output as the 128 x 128 kernel: bit for bit, ragged M and the shortest K (four k-tiles: the prologue and the drain meet) included."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    if lib.mi_plane_format() != 2:
+        pytest.skip("the register-tile kernel exists in the fp16 two-plane build")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    outs = []
+    try:
+        _lib.check(lib.mi_debug_set_planes_big(0, 1))
+        for rt in (0, 2):
+            _lib.check(lib.mi_debug_set_planes_rt(rt, 1))
+            out = torch.full((M, N), float("nan"), device="cuda")
+            for _ in range(3 if rt else 1):
+                _lib.check(lib.mi_debug_gemm(2, C.c_void_p(A.data_ptr()), K, C.c_void_p(W.data_ptr()), K, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+                torch.cuda.synchronize()
+                outs.append(out.clone())
+    finally:
+        _lib.check(lib.mi_debug_set_planes_rt(2, 16384))
         _lib.check(lib.mi_debug_set_planes_big(1, 65536))
     for o in outs[1:]:
         assert torch.equal(outs[0], o)

@@ -362,7 +362,8 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     _lib.check(_lib.load().mi_debug_set_mg_planes(3 if planes == 3 else 1 if planes else 0))
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
     if planes == 2:   # every qualifying product (epilogue extensions included) on the 256 x 256 LDS-DMA kernel, whatever its row count
-        _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))
+        _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))   # (the other cases take the default route: the 128 x 256 register-tile
+        _lib.check(_lib.load().mi_debug_set_planes_rt(0, 0))    #  kernel of csrc/edge_stage.hip for these products)
     try:
         gb = m.decoder.make_batch(na)
         E = gb.graph(frac, cell)["src"].shape[0]
@@ -392,6 +393,7 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
         _lib.check(_lib.load().mi_debug_set_mg_planes(1))
         _lib.check(_lib.load().mi_debug_set_mg_lean(1))
         _lib.check(_lib.load().mi_debug_set_planes_big(1, 65536))
+        _lib.check(_lib.load().mi_debug_set_planes_rt(2, 0))
 
 
 # ---- the network at the size the benchmark times it: GemNetHParams() defaults (512 / 512 / 64 / 16 / 16, 4 blocks, 28.3 M parameters),
