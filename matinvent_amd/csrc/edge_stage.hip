@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ++stamp_i;
     };
     stamp();
+    if (a.clk && tid == 0) a.clk[(size_t)(tile * 2 + half) * 8 + 4] = __builtin_amdgcn_s_memrealtime();   // (100 MHz: stamps 4 / 5 give the shader clock the other four ran at)
 
     // ---- A operand: k-tile kt = one 16 KiB block [plane][128 rows][64 B] of the plane set, 16 pieces of 1 KiB, four per wave ----
     // LDS image of a stage = the plane GEMM's: 64-byte rows, 16-byte piece c of row r at position c ^ ((r >> 2) & 3)
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     stamp();
+    if (a.clk && tid == 0) a.clk[(size_t)(tile * 2 + half) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     sat_report(sat);
 }
 
@@ -562,13 +564,16 @@ __global__ void pack_frag_wff_pair_kernel(const float* __restrict__ W1, int edge
     for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dst + ((((size_t)ct * KS + ks) * 2 + pl) * 64 + kg * 32 + l31) * 8) = pk[pl];
 }
 
-template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1b_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
-                                                                                                     PlanesEpilogue pe, unsigned long long* clk) {
+// NJ: 32-column MFMA tiles per wave.  1: 128 pairs x 128 columns per workgroup, two workgroups per CU (128 accumulator registers: two sets
+// of 4 x 1 tiles) -- every activation fragment read from LDS feeds ONE column tile, 8 ds_read_b128 per 12 MFMAs: 170 B per cycle and CU,
+// above what LDS delivers (128), which is why this form's loop ran at 60 % of the matrix pipe's floor.  2: 128 pairs x 256 columns per
+// workgroup, ONE workgroup per CU with 512 registers per lane (two accumulator sets of 4 x 2 tiles = 256): half the LDS reads per MFMA.
+template <int D, int NJ>
+__device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __restrict__ Wf, int M, int N, int K, PlanesEpilogue& pe, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg = lane >> 5;
-    const int KT = K / 32, KS = K / 16, nq = N / 128;   // k-tiles, k-steps, column quarters
+    const int KT = K / 32, KS = K / 16, nq = N / (128 * NJ);   // k-tiles, k-steps, column blocks of a row tile
     const int id = blockIdx.x;
     // this layer's M1 scale from the absmax slots and the weight bounds; workgroup 0 publishes all six scales (as the plane GEMM does)
     float cps_local = 0.f;
@@ -626,20 +631,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dma_tile(1, 1);
     dma_tile(2, 2);
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wf, N * K * 4);
-    const int voffw = lane * 16 + ((4 * qt + wave) * KS) * 2048;   // the wave's column tile: columns 128 qt + 32 wave .. + 31
-    u32x4 ring[D][2];
-    auto ring_load = [&](int ks, u32x4 (&w)[2]) {
+    int voffw[NJ];   // the wave's column tiles: columns 128 NJ qt + 32 NJ wave + 32 t .. + 31
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw + pl * 1024, ks * 2048, 0);
+    for (int t = 0; t < NJ; ++t) voffw[t] = lane * 16 + (((4 * qt + wave) * NJ + t) * KS) * 2048;
+    u32x4 ring[D][NJ][2];
+    auto ring_load = [&](int ks, u32x4 (&w)[NJ][2]) {
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
 
-    f32x16 acc[4][1], accS[4][1];
+    f32x16 acc[4][NJ], accS[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -648,12 +659,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
         }
     };
-    auto mma = [&](const u32x4 (&w)[2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+    auto mma = [&](const u32x4 (&w)[NJ][2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
     static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
     const int khalf = KT / 2;
@@ -666,14 +679,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int k = kt + h2;
             if (k == khalf) {   // the cosine half of K goes into the second accumulator set
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    accS[i][0] = acc[i][0];
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-                }
+                    for (int j = 0; j < NJ; ++j) {
+                        accS[i][j] = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    }
             }
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (NJ == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (4 DMA pieces + 8 ring loads per k-tile, as in edge_gemm2b_kernel)
             __syncthreads();
             if (k == 0) stamp();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
@@ -689,25 +705,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     stamp();
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    planes_epilogue_pairs<4, 1>(pe, accS, acc, row0, qt * 128 + wave * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
+    planes_epilogue_pairs<4, NJ>(pe, accS, acc, row0, (qt * 4 + wave) * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
     stamp();
 }
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1b_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                     PlanesEpilogue pe, unsigned long long* clk) {
+    edge_gemm1_body<D, 1>(A, Wf, M, N, K, pe, clk);
+}
+#if MI_HAVE_ABLATION_KERNELS   // (512 registers and 36 bytes of scratch; measured 11-13 % SLOWER end to end than the plane GEMM: DESIGN 16.3a)
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void edge_gemm1c_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                     PlanesEpilogue pe, unsigned long long* clk) {
+    edge_gemm1_body<D, 2>(A, Wf, M, N, K, pe, clk);
+}
+#endif
 
 unsigned long long* g_edge1_clk = nullptr;
 
 int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS); });
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+#if MI_HAVE_ABLATION_KERNELS
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1c_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+#endif
+    });
     MI_HIP(attr_err);
     const int H = net->H, K = 2 * net->Kh;
     pe.out_scale = 1.f / (A.scale * PL_SW);
-    int nblk = (H / 128) * ((cdiv(M, 128) + 7) / 8 * 8);
+    const bool wide = MI_HAVE_ABLATION_KERNELS && g_edge1_fused == 2 && H % 256 == 0;   // 128 x 256 tiles, one four-wave workgroup per CU with 512 registers per lane
+    int nblk = (H / (wide ? 256 : 128)) * ((cdiv(M, 128) + 7) / 8 * 8);
     if (pe.diag_C0) {
         pe.diag_block0 = nblk;
         nblk += cdiv(pe.diag_nodes, 8);
     }
-    hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, net->Wffc + (size_t)layer * ((size_t)H * K * 2), M, H, K, pe, g_edge1_clk);
+    const u16* Wf = net->Wffc + (size_t)layer * ((size_t)H * K * 2);
+#if MI_HAVE_ABLATION_KERNELS
+    if (wide) hipLaunchKernelGGL((edge_gemm1c_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
+    else
+#endif
+    hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
     MI_KERNEL_CHECK();
     return MI_OK;
 }

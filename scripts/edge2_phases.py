@@ -39,6 +39,19 @@ print(f"{B} crystals, {nt} row tiles, variant {var}; s_memtime ticks, mean / max
 for k, nm in enumerate(["first chunk + ring + tables", "main loop (4 chunks x 8 k-steps)", "epilogue"]):
     print(f"  {nm:34s} {d[:, k].mean():9.1f} {d[:, k].max():9d}")
 print("  span of the launch:", c[:, 3].max() - c[:, 0].min(), " mean tile:", (c[:, 3] - c[:, 0]).mean())
+if var == 1:   # stamps 4 / 5: s_memrealtime (100 MHz) at the tile's first and last stamp -> the shader clock the s_memtime stamps ran at
+    rt = (c[:, 5] - c[:, 4]).astype(np.float64)
+    ok = rt > 0
+    print(f"  shader clock during the launch: {np.median((c[ok, 3] - c[ok, 0]) / rt[ok]) * 0.1:.2f} GHz (median over tiles; realtime span of the launch "
+          f"{(c[ok, 5].max() - c[ok, 4].min()) * 0.01:.1f} us)")
+if var == 1:   # occupancy over the launch from the realtime stamps (10 ns ticks): how many workgroups are alive, decile by decile
+    t0, t1 = c[ok, 4].min(), c[ok, 5].max()
+    edges = np.linspace(t0, t1, 11)
+    alive = [np.mean([np.sum((c[ok, 4] <= x) & (c[ok, 5] > x)) for x in np.linspace(edges[i], edges[i + 1], 20, endpoint=False)]) for i in range(10)]
+    print("  workgroups alive, by decile of the launch:", " ".join(f"{a:.0f}" for a in alive), f"  (512 slots; workgroup-time / (span x 512) = "
+          f"{np.sum(c[ok, 5] - c[ok, 4]) / ((t1 - t0) * 512.0):.2f})")
+    life = (c[ok, 5] - c[ok, 4]) * 0.01
+    print(f"  workgroup life: median {np.median(life):.1f} us, 10 % / 90 %: {np.percentile(life, 10):.1f} / {np.percentile(life, 90):.1f} us")
 # the first edge GEMM (pair mode)
 npairs = B * n * (n - 1) // 2
 nt1 = ((npairs + 127) // 128 + 7) // 8 * 8 * 4
@@ -49,6 +62,9 @@ torch.cuda.synchronize()
 lib.mi_debug_edge1_clock(None)
 c1 = clk1.cpu().numpy().reshape(nt1, 8)
 c1 = c1[c1[:, 3] > 0]
+if len(c1) == 0:
+    print("first edge GEMM: on the plane GEMM (mi_debug_set_edge1_fused(1) selects the register-tile form with this clock)")
+    sys.exit(0)
 d1 = np.diff(c1[:, :4], axis=1)
 print(f"first edge GEMM: {len(c1)} workgroups (128 pairs x 128 columns)")
 for k, nm in enumerate(["first k-tile + ring", "main loop (24 k-tiles)", "epilogue (both edges of a pair)"]):
