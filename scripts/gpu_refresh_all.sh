@@ -1,13 +1,11 @@
 #!/bin/bash
-# round-end evidence at one HEAD: whole GPU suite, rocprofv3 summaries (headline + MatterGen-shaped sampler), every bench line
-HEAD=${1:-unknown}
+# round-end evidence at one HEAD (on the GPU box): whole GPU suite + the driver-shaped line, rocprofv3 summaries (headline, fine-tune,
+# MatterGen-shaped sampler), every secondary bench line.  usage: bash scripts/gpu_refresh_all.sh <tag, e.g. r3> <git head>
+TAG=${1:-r3}; HEAD=${2:-unknown}
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r2_gpu_pytest.log
-bash scripts/profile_round.sh r2 $HEAD > gpurun_out/r2_profile_round.log 2>&1
-bash scripts/gpu_mg_prof.sh $HEAD > gpurun_out/r2_mg_prof.log 2>&1
-for mode in mg-sample sample-default ft-default mg-ft; do
-  python bench.py --mode $mode $([ $mode = mg-ft ] && echo --mg-batch 256) 2> gpurun_out/r2_bench_$mode.err | tail -1 > gpurun_out/r2_bench_$mode.json
-done
-MI_DEBUG_OPTIME=1 python bench.py --mode mg-sample --steps 1 --warmup 1 --no-cpu-baseline 2> gpurun_out/r2_mg_optime.log > /dev/null
-cat gpurun_out/r2_gpu_pytest.log
-for f in default_steps20 default finetune mg-sample sample-default ft-default mg-ft; do echo "$f: $(cut -c1-160 gpurun_out/r2_bench_$f.json)"; done
+bash scripts/gpu_full.sh > gpurun_out/${TAG}_gpu_full.log 2>&1
+bash scripts/profile_round.sh $TAG $HEAD > gpurun_out/${TAG}_profile_round.log 2>&1
+bash scripts/gpu_ft_prof.sh > gpurun_out/${TAG}_ft_prof.log 2>&1
+bash scripts/gpu_mg_prof.sh $HEAD $TAG > gpurun_out/${TAG}_mg_prof.log 2>&1
+bash scripts/gpu_secondary.sh > gpurun_out/${TAG}_secondary.log 2>&1
+tail -12 gpurun_out/${TAG}_gpu_full.log; cat gpurun_out/${TAG}_secondary.log
