@@ -331,7 +331,7 @@ def _edge_stage_roofline(lib, module, edges_total, pairs_total, evals):
     fp32_flops = evals * L * (pairs_total * 2 * (6 * F) * H + edges_total * 2 * H * H)   # Fourier block over pairs + second linear over edges
     busy_ms = max(union_ms.value, 1e-9)
     issued = terms * fp32_flops / (busy_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer over one crystal group)", "achieved": issued,
+    return {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + edge_gemm2b_kernel / gemm_planes_kernel (edge MLP of one layer over one crystal group; the second GEMM on the register-tile kernel in inference forwards at hidden_dim 512)", "achieved": issued,
             "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "launches": int(n_launch.value),
             "avg_launch_ms": tot_ms.value / max(1, n_launch.value), "stage_busy_ms": busy_ms, "achieved_fp32_equivalent": issued / terms,
             "note": "flops of all bracketed launches / union of their execution intervals (concurrent groups overlap); small ragged sets are "
@@ -766,7 +766,7 @@ def main():
             # every fp32 product is issued as THREE fp16 MFMA products (two-plane fp16 operands; six bf16 products in the three-plane
             # bf16 build): price the matrix pipe with what it executes (fp16 and bf16 MFMA have the same dense peak)
             terms = 3 if lib.mi_plane_format() == 2 else 6
-            kernel, issued, peak = "gemm_planes_kernel<pair> + gemm_planes_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
+            kernel, issued, peak = "gemm_planes_kernel<pair> + edge_gemm2b_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges with the edge -> node sum)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
             dtype = "f32 via 2-plane fp16 split (3 fp16 MFMA terms, f32 accumulate)" if terms == 3 else "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
