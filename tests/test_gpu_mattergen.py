@@ -342,10 +342,29 @@ def test_fine_tune_step_in_chunks_equals_the_unchunked_step(monkeypatch):
         assert float((w0[k] - w1[k]).abs().max()) <= 2e-6, k   # (lr 1e-4: an Adam step moves a weight by at most ~1e-4)
 
 
+@pytest.fixture(scope="module")
+def large_tile_case():
+    """The oracle side of test_forward_at_a_size_where_the_large_tile_products_run, computed once for all its variants (the CPU forward and
+    autograd backward of 110 crystals are ~20 s each)."""
+    hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
+    hp = M.GemNetHParams(**hpd)
+    P = M.init_params(hp, seed=8, head_scale=0.5)
+    na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
+    taps = {}
+    ref = M.gemnet_forward(P, hp, frac, cell, a, na, t, taps=taps)
+    N, B = int(na.sum()), len(na)
+    up, uc, ul = torch.randn(N, 3, generator=g), M.symmetric_noise(torch.randn(B, 3, 3, generator=g)), torch.randn(N, 101, generator=g)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    refg = M.gemnet_forward(Pg, hp, frac, cell, a, na, t)
+    ((refg["pos"] * up).sum() + (refg["cell"] * uc).sum() + (refg["atomic_numbers"] * ul).sum()).backward()
+    return dict(hpd=hpd, hp=hp, P=P, na=na, frac=frac, cell=cell, a=a, t=t, taps=taps, ref={k: v.detach() for k, v in ref.items()}, up=up, uc=uc, ul=ul,
+                grads={k: v.grad.clone() for k, v in Pg.items()})
+
+
 @pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
                          ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "pre-split-plane-sets-lds-dma-256-tiles",
                               "pre-split-plane-sets-forward-only", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
-def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
+def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, large_tile_case):
     """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
     (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values; inference keeps one
     format per edge-level tensor and folds the skip merges into the residual stacks -- `lean`, also run switched off) or on the
@@ -353,11 +372,9 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
     the plane-set variants also through the backward (whose edge-level data gradients run on the plane-set kernel too, dZ written as a
     plane set by the activation-gradient pass -- `planes` = 3 keeps them on the fp32-operand kernel)."""
     from matinvent_amd import _lib
-    hpd = dict(M.TINY, emb_atom=256, emb_edge=256, num_blocks=2)
-    hp = M.GemNetHParams(**hpd)
-    P = M.init_params(hp, seed=8, head_scale=0.5)
-    m = _module(hpd, P)
-    na, frac, cell, a, t, g = _case([20] * 110, seed=21, cell_scale=5.5)
+    c = large_tile_case
+    hp, P, na, frac, cell, a, t, taps, ref = c["hp"], c["P"], c["na"], c["frac"], c["cell"], c["a"], c["t"], c["taps"], c["ref"]
+    m = _module(c["hpd"], P)
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
     _lib.check(_lib.load().mi_debug_set_mg_planes(3 if planes == 3 else 1 if planes else 0))
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
@@ -368,8 +385,6 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
         gb = m.decoder.make_batch(na)
         E = gb.graph(frac, cell)["src"].shape[0]
         assert E * 2 >= 256 * 128, E   # (E / 128) x (256 / 128) output tiles: the large-tile branch
-        taps = {}
-        ref = M.gemnet_forward(P, hp, frac, cell, a, na, t, taps=taps)
         with torch.no_grad():
             out = m.decoder(frac, cell, a, t, gb)
         for k in ("pos", "cell", "atomic_numbers"):
@@ -379,15 +394,11 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean):
                 _rel(gb.tap(name), taps[name].reshape(-1), 2e-5, f"{name} (planes={planes} f16={f16} lean={lean})")
         assert _lib.saturation_events(reset=True) == 0
         if planes:   # the training forward + backward through the same plane-set layers: parameter gradients vs the oracle's autograd
-            N, B = int(na.sum()), len(na)
-            up, uc, ul = torch.randn(N, 3, generator=g), M.symmetric_noise(torch.randn(B, 3, 3, generator=g)), torch.randn(N, 101, generator=g)
-            Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-            refg = M.gemnet_forward(Pg, hp, frac, cell, a, na, t)
-            ((refg["pos"] * up).sum() + (refg["cell"] * uc).sum() + (refg["atomic_numbers"] * ul).sum()).backward()
+            up, uc, ul = c["up"], c["uc"], c["ul"]
             o2 = m.decoder(frac, cell, a, t, gb)
             ((o2["pos"] * up.cuda()).sum() + (o2["cell"] * uc.cuda()).sum() + (o2["atomic_numbers"] * ul.cuda()).sum()).backward()
             for k, (o, n, shape) in m.decoder.layout.items():
-                _rel(m.decoder.theta.grad[o:o + n].view(shape), Pg[k].grad, 5e-5, f"grad {k}")
+                _rel(m.decoder.theta.grad[o:o + n].view(shape), c["grads"][k], 5e-5, f"grad {k}")
     finally:
         _lib.check(_lib.load().mi_debug_set_mg_f16(0))
         _lib.check(_lib.load().mi_debug_set_mg_planes(1))
