@@ -370,7 +370,9 @@ int mi_debug_set_planes_dma(int mode);
 int mi_debug_set_node_fused(int on);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
- * 1 (default) = on (needs the node-chain launch above), 0 = the 128 x 128-tile plane GEMM.  Returns the previous setting. */
+ * 1 (default) = on (inference forwards, next to the node-chain launch above), 5 = training forwards too, with the pre-activation kept
+ * for the backward pass (a recorded ablation: 6-8 % slower on the fine-tune line), 0 = the 128 x 128-tile plane GEMM.  Returns the
+ * previous setting. */
 int mi_debug_set_edge2_fused(int on);
 /* The pair-mode first edge GEMM (Fourier block over unordered atom pairs, models/diffcsp/cspnet.py:59-74) on the same form -- 128 x 128
  * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 1 = on for hidden_dim

@@ -712,7 +712,9 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 pd.C = t.dM1;
                 pd.ldc = H;
                 pd.absmax = b->absmax + 2 * L + 1;  // max |dM1|: bounds the pair-mode weight gradient's operands
-                MI_TRY(gemm_planes(dzp, make_planes(net->W2Tpl + (size_t)l * planes_elems(H, H), H), (int)E, H, H, pd, s));
+                Planes w2t = make_planes(net->W2Tpl + (size_t)l * planes_elems(H, H), H);
+                if (net->W2Tf) w2t.frag = net->W2Tf + (size_t)l * frag_elems(H, H);   // (from 16384 edges up: the 128 x 256 register-tile kernel)
+                MI_TRY(gemm_planes(dzp, w2t, (int)E, H, H, pd, s));
             } else {
                 MI_TRY(gemm_nt(Z2, H, net->W2T + l * (size_t)H * H, H, t.dM1, H, (int)E, H, H, GemmEpilogue(), s));
             }
@@ -880,6 +882,7 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
         MI_HIP(hipMalloc((void**)&n->WhhT, (size_t)L * 2 * H * H * 4));
         MI_HIP(hipMalloc((void**)&n->WaT, (size_t)H * H * 4));
         if (MI_PLANES_FP16 && H % 32 == 0) MI_HIP(hipMalloc((void**)&n->W2Tpl, (size_t)L * planes_elems(H, H) * sizeof(u16)));
+        if (MI_PLANES_FP16 && H % 256 == 0) MI_HIP(hipMalloc((void**)&n->W2Tf, (size_t)L * frag_elems(H, H) * sizeof(u16)));
     }
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
@@ -888,6 +891,7 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
             Planes wp = make_planes(n->W2Tpl + (size_t)l * planes_elems(H, H), H);
             hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((H + 127) / 128 * 128) * wp.KT * 16, 256)), dim3(256), 0, s,
                                n->W2T + (size_t)l * H * H, H, H, H, wp, 0);
+            if (n->W2Tf) MI_TRY(pack_frag_from_planes(wp, H, H, n->W2Tf + (size_t)l * frag_elems(H, H), s));
         }
         hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, n->Wn2T + (size_t)l * H * H);
         hipLaunchKernelGGL(transpose_kernel, g1(2 * H * H), dim3(256), 0, s, n->p(p + "node_mlp.0.weight"), 2 * H, H, 2 * H,

@@ -18,6 +18,7 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
+int g_edge2_train = 0;            // 1: the training forward's second edge GEMM on the register-tile kernel too, pre-activation kept (measured slower: its 4-byte Z2 stores)
 int g_planes_rt = 2;              // register-tile kernel for every qualifying product (gemm_split.h / edge_stage.hip); 1 = only those with epilogue extensions
 int g_planes_rt_min_rows = 16384;
 int g_planes_big_seg_min_rows = 0;
@@ -545,7 +546,7 @@ __global__ void act_scales_kernel(const unsigned* __restrict__ pq, const unsigne
 // agg[i] = (sum of this node's slots) / degree  -> cat[i][H:2H]       (scatter mean, cspnet.py:79)
 // aggpl (optional): the same values as a bf16 plane set (N x H).
 __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* __restrict__ rowptr,
-                                    float* __restrict__ cat, int N, int H, Planes aggpl = Planes()) {
+                                    float* __restrict__ cat, int N, int H, Planes aggpl = Planes(), int seg_shift = 5) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if ((H & 7) == 0 && (((uintptr_t)part | (uintptr_t)cat) & 15) == 0) {   // eight consecutive columns per thread: 16-byte accesses throughout
         const int h8 = H >> 3;
@@ -554,7 +555,7 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (e1 > e0) {
-            const int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
+            const int t0 = e0 >> seg_shift, t1 = (e1 - 1) >> seg_shift;   // (row blocks behind the partial sums: 32 rows, or 128 from edge_stage.hip)
             for (int sl = 0; sl <= t1 - t0; ++sl) {
                 const float* p = part + ((size_t)sl * N + i) * H + f;
                 a += *reinterpret_cast<const f32x4*>(p);
@@ -588,7 +589,7 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
     int e0 = rowptr[i], e1 = rowptr[i + 1];
     float s = 0.f;
     if (e1 > e0) {
-        int t0 = e0 >> 5, t1 = (e1 - 1) >> 5;
+        int t0 = e0 >> seg_shift, t1 = (e1 - 1) >> seg_shift;
         for (int sl = 0; sl <= t1 - t0; ++sl) s += part[((size_t)sl * N + i) * H + f];
         s = s / (float)(e1 - e0);
     }
@@ -1090,8 +1091,13 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 } else {
                     MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
                 }
-                if (fused && edge_gemm2_supported(net)) {   // 128-row x H-column register tiles, segmented sum on the matrix pipe (edge_stage.hip)
-                    MI_TRY(edge_gemm2(net, b, l, s));
+                // 128-row register tiles, segmented sum on the matrix pipe (edge_stage.hip): inference forwards next to the node-chain launch.
+                // (mi_debug_set_edge2_fused(5): the training forward too, with the pre-activation kept for the backward pass -- a recorded
+                // ablation: the kernel's result layout makes the [E, H] pre-activation 4-byte stores, 16.1-16.3 k against 17.1-17.7 k
+                // crystal-timesteps/s with the plane GEMM's row-major epilogue)
+                const bool eg2_train = train && g_edge2_train && MI_PLANES_FP16 && g2e.pre_act && g2e.ld_pre == H && !use_hi && edge_gemm2_supported(net);
+                if ((fused && edge_gemm2_supported(net)) || eg2_train) {
+                    MI_TRY(edge_gemm2(net, b, l, s, eg2_train ? g2e.pre_act : nullptr));
                     b->seg_shift = 7;
                 } else {
                 PlanesEpilogue pe2;   // M2 never reaches HBM: the edge -> node sum happens in the epilogue
@@ -1105,7 +1111,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 }
                 MI_TRY(prof_end(net, s, ps));
                 MI_TRY(to(ns));
-                if (!fused) hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp);
+                if (!fused) hipLaunchKernelGGL(finalize_agg_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, ns, b->part, b->rowptr, cat, N, H, aggp, b->seg_shift);
                 MI_KERNEL_CHECK();
             } else {
                 MI_TRY(gemm_nt(b->FF, F6, net->Wff + (size_t)l * H * F6, F6, b->M1, H, E, H, F6, g1e, s));
@@ -1263,6 +1269,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->C0) (void)hipFree(n->C0);
     if (n->W2pl) (void)hipFree(n->W2pl);
     if (n->W2Tpl) (void)hipFree(n->W2Tpl);
+    if (n->W2Tf) (void)hipFree(n->W2Tf);
     if (n->Wlnpl) (void)hipFree(n->Wlnpl);
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);

@@ -25,6 +25,7 @@
 
 namespace mi {
 
+extern int g_edge2_train;
 int g_edge2_fused = 1;   // inference forwards at hidden_dim 512: the second edge GEMM on the 128 x 512 register-tile kernel (0: plane GEMM)
 
 #if MI_PLANES_FP16
@@ -38,6 +39,7 @@ struct EdgeGemm2Args {
     const int* rowptr;        // [N + 1]
     float* part;              // [nslots][N][H], slot = tile - (first row of the node >> 7)
     int E, N;
+    float* Z2 = nullptr;      // optional (training forward): the pre-activation M1 W2^T + b2, fp32 [E][H], kept for the backward pass
     unsigned long long* clk;  // optional phase clock: [tile][8] s_memtime stamps (mi_debug_edge2_clock)
 };
 
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int EG2B_STAGE = 2 * 128 * 64, EG2B_NST = 4;                   // [plane][row 128][32 k halfs]
 constexpr int EG2B_LDS = EG2B_NST * EG2B_STAGE + 128 * 4 + 128 * 4;      // stages (overlaid by the S fragments in the epilogue) + srcl + slotb
 
-template <int D>
+template <int D, bool SAVE_Z = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm2b_kernel(EdgeGemm2Args a) {
     constexpr int H = 512, KS = H / 16, KT = H / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -391,7 +393,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     f16x8 mh, ml;
 #pragma unroll
                     for (int idx = 0; idx < 8; idx += 2) {
-                        const float v0 = silu_fast(av[8 * u + idx] * os + bcol), v1 = silu_fast(av[8 * u + idx + 1] * os + bcol);
+                        const float z0 = av[8 * u + idx] * os + bcol, z1 = av[8 * u + idx + 1] * os + bcol;
+                        if (SAVE_Z && lb0 == 0) {   // rows (r & 3) + 8 (r >> 2) + 4 kg of the 32-row block, r = 8 u + idx: a half-wave writes one 128-byte line
+                            const int r0 = row0 + rb * 32 + (idx & 3) + 8 * (2 * u + (idx >> 2)) + 4 * kg;
+                            if (r0 < a.E) a.Z2[(size_t)r0 * H + col] = z0;
+                            if (r0 + 1 < a.E) a.Z2[(size_t)(r0 + 1) * H + col] = z1;
+                        }
+                        const float v0 = silu_fast(z0), v1 = silu_fast(z1);
                         unsigned p[3];
                         pl_split_pair_acc(v0, v1, s_m2, p, sat);
                         const f16x2 h = __builtin_bit_cast(f16x2, p[0]), lo = __builtin_bit_cast(f16x2, p[1]);
@@ -764,13 +772,14 @@ int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s) {
 
 unsigned long long* g_edge2_clk = nullptr;
 
-int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
+int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
     });
     MI_HIP(attr_err);
     const int H = net->H;
@@ -784,7 +793,13 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s) {
     a.part = b->part;
     a.E = (int)b->E;
     a.N = b->N;
+    a.Z2 = Z2;
     a.clk = g_edge2_clk;
+    if (Z2) {   // the training forward: form B with the pre-activation kept
+        hipLaunchKernelGGL((edge_gemm2b_kernel<4, true>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
+        MI_KERNEL_CHECK();
+        return MI_OK;
+    }
     // 1 (default): form B -- 128 x 256 tiles, four waves, two workgroups per CU; 2 / 3: the eight-wave 128 x 512 form (ablations)
     if (g_edge2_fused == 2) hipLaunchKernelGGL((edge_gemm2_kernel<2, 2>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
     else if (g_edge2_fused == 3) hipLaunchKernelGGL((edge_gemm2_kernel<4, 1>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
@@ -827,7 +842,7 @@ int gemm_rt(const Planes&, const u16*, int, int, int, const PlanesEpilogue&, boo
 size_t frag_elems(int N, int K) { return (size_t)N * K * 2; }
 int pack_frag_from_planes(const Planes&, int, int, u16*, hipStream_t) { return MI_ESTATE; }
 
-int edge_gemm2(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
+int edge_gemm2(mi_net*, mi_batch*, int, hipStream_t, float*) { return MI_ESTATE; }
 bool edge_gemm2_supported(const mi_net*) { return false; }
 int edge_gemm1(mi_net*, const Planes&, int, int, PlanesEpilogue, hipStream_t) { return MI_ESTATE; }
 bool edge_gemm1_supported(const mi_net*) { return false; }
@@ -854,7 +869,8 @@ extern "C" int mi_debug_edge1_clock(void* dev_buffer) {
 
 extern "C" int mi_debug_set_edge2_fused(int on) {
     const int was = mi::g_edge2_fused;
-    mi::g_edge2_fused = on;
+    mi::g_edge2_fused = on == 5 ? 1 : on;
+    mi::g_edge2_train = on == 5;   // (5: the training forward too, with the pre-activation kept -- measured 6-8 % SLOWER on the fine-tune line)
     return was;
 }
 

@@ -43,6 +43,7 @@ struct mi_net {
     // transposed copies for the data-gradient GEMMs (training), rebuilt with the packs
     float* W2T = nullptr;    // [L][H][H]
     unsigned short* W2Tpl = nullptr;  // [L] plane sets of W2T (fp16 plane format): the W operand of the dM1 data gradient
+    unsigned short* W2Tf = nullptr;   // [L] the same in MFMA fragment order (Planes::frag: the register-tile GEMM, hidden_dim % 256 == 0)
     float* Wn2T = nullptr;   // [L][H][H]
     float* Wn1T = nullptr;   // [L][2H][H]
     float* WhhT = nullptr;   // [L][H][2H]
@@ -172,7 +173,8 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
 bool edge_gemm1_supported(const mi_net* net);
 int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
-int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s);
+extern int g_edge2_train;
+int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2 = nullptr);   // Z2: optional pre-activation output (training forward)
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
 }  // namespace mi
