@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -25 > gpurun_out/full_pytest.log
 tail -22 gpurun_out/full_pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench20.json 2> gpurun_out/bench20.err; echo "bench rc=$?"
 python - <<'PY'
 import json
