@@ -378,7 +378,8 @@ int mi_debug_set_edge2_fused(int on);
  * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 1 = on for hidden_dim
  * multiples of 128, 0 (default: the two measure equal, this product is bound by its epilogue) = the plane GEMM; 2 = 128 x 256 tiles, one
  * workgroup per CU with 512 registers per lane (half the LDS reads per MFMA; measured 11-13 % slower end to end; exists only in a
- * -DMI_ABLATION_KERNELS build, otherwise 2 runs form 1).  Same epilogue: bit-identical M1.  Returns the previous setting. */
+ * -DMI_ABLATION_KERNELS build, otherwise 2 runs form 1); 3 = the 128 x 128 tile as 2 x 2 waves of 64 pairs x 64 columns (half the LDS reads,
+ * twice the weight fetches; 12 % slower; ablation build only).  Same epilogue: bit-identical M1.  Returns the previous setting. */
 int mi_debug_set_edge1_fused(int on);
 /* Phase clock of that kernel (measurement only): device buffer of [row tiles][8] 64-bit s_memtime stamps (start, first operand chunk
  * landed, main loop done, epilogue done); nullptr = off.  `on` = 2 above selects the variant with a two-deep weight ring and

@@ -576,12 +576,17 @@ __global__ void pack_frag_wff_pair_kernel(const float* __restrict__ W1, int edge
 // of 4 x 1 tiles) -- every activation fragment read from LDS feeds ONE column tile, 8 ds_read_b128 per 12 MFMAs: 170 B per cycle and CU,
 // above what LDS delivers (128), which is why this form's loop ran at 60 % of the matrix pipe's floor.  2: 128 pairs x 256 columns per
 // workgroup, ONE workgroup per CU with 512 registers per lane (two accumulator sets of 4 x 2 tiles = 256): half the LDS reads per MFMA.
-template <int D, int NJ>
+// MI: 32-row MFMA tiles per wave.  4: a wave owns all 128 pairs of the tile; 2 (with NJ = 2): the four waves are 2 x 2 -- a wave owns 64 pairs x 64
+// columns, the same 128 accumulator registers and the same 128 x 128 workgroup tile as (4, 1), but each activation fragment feeds TWO column
+// tiles (4 LDS reads per 12 MFMAs instead of 8) at the price of each weight fragment being fetched by two waves (L2 -> CU traffic doubles).
+template <int D, int MI, int NJ>
 __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __restrict__ Wf, int M, int N, int K, PlanesEpilogue& pe, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg = lane >> 5;
-    const int KT = K / 32, KS = K / 16, nq = N / (128 * NJ);   // k-tiles, k-steps, column blocks of a row tile
+    constexpr int WM = 4 / MI, WN = 4 / WM, WGC = 32 * NJ * WN;   // wave rows x wave columns of the workgroup, its columns
+    const int KT = K / 32, KS = K / 16, nq = N / WGC;   // k-tiles, k-steps, column blocks of a row tile
+    const int wm = wave / WN, wn = wave % WN;
     const int id = blockIdx.x;
     // this layer's M1 scale from the absmax slots and the weight bounds; workgroup 0 publishes all six scales (as the plane GEMM does)
     float cps_local = 0.f;
@@ -639,9 +644,9 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     dma_tile(1, 1);
     dma_tile(2, 2);
     const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wf, N * K * 4);
-    int voffw[NJ];   // the wave's column tiles: columns 128 NJ qt + 32 NJ wave + 32 t .. + 31
+    int voffw[NJ];   // the wave's column tiles: columns WGC qt + 32 NJ wn + 32 t .. + 31
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) voffw[t] = lane * 16 + (((4 * qt + wave) * NJ + t) * KS) * 2048;
+    for (int t = 0; t < NJ; ++t) voffw[t] = lane * 16 + (((WN * qt + wn) * NJ + t) * KS) * 2048;
     u32x4 ring[D][NJ][2];
     auto ring_load = [&](int ks, u32x4 (&w)[NJ][2]) {
 #pragma unroll
@@ -652,26 +657,26 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
 
-    f32x16 acc[4][NJ], accS[4][NJ];
+    f32x16 acc[MI][NJ], accS[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+    auto read_a = [&](int st, int s2, f16x8 (&af)[MI][2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+        for (int i = 0; i < MI; ++i) {
+            const int r = (wm * MI + i) * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
         }
     };
-    auto mma = [&](const u32x4 (&w)[NJ][2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+    auto mma = [&](const u32x4 (&w)[NJ][2], const f16x8 (&af)[MI][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
@@ -687,7 +692,7 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
             const int k = kt + h2;
             if (k == khalf) {   // the cosine half of K goes into the second accumulator set
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         accS[i][j] = acc[i][j];
@@ -701,7 +706,7 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
             __syncthreads();
             if (k == 0) stamp();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
-            f16x8 af[4][2];
+            f16x8 af[MI][2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 read_a(k & 3, s2, af);
@@ -713,20 +718,27 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     }
     stamp();
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    planes_epilogue_pairs<4, NJ>(pe, accS, acc, row0, (qt * 4 + wave) * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
+    planes_epilogue_pairs<MI, NJ>(pe, accS, acc, row0 + wm * MI * 32, qt * WGC + wn * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
     stamp();
 }
 
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1b_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
                                                                                                      PlanesEpilogue pe, unsigned long long* clk) {
-    edge_gemm1_body<D, 1>(A, Wf, M, N, K, pe, clk);
+    edge_gemm1_body<D, 4, 1>(A, Wf, M, N, K, pe, clk);
 }
+#if MI_HAVE_ABLATION_KERNELS   // (2 x 2 waves of 64 x 64: 256 registers and 64 bytes of scratch; measured 12 % SLOWER end to end -- every weight fragment is fetched by two waves)
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1d_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                     PlanesEpilogue pe, unsigned long long* clk) {
+    edge_gemm1_body<D, 2, 2>(A, Wf, M, N, K, pe, clk);
+}
+#endif
 #if MI_HAVE_ABLATION_KERNELS   // (512 registers and 36 bytes of scratch; measured 11-13 % SLOWER end to end than the plane GEMM: DESIGN 16.3a)
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void edge_gemm1c_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
                                                                                                      PlanesEpilogue pe, unsigned long long* clk) {
-    edge_gemm1_body<D, 2>(A, Wf, M, N, K, pe, clk);
+    edge_gemm1_body<D, 4, 2>(A, Wf, M, N, K, pe, clk);
 }
 #endif
 
@@ -738,6 +750,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     std::call_once(once, [] {
         attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
 #if MI_HAVE_ABLATION_KERNELS
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1d_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1c_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
 #endif
     });
@@ -753,6 +766,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     const u16* Wf = net->Wffc + (size_t)layer * ((size_t)H * K * 2);
 #if MI_HAVE_ABLATION_KERNELS
     if (wide) hipLaunchKernelGGL((edge_gemm1c_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
+    else if (g_edge1_fused == 3) hipLaunchKernelGGL((edge_gemm1d_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);   // 2 x 2 waves of 64 x 64
     else
 #endif
     hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
