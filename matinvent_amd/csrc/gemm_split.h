@@ -855,15 +855,26 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                         }
                     };
                     float pii[8], pjj[8], pij[8], pji[8], gg[8], bb[8];
+#if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 2)   // timing diagnostic (wrong results): no row gathers
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pii[k] = pjj[k] = pij[k] = pji[k] = gg[k] = 0.25f * (float)(ni + nj + gr);
+#else
                     ld8(pii, ep.row_bias + (size_t)ni * ep.ld_row_bias + col);    // P_i[i]
                     ld8(pjj, ep.row_bias2 + (size_t)nj * ep.ld_row_bias2 + col);  // P_j[j]
                     ld8(pij, ep.row_bias + (size_t)nj * ep.ld_row_bias + col);    // P_i[j]
                     ld8(pji, ep.row_bias2 + (size_t)ni * ep.ld_row_bias2 + col);  // P_j[i]
                     ld8(gg, ep.row_bias3 + (size_t)gr * ep.ld_row_bias3 + col);
+#endif
                     if (ep.bias) ld8(bb, ep.bias + col);
 #pragma unroll
                     for (int dir = 0; dir < 2; ++dir) {
+#if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 16)  // (timing diagnostic, wrong results: every store lands in the first 1024 rows -- the same instructions, no HBM-side traffic)
+                        const int erow = (dir == 0 ? h_e1[i][u] : h_e2[i][u]) & 1023;
+#elif defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 8)   // (timing diagnostic, wrong results: both directions of a pair in adjacent rows 2 p, 2 p + 1)
+                        const int erow = 2 * row + dir;
+#else
                         const int erow = dir == 0 ? h_e1[i][u] : h_e2[i][u];
+#endif
                         float v[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -876,10 +887,12 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                             *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                             *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
                         }
+#if !(defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 4))   // (timing diagnostic, wrong results: 4 = no SiLU)
                         if (ep.act == ACT_SILU) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
                         }
+#endif
                         u32x4 o[3];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -889,6 +902,9 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
                         }
+#if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 1)   // (timing diagnostic, wrong results: 1 = one plane store per tile and lane instead of all)
+                        if ((o[0][0] ^ o[1][1]) == 0x12345677u)
+#endif
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
                     }
