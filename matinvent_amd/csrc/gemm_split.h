@@ -906,7 +906,10 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                         if ((o[0][0] ^ o[1][1]) == 0x12345677u)
 #endif
 #pragma unroll
-                        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            // (non-temporal stores measured equal: 44.4 / 48.9-50.6 against 44.6 / 49.8-50.6 structures/s on one / four chains)
+                            *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                        }
                     }
                 }
             }
