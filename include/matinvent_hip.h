@@ -374,6 +374,15 @@ int mi_debug_set_node_fused(int on);
  * for the backward pass (a recorded ablation: 6-8 % slower on the fine-tune line), 0 = the 128 x 128-tile plane GEMM.  Returns the
  * previous setting. */
 int mi_debug_set_edge2_fused(int on);
+/* Both edge products of a layer and the edge -> node sums in ONE launch (csrc/edge_fused.hip: a workgroup owns 64 atom pairs, M1 stays
+ * in LDS; inference forwards, fc pair mode, hidden_dim 512, next to the node-chain launch): 1 = on, 0 (default) = the pair GEMM + the
+ * second edge GEMM.  M1 is bit-identical; the partial sums are formed over other row groups.  A recorded experiment (parity green, 27 %
+ * slower end to end: DESIGN 16.4) that exists in -DMI_ABLATION_KERNELS builds only; the default library ignores 1.  Returns the previous
+ * setting. */
+int mi_debug_set_edge_fused(int on);
+/* Phase clock of that launch: dev_buffer = [workgroups][16] uint64 s_memtime stamps (0 entry, 1 + 3c / 2 + 3c / 3 + 3c: first product /
+ * pair epilogue / second product of column chunk c, 13 exit), NULL = off. */
+int mi_debug_edge_fused_clock(void* dev_buffer);
 /* The pair-mode first edge GEMM (Fourier block over unordered atom pairs, models/diffcsp/cspnet.py:59-74) on the same form -- 128 x 128
  * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 1 = on for hidden_dim
  * multiples of 128, 0 (default: the two measure equal, this product is bound by its epilogue) = the plane GEMM; 2 = 128 x 256 tiles, one

@@ -772,6 +772,7 @@ int dev_alloc(mi_batch* b, T** p, size_t n) {
 template int dev_alloc<float>(mi_batch*, float**, size_t);
 template int dev_alloc<int>(mi_batch*, int**, size_t);
 template int dev_alloc<unsigned short>(mi_batch*, unsigned short**, size_t);
+template int dev_alloc<unsigned>(mi_batch*, unsigned**, size_t);
 
 // bench.py's roofline hook: bracket the dominant stage (the per-edge MLP of one layer) with events
 struct ProfSlot {
@@ -1077,6 +1078,13 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         pe1.diag_node2graph = b->node2graph;
                         pe1.diag_e = b->e_diag;
                         pe1.diag_nodes = N;
+                    }
+                    const bool efused = fused && fold && MI_PLANES_FP16 && edge_fused_supported(net, b);
+                    if (efused) {   // both edge products and the edge -> node sums in one launch, M1 stays in LDS (edge_fused.hip)
+                        MI_TRY(edge_fused(net, b, l, s));
+                        b->seg_shift = -1;
+                        MI_TRY(prof_end(net, s, ps));
+                        continue;   // (fused: the rest of the layer runs in node_chain(l + 1))
                     }
                     if (b->Np > 0 && fold && edge_gemm1_supported(net))   // 128 x 128 tiles, weights straight from L2 in fragment order (edge_stage.hip)
                         MI_TRY(edge_gemm1(net, make_planes(b->FFpl, Kp, PL_S_UNIT), l, (int)b->Np, pe1, s));
@@ -1448,6 +1456,39 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     b->Np = (int64_t)pr_i.size();
     pr_off[B] = (int)pr_i.size();
     rowptr[N] = (int)e;
+    // edge_fused.hip's tables: 64-pair tiles, slots of a node's partial sums (see mi_batch)
+    std::vector<int> ef_tile0(std::max(N, 1), 1 << 30);   // (nodes of crystals without pairs: no pair tile)
+    std::vector<unsigned> ef_mask(std::max(N, 1), 0u);
+    if (!knn && b->Np > 0) {
+        int span = 0;
+        for (int g = 0; g < B; ++g) {
+            const int n = num_atoms_host[g], o = b->node_off_h[g];
+            if (pr_off[g + 1] > pr_off[g]) {
+                const int t0 = pr_off[g] >> 6, t1 = (pr_off[g + 1] - 1) >> 6;
+                span = std::max(span, t1 - t0 + 1);
+                for (int i = 0; i < n; ++i) ef_tile0[o + i] = t0;
+            }
+        }
+        b->ef_nslots = span + 1;
+        b->ef_ok = b->ef_nslots <= 32;
+        if (b->ef_ok) {
+            for (size_t q = 0; q < pr_i.size(); ++q) {
+                const int t = (int)(q >> 6);
+                ef_mask[pr_i[q]] |= 1u << (t - ef_tile0[pr_i[q]]);
+                ef_mask[pr_j[q]] |= 1u << (t - ef_tile0[pr_j[q]]);
+            }
+            for (int v = 0; v < N; ++v) ef_mask[v] |= 1u << (b->ef_nslots - 1);
+            for (size_t q0 = 0; q0 < pr_i.size() && b->ef_ok; q0 += 64) {   // every tile's node range must fit the 128 local nodes of its S matrix
+                int lo = pr_i[q0], hi = pr_j[q0];
+                for (size_t q = q0; q < std::min(pr_i.size(), q0 + 64); ++q) {
+                    lo = std::min(lo, pr_i[q]);
+                    hi = std::max(hi, pr_j[q]);
+                }
+                if (hi - lo + 1 > 128) b->ef_ok = false;
+            }
+        }
+        if (b->ef_ok && MI_HAVE_ABLATION_KERNELS) nslots = std::max(nslots, b->ef_nslots);   // (edge_fused.hip exists in ablation builds only)
+    }
     b->nslots = nslots;
     const int H = net->H, L = net->L;
     const size_t NH = (size_t)N * H;
@@ -1477,6 +1518,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(pair_e2, (size_t)b->Np);
     A_(pair_graph, (size_t)b->Np);
     A_(pair_off, B + 1);
+    A_(ef_tile0, (size_t)std::max(N, 1));
+    if (rc == MI_OK) rc = dev_alloc(b, &b->ef_mask, (size_t)std::max(N, 1));
     A_(e_diag, knn ? 0 : N);
     A_(M1pl, planes_elems(E, H));
     A_(lnpl, planes_elems(N, H));
@@ -1531,6 +1574,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     if (he == hipSuccess) he = up(b->pair_e2, pr_e2);
     if (he == hipSuccess) he = up(b->pair_graph, pr_g);
     if (he == hipSuccess) he = up(b->pair_off, pr_off);
+    if (he == hipSuccess) he = up(b->ef_tile0, ef_tile0);
+    if (he == hipSuccess) he = hipMemcpy(b->ef_mask, ef_mask.data(), ef_mask.size() * sizeof(unsigned), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = up(b->e_diag, ediag);
     if (he != hipSuccess) {
         set_error("index table upload failed: %s", hipGetErrorString(he));

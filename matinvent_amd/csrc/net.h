@@ -92,7 +92,13 @@ struct mi_batch {
     int64_t E = 0;      // edges of the current graph (fixed for fc; rewritten by every forward for knn)
     int64_t E_cap = 0;  // edge capacity every per-edge buffer is sized for (= E for fc)
     int nslots = 1;
-    int seg_shift = 5;  // log2 of the row-block size behind the partial sums currently in `part` (5: plane GEMM epilogue; 7: edge_stage.hip)
+    int seg_shift = 5;  // log2 of the row-block size behind the partial sums currently in `part` (5: plane GEMM epilogue; 7: edge_stage.hip; -1: edge_fused.hip, slots by mask)
+    // edge_fused.hip (fc pair mode): 64-pair tiles.  ef_tile0[v] = first pair tile of v's crystal, ef_mask[v] = slots (tile - ef_tile0, and
+    // ef_nslots - 1 for the self-edge tile) that hold a partial sum of v; ef_ok: every tile's node range fits 128 and ef_nslots <= 32
+    int* ef_tile0 = nullptr;
+    unsigned* ef_mask = nullptr;
+    int ef_nslots = 0;
+    bool ef_ok = false;
     // knn edge style (CSPNet.gen_edges knn branch, graph.hip)
     int knn = 0, max_neighbors = 0, cap_per_node = 0, deg_cap = 0, nmax = 0;
     // pair tables of the fc edge list (unordered node pairs i < j of each crystal): the first edge GEMM runs over pairs
@@ -174,6 +180,8 @@ bool edge_gemm1_supported(const mi_net* net);
 int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
 extern int g_edge2_train;
+int edge_fused(mi_net* net, mi_batch* b, int layer, hipStream_t s);   // edge_fused.hip: both edge products of a layer in one launch (M1 stays in LDS)
+bool edge_fused_supported(const mi_net* net, const mi_batch* b);
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2 = nullptr);   // Z2: optional pre-activation output (training forward)
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);

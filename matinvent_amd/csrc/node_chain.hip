@@ -58,6 +58,8 @@ struct NodeChainArgs {
     const float* part = nullptr;    // [nslots][N][H] partial sums of the edge -> node reduction
     const int* rowptr = nullptr;    // [N + 1] CSR rows (degree, slots)
     int seg_shift = 5;              // log2 of the row-block size the partial sums were formed over (32 rows: plane GEMM; 128: edge_stage.hip)
+    const unsigned* slotmask = nullptr;   // optional [N]: bit s set = slot s holds a partial sum of this node (edge_fused.hip: a node's edges sit in
+    int nslots = 0;                       // several 64-pair tiles + the self-edge tile); summed in increasing slot order instead of the CSR slot range
     const float* xpart = nullptr;   // LayerNorm(h) W0[:, :H]^T of layer l-1 (computed with its P_i / P_j), row stride ld_xpart
     int ld_xpart = 0;
     const u16* Wagg = nullptr;      // fragment-order packs (H x H)
@@ -187,6 +189,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 e0[r] = i < N ? a.rowptr[i] : 0;
                 e1[r] = i < N ? a.rowptr[i + 1] : 0;
             }
+            f32x4 xsum[RPW], ysum[RPW];
+            bool any[RPW];
+            if (a.slotmask) {   // slots by mask (a node's partial sums come from every tile that holds one of its edges)
+                unsigned mk[RPW];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int i = row0 + wave * RPW + r;
+                    mk[r] = i < N ? a.slotmask[i] : 0u;
+                    xsum[r] = ysum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    any[r] = mk[r] != 0u && e1[r] > e0[r];
+                }
+                for (int sl = 0; sl < a.nslots; ++sl) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const int i = row0 + wave * RPW + r;
+                        if (act && ((mk[r] >> sl) & 1u)) {
+                            const float* p = a.part + ((size_t)sl * N + i) * H + c0;
+                            xsum[r] += *reinterpret_cast<const f32x4*>(p);
+                            ysum[r] += *reinterpret_cast<const f32x4*>(p + 4);
+                        }
+                    }
+                }
+                ring_fill(rs_agg, wave * TW);
+            } else {
             f32x4 x[RPW], y[RPW], x1[RPW], y1[RPW];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
@@ -208,11 +234,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             ring_fill(rs_agg, wave * TW);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int row = wave * RPW + r, i = row0 + row;
+                const int i = row0 + wave * RPW + r;
                 const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
-                if (!act) continue;
                 f32x4 xs = x[r], ys = y[r];
-                if (ns > 1) {
+                if (act && ns > 1) {
                     xs += x1[r];
                     ys += y1[r];
                     for (int sl = 2; sl < ns; ++sl) {
@@ -221,7 +246,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                         ys += *reinterpret_cast<const f32x4*>(p + 4);
                     }
                 }
-                if (ns > 0) {
+                xsum[r] = xs;
+                ysum[r] = ys;
+                any[r] = ns > 0;
+            }
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r;
+                if (!act) continue;
+                f32x4 xs = xsum[r], ys = ysum[r];
+                if (any[r]) {
                     const float d = (float)(e1[r] - e0[r]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -474,6 +509,10 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
         a.part = b->part;
         a.rowptr = b->rowptr;
         a.seg_shift = b->seg_shift;
+        if (b->seg_shift < 0) {   // (edge_fused.hip wrote the partial sums: slots by mask)
+            a.slotmask = b->ef_mask;
+            a.nslots = b->ef_nslots;
+        }
         a.xpart = b->PQ + 2 * H;
         a.ld_xpart = 3 * H;
         a.Wagg = base;
