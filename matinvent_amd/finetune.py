@@ -412,9 +412,15 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
         return _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma,
                                        device, noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats)
     finally:
-        flush_wgrads()   # (nothing pending unless an exception cut a window short)
-        for ab in handles:
-            ab.set_wgrad_window(agent.decoder, 0)
+        import sys
+        failing = sys.exc_info()[0] is not None
+        try:   # (nothing pending unless an exception cut a window short -- and then its own error must not replace that exception)
+            flush_wgrads()
+            for ab in handles:
+                ab.set_wgrad_window(agent.decoder, 0)
+        except Exception:
+            if not failing:
+                raise
 
 
 def _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma, device,
