@@ -381,6 +381,9 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     # contraction over all their rows instead of one short contraction (1.7k rows per group at 256 x 20 atoms) per micro-step: the
     # agent's batch handles keep the operand rows of up to WGRAD_WINDOW micro-steps (see include/matinvent_hip.h).
     window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
+    dec = agent.decoder
+    slot_bytes = 7 * max(nodes[k + 1] - nodes[k] for k in range(groups)) * dec.hidden_dim * dec.num_layers * 4   # operand rows of one micro-step
+    window = max(0, min(window, (8 << 30) // max(1, slot_bytes)))   # at most 8 GB of kept rows per group
     handles = []
     for k in range(groups):
         agent.shard_offsets = offs[k]
