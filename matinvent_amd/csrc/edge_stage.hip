@@ -793,7 +793,9 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
         attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+#if MI_HAVE_ABLATION_KERNELS
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+#endif
     });
     MI_HIP(attr_err);
     const int H = net->H;
@@ -809,10 +811,14 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     a.N = b->N;
     a.Z2 = Z2;
     a.clk = g_edge2_clk;
-    if (Z2) {   // the training forward: form B with the pre-activation kept
+    if (Z2) {   // the training forward: form B with the pre-activation kept (228 spilled registers: an ablation instantiation)
+#if MI_HAVE_ABLATION_KERNELS
         hipLaunchKernelGGL((edge_gemm2b_kernel<4, true>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
         MI_KERNEL_CHECK();
         return MI_OK;
+#else
+        MI_CHECK(false, MI_EINVAL, "edge_gemm2 with the pre-activation kept is an ablation instantiation: rebuild with MI_EXTRA_FLAGS=-DMI_ABLATION_KERNELS");
+#endif
     }
     // 1 (default): form B -- 128 x 256 tiles, four waves, two workgroups per CU; 2 / 3: the eight-wave 128 x 512 form (ablations)
     if (g_edge2_fused == 2) hipLaunchKernelGGL((edge_gemm2_kernel<2, 2>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
@@ -884,7 +890,7 @@ extern "C" int mi_debug_edge1_clock(void* dev_buffer) {
 extern "C" int mi_debug_set_edge2_fused(int on) {
     const int was = mi::g_edge2_fused;
     mi::g_edge2_fused = on == 5 ? 1 : on;
-    mi::g_edge2_train = on == 5;   // (5: the training forward too, with the pre-activation kept -- measured 6-8 % SLOWER on the fine-tune line)
+    mi::g_edge2_train = on == 5 && MI_HAVE_ABLATION_KERNELS;   // (5: the training forward too, with the pre-activation kept -- measured 6-8 % SLOWER on the fine-tune line; ablation builds only)
     return was;
 }
 
