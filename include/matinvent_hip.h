@@ -370,9 +370,8 @@ int mi_debug_set_planes_dma(int mode);
 int mi_debug_set_node_fused(int on);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
- * 1 (default) = on (inference forwards, next to the node-chain launch above), 5 = training forwards too, with the pre-activation kept
- * for the backward pass (a recorded ablation: 6-8 % slower on the fine-tune line; its instantiation spills registers and exists in
- * -DMI_ABLATION_KERNELS builds only, otherwise 5 acts as 1), 0 = the 128 x 128-tile plane GEMM.  Returns the previous setting. */
+ * 1 (default) = on (inference forwards, next to the node-chain launch above; training forwards too, with the pre-activation kept
+ * for the backward pass), 4 = inference forwards only, 0 = the 128 x 128-tile plane GEMM.  Returns the previous setting. */
 int mi_debug_set_edge2_fused(int on);
 /* Both edge products of a layer and the edge -> node sums in ONE launch (csrc/edge_fused.hip: a workgroup owns 64 atom pairs, M1 stays
  * in LDS; inference forwards, fc pair mode, hidden_dim 512, next to the node-chain launch): 1 = on, 0 (default) = the pair GEMM + the

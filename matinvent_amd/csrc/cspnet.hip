@@ -18,7 +18,7 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
-int g_edge2_train = 0;            // 1: the training forward's second edge GEMM on the register-tile kernel too, pre-activation kept (measured slower: its 4-byte Z2 stores)
+int g_edge2_train = 1;            // the training forward's second edge GEMM on the register-tile kernel too, its pre-activation written row-major through LDS patches
 int g_planes_rt = 2;              // register-tile kernel for every qualifying product (gemm_split.h / edge_stage.hip); 1 = only those with epilogue extensions
 int g_planes_rt_min_rows = 16384;
 int g_planes_big_seg_min_rows = 0;
@@ -1099,10 +1099,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 } else {
                     MI_TRY(gemm_planes(ffp, wffp, E, H, F6, pe1, s));
                 }
-                // 128-row register tiles, segmented sum on the matrix pipe (edge_stage.hip): inference forwards next to the node-chain launch.
-                // (mi_debug_set_edge2_fused(5): the training forward too, with the pre-activation kept for the backward pass -- a recorded
-                // ablation: the kernel's result layout makes the [E, H] pre-activation 4-byte stores, 16.1-16.3 k against 17.1-17.7 k
-                // crystal-timesteps/s with the plane GEMM's row-major epilogue)
+                // 128-row register tiles, segmented sum on the matrix pipe (edge_stage.hip): inference forwards next to the node-chain launch, and
+                // the training forward with the pre-activation kept for the backward pass (written row-major through per-wave LDS patches: as
+                // 4-byte stores from the result layout the instantiation spilled 228 registers and LOST 6-8 %; this form gains 1.9 % on the
+                // fine-tune line).  The partial sums then round M2 to the plane format's 22 bits, as in inference.
                 const bool eg2_train = train && g_edge2_train && MI_PLANES_FP16 && g2e.pre_act && g2e.ld_pre == H && !use_hi && edge_gemm2_supported(net);
                 if ((fused && edge_gemm2_supported(net)) || eg2_train) {
                     MI_TRY(edge_gemm2(net, b, l, s, eg2_train ? g2e.pre_act : nullptr));

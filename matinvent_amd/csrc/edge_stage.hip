@@ -353,6 +353,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     stamp();
 
+    if constexpr (SAVE_Z) {
+        // training forward: Z2 = acc / (s_A s_W) + b2 is kept for the backward pass.  In the result layout that would be 128 four-byte
+        // stores per lane; through a per-wave LDS patch (the plane GEMM's planes_store_preact_rows) every store is a 16-byte row-major piece.
+        __syncthreads();   // every wave is out of the main loop: the patches overlay the operand stages
+        float* stage = reinterpret_cast<float*>(smem) + wave * 1152;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rb = row0 + i * 32, cb = half * 256 + wave * 64 + j * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r] * os;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = lane + 64 * u, rl = q >> 2, c8 = (q & 3) * 8;
+                    const int row = rb + rl, col = cb + c8;
+                    f32x4 z0 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8);
+                    f32x4 z1 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8 + 4);
+                    if (row < a.E) {
+                        z0 += *reinterpret_cast<const f32x4*>(a.b2 + col);
+                        z1 += *reinterpret_cast<const f32x4*>(a.b2 + col + 4);
+                        float* d = a.Z2 + (size_t)row * H + col;
+                        *reinterpret_cast<f32x4*>(d) = z0;
+                        *reinterpret_cast<f32x4*>(d + 4) = z1;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+
     // ---- epilogue (as in the eight-wave form): SiLU -> two fp16 planes -> part = S x M2 on the matrix pipe ----
     const int cnt = (nrows > 0 ? a.src[row0 + nrows - 1] - node_first + 1 : 0);
     u16* sfr = reinterpret_cast<u16*>(smem);
@@ -393,13 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     f16x8 mh, ml;
 #pragma unroll
                     for (int idx = 0; idx < 8; idx += 2) {
-                        const float z0 = av[8 * u + idx] * os + bcol, z1 = av[8 * u + idx + 1] * os + bcol;
-                        if (SAVE_Z && lb0 == 0) {   // rows (r & 3) + 8 (r >> 2) + 4 kg of the 32-row block, r = 8 u + idx: a half-wave writes one 128-byte line
-                            const int r0 = row0 + rb * 32 + (idx & 3) + 8 * (2 * u + (idx >> 2)) + 4 * kg;
-                            if (r0 < a.E) a.Z2[(size_t)r0 * H + col] = z0;
-                            if (r0 + 1 < a.E) a.Z2[(size_t)(r0 + 1) * H + col] = z1;
-                        }
-                        const float v0 = silu_fast(z0), v1 = silu_fast(z1);
+                        const float v0 = silu_fast(av[8 * u + idx] * os + bcol), v1 = silu_fast(av[8 * u + idx + 1] * os + bcol);
                         unsigned p[3];
                         pl_split_pair_acc(v0, v1, s_m2, p, sat);
                         const f16x2 h = __builtin_bit_cast(f16x2, p[0]), lo = __builtin_bit_cast(f16x2, p[1]);
@@ -793,9 +818,7 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
         attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
-#if MI_HAVE_ABLATION_KERNELS
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
-#endif
     });
     MI_HIP(attr_err);
     const int H = net->H;
@@ -811,14 +834,10 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     a.N = b->N;
     a.Z2 = Z2;
     a.clk = g_edge2_clk;
-    if (Z2) {   // the training forward: form B with the pre-activation kept (228 spilled registers: an ablation instantiation)
-#if MI_HAVE_ABLATION_KERNELS
+    if (Z2) {   // the training forward: form B with the pre-activation kept (written row-major through per-wave LDS patches)
         hipLaunchKernelGGL((edge_gemm2b_kernel<4, true>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
         MI_KERNEL_CHECK();
         return MI_OK;
-#else
-        MI_CHECK(false, MI_EINVAL, "edge_gemm2 with the pre-activation kept is an ablation instantiation: rebuild with MI_EXTRA_FLAGS=-DMI_ABLATION_KERNELS");
-#endif
     }
     // 1 (default): form B -- 128 x 256 tiles, four waves, two workgroups per CU; 2 / 3: the eight-wave 128 x 512 form (ablations)
     if (g_edge2_fused == 2) hipLaunchKernelGGL((edge_gemm2_kernel<2, 2>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
@@ -889,8 +908,8 @@ extern "C" int mi_debug_edge1_clock(void* dev_buffer) {
 
 extern "C" int mi_debug_set_edge2_fused(int on) {
     const int was = mi::g_edge2_fused;
-    mi::g_edge2_fused = on == 5 ? 1 : on;
-    mi::g_edge2_train = on == 5 && MI_HAVE_ABLATION_KERNELS;   // (5: the training forward too, with the pre-activation kept -- measured 6-8 % SLOWER on the fine-tune line; ablation builds only)
+    mi::g_edge2_fused = on == 4 ? 1 : on;
+    mi::g_edge2_train = on == 1;   // (4: inference forwards only -- the training forward keeps the 128 x 128 plane GEMM)
     return was;
 }
 
