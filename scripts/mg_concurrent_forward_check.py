@@ -41,6 +41,24 @@ seqr = [fwd(k, taps) for k in range(G)]
 seqr2 = [fwd(k, taps) for k in range(G)]
 print("sequential reproducible:", all(torch.equal(seqr[k][kk], seqr2[k][kk]) for k in range(G) for kk in seqr[k]))
 pool = concurrent_streams(G, m.device)
+if len(sys.argv) > 1 and sys.argv[1] == "cu-mask":
+    # experiment: every chain on its own quarter of the CUs (hipExtStreamCreateWithCUMask) -- no two chains ever share a CU, so no wave of one
+    # is ever preempted for another.  If the differences disappear, they come from queue oversubscription, not from the kernels.
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+    pool = []
+    for k in range(G):
+        mask = (C.c_uint32 * words)()
+        for cu in range(ncu):
+            if cu % G == k:   # (interleaved: every chain gets CUs of every XCD / shader engine, whatever the bit order means)
+                mask[cu // 32] |= 1 << (cu % 32)
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(words), mask)
+        assert rc == 0, f"hipExtStreamCreateWithCUMask: {rc}"
+        pool.append(torch.cuda.ExternalStream(st.value))
+    print(f"chains on CU-masked streams: {ncu} CUs, {ncu // G} per chain")
 cur = torch.cuda.current_stream()
 def cmp(out, label):
     bad = [(k, kk, "size" if out[k][kk].shape != seqr[k][kk].shape else float((out[k][kk].double() - seqr[k][kk].double()).abs().max())) for k in range(G) for kk in seqr[k]
