@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = 0.01f * (lane + i);
     if (MODE == 3) {   // top-level split: waves 0-3 run a pure MFMA loop, waves 4-7 a pure VALU loop (one of each per SIMD)
-        if (SEL == 0 ? wave < 4 : SEL == 1 ? (wave & 1) == 0 : (wave & 2) == 0) {
+        if ((SEL % 10) == 0 ? wave < 4 : (SEL % 10) == 1 ? (wave & 1) == 0 : (SEL % 10) == 2 ? (wave & 2) == 0 : (SEL % 10) == 3 ? true : false) {
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
@@ -26,7 +26,14 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
             if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[q] * -1.44269504f)) + 0.25f;
+                for (int q = 0; q < 8; ++q) {
+                    if (SEL >= 10) {   // plain full-rate VALU work (no transcendental unit): 12 dependent fmas per value
+#pragma unroll
+                        for (int t = 0; t < 12; ++t) v[q] = __builtin_fmaf(v[q], 0.999f, 0.001f);
+                    } else {
+                        v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[q] * -1.44269504f)) + 0.25f;
+                    }
+                }
             }
         }
         float s3 = 0.f;
@@ -81,5 +88,8 @@ int main() {
     printf("  ... with the VALU waves at s_setprio 1: %.2f ms   at s_setprio 3: %.2f ms\n", p1, p3);
     const float e0 = run<3, 0, 1>(8, iters), e1 = run<3, 0, 2>(8, iters), e3 = run<3, 3, 1>(8, iters);
     printf("  MFMA on the even waves: %.2f ms   on waves 0,1,4,5: %.2f ms   even waves, VALU waves at s_setprio 3: %.2f ms\n", e0, e1, e3);
+    // plain fma work instead of exp / rcp in the VALU waves: SEL 13 = MFMA only (all waves), 14 = fma only, 10 / 11 = one of each per SIMD under the two mappings
+    const float f_m = run<3, 0, 13>(8, iters), f_v = run<3, 0, 14>(8, iters), f0 = run<3, 0, 10>(8, iters), f1 = run<3, 0, 11>(8, iters);
+    printf("plain-fma VALU waves: MFMA in all eight waves %.2f ms   fma in all eight %.2f ms   waves 0-3 MFMA + 4-7 fma %.2f ms   even MFMA + odd fma %.2f ms\n", f_m, f_v, f0, f1);
     return 0;
 }
