@@ -227,7 +227,7 @@ def _apply_env_knobs(lib):
     """Experiment knobs (A/B runs of kernel choices); the defaults are what the library ships with."""
     for env, fn in (("MI_DB_MIN_TILES", lib.mi_debug_set_db_min_tiles), ("MI_NODE_PLANES_MIN_ROWS", lib.mi_debug_set_node_planes_min_rows),
                     ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128), ("MI_TN_SPLIT_MIN_ROWS", lib.mi_debug_set_tn_split_min_rows),
-                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused), ("MI_EDGE_FUSED", lib.mi_debug_set_edge_fused)):
+                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused), ("MI_EDGE_FUSED", lib.mi_debug_set_edge_fused), ("MI_MG_NOSYNC", lib.mi_debug_set_mg_nosync)):
         if os.environ.get(env) is not None and os.environ[env] != "":
             fn(int(os.environ[env]))
     if os.environ.get("MI_PLANES_RT", "") != "":   # register-tile form of the large plane products: 0 off, 1 those with epilogue extensions (default), 2 all
@@ -656,6 +656,62 @@ def main_mg_ft(args):
     print(json.dumps(out), flush=True)
 
 
+def measure_traffic_live(args, steps=3, warmup=1, timeout_s=240):
+    """roofline.traffic of the headline line: FETCH_SIZE and WRITE_SIZE of the edge stage's two kernels (pair-mode Fourier GEMM +
+    second-linear GEMM) per dispatch, from two rocprofv3 child runs of this script (`--counter-child`: the same workload, `steps`
+    denoising steps).  Units and correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KiB; on
+    gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes (doubled here); WRITE_SIZE as reported.  Returns (bytes per bench launch
+    or None, provenance dict)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, {"measured": "no: rocprofv3 not found on this box"}
+    here = os.path.abspath(__file__)
+    got, t0 = {}, time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, here, "--steps", str(steps), "--warmup", str(warmup), "--streams", str(args.streams),
+                   "--path", args.path, "--no-cpu-baseline", "--no-counters", "--counter-child"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, {"measured": f"no: the {counter} pass exceeded {timeout_s} s"}
+            dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, {"measured": f"no: the {counter} pass failed (rc {r.returncode})", "stderr_tail": (r.stderr or "")[-300:]}
+            cur = sqlite3.connect(dbs[0]).cursor()
+            per = {}
+            for k, n, v in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
+                per[k.split("(")[0]] = (n, v)
+            got[counter] = per
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    stage = lambda k: ("gemm_planes_kernel<1" in k) or ("edge_gemm2" in k) or ("edge_gemm1" in k) or ("edge_ring" in k) or ("edge_fused" in k)
+    kernels, total = {}, 0.0
+    launches = None
+    for k in sorted(set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"])):
+        if not stage(k):
+            continue
+        nf, f = got["FETCH_SIZE"].get(k, (0, 0.0))
+        nw, w = got["WRITE_SIZE"].get(k, (0, 0.0))
+        fb, wb = 2.0 * f * 1024.0, w * 1024.0
+        kernels[k[:80]] = {"dispatches": nf, "fetch_bytes": fb, "write_bytes": wb}
+        total += fb + wb   # (one dispatch of each kernel per bench launch = the edge stage of one layer)
+        launches = nf if launches is None else min(launches, nf)
+    if not kernels:
+        return None, {"measured": "no: the edge-stage kernels do not appear in the counter passes"}
+    return total, {"measured": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command line, after the timed region",
+                   "steps_per_pass": steps, "per_kernel": kernels, "wall_s": round(time.perf_counter() - t0, 1),
+                   "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): start the N ranks ourselves, one
     process per GPU, through torch.distributed.run on the loopback address, and pass their output through -- rank 0 prints
@@ -689,6 +745,8 @@ def main():
                     "steps that each start from the physical-density state")
     ap.add_argument("--mg-chains", type=int, default=1, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams (default 1: at this size "
                     "concurrent chains of the MatterGen-shaped sampler are not run-to-run reproducible, DESIGN 17)")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE child passes that fill roofline.traffic")
+    ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)   # (the child of those passes: the timed chain only, no JSON)
     ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "mg-ft", "sample-default", "ft-default"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
@@ -748,6 +806,9 @@ def main():
     n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.mi_profile_read(m.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
     _lib.check(lib.mi_profile_enable(m.decoder._h, 0))
+    if args.counter_child:   # (under rocprofv3 --pmc: the dispatches are what is wanted, nothing is printed)
+        torch.cuda.synchronize()
+        return
     finite = all(bool(torch.isfinite(v).all()) for v in (final["frac_coords"], final["lattices"], final["atom_types"]))
     sat = _lib.saturation_events(reset=True)   # fp16-plane conversions that clamped during the run (0 = the format held)
 
@@ -772,16 +833,13 @@ def main():
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
             issued, peak, dtype = fp32_equiv, PEAK_F32_MFMA_TFLOPS, "f32"
         y_eval = bytes_per_crystal_eval(NATOM)
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
-        # separate passes, corrected as the MI355X guide prescribes; scripts/rocprof_summary.py writes the file).  bench.py cannot
-        # read hardware counters itself, so the figure is the profiled one and carries its provenance; absent file -> null.
-        traffic, traffic_src = None, None
-        import glob
-        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_rocprofv3_summary_traffic.json")))
-        if args.path == "split-gemm" and world == 1 and cands:   # the newest committed PMC passes; their HEAD is stated next to the number
-            tr = json.load(open(cands[-1]))
-            traffic = tr["bytes_per_dispatch"] * tr["dispatches_per_bench_launch"]
-            traffic_src = {"file": os.path.relpath(cands[-1], os.path.dirname(os.path.abspath(__file__))), "profiled_head": tr.get("head", "round 1")}
+        # HBM-side bytes per launch, MEASURED BY THIS RUN: two short child runs of this same command line under rocprofv3 (--pmc
+        # FETCH_SIZE, then --pmc WRITE_SIZE: separate passes, corrected as the MI355X guide prescribes), after the timed region.  A
+        # property of the code that was just timed -- no committed file can go stale behind a kernel change.  null (with the reason)
+        # when rocprofv3 is missing or a pass fails; --no-counters skips the passes.
+        traffic, traffic_src = None, {"measured": "skipped (--no-counters)" if args.no_counters else "not applicable to this path / world size"}
+        if args.path == "split-gemm" and world == 1 and not args.no_counters:
+            traffic, traffic_src = measure_traffic_live(args)
         out = {
             "metric": "crystal structures/sec (1000-step reverse diffusion)", "value": value, "unit": "structures/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,

@@ -40,6 +40,11 @@ typedef struct mi_batch mi_batch;   /* one batch of crystals: index tables + wor
 
 const char* mi_last_error(void);
 int mi_version(void);
+/* roctx ranges for host-side phases (the library brackets its own sampler steps and fine-tune micro-steps; the host mirror uses this
+ * pair around the gradient all-reduce -- pipeline/mat_invent.py:166,177 is where the reference steps its optimizer).  No-ops unless
+ * MI_ROCTX=1 is set when the library is loaded; show up under `rocprofv3 --marker-trace`. */
+int mi_trace_push(const char* name);
+int mi_trace_pop(void);
 
 /* ---------------------------------------------------------------------------------------
  * Score network  --  replaces CSPNet (models/diffcsp/cspnet.py:94-294) as built by
@@ -452,7 +457,11 @@ int mi_gemnet_graph(mi_gemnet* net, mi_gbatch* b, const float* pos, const float*
 /* copy out the current graph (any pointer may be NULL): src/dst [E], img [E][3], swap [E] (index of the reverse edge),
  * rowptr [N+1] (edges are sorted by dst), D [E], V [E][3] (unit vector from dst to the periodic image of src) */
 int mi_gemnet_graph_read(const mi_gbatch* b, int* src, int* dst, int* img, int* swap, int* rowptr, float* D, float* V, void* stream);
-/* The denoiser.  train != 0 keeps the activations for mi_gemnet_backward (one pending backward per batch handle). */
+/* The denoiser.  `train` is a bit set: 1 keeps the activations for mi_gemnet_backward (one pending backward per batch handle);
+ * 2 (inference only) runs WITHOUT the host synchronisation that reads the graph's edge count: the edge-level launches are sized by the
+ * capacity 2 max_neighbors N and read the count on the device, and a crystal over a graph capacity is taken out of the graph (no
+ * edges) instead of failing the call -- its flag stays in the handle until mi_gbatch_graph_status reads it.  The reverse-diffusion
+ * chain (models/mattergen/sample.py:27-64 drives 2 x 1000 such evaluations per batch) uses this form. */
 int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* atomic_numbers,
                       const float* t, float* out_pos, float* out_cell, float* out_logits, int train, void* stream);
 /* grad_theta += dLoss/dtheta given dLoss/d(out_pos, out_cell, out_logits) (any may be NULL = zero) */
@@ -471,6 +480,20 @@ int mi_debug_set_mg_planes(int on);
  * residual stack they close and the radial weighting into the edge -> atom sum: 1 (default) / 0 = both formats and separate passes,
  * as the training forward always does.  Same results to fp32 rounding; the tests run both. */
 int mi_debug_set_mg_lean(int on);
+/* The sampler's forwards without a host round trip per evaluation (mi_gemnet_forward, bit 2): 1 (default) / 0 = the synchronising
+ * form.  Returns the previous setting.  Same results bit for bit; the tests run both. */
+int mi_debug_set_mg_nosync(int on);
+/* In-degree capacity of the periodic graph (default and maximum 128 = the triplet kernels' LDS capacity; <= 0 restores it): a crystal
+ * holding an atom with more in-edges is taken out of the graph (flag 4).  Lowering it shrinks the triplet kernels' LDS image of the
+ * sampler's forwards (more workgroups per CU) at the price of flagging denser crystals; the tests use it to exercise the flag path.
+ * Returns the previous value. */
+int mi_debug_set_mg_deg_cap(int cap);
+/* Per-crystal graph-capacity flags after mi_mg_sampler_run / mi_gemnet_forward: bad_host[i] != 0 -- crystal i exceeded a capacity of
+ * the periodic graph at some evaluation (1: more than max_neighbors kept pairs of one atom, 2: more than 512 atoms inside the cutoff
+ * even after shrinking it, 4: an in-degree above 128) and ran without edges from then on: its sample is invalid, the others are
+ * unaffected.  The counterpart of the reference's per-crystal invalid_filter (pipeline/filters/opt_filter.py:49-61), which drops
+ * collapsed crystals one by one after sampling.  bad_host (B ints) and n_bad may be NULL.  Waits for the work queued on `stream`. */
+int mi_gbatch_graph_status(mi_gbatch* b, int* bad_host, int* n_bad, void* stream);
 /* parity taps of the most recent forward: "h<i>" [N,emb_atom], "m<i>" [E,emb_edge] after block i (0 = embedding), "rbf" [E,num_radial] */
 int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, int64_t* numel, void* stream);
 

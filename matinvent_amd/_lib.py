@@ -45,6 +45,8 @@ _P, _I, _L, _U64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
 SIGNATURES = {
     "mi_last_error": (C.c_char_p, []),
     "mi_version": (_I, []),
+    "mi_trace_push": (_I, [C.c_char_p]),
+    "mi_trace_pop": (_I, []),
     "mi_net_create": (_I, [C.POINTER(NetConfig), C.POINTER(_P)]),
     "mi_net_destroy": (None, [_P]),
     "mi_net_num_params": (_L, [_P]),
@@ -120,6 +122,9 @@ SIGNATURES = {
     "mi_debug_set_mg_f16": (_I, [_I]),
     "mi_debug_set_mg_planes": (_I, [_I]),
     "mi_debug_set_mg_lean": (_I, [_I]),
+    "mi_debug_set_mg_nosync": (_I, [_I]),
+    "mi_debug_set_mg_deg_cap": (_I, [_I]),
+    "mi_gbatch_graph_status": (_I, [_P, _P, C.POINTER(_I), _P]),
     "mi_gemnet_tap": (_I, [_P, C.c_char_p, _P, _L, C.POINTER(_L), _P]),
     "mi_mg_sample_marginal": (_I, [_P, C.POINTER(MGCorruption), _P, _P, _P, _P, _U64, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi_mg_sampler_init": (_I, [_P, C.POINTER(MGCorruption), _U64, _P, _P, _P, _P, _P, _P]),
@@ -157,10 +162,21 @@ def load():
     return lib
 
 
+MI_EINVAL, MI_EHIP, MI_ENOMEM, MI_ESTATE = -1, -2, -3, -4   # include/matinvent_hip.h
+
+
+class MIError(RuntimeError):
+    """A failed library call; `code` is the C ABI's return value (MI_EINVAL / MI_EHIP / MI_ENOMEM / MI_ESTATE)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().mi_last_error().decode(errors="replace")
-        raise RuntimeError(f"matinvent_hip {what} failed (code {rc}): {msg}")
+        raise MIError(rc, f"matinvent_hip {what} failed (code {rc}): {msg}")
 
 
 def saturation_events(reset: bool = True) -> int:

@@ -1079,6 +1079,7 @@ static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* p
                          void* aux_stream) {
     MI_CHECK(agent && ab && prior && pb && lengths && angles && frac0 && atom_types && reward && time_freqs && grad_theta, MI_EINVAL,
              "null argument");
+    TraceRange range("mi_ft_micro_step");
     MI_CHECK(ab != pb, MI_EINVAL, "agent and prior need separate batch handles (separate workspace)");
     MI_CHECK(ab->B == pb->B && ab->N == pb->N && b_global >= ab->B / (copies > 0 ? copies : 1) && accum_steps >= 1, MI_EINVAL,
              "inconsistent batch arguments");

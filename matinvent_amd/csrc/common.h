@@ -39,6 +39,18 @@ void set_error(const char* fmt, ...);
 
 #define MI_KERNEL_CHECK() MI_HIP(hipGetLastError())
 
+// ---- roctx ranges (tracing hooks around the sampler step, the fine-tune micro-step and the gradient all-reduce) --------
+// Off unless MI_ROCTX=1 is set when the library is loaded; the roctx library is opened at run time (no link dependency), so a
+// `rocprofv3 --marker-trace` run shows one named range per denoising step / micro-step / all-reduce over the kernels it enqueues.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+    explicit TraceRange(const char* name) { trace_push(name); }
+    ~TraceRange() { trace_pop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,5 +1,6 @@
 // CSPNet score network on gfx950: weight packing, node-level kernels, forward orchestration
 // and the mi_net / mi_batch C entry points.  Reference: models/diffcsp/cspnet.py.
+#include <dlfcn.h>
 #include <stdarg.h>
 
 #include <algorithm>
@@ -45,6 +46,36 @@ void sat_register(int (*fetch)(unsigned*, bool)) { sat_readers().push_back(fetch
 int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s);   // edge_stage.hip
 
 static bool cfg_ln_and_wide(const mi_net* n) { return n->cfg.ln && (n->H == 128 || n->H == 256 || n->H == 512); }
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("MI_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+void trace_push(const char* name) {
+    if (roctx().push) roctx().push(name);
+}
+void trace_pop() {
+    if (roctx().pop) roctx().pop();
+}
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -1215,6 +1246,15 @@ extern "C" {
 
 const char* mi_last_error(void) { return mi::g_err; }
 int mi_version(void) { return 1; }
+
+int mi_trace_push(const char* name) {
+    mi::trace_push(name ? name : "mi");
+    return MI_OK;
+}
+int mi_trace_pop(void) {
+    mi::trace_pop();
+    return MI_OK;
+}
 
 int mi_net_create(const mi_net_config* cfg, mi_net** out) {
     MI_CHECK(cfg && out, MI_EINVAL, "null argument");

@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                                                  PlanesEpilogue pe) {
     const int KS = K >> 4, KT = K >> 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    M = pe.rows(M);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kg = lane >> 5;
     const int ncb = N >> 8;

@@ -175,8 +175,14 @@ __device__ __forceinline__ float f16_scale_from_absmax(unsigned bits) {
 // max |x| of a tensor as a bit pattern (order-independent: deterministic); the slot must be zero before the launch
 // (spread_mask: the waves' atomics go to out[blockIdx & mask] -- same-address atomics serialise at ~8.5 ns each in the L2, so a
 // launch of thousands of waves spreads them over a power-of-two row of sub-slots that the reader folds; 0 = one slot)
-static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out, int spread_mask = 0) {
+// (mdev / per_row: optional device-side row count -- the tensor has *mdev rows of per_row elements, n is the capacity)
+static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out, int spread_mask = 0,
+                                          const int* __restrict__ mdev = nullptr, int per_row = 0) {
     float m = 0.f;
+    if (mdev) {
+        const int64_t nd = (int64_t)*mdev * per_row;
+        n = nd < n ? nd : n;
+    }
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // 16-byte loads (4-byte ones ran at 2.3 TB/s on a [64k, 512] tensor)
         const int64_t n4 = n >> 2;
@@ -530,6 +536,15 @@ struct PlanesEpilogue {
     const int* diag_e = nullptr;
     int diag_nodes = 0;
     int diag_block0 = 0;
+    // optional DEVICE-side row count: the launch is sized by an upper bound M (a capacity), the kernel works on min(M, *m_dev) rows.
+    // Lets a chain of launches whose row count is produced on the device (the periodic graph's edge count) run without a host
+    // round trip per evaluation (gemnet.hip, the sampler's forwards).
+    const int* m_dev = nullptr;
+    __device__ __forceinline__ int rows(int M) const {
+        if (!m_dev) return M;
+        const int md = __builtin_amdgcn_readfirstlane(*m_dev);
+        return md < M ? md : M;
+    }
 };
 
 // Power-of-two scales of the three unbounded activation plane sets of a layer from RIGOROUS bounds (fp16 plane format):
@@ -986,6 +1001,7 @@ template <int V, int TM, bool EXT = false, int PF = 1>
 __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int N, int K, const PlanesEpilogue& pe, int rt_base) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32, TN = 2, PLA = BM * 64, PLB = 128 * 64;  // bytes per plane tile in LDS (A, W)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    M = pe.rows(M);
     unsigned char* As = smem;
     unsigned char* Ws = smem + NPL * PLA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1395,6 +1411,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                                                                PlanesEpilogue pe) {
     constexpr int TM = 4, TN = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    M = pe.rows(M);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, kg = lane >> 5;
     // XCD-aware map: both 256-column tiles of a row tile on one XCD (ids go round-robin over the eight XCDs)

@@ -16,6 +16,7 @@
 
 #include <chrono>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,8 @@ int g_mg_bwd_planes = 1;
 // otherwise -- instead of both (elementwise consumers and residual merges reconstruct x = (h0 + h1) / scale, exact in fp32), fold the
 // skip-connection merges into the last layer of the residual stack they close and the radial weighting into the edge -> atom sum.
 // Training forwards keep both formats (the tape's gradient kernels read fp32 rows).
+int g_mg_nosync = 1;   // the sampler's forwards run without a host round trip per evaluation (forward_impl); 0: the synchronising form (mi_debug_set_mg_nosync)
+int g_mg_deg_cap = GN_DEG;   // in-degree capacity a crystal may reach before it is taken out of the graph (<= GN_DEG; mi_debug_set_mg_deg_cap)
 int g_mg_lean = 63;
 static const bool g_optime = getenv("MI_DEBUG_OPTIME") != nullptr;   // bit 0: one format per tensor, bit 1: folded skip merges, bit 2: weighted edge -> atom sum in one pass, bit 3: residuals read from plane sets, bit 4: scalar heads through the derived tensors, bit 5: radial multiplicand / reversed-edge merge in the dense epilogues
 constexpr int64_t MG_PLANES_MIN_ROWS = 4096;
@@ -70,6 +73,7 @@ struct GraphArgs {
     float cutoff;
     int maxnb, R, cap;
     int *ent, *acnt, *deg, *mcount, *meta;
+    int* bad;   // [B] per-crystal capacity flags (1 / 2 / 4 as in meta[2]); a flagged crystal gets NO edges (gg_fix_kernel)
 };
 
 // entries of target a: key = (c << 11) | code for each selected neighbour whose pair is represented by (a, c, code).
@@ -160,7 +164,10 @@ __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
                 else if (m < g.maxnb) lo = mid;
                 else ok = true;
             }
-            if (!ok && lane == 0) atomicOr(&g.meta[2], 2);
+            if (!ok && lane == 0) {
+                atomicOr(&g.meta[2], 2);
+                atomicOr(&g.bad[b], 2);
+            }
             if (m > GN_CAND) m = GN_CAND;
         }
         __builtin_amdgcn_wave_barrier();
@@ -191,8 +198,40 @@ __global__ __launch_bounds__(256) void gg_select_kernel(GraphArgs g) {
         if (lane == 0) {
             g.acnt[n0 + a] = cnt;
             atomicAdd(&g.deg[n0 + a], cnt);
-            if (cnt > g.cap) atomicOr(&g.meta[2], 1);
+            if (cnt > g.cap) {
+                atomicOr(&g.meta[2], 1);
+                atomicOr(&g.bad[b], 1);
+            }
         }
+    }
+}
+
+// A crystal whose neighbour lists do not fit the capacities (flags 1 / 2 from gg_select_kernel, 4 = an in-degree above `dg_cap`, the
+// triplet kernels' LDS capacity of this launch) is taken OUT of the graph: its atoms get no edges in this evaluation and the flag
+// stays in bad[] (sticky until the caller clears it), so the rest of the batch goes on and the caller drops exactly the offending
+// crystals afterwards -- what the reference's invalid_filter does with collapsed cells (pipeline/filters/opt_filter.py:49-61).  It is
+// also what makes every later kernel safe without a host-side check: the edge count of the crystals that remain is at most
+// 2 cap N = E_cap.  One wave per crystal.
+__global__ __launch_bounds__(64) void gg_fix_kernel(const int* __restrict__ node_off, int* __restrict__ deg, int* __restrict__ acnt, int* __restrict__ bad,
+                                                    int* __restrict__ meta, int dg_cap) {
+    const int b = blockIdx.x, lane = threadIdx.x, n0 = node_off[b], n1 = node_off[b + 1];
+    int mx = 0;
+    for (int i = n0 + lane; i < n1; i += 64) mx = deg[i] > mx ? deg[i] : mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    int flags = bad[b];
+    if (mx > dg_cap) flags |= 4;
+    if (flags == 0) return;
+    if (lane == 0) {
+        bad[b] = flags;
+        atomicOr(&meta[2], flags);
+    }
+    for (int i = n0 + lane; i < n1; i += 64) {
+        deg[i] = 0;
+        acnt[i] = 0;
     }
 }
 
@@ -241,7 +280,7 @@ __global__ __launch_bounds__(256) void gg_emit_kernel(EmitArgs g) {
     extern __shared__ int el[];  // [n * cap] entries (a << 17 | key)
     __shared__ int aoff[GN_NMAX + 1];
     __shared__ unsigned rowbuf[4][GN_DEG];
-    if (g.meta[2] != 0 || (int64_t)g.meta[0] > g.E_cap) return;
+    if ((int64_t)g.meta[0] > g.E_cap) return;   // (cannot happen once gg_fix_kernel has removed the crystals over capacity: E <= 2 cap N)
     const int b = blockIdx.x, n0 = g.node_off[b], n = g.node_off[b + 1] - n0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = 2 * g.R + 1;
     if (tid == 0) {
@@ -340,11 +379,21 @@ __global__ __launch_bounds__(256) void gg_emit_kernel(EmitArgs g) {
     }
 }
 
+// Row count of an edge-level launch: `rows` is what the launch was sized for; when the graph's edge count is only known on the device
+// (forwards without a host round trip, see forward_impl) it is a capacity and *mdev (= meta[0]) the number of rows that exist.
+__device__ __forceinline__ int64_t dev_rows(int64_t rows, const int* __restrict__ mdev) {
+    if (!mdev) return rows;
+    const int64_t m = *mdev;
+    return m < rows ? m : rows;
+}
+
 // D, V and the radial basis (polynomial envelope p = 5 x Gaussian smearing on d = D / cutoff): one thread per (edge, radial index)
 __global__ void edge_geom_rbf_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int* __restrict__ src,
                                      const int* __restrict__ dst, const int* __restrict__ code, const int* __restrict__ edge_graph, int R_img,
-                                     float cutoff, int NR, int64_t E, float* __restrict__ D, float* __restrict__ V, float* __restrict__ rbf) {
+                                     float cutoff, int NR, int64_t E, float* __restrict__ D, float* __restrict__ V, float* __restrict__ rbf,
+                                     const int* __restrict__ mdev = nullptr) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    E = dev_rows(E, mdev);
     if (idx >= E * NR) return;
     const int e = (int)(idx / NR), r = (int)(idx % NR);
     const float* L = cell + (size_t)edge_graph[e] * 9;
@@ -569,8 +618,8 @@ __device__ __forceinline__ f32x2 src_load2(const Src& s, int64_t r, int c, int c
     return f32x2{x * inv, y * inv};
 }
 // plane set -> fp32 rows (a consumer without a plane-reading form, or a debug tap, asked for a tensor kept as planes only)
-__global__ __launch_bounds__(256) void pl_to_f32_kernel(Src a, float* __restrict__ y, int64_t rows, int cols) {
-    const int64_t n = rows * (cols / 2);
+__global__ __launch_bounds__(256) void pl_to_f32_kernel(Src a, float* __restrict__ y, int64_t rows, int cols, const int* __restrict__ mdev = nullptr) {
+    const int64_t n = dev_rows(rows, mdev) * (cols / 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (cols / 2);
         const int c = (int)(i % (cols / 2)) * 2;
@@ -595,9 +644,10 @@ __global__ __launch_bounds__(256) void segsum_mul_kernel(Src X, const float* __r
 // y = a * b (fp32) + plane set + absmax; grid-stride over column pairs (one atomic per wave of a FIXED-size grid: a wave-per-pair-block
 // launch serialised a million atomics on one address -- 8.8 ms instead of 0.3)
 constexpr int EW_GRID = 4096;
-__global__ __launch_bounds__(256) void mul_pl_kernel(Src a, Src b, float* __restrict__ y, Planes P, unsigned* amax, int64_t rows, int cols) {
+__global__ __launch_bounds__(256) void mul_pl_kernel(Src a, Src b, float* __restrict__ y, Planes P, unsigned* amax, int64_t rows, int cols,
+                                                     const int* __restrict__ mdev = nullptr) {
     float m = 0.f;
-    const int64_t n = rows * (cols / 2);
+    const int64_t n = dev_rows(rows, mdev) * (cols / 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (cols / 2);
         const int c = (int)(i % (cols / 2)) * 2;
@@ -611,9 +661,9 @@ __global__ __launch_bounds__(256) void mul_pl_kernel(Src a, Src b, float* __rest
 }
 // y = (a + b[perm]) * s (fp32) + optional plane set + absmax
 __global__ __launch_bounds__(256) void axpby_pl_kernel(Src a, Src b, const int* __restrict__ perm, float s, float* __restrict__ y, Planes P, unsigned* amax,
-                                                       int64_t rows, int cols) {
+                                                       int64_t rows, int cols, const int* __restrict__ mdev = nullptr) {
     float m = 0.f;
-    const int64_t n = rows * (cols / 2);
+    const int64_t n = dev_rows(rows, mdev) * (cols / 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (cols / 2);
         const int c = (int)(i % (cols / 2)) * 2;
@@ -627,10 +677,10 @@ __global__ __launch_bounds__(256) void axpby_pl_kernel(Src a, Src b, const int* 
     note_absmax(amax, m);
 }
 // fp32 [rows][cols] -> plane set with the fixed scale of P (the radial basis, |x| <= 1); column padding written as zero
-__global__ void split_fixed_kernel(const float* __restrict__ x, Planes P, int64_t rows, int cols) {
+__global__ void split_fixed_kernel(const float* __restrict__ x, Planes P, int64_t rows, int cols, const int* __restrict__ mdev = nullptr) {
     const int cp = P.KT * 16;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cp) return;
+    if (i >= dev_rows(rows, mdev) * cp) return;
     const int64_t r = i / cp;
     const int c = (int)(i % cp) * 2;
     store_pl_pair(P, r, c, c < cols ? x[r * cols + c] : 0.f, c + 1 < cols ? x[r * cols + c + 1] : 0.f);
@@ -915,8 +965,10 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     if (lane == 0) y[r] = acc ? y[r] + s : s;
 }
 // short rows (K <= 16, a power of two): y[e] (+)= sum_k A[e][k] B[e][k], 64 / K rows per wave
-__global__ __launch_bounds__(256) void rowdot_short_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ y, int64_t rows, int K, int acc) {
+__global__ __launch_bounds__(256) void rowdot_short_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ y, int64_t rows, int K, int acc,
+                                                           const int* __restrict__ mdev = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    rows = dev_rows(rows, mdev);
     const int64_t r = i / K;
     float s = r < rows ? A[i] * Bm[i] : 0.f;
     for (int o = K >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1149,6 +1201,19 @@ struct mi_gbatch {
     int B = 0, N = 0;
     int64_t E = 0, E_cap = 0;
     int deg_max = mi::GN_DEG;   // largest in-degree of the current graph (host copy: sizes the triplet kernels' LDS)
+    // Forwards without a host round trip (the sampler's, see forward_impl): E is then the CAPACITY the launches are sized for and the
+    // kernels read the edge count from meta[0]; crystals over a graph capacity are taken out on the device and remembered in bad[].
+    bool nosync = false;
+    int* bad = nullptr;            // [B] device: sticky per-crystal capacity flags (gg_fix_kernel)
+    int* status_h = nullptr;       // pinned host mirror of bad[] (mi_gbatch_graph_status)
+    // the activation arena of such forwards is COMPACT: an fp32 tensor that lives as a plane set only reserves no rows (ordinal of its
+    // take call not in mat_ord, the set of tensors some consumer materialises); both found by the dry passes, cached per program shape
+    bool compact = false, collect = false;
+    int take_idx = 0;
+    std::set<int> mat_ord;
+    std::map<const float*, int> ord_of;
+    uint64_t dry_key = 0;
+    size_t dry_need = 0;
     int64_t node_offset = 0, graph_offset = 0;
     std::vector<int> num_atoms_h, node_off_h;
     int *num_atoms = nullptr, *node_off = nullptr, *node2graph = nullptr;
@@ -1235,7 +1300,20 @@ struct Ctx {
     hipStream_t s;
     bool dry, train;
     int rc = MI_OK;
-    float* take(size_t n) { return b->fwd.take(n); }
+    float* take(size_t n) {
+        ++b->take_idx;
+        return b->fwd.take(n);
+    }
+    // the fp32 rows of an op's output.  plane_only: the producer writes the plane set alone (lean inference); in a compact arena such
+    // a tensor gets a 256-byte placeholder (its address is still the key of the per-forward tables) unless a consumer materialises it
+    float* take_y(size_t n, bool plane_only) {
+        const int ord = b->take_idx;
+        float* y = take((plane_only && b->compact && !b->collect && !b->mat_ord.count(ord)) ? 1 : n);
+        if (b->collect) b->ord_of[y] = ord;
+        return y;
+    }
+    // device-side row count of an edge-level launch (NULL: the host's count is exact)
+    const int* mdev(int64_t M) const { return (b->nosync && M == b->E) ? b->meta : nullptr; }
     u16* take_planes(int64_t rows, int cols) {
         static const bool dbg_arena = getenv("MI_DEBUG_ARENA") != nullptr;
         if (dbg_arena) fprintf(stderr, "[arena %s] planes %lld x %d at %zu\n", dry ? "dry" : "run", (long long)rows, cols, b->fwd.top);
@@ -1250,7 +1328,10 @@ struct Ctx {
         if (!slot && b->amax_used < AMAX_SLOTS) {
             need_f32(x);
             slot = b->amax_pool + (size_t)AMAX_W * b->amax_used++;
-            if (!dry && n > 0) hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1);
+            const bool edge_rows = b->nosync && b->E > 0 && n % b->E == 0;
+            if (!dry && n > 0)
+                hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1,
+                                   edge_rows ? b->meta : (const int*)nullptr, edge_rows ? (int)(n / b->E) : 0);
         }
         return slot;
     }
@@ -1285,13 +1366,21 @@ static void materialize_f32(mi_gbatch* b, const float* X, hipStream_t s) {
     const mi_gbatch::PlInfo& pi = b->pl_of.at(X);
     if (d.rows > 0)
         hipLaunchKernelGGL(pl_to_f32_kernel, dim3((unsigned)std::min<int64_t>(4096, (d.rows * (d.cols / 2) + 255) / 256)), dim3(256), 0, s,
-                           Src{nullptr, make_planes(pi.pl, d.cols, pi.scale, pi.dsc)}, const_cast<float*>(X), d.rows, d.cols);
+                           Src{nullptr, make_planes(pi.pl, d.cols, pi.scale, pi.dsc)}, const_cast<float*>(X), d.rows, d.cols,
+                           (b->nosync && d.rows == b->E) ? b->meta : (const int*)nullptr);
     b->absent.erase(it);
 }
 void Ctx::need_f32(const float* X) {
     if (!X || !is_absent(X)) return;
-    if (dry) b->absent.erase(X);
-    else materialize_f32(b, X, s);
+    if (dry) {
+        if (b->collect) {
+            auto it = b->ord_of.find(X);
+            if (it != b->ord_of.end()) b->mat_ord.insert(it->second);
+        }
+        b->absent.erase(X);
+    } else {
+        materialize_f32(b, X, s);
+    }
 }
 
 // MI_DEBUG_OPTIME=1: every op of the program is bracketed by stream synchronisations and its wall time printed (a per-layer profile
@@ -1445,11 +1534,11 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
     const int N = w.rows;
     if (ldy == 0) ldy = N;
     OpTimer optimer(c, "dense " + wname, M, N, K);
-    float* Y = c.take((size_t)M * ldy);
-    float* Z = (act != ACT_NONE && c.train) ? c.take((size_t)M * N) : nullptr;
     // edge-level layers whose input carries a plane set run on the pre-split plane kernel
     auto xin = c.b->pl_of.find(X);
     const bool planes = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 7) == 0 && ldy == N && bname.empty() && xin != c.b->pl_of.end();
+    float* Y = c.take_y((size_t)M * ldy, planes && want_pl && c.lean());
+    float* Z = (act != ACT_NONE && c.train) ? c.take((size_t)M * N) : nullptr;
     u16* Ypl = (planes && want_pl) ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};   // (registered in the dry run too: both runs must take the same decisions)
     const bool lean_y = Ypl && c.lean();   // the consumers of Y read the plane set: its fp32 rows are not written
@@ -1523,6 +1612,7 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         }
         Planes Wp = make_planes(wp.pl, K, wp.scale);
         Wp.frag = wp.frag;
+        pe.m_dev = c.mdev(M);
         CTX_TRY(c, gemm_planes(make_planes(xi.pl, K, xi.scale, xi.dsc), Wp, (int)M, N, K, pe, c.s));
         if (c.train) {
             GOp o;
@@ -1546,6 +1636,11 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
             o.s = scale;
             c.b->tape.push_back(o);
         }
+        return Y;
+    }
+    if (c.mdev(M)) {   // (every edge-level layer of a lean plane-mode forward takes the branch above)
+        set_error("forward without a host round trip: edge-level layer %s is not on the plane-set kernel", wname.c_str());
+        c.rc = MI_ESTATE;
         return Y;
     }
     GemmEpilogue ep;
@@ -1614,8 +1709,8 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
 }
 static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool want_pl = false) {
     OpTimer optimer(c, "mul", M, N, 0);
-    float* Y = c.take((size_t)M * N);
     const bool pl = c.pm() && want_pl && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;
+    float* Y = c.take_y((size_t)M * N, pl && c.lean());
     u16* Ypl = pl ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     const bool lean_y = Ypl && c.lean();
@@ -1633,7 +1728,9 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
         if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
         c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
         hipLaunchKernelGGL(mul_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, sa, sb, lean_y ? (float*)nullptr : Y,
-                           make_planes(Ypl, N, 1.f, dsc), c.new_amax(Y), M, N);
+                           make_planes(Ypl, N, 1.f, dsc), c.new_amax(Y), M, N, c.mdev(M));
+    } else if (c.mdev(M)) {
+        c.rc = MI_ESTATE;
     } else
     hipLaunchKernelGGL(mul_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, Y, M * N);
     if (c.train) {
@@ -1650,8 +1747,8 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
 }
 static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N, bool perm = false, bool want_pl = false) {
     OpTimer optimer(c, perm ? "axpby (row-permuted)" : "axpby", M, N, 0);
-    float* Y = c.take((size_t)M * N);
     const bool big = c.pm() && M >= MG_PLANES_MIN_ROWS && (N & 1) == 0;   // edge-level: the output's absmax is tracked on the way
+    float* Y = c.take_y((size_t)M * N, big && want_pl && c.lean());
     u16* Ypl = (big && want_pl) ? c.take_planes(M, N) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     const bool lean_y = Ypl && c.lean();
@@ -1672,7 +1769,9 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
         }
         hipLaunchKernelGGL(axpby_pl_kernel, dim3((unsigned)std::min<int64_t>(EW_GRID, nblk(M * (N / 2)))), dim3(256), 0, c.s, sa, sb, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2,
-                           lean_y ? (float*)nullptr : Y, Ypl ? make_planes(Ypl, N, 1.f, dsc) : Planes(), c.new_amax(Y), M, N);
+                           lean_y ? (float*)nullptr : Y, Ypl ? make_planes(Ypl, N, 1.f, dsc) : Planes(), c.new_amax(Y), M, N, c.mdev(M));
+    } else if (c.mdev(M)) {
+        c.rc = MI_ESTATE;
     } else
     hipLaunchKernelGGL(axpby_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, A, Bm, perm ? c.b->swap : (const int*)nullptr, GN_ISQ2, Y, M, N);
     if (c.train) {
@@ -1729,9 +1828,9 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     OpTimer optimer(c, "triplet", c.b->E, 0, 0);
     const mi_gemnet_config& g = c.net->cfg;
     const int64_t E = c.b->E;
-    float* Y = c.take((size_t)E * g.emb_cbf * g.emb_trip);
     const int NT = g.emb_cbf * g.emb_trip;
     const bool pl = c.pm() && E >= MG_PLANES_MIN_ROWS && (g.emb_trip & 1) == 0;
+    float* Y = c.take_y((size_t)E * g.emb_cbf * g.emb_trip, pl && !c.train);
     u16* Ypl = pl ? c.take_planes(E, NT) : nullptr;
     if (Ypl) c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, nullptr, 1.f};
     c.need_f32(xd);
@@ -1781,6 +1880,10 @@ static void op_rowdot(Ctx& c, const float* A, const float* Bm, const std::string
     c.need_f32(A);
     c.need_f32(Bm);
     if (c.dry || !CTX_OK(c) || c.b->E == 0) return;
+    if (c.mdev(c.b->E)) {
+        c.rc = MI_ESTATE;
+        return;
+    }
     const GParam& w = c.net->P(wname);
     hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(nblk(c.b->E, 4)), dim3(256), 0, c.s, A, Bm, c.net->theta + w.off, y, c.b->E, K, acc ? 1 : 0);
     if (c.train) {
@@ -1802,7 +1905,7 @@ static void op_rowdot_short(Ctx& c, const float* A, const float* Bm, float* y, i
     c.need_f32(A);
     c.need_f32(Bm);
     if (c.dry || !CTX_OK(c) || c.b->E == 0 || c.train) return;
-    hipLaunchKernelGGL(rowdot_short_kernel, dim3(nblk(c.b->E * K)), dim3(256), 0, c.s, A, Bm, y, c.b->E, K, acc ? 1 : 0);
+    hipLaunchKernelGGL(rowdot_short_kernel, dim3(nblk(c.b->E * K)), dim3(256), 0, c.s, A, Bm, y, c.b->E, K, acc ? 1 : 0, c.mdev(c.b->E));
 }
 
 // `outer` (lean inference, n > 0): the skip connection the stack closes, (outer + stack(x)) / sqrt(2), folded into its last layer
@@ -1848,6 +1951,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     const int64_t E = b->E;
     const int N = b->N, B = b->B;
     b->fwd.top = 0;
+    b->take_idx = 0;
     b->tape.clear();
     b->taps.clear();
     b->amax_of.clear();
@@ -1869,10 +1973,10 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     if (!c.dry && CTX_OK(c)) {
         if (E > 0)
             hipLaunchKernelGGL(edge_geom_rbf_kernel, dim3(nblk(E * R)), dim3(256), 0, c.s, pos, cell, b->src, b->dst, b->code, b->edge_graph, g.max_images,
-                               g.cutoff, R, E, b->D, b->V, rbf);
+                               g.cutoff, R, E, b->D, b->V, rbf, c.mdev(E));
         if (rbf_pl && E > 0) {
             const Planes P = make_planes(rbf_pl, R, PL_S_UNIT);
-            hipLaunchKernelGGL(split_fixed_kernel, dim3(nblk(E * P.KT * 16)), dim3(256), 0, c.s, rbf, P, E, R);
+            hipLaunchKernelGGL(split_fixed_kernel, dim3(nblk(E * P.KT * 16)), dim3(256), 0, c.s, rbf, P, E, R, c.mdev(E));
             unsigned* one = c.new_amax(rbf);   // bound 1 (envelope x Gaussian)
             if (one) MI_HIP_VOID(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x3f800000, 1, c.s));
         }
@@ -1973,20 +2077,31 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     }
 }
 
-static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, hipStream_t s) {
+// nosync: no host round trip -- the launches that follow are sized by the capacity E_cap and read the edge count from meta[0]; crystals
+// over a capacity keep their flag in b->bad (sticky: the caller clears it at the start of a chain and reads it back at its end)
+static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, hipStream_t s, bool nosync = false) {
     const mi_gemnet_config& g = net->cfg;
     MI_HIP(hipMemsetAsync(b->meta, 0, 4 * sizeof(int), s));
-    GraphArgs ga{pos, cell, b->node_off, g.cutoff, g.max_neighbors, g.max_images, b->cap, b->ent, b->acnt, b->deg, b->mcount, b->meta};
+    if (!nosync) MI_HIP(hipMemsetAsync(b->bad, 0, (size_t)std::max(b->B, 1) * sizeof(int), s));
+    GraphArgs ga{pos, cell, b->node_off, g.cutoff, g.max_neighbors, g.max_images, b->cap, b->ent, b->acnt, b->deg, b->mcount, b->meta, b->bad};
     int nmax_sel = 1;
     for (int v : b->num_atoms_h) nmax_sel = std::max(nmax_sel, v);
     MI_HIP(hipMemsetAsync(b->deg, 0, (size_t)std::max(b->N, 1) * sizeof(int), s));
     hipLaunchKernelGGL(gg_select_kernel, dim3(b->B, (nmax_sel + 3) / 4), dim3(256), 0, s, ga);
+    const int dg_cap = std::max(4, std::min(GN_DEG, g_mg_deg_cap));
+    hipLaunchKernelGGL(gg_fix_kernel, dim3(b->B), dim3(64), 0, s, b->node_off, b->deg, b->acnt, b->bad, b->meta, dg_cap);
     hipLaunchKernelGGL(gg_scan_kernel, dim3(1), dim3(1024), 0, s, b->deg, b->N, b->rowptr, b->meta);
     EmitArgs ea{b->node_off, b->ent, b->acnt, b->rowptr, b->meta, b->cap, g.max_images, b->E_cap, b->src, b->dst, b->code, b->ekey, b->swap, b->edge_graph};
     int nmax = 1;
     for (int v : b->num_atoms_h) nmax = std::max(nmax, v);
     hipLaunchKernelGGL(gg_emit_kernel, dim3(b->B), dim3(256), (size_t)nmax * b->cap * sizeof(int), s, ea);
     MI_KERNEL_CHECK();
+    b->nosync = nosync;
+    if (nosync) {
+        b->E = b->E_cap;
+        b->deg_max = dg_cap;   // (the triplet kernels' LDS image is sized for the capacity: no crystal left in the graph exceeds it)
+        return MI_OK;
+    }
     int meta[4];
     MI_HIP(hipMemcpyAsync(meta, b->meta, sizeof(meta), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
@@ -1998,21 +2113,48 @@ static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const flo
     return MI_OK;
 }
 
-static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* types, const float* t, bool train, hipStream_t s) {
+// nosync (inference only; the sampler's forwards): the graph's edge count stays on the device.  Every edge-level launch is sized by the
+// capacity E_cap = 2 max_neighbors N and reads the count from meta[0] (PlanesEpilogue::m_dev, dev_rows); the program's shape is then
+// the same for every evaluation, so its dry passes run once per handle, and the arena is compact (see mi_gbatch).  Needs the lean
+// plane-mode program (every edge-level layer on the plane-set kernel); otherwise the call falls back to the synchronising form.
+static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const float* cell, const int* types, const float* t, bool train, hipStream_t s,
+                        bool nosync = false) {
     MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_gemnet_forward before mi_gemnet_set_params");
     b->tape_valid = false;
-    MI_TRY(graph_build(net, b, pos, cell, s));
-    Ctx dry{net, b, s, true, train};
+    nosync = nosync && !train && MI_PLANES_FP16 && g_mg_planes && g_gemm_mode != 0 && (g_mg_lean & 63) == 63 && b->E_cap >= MG_PLANES_MIN_ROWS && !g_optime;
+    MI_TRY(graph_build(net, b, pos, cell, s, nosync));
     char* const real_base = b->fwd.base;
-    if (!real_base) b->fwd.base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // (the dry run keys tables by tensor address: never a null one)
-    run_program(dry, pos, cell, types, t);
-    b->fwd.base = real_base;
-    const size_t need = b->fwd.top;
+    size_t need = 0;
+    b->compact = nosync;
+    b->collect = false;
+    const uint64_t key = nosync ? (((uint64_t)b->E << 8) | (uint64_t)(g_mg_lean & 63) | 0x80u) : 0;
+    if (nosync && b->dry_key == key) {
+        need = b->dry_need;   // (same program as the last such forward of this handle: its dry passes are on file)
+    } else {
+        if (!real_base) b->fwd.base = reinterpret_cast<char*>(uintptr_t(1) << 20);   // (the dry run keys tables by tensor address: never a null one)
+        Ctx dry{net, b, s, true, train};
+        if (nosync) {   // first dry pass: which plane-only tensors does some consumer materialise as fp32 rows?
+            b->collect = true;
+            b->mat_ord.clear();
+            b->ord_of.clear();
+            run_program(dry, pos, cell, types, t);
+            b->collect = false;
+            b->ord_of.clear();
+        }
+        run_program(dry, pos, cell, types, t);
+        b->fwd.base = real_base;
+        need = b->fwd.top;
+        MI_TRY(dry.rc);
+        if (nosync) {
+            b->dry_key = key;
+            b->dry_need = need;
+        }
+    }
     MI_TRY(arena_ensure(b->fwd, need));
     const mi_gemnet_config& g = net->cfg;
     const size_t dz = (size_t)std::max<int64_t>(b->E, b->N) * std::max(std::max(g.emb_edge, g.emb_atom), LOGIT_LD);
     const size_t red = (size_t)1 << 24;
-    if (b->scratch_floats < dz + red) {
+    if (!nosync && b->scratch_floats < dz + red) {   // (the backward's buffers: a forward without a host round trip is inference only)
         if (b->scratch) (void)hipFree(b->scratch);
         b->scratch = nullptr;
         MI_HIP(hipMalloc((void**)&b->scratch, (dz + dz / 8 + red) * sizeof(float)));
@@ -2413,6 +2555,7 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     GA(deg, N);
     GA(mcount, B);
     GA(meta, 4);
+    GA(bad, B);
     GA(rowptr, N + 1);
     GA(src, b->E_cap);
     GA(dst, b->E_cap);
@@ -2440,6 +2583,8 @@ int mi_gbatch_create(const mi_gemnet* net, const int* num_atoms_host, int B, int
     if (e == hipSuccess) e = hipMemcpy(b->node_off, b->node_off_h.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess && N > 0) e = hipMemcpy(b->node2graph, n2g.data(), N * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->rowptr, 0, (N + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(b->bad, 0, (size_t)std::max(B, 1) * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->status_h, (size_t)(B + 4) * sizeof(int), hipHostMallocDefault);
     if (e == hipSuccess) e = hipDeviceSynchronize();   // (the handle will be used on non-blocking side streams: nothing of its set-up may still be in flight on the null stream)
     if (e != hipSuccess) {
         set_error("mi_gbatch_create: %s", hipGetErrorString(e));
@@ -2467,6 +2612,7 @@ void mi_gbatch_destroy(mi_gbatch* b) {
     if (b->bwd_amax) (void)hipFree(b->bwd_amax);
     if (b->bwd_dsc) (void)hipFree(b->bwd_dsc);
     if (b->ts_dev) (void)hipFree(b->ts_dev);
+    if (b->status_h) (void)hipHostFree(b->status_h);
     delete b;
 }
 
@@ -2522,7 +2668,7 @@ int mi_gemnet_forward(mi_gemnet* net, mi_gbatch* b, const float* pos, const floa
     MI_CHECK(net && b && pos && cell && atomic_numbers && t, MI_EINVAL, "null argument");
     if (b->N == 0 || b->B == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    MI_TRY(forward_impl(net, b, pos, cell, atomic_numbers, t, train != 0, s));
+    MI_TRY(forward_impl(net, b, pos, cell, atomic_numbers, t, (train & 1) != 0, s, (train & 2) != 0));
     // (copies by kernel, not hipMemcpyAsync: concurrent sampler chains on four non-blocking streams showed the position head -- the first
     //  copy, issued right behind the kernel that writes its source -- intermittently returning the PREVIOUS evaluation's values)
     if (out_pos) hipLaunchKernelGGL(copy_ld_kernel, dim3(nblk((int64_t)b->N * 3)), dim3(256), 0, s, b->out_pos, 3, out_pos, 3, (int64_t)b->N, 3);
@@ -2551,6 +2697,39 @@ int mi_debug_set_mg_lean(int on) {
     return MI_OK;
 }
 
+int mi_debug_set_mg_deg_cap(int cap) {
+    const int was = mi::g_mg_deg_cap;
+    mi::g_mg_deg_cap = cap <= 0 ? mi::GN_DEG : std::min(cap, mi::GN_DEG);
+    return was;
+}
+
+int mi_debug_set_mg_nosync(int on) {
+    const int was = mi::g_mg_nosync;
+    mi::g_mg_nosync = on != 0;
+    return was;
+}
+
+// Graph-capacity flags of the crystals of `b` after mi_mg_sampler_run (or any forward): bad_host[i] != 0 -- crystal i exceeded a
+// capacity of the periodic graph at some evaluation (1: more than max_neighbors kept pairs of one atom, 2: more than GN_CAND atoms
+// inside the cutoff even after shrinking it, 4: an in-degree above GN_DEG) and ran WITHOUT edges from then on: its sample is invalid
+// and must be dropped, the other crystals are unaffected (the reference's invalid_filter, pipeline/filters/opt_filter.py:49-61, drops
+// collapsed crystals one by one too).  Waits for the work queued on `stream`.  n_bad: number of flagged crystals.
+int mi_gbatch_graph_status(mi_gbatch* b, int* bad_host, int* n_bad, void* stream) {
+    MI_CHECK(b, MI_EINVAL, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = 0;
+    if (b->B > 0) {
+        MI_HIP(hipMemcpyAsync(b->status_h, b->bad, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < b->B; ++i) {
+            if (bad_host) bad_host[i] = b->status_h[i];
+            nb += b->status_h[i] != 0;
+        }
+    }
+    if (n_bad) *n_bad = nb;
+    return MI_OK;
+}
+
 int mi_debug_set_mg_f16(int on) {
     mi::g_mg_f16 = on != 0 && MI_PLANES_FP16;
     return MI_OK;
@@ -2560,6 +2739,7 @@ int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, 
     MI_CHECK(b && name, MI_EINVAL, "null argument");
     auto it = b->taps.find(name);
     MI_CHECK(it != b->taps.end(), MI_EINVAL, "unknown tap %s", name);
+    MI_CHECK(!b->nosync, MI_ESTATE, "taps exist after a synchronising forward only (the sampler's forwards keep the edge count on the device)");
     if (numel) *numel = it->second.second;
     if (out) {
         MI_CHECK(capacity >= it->second.second, MI_EINVAL, "tap %s needs %lld floats", name, (long long)it->second.second);
@@ -2789,7 +2969,12 @@ int mi_mg_sampler_run(mi_gemnet* net, mi_gbatch* b, const mi_mg_corruption* c, i
     hipStream_t s = (hipStream_t)stream;
     const int N = b->N, B = b->B;
     const float dt = n_steps > 1 ? ts_host[0] - ts_host[1] : ts_host[0];
+    // The chain's forwards keep the graph's edge count on the device (no host round trip per evaluation); a crystal over a graph
+    // capacity runs without edges from that evaluation on and keeps its flag: mi_gbatch_graph_status after the chain.
+    const int fwd_flags = g_mg_nosync ? 2 : 0;
+    MI_HIP(hipMemsetAsync(b->bad, 0, (size_t)B * sizeof(int), s));
     for (int i = i_start; i < i_stop; ++i) {
+        TraceRange range("mi_mg_sampler_step");
         const float t = ts_host[i];
         hipLaunchKernelGGL(fill_kernel, dim3(nblk(B)), dim3(256), 0, s, b->t_buf, t, (int64_t)B);
         StepArgs a;
@@ -2811,13 +2996,13 @@ int mi_mg_sampler_run(mi_gemnet* net, mi_gbatch* b, const mi_mg_corruption* c, i
         a.mean_pos = mean_pos;
         a.mean_cell = mean_cell;
         // corrector
-        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, nullptr, 0, stream));
+        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, nullptr, fwd_flags, stream));
         a.n_pos = noise && noise->corr_pos ? noise->corr_pos + (size_t)i * N * 3 : nullptr;
         a.n_cell = noise && noise->corr_cell ? noise->corr_cell + (size_t)i * B * 9 : nullptr;
         a.n_u1 = a.n_u2 = nullptr;
         hipLaunchKernelGGL(mg_corrector_kernel, dim3(B), dim3(64), 0, s, a);
         // predictor
-        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, b->sp_logits, 0, stream));
+        MI_TRY(mi_gemnet_forward(net, b, pos, cell, types, b->t_buf, b->sp_pos, b->sp_cell, b->sp_logits, fwd_flags, stream));
         a.n_pos = noise && noise->pred_pos ? noise->pred_pos + (size_t)i * N * 3 : nullptr;
         a.n_cell = noise && noise->pred_cell ? noise->pred_cell + (size_t)i * B * 9 : nullptr;
         a.n_u1 = noise && noise->pred_u1 ? noise->pred_u1 + (size_t)i * N : nullptr;

@@ -272,6 +272,7 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
             hipLaunchKernelGGL(wrap_copy_kernel, dim3(cdiv(n3, 256)), dim3(256), 0, s, frac, rec->frac_coords + t_start * n3, (int64_t)n3);
     }
     for (int t = t_start; t > t_stop; --t) {
+        TraceRange range("mi_sampler_step");
         hipLaunchKernelGGL(time_embedding_kernel, dim3(cdiv((int64_t)B * net->TD, 256)), dim3(256), 0, s, (const int*)nullptr, time_freqs, b->temb, B,
                            net->TD, t);
         // corrector

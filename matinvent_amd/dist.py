@@ -20,16 +20,49 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def allreduce_flat_(buf: torch.Tensor):
-    """In-place SUM all-reduce of one flat buffer (the whole gradient: 4P bytes, one message)."""
-    if is_dist() and dist.get_world_size() > 1:
-        if buf.is_cuda and dist.get_backend() == "gloo":  # CPU-backend test runs: stage through the host
-            host = buf.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            buf.copy_(host)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+def _trace_lib():
+    """The HIP library when roctx ranges are on (MI_ROCTX=1), else None: the CPU-only gloo tests never load it."""
+    import os
+    if os.environ.get("MI_ROCTX", "0") in ("", "0"):
+        return None
+    from . import _lib
+    return _lib.load()
+
+
+def _wire_of(buf: torch.Tensor, backend: str):
+    """The tensor that goes on the wire for `buf`: the device buffer itself under RCCL ("nccl": xGMI moves device memory); a pinned
+    host copy under gloo (the CPU tests, and the shared-GPU multi-rank tests: gloo cannot read device memory)."""
+    if buf.is_cuda and backend != "nccl":
+        wire = torch.empty(buf.shape, dtype=buf.dtype, device="cpu", pin_memory=True)
+        wire.copy_(buf, non_blocking=True)
+        torch.cuda.current_stream(buf.device).synchronize()
+        return wire
     return buf
+
+
+def _unwire(buf: torch.Tensor, wire: torch.Tensor):
+    if wire is not buf:
+        buf.copy_(wire, non_blocking=True)
+    return buf
+
+
+def allreduce_flat_(buf: torch.Tensor):
+    """In-place SUM all-reduce of one flat buffer (the whole gradient: 4P bytes, one message; pipeline/mat_invent.py:166,177 is where the
+    reference steps its optimizer -- the all-reduce sits right in front).  ONE code path for every backend: stage (a no-op under RCCL),
+    reduce, unstage; the only line a gloo run does not execute with the arguments of an RCCL run is the collective itself."""
+    if not (is_dist() and dist.get_world_size() > 1):
+        return buf
+    assert buf.is_contiguous() and buf.dtype == torch.float32, "the flat gradient / accumulator buffer is one contiguous fp32 vector"
+    lib = _trace_lib()
+    if lib is not None:
+        lib.mi_trace_push(b"mi_grad_allreduce")
+    try:
+        wire = _wire_of(buf, dist.get_backend())
+        dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+        return _unwire(buf, wire)
+    finally:
+        if lib is not None:
+            lib.mi_trace_pop()
 
 
 def all_gather_objects(obj):

@@ -170,6 +170,14 @@ class GBatch:
                    "mi_gemnet_graph_read")
         return {k: (v.long() if v.dtype == torch.int32 else v) for k, v in out.items()}
 
+    def graph_status(self):
+        """Per-crystal graph-capacity flags of the forwards since the last chain started (mi_gbatch_graph_status): int32 [B] on the
+        CPU, non-zero = the crystal exceeded a capacity of the periodic graph and ran without edges from then on (its sample is
+        invalid; the other crystals are unaffected).  Waits for the current stream."""
+        out = (C.c_int * max(self.num_graphs, 1))()
+        _lib.check(self._lib.mi_gbatch_graph_status(self._h, out, None, _stream()), "mi_gbatch_graph_status")
+        return torch.tensor(list(out)[:self.num_graphs], dtype=torch.int32)
+
     def tap(self, name):
         n = C.c_int64()
         _lib.check(self._lib.mi_gemnet_tap(self._h, name.encode(), None, 0, C.byref(n), _stream()), "mi_gemnet_tap")
@@ -494,6 +502,7 @@ class MatterGenModule(nn.Module):
             for e in err:
                 if e is not None:
                     raise e
+            self._last_chain_batches = [o[2] for o in out]
             merged = []
             for which in (0, 1):
                 ds = [o[which] for o in out]
@@ -503,7 +512,19 @@ class MatterGenModule(nn.Module):
                             v.record_stream(cur)
                 merged.append({k: torch.cat([d[k] for d in ds]) for k in ds[0]})
             return merged[0], merged[1]
-        return self._sample_chain(na_all, n_steps, eps_t, seed, noise, i_stop, node_offset, graph_offset, i_start, state, slot=0)
+        sample, mean, gb = self._sample_chain(na_all, n_steps, eps_t, seed, noise, i_stop, node_offset, graph_offset, i_start, state, slot=0)
+        self._last_chain_batches = [gb]
+        return sample, mean
+
+    def last_sample_invalid(self):
+        """bool [B] (CPU): crystals of the most recent `sample` call whose periodic graph exceeded a capacity at some evaluation (a cell
+        that collapsed mid-chain: more than max_neighbors kept pairs of one atom, or more atoms inside the cutoff than the candidate
+        lists hold).  The chain takes such a crystal out of the graph and goes on -- no host round trip per evaluation, and one
+        diverging crystal does not cost the batch; the caller drops it, as the reference's invalid_filter drops collapsed structures
+        one by one (pipeline/filters/opt_filter.py:49-61).  Synchronises the device."""
+        torch.cuda.synchronize(self.device)
+        flags = [gb.graph_status() for gb in getattr(self, "_last_chain_batches", [])]
+        return (torch.cat(flags) != 0) if flags else torch.zeros(0, dtype=torch.bool)
 
     def _sample_chain(self, num_atoms, n_steps, eps_t, seed, noise, i_stop, node_offset, graph_offset, i_start, state, slot=0):
         """One chain over one batch handle on the current stream."""
@@ -539,7 +560,7 @@ class MatterGenModule(nn.Module):
         del keep
         sample = dict(pos=pos, cell=cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
         mean = dict(pos=mean_pos, cell=mean_cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
-        return sample, mean
+        return sample, mean, gb
 
 
 # ---- sampler ------------------------------------------------------------------------------------------------------------------------
@@ -554,6 +575,9 @@ class MatterGenSampler:
     n_steps: int = 1000
     eps_t: float = 1e-3
     seed: int = 0
+    discarded: int = 0                  # crystals dropped so far because their periodic graph went over capacity (collapsed cells)
+    max_discard_fraction: float = 0.5   # generate() warns per batch and raises when more than this share of a call's request is gone
+    _dropped_call: int = 0
 
     def generate(self, model: MatterGenModule, batch_size=None, num_batches=None, **kwargs):
         from .dist import all_gather_objects, broadcast_object, shard_range
@@ -574,16 +598,16 @@ class MatterGenSampler:
             try:
                 _, mean = model.sample(na[lo:hi], n_steps=self.n_steps, eps_t=self.eps_t, seed=self.seed, node_offset=int(np.sum(na[:lo])), graph_offset=lo,
                                        chains=kwargs.get("chains"))
-            except RuntimeError as e:
-                # A crystal whose cell collapses mid-chain (plausible with an untrained or diverging denoiser and the Langevin cell
-                # corrector) overflows the periodic graph's per-atom capacities; the library refuses to truncate the neighbour list
-                # (MI_ENOMEM "periodic graph: capacity exceeded").  Such a batch is DISCARDED -- the RL step goes on with the other
-                # batches' crystals, as the reference's invalid_filter would have dropped the collapsed ones (opt_filter.py:49-61).
-                if "periodic graph" not in str(e):
+                invalid = model.last_sample_invalid()
+            except _lib.MIError as e:
+                # (only the synchronising form of the forward -- mi_debug_set_mg_nosync(0) -- refuses a batch: there a crystal over a
+                #  graph capacity fails the whole call, MI_ENOMEM, and nothing of the batch can be kept)
+                if e.code != _lib.MI_ENOMEM:
                     raise
                 import logging
                 logging.getLogger(__name__).warning("MatterGenSampler.generate: batch %d discarded (%s)", bi, e)
                 _lib.saturation_events(reset=True)
+                self._dropped_call += hi - lo
                 continue
             _lib.check_saturation("MatterGenSampler.generate")
             from .structure import check_structures_counts   # geometric validity quantities where the final state lives (K18)
@@ -591,14 +615,32 @@ class MatterGenSampler:
             pos, cell, types, nat = (mean[k].detach().cpu() for k in ("pos", "cell", "atomic_numbers", "num_atoms"))
             lengths, angles = lattices_to_params_shape(cell)
             off = [0] + torch.cumsum(nat, 0).tolist()
+            # A crystal whose cell collapsed mid-chain (plausible with an untrained or diverging denoiser and the Langevin cell corrector)
+            # overflowed the periodic graph's per-atom capacities; the chain took it out of the graph instead of truncating its
+            # neighbour list, and ONLY that crystal is dropped here -- as the reference's invalid_filter does (opt_filter.py:49-61).
+            n_inv = int(invalid.sum())
+            if n_inv:
+                import logging
+                self._dropped_call += n_inv
+                logging.getLogger(__name__).warning("MatterGenSampler.generate: batch %d: %d of %d crystals dropped (periodic graph over capacity: collapsed cells)",
+                                                    bi, n_inv, len(nat))
             for i in range(len(nat)):
+                if bool(invalid[i]):
+                    continue
                 g = ChemGraph(pos[off[i]:off[i + 1]], cell[i:i + 1], types[off[i]:off[i + 1]], int(nat[i]))
                 g.geometry = {"max_cell_edge": float(geom[i, 0]), "min_distance": float(geom[i, 1]), "volume": float(geom[i, 2])}
                 graphs.append(g)
                 strucs.append(SimpleStructure(lengths=lengths[i].tolist(), angles=angles[i].tolist(), species=g.atomic_numbers.tolist(),
                                               frac_coords=g.pos.numpy()))
+        dropped, self._dropped_call = self._dropped_call, 0
+        self.discarded += dropped
         if world > 1:
-            parts = all_gather_objects((graphs, strucs))
+            parts = all_gather_objects((graphs, strucs, dropped))
             graphs = [g for pp in parts for g in pp[0]]
             strucs = [s for pp in parts for s in pp[1]]
+            dropped = sum(pp[2] for pp in parts)
+        asked = batch_size * num_batches
+        if dropped > self.max_discard_fraction * asked:   # (every rank sees the same counts: they raise or go on together)
+            raise RuntimeError(f"MatterGenSampler.generate: {dropped} of {asked} sampled crystals dropped (periodic graph over capacity: the denoiser "
+                               f"collapses its cells); more than max_discard_fraction = {self.max_discard_fraction} of the request")
         return graphs, strucs

@@ -86,7 +86,8 @@ for k in range(G):
         torch.cuda.current_stream().synchronize()
 cmp(out, "main thread, side streams, serial:")
 # (3) concurrent, 2 groups then 4
-for ng in [4] * 24:
+import os
+for ng in [4] * int(os.environ.get("MI_CONC_TRIALS", "24")):
     out = [None] * G
     ready = cur.record_event()
     def run(k):

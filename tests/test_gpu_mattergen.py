@@ -256,6 +256,72 @@ def test_concurrent_chains_reproduce_the_single_chain():
         #  continuous function of its input -- DESIGN section 11 -- so a rounding difference moves single atoms by O(1))
 
 
+def test_sampler_without_a_host_round_trip_equals_the_synchronising_form():
+    """The chain's forwards keep the graph's edge count on the device (mi_gemnet_forward bit 2: launches sized by the capacity, the
+    count read from meta[0], a compact activation arena sized once per handle).  Same kernels on the same rows in the same order as the
+    form that synchronises once per evaluation to read the count: the samples must agree BIT FOR BIT, at a size where the plane-set
+    layers run in both forms (6.7 k edges, capacity 13.4 k)."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    hpd = dict(M.TINY, emb_atom=128, emb_edge=128)
+    hp = M.GemNetHParams(**hpd)
+    m = _module(hpd, M.init_params(hp, seed=6, head_scale=20.0))
+    na = [20] * 40 + [7, 12, 1, 20]
+    try:
+        lib.mi_debug_set_mg_nosync(0)
+        s0, m0 = m.sample(na, n_steps=1000, seed=9, i_stop=3)
+        lib.mi_debug_set_mg_nosync(1)
+        s1, m1 = m.sample(na, n_steps=1000, seed=9, i_stop=3)
+        inv = m.last_sample_invalid()
+        s2, m2 = m.sample(na, n_steps=1000, seed=9, i_stop=3)   # (second call: the program's dry passes come from the handle's cache)
+    finally:
+        lib.mi_debug_set_mg_nosync(1)
+    assert inv.shape == (len(na),) and not bool(inv.any())
+    for key in ("pos", "cell", "atomic_numbers"):
+        assert torch.equal(m0[key], m1[key]) and torch.equal(s0[key], s1[key]), key
+        assert torch.equal(m1[key], m2[key]) and torch.equal(s1[key], s2[key]), key
+    assert bool(torch.isfinite(m1["pos"]).all()) and bool(torch.isfinite(m1["cell"]).all())
+    assert _lib.saturation_events(reset=True) == 0
+
+
+def test_a_crystal_over_a_graph_capacity_is_dropped_alone():
+    """A crystal with an in-degree above the graph's capacity (128 in-edges, the triplet kernels' LDS image; lowered to 24 here so that a
+    dense cell exceeds it -- a collapsed cell is what would do it in a chain) fails the synchronising forward as a whole (MI_ENOMEM).
+    The chain's forwards take that ONE crystal out of the graph on the device, remember its flag, and go on: the other crystals'
+    samples are those of a batch that never held it, up to the plane format's batch-composition rounding (the reference drops
+    collapsed crystals one by one after sampling, pipeline/filters/opt_filter.py:49-61)."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    hpd = dict(M.TINY, emb_atom=128, emb_edge=128, max_neighbors=32)
+    hp = M.GemNetHParams(**hpd)
+    m = _module(hpd, M.init_params(hp, seed=6, head_scale=20.0))
+    g = torch.Generator().manual_seed(4)
+    na = [20, 40, 40]
+    N = sum(na)
+    cell = torch.stack([2.4 * torch.eye(3), 13.0 * torch.eye(3), 13.5 * torch.eye(3)]) + 0.1 * M.symmetric_noise(torch.randn(3, 3, 3, generator=g))
+    state = dict(pos=torch.rand(N, 3, generator=g).cuda(), cell=cell.cuda(), atomic_numbers=torch.randint(1, 101, (N,), generator=g).cuda())
+    t = torch.full((3,), 0.1)
+    kw = dict(n_steps=1000, seed=5, i_start=900, i_stop=901)
+    try:
+        lib.mi_debug_set_mg_deg_cap(24)
+        with pytest.raises(_lib.MIError) as ei, torch.no_grad():
+            m.decoder(state["pos"], state["cell"], state["atomic_numbers"], t, m.decoder.make_batch(torch.tensor(na)))
+        assert ei.value.code == _lib.MI_ENOMEM and "periodic graph" in str(ei.value)
+        s_all, m_all = m.sample(na, state={k: v.clone() for k, v in state.items()}, **kw)
+        inv = m.last_sample_invalid()
+        assert inv.tolist() == [True, False, False]
+        assert all(bool(torch.isfinite(m_all[k].float()).all()) for k in ("pos", "cell"))
+        rest = dict(pos=state["pos"][20:].clone(), cell=state["cell"][1:].clone(), atomic_numbers=state["atomic_numbers"][20:].clone())
+        s_r, m_r = m.sample(na[1:], state=rest, node_offset=20, graph_offset=1, **kw)
+        assert not bool(m.last_sample_invalid().any())
+    finally:
+        lib.mi_debug_set_mg_deg_cap(0)
+    assert torch.equal(m_all["atomic_numbers"][20:], m_r["atomic_numbers"])
+    assert float((m_all["cell"][1:] - m_r["cell"]).abs().max()) <= 2e-3 * float(m_r["cell"].abs().max())
+    d = (m_all["pos"][20:] - m_r["pos"]).abs()
+    assert float(torch.minimum(d, 1 - d).median()) <= 1e-4
+
+
 def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
     """matinvent_amd.finetune.ft_step on the MatterGen-shaped module (the reference's loop, pipeline/mat_invent.py:150-177, over
     add_noise / calc_sample_loss / calc_kl_reg, fused Adam on the flat parameter vector) against the same loop over the oracle with
