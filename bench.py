@@ -508,7 +508,7 @@ def measure_mg(args, K, W, ctx=None):
     state["cell"] = 0.5 * (state["cell"] + state["cell"].transpose(1, 2))
     i0 = 500
     E0 = int(m._batch_for(torch.tensor(na)).graph(state["pos"], state["cell"])["src"].shape[0])
-    chains = max(1, int(getattr(args, "mg_chains", 1)))
+    chains = max(1, int(getattr(args, "mg_chains", 4)))
     okw = dict(node_offset=rank * N, graph_offset=rank * Bm)   # global ids: every rank samples its own crystals of one global batch (weak scaling)
     s, _ = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0, i_stop=i0 + W, state=state, chains=chains, **okw)
     st = dict(pos=s["pos"], cell=s["cell"], atomic_numbers=s["atomic_numbers"])
@@ -743,8 +743,8 @@ def main():
     ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
     ap.add_argument("--mg-free-chain", action="store_true", help="--mode mg-sample: time the free-running random-init chain (emptying graph) instead of "
                     "steps that each start from the physical-density state")
-    ap.add_argument("--mg-chains", type=int, default=1, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams (default 1: at this size "
-                    "concurrent chains of the MatterGen-shaped sampler are not run-to-run reproducible, DESIGN 17)")
+    ap.add_argument("--mg-chains", type=int, default=4, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams (default 4, the "
+                    "sampler's own automatic choice at this size; bit-reproducible since the library is built without packed-fp32 instructions, DESIGN 18)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE child passes that fill roofline.traffic")
     ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)   # (the child of those passes: the timed chain only, no JSON)
     ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "mg-ft", "sample-default", "ft-default"], default="sample",

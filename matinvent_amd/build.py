@@ -17,6 +17,14 @@ OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["cspnet.hip", "node_chain.hip", "edge_stage.hip", "edge_fused.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
 ARCH = ["--offload-arch=gfx950"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+# NO packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) in device code.  Measured on MI355X
+# (scripts/force_fwd_repro.hip): a wave that executes them while waves of ANOTHER kernel with LDS traffic and
+# MFMAs share its SIMD -- i.e. whenever two streams run concurrently, which the samplers' concurrent chains do -- intermittently gets
+# wrong results in lanes 48-63 of a packed result.  The compiler forms these instructions by itself (SLP vectorisation of fp32 pairs);
+# without the target feature it selects the scalar forms.  Cost: none measurable (50.0 / 50.1 against 49.4-50.4 structures/s on the
+# headline, same box); effect: 120 of 120 trials of four concurrent MatterGen-shaped forwards bit-identical, against 103 of 120.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+CFLAGS += NO_PACKED_FP32
 
 
 def _headers():
@@ -64,7 +72,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     cmd = [hipcc] + ARCH + CFLAGS + extra + ["-c", src, "-o", obj]
                     if verbose:
                         print(" ".join(cmd), flush=True)
-                    subprocess.run(cmd, check=True)
+                    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+                    # (the host half of the compilation does not know the device-only target feature and says so: not a diagnostic of ours)
+                    err = "\n".join(ln for ln in (r.stderr or "").splitlines() if "is not a recognized feature for this target" not in ln)
+                    if err.strip():
+                        print(err, file=sys.stderr, flush=True)
+                    if r.returncode != 0:
+                        raise subprocess.CalledProcessError(r.returncode, cmd)
                     with open(obj + ".flags", "w") as f:
                         f.write(tag)
                 return obj

@@ -1134,8 +1134,11 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 // the training forward with the pre-activation kept for the backward pass (written row-major through per-wave LDS patches: as
                 // 4-byte stores from the result layout the instantiation spilled 228 registers and LOST 6-8 %; this form gains 1.9 % on the
                 // fine-tune line).  The partial sums then round M2 to the plane format's 22 bits, as in inference.
-                const bool eg2_train = train && g_edge2_train && MI_PLANES_FP16 && g2e.pre_act && g2e.ld_pre == H && !use_hi && edge_gemm2_supported(net);
-                if ((fused && edge_gemm2_supported(net)) || eg2_train) {
+                // (fully connected lists only: the kernel sizes its per-tile node tables for at most 128 consecutive node ids per 128-row tile, which
+                //  holds when every node has an edge -- a knn list may hold zero-degree atoms inside a tile's span; those batches keep the plane GEMM)
+                const bool eg2_ok = edge_gemm2_supported(net) && !b->knn;
+                const bool eg2_train = train && g_edge2_train && MI_PLANES_FP16 && g2e.pre_act && g2e.ld_pre == H && !use_hi && eg2_ok;
+                if ((fused && eg2_ok) || eg2_train) {
                     MI_TRY(edge_gemm2(net, b, l, s, eg2_train ? g2e.pre_act : nullptr));
                     b->seg_shift = 7;
                 } else {
@@ -1259,7 +1262,10 @@ int mi_trace_pop(void) {
 int mi_net_create(const mi_net_config* cfg, mi_net** out) {
     MI_CHECK(cfg && out, MI_EINVAL, "null argument");
     const int H = cfg->hidden_dim;
-    MI_CHECK(H == 64 || H == 128 || H == 256 || H == 512, MI_EINVAL, "hidden_dim must be 64/128/256/512, got %d", H);
+    // any multiple of 64 up to 512 on the GEMM forms (the reference's code default is 128, cspnet.py:98-113; its real hparams.yaml is unreachable,
+    // models/suite/diffcsp.py:52-55, so a checkpoint of another width must not be refused outright); the register-chained f32 edge kernel, the
+    // node-chain launch and the 128 x 512 register-tile GEMM exist for their own widths only and the forward falls back to the plane GEMMs
+    MI_CHECK(H >= 64 && H <= 512 && H % 64 == 0, MI_EINVAL, "hidden_dim must be a multiple of 64 in 64..512, got %d", H);
     MI_CHECK(cfg->num_layers >= 1 && cfg->num_freqs >= 1, MI_EINVAL, "num_layers/num_freqs must be >= 1");
     MI_CHECK(cfg->time_dim > 0 && cfg->time_dim % 4 == 0, MI_EINVAL, "time_dim must be a positive multiple of 4");
     mi_net* n = new mi_net();
@@ -1750,6 +1756,8 @@ int mi_set_edge_pairs(int on) {
 
 int mi_net_set_edge_mode(mi_net* net, int mode) {
     MI_CHECK(net && (mode == MI_EDGE_FUSED_F32 || mode == MI_EDGE_GEMM), MI_EINVAL, "unknown edge mode %d", mode);
+    MI_CHECK(mode != MI_EDGE_FUSED_F32 || net->H == 64 || net->H == 128 || net->H == 256 || net->H == 512, MI_EINVAL,
+             "the register-chained f32 edge kernel exists for hidden_dim 64/128/256/512, not %d", net->H);
     net->edge_mode = mode;
     return MI_OK;
 }

@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- A operand: k-tile kt = one 16 KiB block [plane][128 rows][64 B] of the plane set, 16 pieces of 1 KiB, four per wave ----
     // LDS image of a stage = the plane GEMM's: 64-byte rows, 16-byte piece c of row r at position c ^ ((r >> 2) & 3)
+#if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 32)   // (timing diagnostic, wrong results: M1 is READ from its first eight row tiles -- with bit 16, the whole M1 round trip stays inside the L2s)
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(a.A.base + a.A.tile(tile & 7, 0), a.A.KT * 24576);
+#else
     const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(a.A.base + a.A.tile(tile, 0), a.A.KT * 24576);
+#endif
     const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     auto dma_tile = [&](int kt, int st) {
 #pragma unroll
@@ -908,7 +912,8 @@ extern "C" int mi_debug_edge1_clock(void* dev_buffer) {
 }
 
 extern "C" int mi_debug_set_edge2_fused(int on) {
-    const int was = mi::g_edge2_fused;
+    // (returns the previous MODE, so that save-and-restore through the return value is exact: 4 = inference forwards only)
+    const int was = (mi::g_edge2_fused == 1 && !mi::g_edge2_train) ? 4 : mi::g_edge2_fused;
     mi::g_edge2_fused = on == 4 ? 1 : on;
     mi::g_edge2_train = on == 1;   // (4: inference forwards only -- the training forward keeps the 128 x 128 plane GEMM)
     return was;

@@ -7,8 +7,6 @@ same buffers (`beta_scheduler.*`, `sigma_scheduler.*`), same methods
 """
 import ctypes as C
 
-import os
-
 import torch
 import torch.nn as nn
 

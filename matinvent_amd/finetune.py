@@ -14,6 +14,7 @@ import logging
 
 import torch
 
+from . import _lib
 from .data import CrystalBatchData, CrystalDataset
 from .dist import allreduce_flat_, rank_world, shard_range
 from .optim import FusedAdam
@@ -383,13 +384,22 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
     dec = agent.decoder
     slot_bytes = 7 * max(nodes[k + 1] - nodes[k] for k in range(groups)) * dec.hidden_dim * dec.num_layers * 4   # operand rows of one micro-step
-    window = max(0, min(window, (8 << 30) // max(1, slot_bytes)))   # at most 8 GB of kept rows per group
+    # at most 8 GB of kept rows per group AND 24 GB over all groups (the windows of the groups are live together)
+    window = max(0, min(window, (8 << 30) // max(1, slot_bytes), (24 << 30) // max(1, slot_bytes * groups)))
     handles = []
     for k in range(groups):
         agent.shard_offsets = offs[k]
         ab = agent._batch_for(batches[k].__dict__.setdefault("_mi_na", batches[k].num_atoms.cpu()))
-        ab.set_wgrad_window(agent.decoder, window if window > 1 else 0)
         handles.append(ab)
+    try:
+        for ab in handles:
+            ab.set_wgrad_window(agent.decoder, window if window > 1 else 0)
+    except _lib.MIError as e:   # the window is an optimisation: out of memory for it -> the immediate form, not a failed fine-tune step
+        if e.code != _lib.MI_ENOMEM:
+            raise
+        window = 0
+        for ab in handles:
+            ab.set_wgrad_window(agent.decoder, 0)
 
     def flush_wgrads():
         for k in range(groups):

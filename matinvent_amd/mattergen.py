@@ -454,19 +454,18 @@ class MatterGenModule(nn.Module):
 
         `chains` > 1 splits the crystals into that many contiguous groups whose chains run CONCURRENTLY on separate HIP streams, as
         DiffCSPModule.sample does: crystals never interact, the Philox draws are indexed by global atom / crystal id and the corrector's
-        step sizes are per crystal, so the result is bit for bit that of the groups sampled one after the other (tested); one chain's
-        host synchronisation per evaluation (the edge count) and its short kernels then overlap the other chains' dense layers
-        (3.5 -> 3.9 / 4.0 / 4.1 structures/s with 2 / 3 / 4 chains at 256 x 20 atoms).  Against the unsplit batch the samples agree
-        to the plane format's rounding only: the power-of-two scales of the plane sets are derived from batch-wide maxima.
-        None = automatic (by the number of atoms)."""
+        step sizes are per crystal, so the result is bit for bit that of the groups sampled one after the other (tested, also at the
+        benchmark size of four 64-crystal chains); one chain's graph / triplet / node-level kernels and the tails of its dense layers
+        then run under the other chains' dense layers.  Against the unsplit batch the samples agree to the plane format's rounding
+        only: the power-of-two scales of the plane sets are derived from batch-wide maxima.
+        None = automatic (by the number of atoms; what MatterGenSampler.generate uses)."""
         na_all = [int(v) for v in torch.as_tensor(num_atoms).tolist()]
         if chains is None:
-            # ROUND 3: concurrent chains are OFF by default.  At the benchmark size (four groups of 64 crystals, ~64 k edges each) two runs of
-            # the same concurrent sample do not reproduce each other: one quarter-wave of the position head's output (16 consecutive atoms of
-            # one group) intermittently differs -- inputs, graph, per-edge force scalars and unit vectors verified identical, a single chain and
-            # up to 32-crystal groups bit-reproducible, the pinned DiffCSP sampler's concurrent chains bit-reproducible (DESIGN 17;
-            # scripts/mg_concurrent_forward_check.py).  Until that is understood a sampler that cannot reproduce itself is not the default.
-            chains = 1
+            # Automatic: two chains from 512 atoms up, four from 2048.  (Round 3 switched this off: at the benchmark size four concurrent
+            # chains did not reproduce themselves run to run.  Round 4 found the cause -- packed-fp32 VALU instructions give wrong results in
+            # lanes 48-63 when another stream's LDS + MFMA kernel shares the SIMD, scripts/force_fwd_repro.hip -- and the library is now
+            # built without those instructions, matinvent_amd/build.py: 120 of 120 trials of four concurrent forwards bit-identical.)
+            chains = 4 if sum(na_all) >= 2048 else 2 if sum(na_all) >= 512 else 1
         chains = max(1, min(int(chains), len(na_all)))
         if chains > 1 and noise is None:
             import threading

@@ -107,8 +107,12 @@ def test_forward_north_star_hparams_golden(golden, path):
     (128, 3, 10, [5, 0, 9, 20, 20, 4]),           # an empty crystal
     (256, 2, 16, [20] * 9 + [3]),
     (64, 1, 8, [40, 33, 2]),                      # node runs spanning three 32-edge tiles
+    (192, 2, 10, [5, 0, 9, 20, 20, 4]),           # widths that are multiples of 64 but not powers of two: plane GEMMs throughout
+    (384, 2, 16, [20] * 9 + [3]),
 ])
 def test_forward_vs_oracle_ragged(H, L, F, num_atoms, path):
+    if H not in (64, 128, 256, 512) and path[1] == "fused_f32":
+        pytest.skip("the register-chained f32 edge kernel exists for hidden_dim 64/128/256/512 only (mi_net_set_edge_mode refuses the others)")
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P = O.init_params(hp, seed=3)
     # non-trivial LayerNorm affine so that its parameters are exercised

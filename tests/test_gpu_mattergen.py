@@ -551,8 +551,10 @@ def test_benchmark_size_crystal_groups_vs_the_unsplit_batch(bench_net):
           atoms is NOT bounded: with random-init weights (heads scaled so that score x std is of order one) the Langevin step size
           2 (snr |z| / |score|)^2 and the 50-nearest selection amplify a 1e-6 difference to O(0.1) for a few atoms (measured: 0.16 for the worst
           atom, 9e-4 of max|cell|) -- DESIGN 11 records the same for the oracle against itself under a 1e-6 perturbation;
-      (c) CONCURRENT chains (`chains=4`) are reported, not asserted: at this size two runs of the same concurrent sample do not reproduce each
-          other -- which is why `chains` defaults to 1 for this sampler."""
+      (c) CONCURRENT chains (`chains=4`, the sampler's automatic choice at this size): two runs give the same bits, and those of the groups
+          sampled one after the other.  (Round 3 could only report this: one quarter-wave of the position head intermittently differed.
+          The cause was a fault of packed-fp32 VALU instructions next to another stream's LDS + MFMA kernel, scripts/force_fwd_repro.hip;
+          the library is built without those instructions, matinvent_amd/build.py)"""
     hp, P, m = bench_net
     s = _bench_state(BENCH_B)
     with torch.no_grad():
@@ -597,6 +599,58 @@ def test_benchmark_size_crystal_groups_vs_the_unsplit_batch(bench_net):
     print(f"MEASURED four CONCURRENT chains: run vs run cell {dcc:.3e}, worst atom {float(dd.max()):.3e}, atoms that differ {int((dd > 0).sum())}; "
           f"vs the groups one after the other cell {dcs:.3e}, worst atom {float(ds.max()):.3e}, atoms that differ {int((ds > 0).sum())}")
     assert all(bool(torch.isfinite(c1[k].float()).all()) for k in c1) and ntc == 0
+    for k in ("pos", "cell", "atomic_numbers"):
+        assert torch.equal(c1[k], c2[k]), f"{k}: two runs of four concurrent chains differ"
+        assert torch.equal(c1[k], g1[k]), f"{k}: four concurrent chains differ from the same groups sampled one after the other"
+
+
+def test_benchmark_size_concurrent_forwards_are_bit_reproducible(bench_net):
+    """Four 64-crystal groups evaluated CONCURRENTLY (four host threads, four streams, one batch handle each) against the same four
+    forwards run one after the other: every output bit-identical in each of 40 trials.  With packed-fp32 VALU instructions in the
+    library's small kernels 14 % of such trials differed in one quarter-wave of the position head (round 3's open finding; the fault is
+    reproduced without any library code by scripts/force_fwd_repro.hip); the library is built without them (matinvent_amd/build.py)."""
+    import threading
+    from matinvent_amd.streams import concurrent_streams
+    hp, P, m = bench_net
+    G, Bg = 4, 64
+    groups = []
+    for k in range(G):
+        s = _bench_state(Bg, seed=10 + k)
+        groups.append({kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in s.items() if kk != "g"})
+    gbs = [m.decoder.make_batch(gr["na"].cpu()) for gr in groups]
+    m.decoder.sync()
+
+    def fwd(k):
+        gr = groups[k]
+        with torch.no_grad():   # (grad mode is thread-local: every worker thread needs its own)
+            return {kk: v.clone() for kk, v in m.decoder(gr["frac"], gr["cell"], gr["a"], gr["t"], gbs[k]).items()}
+
+    ref = [fwd(k) for k in range(G)]
+    torch.cuda.synchronize()
+    pool = concurrent_streams(G, m.device)
+    cur = torch.cuda.current_stream()
+    differing = []
+    for trial in range(40):
+        out, err = [None] * G, [None] * G
+        ready = cur.record_event()
+
+        def run(k):
+            try:
+                with torch.cuda.stream(pool[k]):
+                    pool[k].wait_event(ready)
+                    out[k] = fwd(k)
+                    cur.wait_event(pool[k].record_event())
+            except BaseException as e:
+                err[k] = e
+        th = [threading.Thread(target=run, args=(k,)) for k in range(G)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        assert all(e is None for e in err), err
+        differing += [(trial, k, kk) for k in range(G) for kk in ref[k] if not torch.equal(out[k][kk], ref[k][kk])]
+    del gbs
+    _drop_handles(m)
+    assert not differing, f"{len(differing)} outputs of concurrent forwards differ from the sequential ones: {differing[:6]}"
 
 
 def test_benchmark_size_fine_tune_window_vs_the_oracle(bench_net):
