@@ -527,6 +527,8 @@ def measure_mg(args, K, W, ctx=None):
         s, mean = m.sample(na, n_steps=T, seed=SEED_NOISE, i_start=i0 + W, i_stop=i0 + W + K, state=st, chains=chains, **okw)
     dist_barrier(ctx)
     elapsed = dist_max_time(ctx, time.perf_counter() - t0)
+    if getattr(args, "counter_child", False):
+        return None
     gr = m._batch_for(torch.tensor(na)).graph(s["pos"], s["cell"])
     E = int(gr["src"].shape[0])
     finite = bool(torch.isfinite(mean["pos"]).all()) and bool(torch.isfinite(mean["cell"]).all())
@@ -546,18 +548,15 @@ def measure_mg(args, K, W, ctx=None):
     alg_gbps = y_eval * 2 * Bm * K * world / elapsed / 1e9
     hbm = {"bound": "hbm", "achieved": alg_gbps, "peak": PEAK_HBM_TBPS * 1e3 * world, "unit": "GB/s", "frac": alg_gbps / (PEAK_HBM_TBPS * 1e3 * world),
            "algorithmic_bytes_per_crystal_evaluation": y_eval, "flops_per_byte": flops_eval / Bm / y_eval,
-           "counter_over_algorithmic": None, "counter_GBps_single_chain": None}
-    import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_mattergen_sampler_traffic.json")))
-    if cands:
-        tr = json.load(open(cands[-1]))
-        if "whole_trace" in tr:
-            w = tr["whole_trace"]
-            steps_in_trace = tr.get("steps_in_trace", 4)   # (the profiled command: 1 warm-up + 3 timed steps, two evaluations each)
-            hbm.update(counter_over_algorithmic=w["bytes"] / (steps_in_trace * 2 * Bm * y_eval), counter_GBps_single_chain=w["GBps"],
-                       counter_frac_of_peak_single_chain=w["frac_of_8TBps"], source=os.path.relpath(cands[-1], ROOT), profiled_head=tr.get("head"),
-                       note=f"counter figures: all kernels of the profiled SINGLE-CHAIN run (FETCH_SIZE x2 + WRITE_SIZE over their kernel time; "
-                            f"{100 * w['share_of_trace_time_covered']:.0f} % of the trace's kernel time covered)")
+           "counter_over_algorithmic": None, "counter_GBps": None}
+    if world == 1 and not getattr(args, "no_counters", False) and getattr(args, "mg_live_counters", True):
+        step_bytes, src = measure_mg_traffic_live(args)   # (the bytes the kernels of a step actually moved, measured by this run)
+        hbm["counter_source"] = src
+        if step_bytes is not None:
+            hbm["counter_bytes_per_step"] = step_bytes
+            hbm["counter_over_algorithmic"] = step_bytes / (2 * Bm * y_eval)
+            hbm["counter_GBps"] = step_bytes * K / elapsed / 1e9
+            hbm["counter_frac_of_peak"] = hbm["counter_GBps"] / (PEAK_HBM_TBPS * 1e3)
     if rank != 0:
         return None
     return {"metric": "crystal structures/sec (1000-step reverse diffusion), MatterGen-shaped network", "value": world * Bm * K / (T * elapsed), "unit": "structures/s",
@@ -656,12 +655,10 @@ def main_mg_ft(args):
     print(json.dumps(out), flush=True)
 
 
-def measure_traffic_live(args, steps=3, warmup=1, timeout_s=240):
-    """roofline.traffic of the headline line: FETCH_SIZE and WRITE_SIZE of the edge stage's two kernels (pair-mode Fourier GEMM +
-    second-linear GEMM) per dispatch, from two rocprofv3 child runs of this script (`--counter-child`: the same workload, `steps`
-    denoising steps).  Units and correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KiB; on
-    gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes (doubled here); WRITE_SIZE as reported.  Returns (bytes per bench launch
-    or None, provenance dict)."""
+def _counter_passes(extra_argv, timeout_s=240):
+    """FETCH_SIZE and WRITE_SIZE of every kernel of `python bench.py <extra_argv> --counter-child`, from two rocprofv3 child runs (the
+    counters in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Returns ({counter: {kernel: (dispatches,
+    average KiB)}}, None) or (None, reason)."""
     import glob
     import shutil
     import sqlite3
@@ -669,33 +666,42 @@ def measure_traffic_live(args, steps=3, warmup=1, timeout_s=240):
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
-        return None, {"measured": "no: rocprofv3 not found on this box"}
+        return None, "no: rocprofv3 not found on this box"
     here = os.path.abspath(__file__)
-    got, t0 = {}, time.perf_counter()
+    got = {}
     tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, here, "--steps", str(steps), "--warmup", str(warmup), "--streams", str(args.streams),
-                   "--path", args.path, "--no-cpu-baseline", "--no-counters", "--counter-child"]
-            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, here] + list(extra_argv) + ["--no-cpu-baseline", "--no-counters", "--counter-child"]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
-                return None, {"measured": f"no: the {counter} pass exceeded {timeout_s} s"}
+                return None, f"no: the {counter} pass exceeded {timeout_s} s"
             dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return None, {"measured": f"no: the {counter} pass failed (rc {r.returncode})", "stderr_tail": (r.stderr or "")[-300:]}
+                return None, f"no: the {counter} pass failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
             cur = sqlite3.connect(dbs[0]).cursor()
-            per = {}
-            for k, n, v in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
-                per[k.split("(")[0]] = (n, v)
-            got[counter] = per
+            got[counter] = {k.split("(")[0]: (n, v) for k, n, v in
+                            cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,))}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return got, None
+
+
+COUNTER_CORRECTION = "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"
+
+
+def measure_traffic_live(args, steps=3, warmup=1):
+    """roofline.traffic of the headline line: FETCH_SIZE and WRITE_SIZE of the edge stage's two kernels (pair-mode Fourier GEMM +
+    second-linear GEMM) per dispatch, measured by THIS run (see _counter_passes; `steps` denoising steps of the same workload).
+    Returns (bytes per bench launch or None, provenance dict)."""
+    t0 = time.perf_counter()
+    got, why = _counter_passes(["--steps", str(steps), "--warmup", str(warmup), "--streams", str(args.streams), "--path", args.path])
+    if got is None:
+        return None, {"measured": why}
     stage = lambda k: ("gemm_planes_kernel<1" in k) or ("edge_gemm2" in k) or ("edge_gemm1" in k) or ("edge_ring" in k) or ("edge_fused" in k)
     kernels, total = {}, 0.0
-    launches = None
     for k in sorted(set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"])):
         if not stage(k):
             continue
@@ -704,12 +710,23 @@ def measure_traffic_live(args, steps=3, warmup=1, timeout_s=240):
         fb, wb = 2.0 * f * 1024.0, w * 1024.0
         kernels[k[:80]] = {"dispatches": nf, "fetch_bytes": fb, "write_bytes": wb}
         total += fb + wb   # (one dispatch of each kernel per bench launch = the edge stage of one layer)
-        launches = nf if launches is None else min(launches, nf)
     if not kernels:
         return None, {"measured": "no: the edge-stage kernels do not appear in the counter passes"}
     return total, {"measured": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command line, after the timed region",
-                   "steps_per_pass": steps, "per_kernel": kernels, "wall_s": round(time.perf_counter() - t0, 1),
-                   "correction": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
+                   "steps_per_pass": steps, "per_kernel": kernels, "wall_s": round(time.perf_counter() - t0, 1), "correction": COUNTER_CORRECTION}
+
+
+def measure_mg_traffic_live(args, steps=2, warmup=1):
+    """HBM-side bytes of ALL kernels of the MatterGen-shaped sampler's step (FETCH_SIZE x2 + WRITE_SIZE, every dispatch of the child run),
+    measured by this run.  Returns (bytes per step or None, provenance dict)."""
+    t0 = time.perf_counter()
+    got, why = _counter_passes(["--mode", "mg-sample", "--steps", str(steps), "--warmup", str(warmup), "--mg-batch", str(args.mg_batch), "--mg-chains", str(args.mg_chains)], timeout_s=300)
+    if got is None:
+        return None, {"measured": why}
+    total = sum(2.0 * v * 1024.0 * n for n, v in got["FETCH_SIZE"].values()) + sum(v * 1024.0 * n for n, v in got["WRITE_SIZE"].values())
+    return total / (steps + warmup), {"measured": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of `--mode mg-sample`, every dispatch of the run "
+                                                  "(its set-up included: two graph builds)", "steps_per_pass": steps + warmup, "wall_s": round(time.perf_counter() - t0, 1),
+                                      "correction": COUNTER_CORRECTION}
 
 
 def _self_launch(n):

@@ -326,6 +326,11 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
 /* One wave busy-waiting ~`cycles` shader clocks on `stream`: lets the host side test whether two HIP streams really execute
  * concurrently (streams may share a hardware queue, which serialises them). */
 int mi_debug_spin(long long cycles, void* stream);
+/* Test hook for SinusoidsEmbedding (models/diffcsp/cspnet.py:12-24) as the edge stage consumes it: the pair-mode Fourier operand of
+ * Np atom pairs (i, j), d = (frac[j] - frac[i]) % 1, rebuilt as fp32 from its plane set -- out[Np][6F] = [sin(2 pi k d_c) | cos(...)],
+ * column c * F + k.  The product path never materialises these values in fp32; the tests compare them with the reference's golden
+ * embedding.  All pointers are device pointers; synchronises `stream`. */
+int mi_debug_fourier_pairs(const float* frac, const int* pair_i, const int* pair_j, int64_t Np, int F, float* out, void* stream);
 /* Tuning knob: smallest number of 256-row tiles for which the double-buffered plane GEMM is used (default 256). */
 int mi_debug_set_db_min_tiles(int n);
 /* Tuning knob: smallest node count for which the node-level products (P_i/P_j projections, node MLP) run on the plane-set

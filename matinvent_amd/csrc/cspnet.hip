@@ -1678,6 +1678,42 @@ int mi_set_gemm_mode(int mode) {
     return MI_OK;
 }
 
+// The pair-mode Fourier operand of `Np` atom pairs, read back as fp32: out[p][0:3F] = sin(2 pi k d_c), out[p][3F:6F] = cos(...) in
+// SinusoidsEmbedding's column order (c * F + k), each value the exact sum of its planes divided by the plane scale.
+__global__ void debug_fourier_read_kernel(mi::Planes FF, int64_t Np, int F, int Kh, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F3 = 3 * F;
+    if (idx >= Np * 2 * F3) return;
+    const int64_t p = idx / (2 * F3);
+    const int c = (int)(idx % (2 * F3)), col = c < F3 ? c : Kh + (c - F3);
+    float v = 0.f;
+    for (int pl = mi::NPL - 1; pl >= 0; --pl) {
+        const mi::u16 w = FF.base[FF.elem((int)p, col, pl)];
+#if MI_PLANES_FP16
+        v += (float)__builtin_bit_cast(_Float16, w);
+#else
+        v += __uint_as_float((unsigned)w << 16);
+#endif
+    }
+    out[idx] = v / FF.s();
+}
+int mi_debug_fourier_pairs(const float* frac, const int* pair_i, const int* pair_j, int64_t Np, int F, float* out, void* stream) {
+    MI_CHECK(frac && pair_i && pair_j && out && Np > 0 && F > 0, MI_EINVAL, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int Kh = (3 * F + 31) / 32 * 32;
+    mi::u16* buf = nullptr;
+    MI_HIP(hipMalloc((void**)&buf, mi::planes_elems(Np, 2 * Kh) * sizeof(mi::u16)));
+    mi::Planes ffp = mi::make_planes(buf, 2 * Kh, mi::PL_S_UNIT);
+    const int64_t nthr = (Np + 127) / 128 * 128 * (int64_t)(Kh / 8);
+    hipLaunchKernelGGL(mi::fourier_pair_planes_kernel, dim3((unsigned)mi::cdiv(nthr, 256)), dim3(256), 0, s, frac, pair_i, pair_j, ffp, Np, F, Kh);
+    hipLaunchKernelGGL(debug_fourier_read_kernel, dim3((unsigned)mi::cdiv(Np * 6 * F, 256)), dim3(256), 0, s, ffp, Np, F, Kh, out);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    MI_HIP(e);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
 int mi_debug_set_db_min_tiles(int n) {
     if (n < 0) g_pair_kernel = 1;  // negative: also let pair-mode GEMMs pick the kernel by size
     g_planes_db_min_tiles = n < 0 ? -n : n;

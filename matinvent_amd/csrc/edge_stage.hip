@@ -465,6 +465,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // N % 256 == 0; the column blocks of a row tile run on the same XCD.  Same products, same k order, same epilogue function as the
 // 128 x 128 plane kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef MI_RT_PF_AT
+#define MI_RT_PF_AT 5   // k-tiles before the end of the loop at which the epilogue's operands are touched (0: never)
+#endif
 template <bool EXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
                                                                                                  PlanesEpilogue pe) {
@@ -530,6 +533,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
+    // EXT: the epilogue's row-wise operands -- the residual and the second merge as plane sets, the multiplicand as fp32 rows; 128 KB per
+    // workgroup each -- are first touched in the epilogue, where every 32 x 32 tile waits one HBM latency for them with nothing left to
+    // cover it (590 us against 454 us for the same product without them).  Three k-tiles before the loop ends, every lane touches
+    // one word of four of their 128-byte lines: by the time the epilogue asks, the lines are in this XCD's L2.  The words are kept alive
+    // to the kernel's end (`pf`), so the compiler orders nothing behind them but its own bookkeeping.
+    unsigned pfv[4][4];   // (raw words, consumed by an empty asm at the kernel's end: nothing waits for them before that)
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pfv[o][q] = 0;
+    int pf_row2 = 0;
+    if constexpr (EXT) {
+        if (pe.res2_rows && pe.residual2) {
+            const int r = row0 + (tid >> 1);
+            pf_row2 = r < M ? pe.res2_rows[r] : 0;
+        }
+    }
+    auto prefetch_epilogue_operands = [&]() {
+        if constexpr (EXT) {
+            const int col0 = cb * 256;
+            auto touch_planes = [&](const Planes& P, unsigned (&w)[4]) {   // 8 column tiles x 2 planes x 64 lines (128 rows x 64 B) = 1024 lines
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int line = tid + 256 * q, blk = line >> 6, ct = blk >> 1, plane = blk & 1, ln = line & 63;
+                    w[q] = *reinterpret_cast<const unsigned*>(P.base + P.tile(tile, (col0 >> 5) + ct) + (size_t)plane * 4096 + ln * 64);
+                }
+            };
+            auto touch_rows = [&](const float* X, int ld, int row, unsigned (&w)[4]) {   // this thread's half of one row: 4 of its 8 lines
+                if (row0 + (tid >> 1) < M)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = __float_as_uint(X[(size_t)row * ld + col0 + ((tid & 1) * 4 + q) * 32]);
+            };
+            if (pe.res_pl.base) touch_planes(pe.res_pl, pfv[0]);
+            if (pe.res2_pl.base) touch_planes(pe.res2_pl, pfv[1]);
+            if (pe.post_mul) touch_rows(pe.post_mul, pe.ld_post_mul, row0 + (tid >> 1), pfv[2]);
+            if (pe.residual2) touch_rows(pe.residual2, pe.ld_res2, pe.res2_rows ? pf_row2 : row0 + (tid >> 1), pfv[3]);
+        }
+    };
     // (waits as in edge_gemm2b_kernel: k-tile k's DMA pieces were issued at least 8 + 12 + 12 vector-memory operations ago)
 #pragma unroll 1
     for (int kt = 0; kt < KT; kt += 2) {
@@ -539,6 +580,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             __syncthreads();
+            // (extra loads only put more operations behind a k-tile's DMA pieces: the counted waits stay sufficient)
+            if (MI_RT_PF_AT > 0 && k == KT - MI_RT_PF_AT) prefetch_epilogue_operands();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
             f16x8 af[4][2];
 #pragma unroll
@@ -552,6 +595,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();   // every wave is done with the stages: they become the epilogue's per-wave patches
     planes_epilogue_rows<4, 2, EXT>(pe, acc, row0, cb * 256 + wave * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    if constexpr (EXT) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(pfv[o][q]));
+    }
 }
 
 // plane set [N x K] -> fragment order (exact copy): one thread per (row, 8-k chunk)

@@ -70,6 +70,31 @@ def test_time_embedding_golden(golden):
     _close(emb(torch.from_numpy(g["t"])), g["time_256"], 2e-6, "time embedding, pinned table")
 
 
+@pytest.mark.parametrize("F", [8, 128])
+def test_fourier_operand_golden(golden, F):
+    """SinusoidsEmbedding (cspnet.py:12-24) as the edge stage consumes it: the pair-mode Fourier operand kernel, its two fp16 planes summed
+    back to fp32, against the reference's embedding of the same differences (g4: `sin_F8`, `sin_F128`).  The product path never holds these
+    values in fp32, so every other test sees them only through a forward.  Tolerance: 2^-21 of the unit range for the plane format (22
+    significant bits at scale 2^6) + the device sin / cos against the generating host's libm (1.2e-7, common.h) + the argument's own
+    rounding, which the reference shares only up to the order of its multiplications: 2 pi k d carries k <= 127 ulps of 2 pi d."""
+    import ctypes as C
+    from matinvent_amd import _lib
+    g = golden("g4_embeddings")
+    x = torch.from_numpy(g["x"]).float()
+    n = x.shape[0]
+    frac = torch.cat([torch.zeros(1, 3), x]).cuda().contiguous()            # atom 0 at the origin: d(0, j) = x_j % 1
+    pi = torch.zeros(n, dtype=torch.int32, device="cuda")
+    pj = torch.arange(1, n + 1, dtype=torch.int32, device="cuda")
+    out = torch.empty(n, 6 * F, device="cuda")
+    _lib.check(_lib.load().mi_debug_fourier_pairs(C.c_void_p(frac.data_ptr()), C.c_void_p(pi.data_ptr()), C.c_void_p(pj.data_ptr()), n, F,
+                                                  C.c_void_p(out.data_ptr()), None), "mi_debug_fourier_pairs")
+    ref = torch.from_numpy(g[f"sin_F{F}"])
+    err = (out.cpu() - ref).abs()
+    k = torch.arange(F).repeat(6).float()                                   # frequency of every column
+    bound = 2.0 ** -21 + 1.2e-7 + (k + 1) * 2 * torch.pi * 2.0 ** -24 * 1.5
+    assert bool((err <= bound[None, :]).all()), f"F={F}: max err {float(err.max()):.3e} at column {int(err.max(0).values.argmax())}"
+
+
 def test_forward_tiny_golden(golden, path):
     g = golden("g5a_cspnet_tiny")
     net = _net(64, 2, 8, params_from_golden(g), path)
