@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 128 x 128 plane kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------------------------------------------
 #ifndef MI_RT_PF_AT
-#define MI_RT_PF_AT 5   // k-tiles before the end of the loop at which the epilogue's operands are touched (0: never)
+#define MI_RT_PF_AT 0   // k-tiles before the end of the loop at which the epilogue's operands are touched (0: never -- measured: no gain, see below)
 #endif
 template <bool EXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
@@ -533,11 +533,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
-    // EXT: the epilogue's row-wise operands -- the residual and the second merge as plane sets, the multiplicand as fp32 rows; 128 KB per
-    // workgroup each -- are first touched in the epilogue, where every 32 x 32 tile waits one HBM latency for them with nothing left to
-    // cover it (590 us against 454 us for the same product without them).  Three k-tiles before the loop ends, every lane touches
-    // one word of four of their 128-byte lines: by the time the epilogue asks, the lines are in this XCD's L2.  The words are kept alive
-    // to the kernel's end (`pf`), so the compiler orders nothing behind them but its own bookkeeping.
+    // EXT (a recorded ablation, off: MI_RT_PF_AT = 0): the epilogue's row-wise operands -- the residual and the second merge as plane sets,
+    // the multiplicand as fp32 rows; 128 KB per workgroup each -- are first touched in the epilogue (590 us against 454 us for the same
+    // product without them).  Touching one word of each of their 128-byte lines 3 / 5 / 8 k-tiles before the loop ends, so that the
+    // epilogue finds them in this XCD's L2, measured 2.54 / 2.52 / 2.52 structures/s against 2.56 on one chain of the MatterGen-shaped
+    // sampler and 2.67-2.76 against 2.71-2.79 on four: the epilogue is not waiting for these lines (two workgroups per CU cover each
+    // other's loads); the extra time of the EXT form is its arithmetic and its stores.
     unsigned pfv[4][4];   // (raw words, consumed by an empty asm at the kernel's end: nothing waits for them before that)
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();   // every wave is done with the stages: they become the epilogue's per-wave patches
     planes_epilogue_rows<4, 2, EXT>(pe, acc, row0, cb * 256 + wave * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
-    if constexpr (EXT) {
+    if constexpr (EXT && MI_RT_PF_AT > 0) {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
 #pragma unroll
