@@ -1,0 +1,137 @@
+"""CPU-only checks of round 4's host logic: MatterGenSampler.generate drops exactly the crystals the chain flagged (not the batch),
+bench.py's live traffic measurement turns two rocprofv3 counter databases into bytes per launch with the guide's corrections, and the
+build recipe carries the flag that keeps packed-fp32 instructions out of the device code."""
+import os
+import sqlite3
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class _FakeModel:
+    """Stands in for MatterGenModule: `sample` returns a mean state for the requested crystals, `last_sample_invalid` the flags the
+    chain would have kept (crystal k of batch b is flagged when (b, k) is in `bad`)."""
+
+    def __init__(self, bad):
+        self.bad, self.calls = bad, 0
+
+    def eval(self):
+        return self
+
+    def sample(self, na, **kw):
+        na = [int(v) for v in na]
+        self._n = len(na)
+        N = sum(na)
+        mean = dict(pos=torch.rand(N, 3), cell=5.0 * torch.eye(3)[None].repeat(len(na), 1, 1), atomic_numbers=torch.ones(N, dtype=torch.long),
+                    num_atoms=torch.tensor(na))
+        self.calls += 1
+        return mean, mean
+
+    def last_sample_invalid(self):
+        flags = torch.zeros(self._n, dtype=torch.bool)
+        for b, k in self.bad:
+            if b == self.calls - 1:
+                flags[k] = True
+        return flags
+
+
+@pytest.fixture()
+def mg(monkeypatch):
+    from matinvent_amd import _lib, mattergen
+    monkeypatch.setattr(_lib, "check_saturation", lambda where: None)
+    monkeypatch.setattr(_lib, "saturation_events", lambda reset=True: 0)
+    import matinvent_amd.structure as st
+    monkeypatch.setattr(st, "check_structures_counts", lambda na, pos, cell: torch.ones(len(na), 3))
+    return mattergen
+
+
+def test_generate_drops_only_the_flagged_crystals(mg):
+    np.random.seed(0)
+    model = _FakeModel(bad={(0, 2), (1, 0), (1, 3)})
+    sampler = mg.MatterGenSampler(n_steps=3)
+    graphs, strucs = sampler.generate(model, batch_size=5, num_batches=2)
+    assert model.calls == 2
+    assert len(graphs) == len(strucs) == 10 - 3          # three crystals dropped, every other one kept
+    assert sampler.discarded == 3
+    # more than max_discard_fraction of a call's request gone: an error, not a short list handed to the RL step
+    model = _FakeModel(bad={(0, k) for k in range(4)})
+    sampler = mg.MatterGenSampler(n_steps=3, max_discard_fraction=0.5)
+    with pytest.raises(RuntimeError, match="4 of 5 sampled crystals dropped"):
+        sampler.generate(model, batch_size=5, num_batches=1)
+
+
+def test_generate_discards_a_batch_only_for_the_synchronising_forms_capacity_error(mg):
+    from matinvent_amd import _lib
+
+    class Refusing(_FakeModel):
+        def sample(self, na, **kw):
+            self.calls += 1
+            if self.calls == 1:
+                raise _lib.MIError(_lib.MI_ENOMEM, "matinvent_hip mi_mg_sampler_run failed (code -3): periodic graph: capacity exceeded")
+            self.calls -= 1
+            return super().sample(na, **kw)
+
+    np.random.seed(0)
+    graphs, _ = mg.MatterGenSampler(n_steps=3, max_discard_fraction=0.9).generate(Refusing(set()), batch_size=4, num_batches=2)
+    assert len(graphs) == 4                                # the refused batch is gone, the other one complete
+
+    class Broken(_FakeModel):
+        def sample(self, na, **kw):
+            raise _lib.MIError(_lib.MI_EHIP, "hipLaunchKernel failed")
+
+    with pytest.raises(_lib.MIError):                      # any other library error is not swallowed
+        mg.MatterGenSampler(n_steps=3).generate(Broken(set()), batch_size=4, num_batches=1)
+
+
+def _counter_db(path, counter, rows):
+    db = sqlite3.connect(path)
+    db.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+    db.executemany("insert into counters_collection values (?, ?, ?)", [(k, counter, v) for k, v in rows])
+    db.commit()
+    db.close()
+
+
+def test_live_traffic_is_two_counter_passes_with_the_guides_corrections(monkeypatch, tmp_path):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    import importlib
+    bench = importlib.import_module("bench")
+    import shutil
+    import subprocess
+    pair = "void mi::gemm_planes_kernel<1, 2, false>(mi::Planes, mi::Planes, int, int, int, mi::PlanesEpilogue, int)"
+    e2 = "void mi::edge_gemm2b_kernel<4, false>(mi::EdgeGemm2Args)"
+    other = "void mi::node_chain_kernel<512, 8, 4>(mi::NodeChainArgs)"
+    values = {"FETCH_SIZE": [(pair, 1000.0), (pair, 3000.0), (e2, 500.0), (other, 7.0)], "WRITE_SIZE": [(pair, 100.0), (e2, 10.0), (other, 3.0)]}
+    seen = []
+
+    def fake_run(cmd, **kw):
+        seen.append(cmd)
+        counter = cmd[cmd.index("--pmc") + 1]
+        out = cmd[cmd.index("-d") + 1]
+        os.makedirs(os.path.join(out, "host"), exist_ok=True)
+        _counter_db(os.path.join(out, "host", "r_results.db"), counter, values[counter])
+        return types.SimpleNamespace(returncode=0, stderr="", stdout="")
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    args = types.SimpleNamespace(streams=4, path="split-gemm")
+    total, src = bench.measure_traffic_live(args)
+    # per launch = one dispatch of each edge-stage kernel: KiB -> bytes, FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported
+    assert total == pytest.approx((2 * 2000.0 + 100.0) * 1024 + (2 * 500.0 + 10.0) * 1024)
+    assert src["measured"].startswith("live") and len(src["per_kernel"]) == 2 and all("node_chain" not in k for k in src["per_kernel"])
+    assert [c[c.index("--pmc") + 1] for c in seen] == ["FETCH_SIZE", "WRITE_SIZE"]                      # separate passes
+    assert all("--counter-child" in c and "--no-counters" in c and "--kernel-trace" not in c for c in seen)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p: False)
+    total, src = bench.measure_traffic_live(args)
+    assert total is None and "rocprofv3 not found" in src["measured"]
+
+
+def test_the_build_keeps_packed_fp32_instructions_out_of_the_device_code():
+    from matinvent_amd import build
+    flags = " ".join(build.CFLAGS)
+    assert "-target-feature -Xclang -packed-fp32-ops" in flags
