@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __res
                 float* zp = Z2 + e * H + 4 * cq;
                 const f32x4 z = *reinterpret_cast<const f32x4*>(zp);
                 f32x4 v;
+                // (the mean's 1 / deg stays an IEEE division -- it is exact for the powers of two and shared by a row; silu' on the hardware transcendentals)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = (d[k] / deg) * silu_grad(z[k]);
+                for (int k = 0; k < 4; ++k) v[k] = (d[k] / deg) * silu_grad_fast(z[k]);
                 *reinterpret_cast<f32x4*>(zp) = v;
                 if (dzp.base) {
                     unsigned lo[3], hi[3];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* _
                                                                   const int* __restrict__ pair_off, float* __restrict__ Dm, float* __restrict__ Dp,
                                                                   float* __restrict__ dPQ, float* __restrict__ dG, float* __restrict__ dsum_part,
                                                                   int H, const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
-    extern __shared__ float tile[];  // dZ1 [n * n][32] | row sums [n][32]
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // dZ1 [n * n][32] | row sums [n][32]   (16-byte pieces: the base must be 16-aligned behind the static table)
     __shared__ unsigned short pij[PAIRS_NMAX * (PAIRS_NMAX - 1) / 2];   // pair k -> (i << 8) | j
     if (dsc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (scales of the weight-gradient operands: see the kernel above)
         const float bnd = 2.2f * __uint_as_float(amax[0]);
@@ -267,9 +268,41 @@ __global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* _
     const int64_t e0 = rowptr[o];
     const int nn = n * n, np = n * (n - 1) / 2;
     float* rs = tile + (size_t)nn * PAIRS_W;
-    for (int e = w; e < nn; e += PAIRS_WORKERS) {
-        const size_t a = (size_t)(e0 + e) * H + c;
-        tile[e * PAIRS_W + lc] = cok ? dM1[a] * silu_grad(Z1[a]) : 0.f;
+    // dZ1 tile: eight lanes x 16 bytes cover a row's 32 columns, a 256-thread pass 32 rows; four passes' loads are issued before the first
+    // value is used (one 4-byte load per lane and row with the libm silu' in between ran this pass at 2 TB/s: 313 us per layer at 256 crystals)
+    const int rq = tid >> 3, c4 = (tid & 7) * 4, cq = blockIdx.y * PAIRS_W + c4;
+    const bool vec = (H & 3) == 0 && cq + 3 < H;
+    for (int eb = 0; eb < nn; eb += 128) {
+        f32x4 d[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = eb + 32 * u + rq;
+            d[u] = z[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < nn) {
+                const size_t a = (size_t)(e0 + e) * H + cq;
+                if (vec) {
+                    d[u] = *reinterpret_cast<const f32x4*>(dM1 + a);
+                    z[u] = *reinterpret_cast<const f32x4*>(Z1 + a);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cq + k < H) {
+                            d[u][k] = dM1[a + k];
+                            z[u][k] = Z1[a + k];
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = eb + 32 * u + rq;
+            if (e < nn) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = d[u][k] * silu_grad_fast(z[u][k]);   // (columns past H: 0 * silu'(0) = 0)
+                *reinterpret_cast<f32x4*>(tile + e * PAIRS_W + c4) = v;
+            }
+        }
     }
     for (int i = tid; i < n; i += 256) {   // pair table in the order of the pair list (i < j, row-major)
         int k = i * n - i * (i + 1) / 2;
@@ -277,12 +310,21 @@ __global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* _
     }
     __syncthreads();
     const int64_t p0 = pair_off[g];
-    if (cok) {
-        for (int k = w; k < np; k += PAIRS_WORKERS) {
-            const int i = pij[k] >> 8, j = pij[k] & 255;
-            const float v1 = tile[(i * n + j) * PAIRS_W + lc], v2 = tile[(j * n + i) * PAIRS_W + lc];
-            Dm[(size_t)(p0 + k) * H + c] = v1 - v2;
-            Dp[(size_t)(p0 + k) * H + c] = v1 + v2;
+    for (int k = rq; k < np; k += 32) {   // the pair rows of the weight-gradient operands: 16-byte pieces, 32 pairs per pass
+        const int i = pij[k] >> 8, j = pij[k] & 255;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + (i * n + j) * PAIRS_W + c4), v2 = *reinterpret_cast<const f32x4*>(tile + (j * n + i) * PAIRS_W + c4);
+        const f32x4 dm = v1 - v2, dp = v1 + v2;
+        const size_t a = (size_t)(p0 + k) * H + cq;
+        if (vec) {
+            *reinterpret_cast<f32x4*>(Dm + a) = dm;
+            *reinterpret_cast<f32x4*>(Dp + a) = dp;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (cq + q < H) {
+                    Dm[a + q] = dm[q];
+                    Dp[a + q] = dp[q];
+                }
         }
     }
     for (int i = w; i < n; i += PAIRS_WORKERS) {   // dPQ[i][0:H] = sum_j dZ1[(i,j)],  dPQ[i][H:2H] = sum_i' dZ1[(i',i)]

@@ -71,6 +71,11 @@ __device__ __forceinline__ float silu_grad(float x) {
     float s = 1.0f / (1.0f + expf(-x));
     return s * (1.0f + x * (1.0f - s));
 }
+// the same on the hardware transcendentals (the backward's streaming passes over [E, H]: a few ulp, far inside the gradient tolerance)
+__device__ __forceinline__ float silu_grad_fast(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+    return s * (1.0f + x * (1.0f - s));
+}
 // python / torch `x % 1.` for floats (torch.remainder): result takes the sign of the divisor
 __device__ __forceinline__ float pymod1(float x) {
     float r = fmodf(x, 1.0f);
