@@ -146,13 +146,20 @@ class DiffCSPModule(nn.Module):
         noised_input = (time_emb, in_types, in_frac, in_lat, cb.num_atoms, cb.batch)
         return noised_input, (rand_l, tar_x, rand_t), cb.batch
 
-    def calc_sample_loss(self, input_all):
-        """diffusion.py:121-138: per-crystal cost_lattice*mse_l + cost_coord*mse_x + cost_type*mse_t."""
+    def predict(self, input_all):
+        """The network evaluation of calc_sample_loss alone (diffusion.py:124-125): library kernels only, no torch arithmetic -- the part
+        that may run on a side stream beside another network's forward (finetune._ft_step_module_surface)."""
+        noised_input, _, node2graph = input_all
+        time_emb, atom_types, frac, lattices, num_atoms, _ = noised_input
+        return self.decoder(time_emb, atom_types, frac, lattices, num_atoms, node2graph, batch=self._batch_for(num_atoms))
+
+    def calc_sample_loss(self, input_all, pred=None):
+        """diffusion.py:121-138: per-crystal cost_lattice*mse_l + cost_coord*mse_x + cost_type*mse_t (`pred`: the output of `predict`,
+        when the caller has run the network already)."""
         noised_input, (rand_l, tar_x, rand_t), node2graph = input_all
         time_emb, atom_types, frac, lattices, num_atoms, _ = noised_input
         B = lattices.shape[0]
-        cb = self._batch_for(num_atoms)
-        pred_l, pred_x, pred_t = self.decoder(time_emb, atom_types, frac, lattices, num_atoms, node2graph, batch=cb)
+        pred_l, pred_x, pred_t = pred if pred is not None else self.predict(input_all)
         loss_lattice = torch.pow(pred_l - rand_l, 2).mean(dim=(1, 2))
         loss_coord = _scatter_mean(torch.pow(pred_x - tar_x, 2).mean(dim=1), node2graph, B)
         loss_type = _scatter_mean(torch.pow(pred_t - rand_t, 2).mean(dim=1), node2graph, B)

@@ -299,15 +299,20 @@ def _ft_step_module_surface(agent, prior, data_list, rewards, lo, hi, n_global, 
                 agent.shard_offsets = prior.shard_offsets = offs
                 agent._noise_calls = calls                                            # (every chunk of a timestep draws from the same Philox step)
                 noised = agent.add_noise(batch, t, noise=noise)                       # :152
-                if aux is not None:   # the frozen prior's forward on a second stream, under the agent's (separate network and batch handle)
+                if aux is not None and hasattr(prior, "predict"):
+                    # the frozen prior's forward on a second stream, under the agent's (separate network and batch handle).  Only the two
+                    # NETWORK evaluations overlap -- kernels of this library, built without packed-fp32 instructions; the loss
+                    # arithmetic is torch's own elementwise kernels, which are not, and runs after the join with nothing beside it.  (The
+                    # prior's sample loss, line :154 of the reference, is computed there and never used: only its prediction is needed.)
                     aux.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(aux), torch.no_grad():
-                        _, prior_pred = prior.calc_sample_loss(noised)                # :154
-                    sample_loss, agent_pred = agent.calc_sample_loss(noised)          # :153
+                        prior_pred = prior.predict(noised)                            # :154
+                    agent_out = agent.predict(noised)
                     torch.cuda.current_stream().wait_stream(aux)
-                    for v in prior_pred.values():
+                    for v in (prior_pred.values() if isinstance(prior_pred, dict) else prior_pred):
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(torch.cuda.current_stream())
+                    sample_loss, agent_pred = agent.calc_sample_loss(noised, pred=agent_out)   # :153
                 else:
                     sample_loss, agent_pred = agent.calc_sample_loss(noised)          # :153
                     with torch.no_grad():

@@ -421,11 +421,20 @@ class MatterGenModule(nn.Module):
                      counts=torch.tensor(gb.num_atoms_list))
         return noisy, batch, t
 
-    def calc_sample_loss(self, noised_input):
-        """pl_module.py:71-81 + SampleLoss (loss.py:36-78): per-crystal sum_field w_field * loss_field, and the model output."""
+    def predict(self, noised_input):
+        """The model output alone (pl_module.py:73) -- library kernels only, no torch arithmetic: the part of calc_sample_loss that may
+        run on a side stream beside another network's forward (finetune._ft_step_module_surface)."""
         noisy, batch, t = noised_input
-        gb, aux = self._batch_for(noisy["counts"]), noisy["aux"]   # THIS module's workspace (agent and prior must not share one)
-        pred = self.decoder(noisy["pos"], noisy["cell"], noisy["atomic_numbers"], t, gb)
+        gb = self._batch_for(noisy["counts"])   # THIS module's workspace (agent and prior must not share one)
+        return self.decoder(noisy["pos"], noisy["cell"], noisy["atomic_numbers"], t, gb)
+
+    def calc_sample_loss(self, noised_input, pred=None):
+        """pl_module.py:71-81 + SampleLoss (loss.py:36-78): per-crystal sum_field w_field * loss_field, and the model output
+        (`pred`: the output of `predict`, when the caller has run the network already)."""
+        noisy, batch, t = noised_input
+        gb, aux = self._batch_for(noisy["counts"]), noisy["aux"]
+        if pred is None:
+            pred = self.predict(noised_input)
         B, n2g = gb.num_graphs, gb.batch
         target = aux["std"] * _d_log_p_wn(aux["delta"], aux["std"])
         l_pos = _scatter_mean(((pred["pos"] - target) ** 2).mean(1), n2g, B)
