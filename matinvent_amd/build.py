@@ -24,7 +24,8 @@ CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 # without the target feature it selects the scalar forms.  Cost: none measurable (50.0 / 50.1 against 49.4-50.4 structures/s on the
 # headline, same box); effect: 120 of 120 trials of four concurrent MatterGen-shaped forwards bit-identical, against 103 of 120.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-CFLAGS += NO_PACKED_FP32
+if not os.environ.get("MI_ALLOW_PACKED_FP32"):   # (ablation only: rebuilds the library of rounds 1-3, e.g. to watch the concurrency tests fail)
+    CFLAGS += NO_PACKED_FP32
 
 
 def _headers():
