@@ -1329,6 +1329,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
     if (n->Wnc) (void)hipFree(n->Wnc);
     if (n->Wffc) (void)hipFree(n->Wffc);
+    if (n->Wffc2) (void)hipFree(n->Wffc2);
     if (n->wbounds) (void)hipFree(n->wbounds);
     for (auto e : n->ev) (void)hipEventDestroy(e);
     delete n;
@@ -1367,6 +1368,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->wbounds, (size_t)n->L * 8 * sizeof(float)));
         if (node_chain_pack_elems(H) && cfg_ln_and_wide(n)) MI_HIP(hipMalloc((void**)&n->Wnc, (size_t)n->L * node_chain_pack_elems(H) * sizeof(u16)));
         if (MI_PLANES_FP16 && H % 128 == 0) MI_HIP(hipMalloc((void**)&n->Wffc, (size_t)n->L * H * 2 * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));
+        if (MI_PLANES_FP16 && H % 256 == 0) MI_HIP(hipMalloc((void**)&n->Wffc2, (size_t)n->L * H * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));   // -2 x the sine block (edge_gemm1e_kernel)
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));

@@ -822,6 +822,182 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Form E (mi_debug_set_edge1_fused(4)): ONE accumulator set on 128 pairs x 256 columns per four-wave workgroup -- the second edge GEMM's
+// register tile (a wave owns 128 pairs x 64 columns: 8 LDS fragment reads per 24 MFMAs, the ratio whose loop runs at the matrix pipe's
+// rate, where the two-set forms above read 8 per 12 and run at 1.7 x its floor).  The price of one set is half a pass more of MFMA work:
+//   pass 1  acc  = [sin | cos] x [Wsin ; Wcos]   (the whole K)      = C + S   -> epilogue of direction i -> j
+//   pass 2  acc += sin x (-2 Wsin)               (the sine half again) = C - S -> epilogue of direction j -> i
+// (-2 Wsin is exact in the fp16 plane format and packed beside the weights, edge_gemm1_pack).  1.5 x the MFMAs at the pipe's rate against
+// 1 x at 1.7 x its floor; the epilogue work per emitted edge is unchanged.  Same products up to the order of the fp32 accumulation: M1
+// agrees with the two-set forms to fp32 round-off, not bit for bit.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1e_kernel(Planes A, const u16* __restrict__ Wf, const u16* __restrict__ Wf2, int M,
+                                                                                                     int N, int K, PlanesEpilogue pe, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int nq = N / 256;
+    const int id = blockIdx.x;
+    float cps_local = 0.f;
+    if (pe.sc_pq) {
+        float dsc[6];
+        act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
+        cps_local = dsc[0];
+        if (id == 0 && tid < 6) {
+            pe.sc_dsc[tid] = dsc[tid];
+            if (pe.sc_dsc2) pe.sc_dsc2[tid] = dsc[tid];
+        }
+    }
+    if (pe.diag_C0 && id >= pe.diag_block0) {  // self edges, as in edge_gemm1_body
+        const float cps = cps_local != 0.f ? cps_local : pe.Cp.s();
+        const int n0 = (id - pe.diag_block0) * 8, n1 = n0 + 8 < pe.diag_nodes ? n0 + 8 : pe.diag_nodes;
+        const float* PQ = pe.ep.row_bias;
+        const int ldpq = pe.ep.ld_row_bias;
+        for (int f = 2 * tid; f < N; f += 512) {
+            const float c0 = pe.diag_C0[f], c1 = pe.diag_C0[f + 1];
+            for (int i = n0; i < n1; ++i) {
+                const int e = pe.diag_e[i], g = pe.diag_node2graph[i];
+                const float* G = pe.ep.row_bias3 + (size_t)g * pe.ep.ld_row_bias3;
+                const float v0 = c0 + ((PQ[(size_t)i * ldpq + f] + PQ[(size_t)i * ldpq + N + f]) + G[f]);
+                const float v1 = c1 + ((PQ[(size_t)i * ldpq + f + 1] + PQ[(size_t)i * ldpq + N + f + 1]) + G[f + 1]);
+                if (pe.ep.pre_act) {
+                    pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f] = v0;
+                    pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f + 1] = v1;
+                }
+                unsigned p[3];
+                pl_split_pair(silu_fast(v0), silu_fast(v1), cps, p);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(pe.Cp.base + pe.Cp.elem(e, f, k)) = p[k];
+            }
+        }
+        return;
+    }
+    const int slot = id >> 3, qt = slot % nq, tile = (slot / nq) * 8 + (id & 7);   // the column halves of a row tile on one XCD
+    const int row0 = tile * 128;
+    if (row0 >= M) return;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (clk && tid == 0) clk[(size_t)(tile * nq + qt) * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(tile, 0), A.KT * 24576);
+    const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+    };
+    static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
+    // one pass over the k-tiles 0 .. KTp - 1 of the Fourier operand against the fragment-order weights Wp (KSp = 2 KTp k-steps per column tile);
+    // the pipeline of edge_gemm2b_kernel: DMA three k-tiles ahead, four-deep weight ring, counted waits
+    auto run_pass = [&](const u16* __restrict__ Wp, int KTp) {
+        const int KSp = 2 * KTp;
+        const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wp, N * KSp * 16 * 4);
+        int voffw[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * qt + 2 * wave + t) * KSp) * 2048;
+        u32x4 ring[D][2][2];
+        auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+        };
+        dma_tile(0, 0);
+        dma_tile(1, 1);
+        dma_tile(2, 2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
+#pragma unroll 1
+        for (int kt = 0; kt < KTp; kt += 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int k = kt + h2;
+                if (k == 0 || k >= KTp - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (4 DMA pieces + 8 ring loads per k-tile, as in edge_gemm2b_kernel)
+                __syncthreads();
+                if (k + 3 < KTp) dma_tile(k + 3, (k + 3) & 3);
+                f16x8 af[4][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    read_a(k & 3, s2, af);
+                    mma(ring[2 * h2 + s2], af);
+                    if (2 * k + s2 + D < KSp) ring_load(2 * k + s2 + D, ring[2 * h2 + s2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    float* patch = reinterpret_cast<float*>(smem) + wave * 1152;
+    const int KT = K / 32;
+    run_pass(Wf, KT);                                   // C + S
+    stamp();
+    __syncthreads();                                    // the epilogue's per-wave patches overlay the operand stages
+    planes_epilogue_pairs_dir<4, 2>(pe, acc, 0, row0, qt * 256 + wave * 64, M, N, lane, patch, cps_local);
+    stamp();
+    __syncthreads();                                    // every wave is done with its patch: the stages take operand tiles again
+    run_pass(Wf2, KT / 2);                              // ... - 2 S
+    stamp();
+    __syncthreads();
+    planes_epilogue_pairs_dir<4, 2>(pe, acc, 1, row0, qt * 256 + wave * 64, M, N, lane, patch, cps_local);
+    stamp();
+}
+
+// fragment-order pack of -2 x the SINE block of the Fourier weights (Kh columns): the second pass of edge_gemm1e_kernel
+__global__ void pack_frag_wff_sin_neg2_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int Kh, u16* __restrict__ dst) {
+    const int KS = Kh / 16, F3 = 3 * F;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (row, 8-k chunk) per thread
+    if (idx >= (int64_t)H * (Kh / 8)) return;
+    const int r = (int)(idx / (Kh / 8)), ch = (int)(idx % (Kh / 8));
+    const int ct = r >> 5, l31 = r & 31, ks = ch >> 1, kg = ch & 1;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i;
+        v[i] = c < F3 ? -2.f * W1[(size_t)r * edge_in + 2 * H + 9 + c] : 0.f;
+    }
+    u32x4 pk[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned p[3];
+        pl_split_pair(v[2 * i], v[2 * i + 1], PL_SW, p);
+        pk[0][i] = p[0];
+        pk[1][i] = p[1];
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dst + ((((size_t)ct * KS + ks) * 2 + pl) * 64 + kg * 32 + l31) * 8) = pk[pl];
+}
+
 unsigned long long* g_edge1_clk = nullptr;
 
 int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s) {
@@ -837,6 +1013,21 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     MI_HIP(attr_err);
     const int H = net->H, K = 2 * net->Kh;
     pe.out_scale = 1.f / (A.scale * PL_SW);
+    if (g_edge1_fused == 4 && H % 256 == 0 && net->Wffc2 && (K / 32) % 4 == 0) {   // form E: one accumulator set, 128 x 256 tiles, the sine half twice
+        static std::once_flag once_e;
+        static hipError_t attr_e = hipSuccess;
+        std::call_once(once_e, [] { attr_e = hipFuncSetAttribute((const void*)edge_gemm1e_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS); });
+        MI_HIP(attr_e);
+        int nblk = (H / 256) * ((cdiv(M, 128) + 7) / 8 * 8);
+        if (pe.diag_C0) {
+            pe.diag_block0 = nblk;
+            nblk += cdiv(pe.diag_nodes, 8);
+        }
+        hipLaunchKernelGGL((edge_gemm1e_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, net->Wffc + (size_t)layer * ((size_t)H * K * 2),
+                           net->Wffc2 + (size_t)layer * ((size_t)H * net->Kh * 2), M, H, K, pe, g_edge1_clk);
+        MI_KERNEL_CHECK();
+        return MI_OK;
+    }
     const bool wide = MI_HAVE_ABLATION_KERNELS && g_edge1_fused == 2 && H % 256 == 0;   // 128 x 256 tiles, one four-wave workgroup per CU with 512 registers per lane
     int nblk = (H / (wide ? 256 : 128)) * ((cdiv(M, 128) + 7) / 8 * 8);
     if (pe.diag_C0) {
@@ -860,6 +1051,9 @@ int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s) {
     const int H = net->H, K = 2 * net->Kh;
     hipLaunchKernelGGL(pack_frag_wff_pair_kernel, dim3(cdiv((int64_t)H * (K / 8), 256)), dim3(256), 0, s, W1, net->edge_in, H, net->F, net->Kh,
                        net->Wffc + (size_t)l * ((size_t)H * K * 2));
+    if (net->Wffc2)
+        hipLaunchKernelGGL(pack_frag_wff_sin_neg2_kernel, dim3(cdiv((int64_t)H * (net->Kh / 8), 256)), dim3(256), 0, s, W1, net->edge_in, H, net->F, net->Kh,
+                           net->Wffc2 + (size_t)l * ((size_t)H * net->Kh * 2));
     MI_KERNEL_CHECK();
     return MI_OK;
 }

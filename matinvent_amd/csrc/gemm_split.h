@@ -933,6 +933,87 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
     sat_report(sat);
 }
 
+// ONE direction of the pair-mode epilogue (edge_gemm1e_kernel, edge_stage.hip): `acc` = the whole Fourier term of direction `dir` of each
+// pair (0: i -> j = C + S, 1: j -> i = C - S, both accumulated on the matrix pipe); the gathers, activation and plane stores of
+// planes_epilogue_pairs for that direction only.  The accumulators are read, not consumed: the caller goes on accumulating into them.
+template <int TM, int TN>
+__device__ __forceinline__ void planes_epilogue_pairs_dir(const PlanesEpilogue& pe, const f32x16 (&acc)[TM][TN], int dir, int row_w, int col_w, int M, int N,
+                                                          int lane, float* stage, float cps_in) {
+    const GemmEpilogue& ep = pe.ep;
+    const float os = pe.oscale(), cps = cps_in != 0.f ? cps_in : pe.Cp.base ? pe.Cp.s() : 1.f;
+    const int l31 = lane & 31, kg = lane >> 5;
+    unsigned sat = 0;
+    int h_a[TM][2], h_b[TM][2], h_gr[TM][2], h_e[TM][2];   // dir 0: P_i[i] + P_j[j] -> row e1;  dir 1: P_i[j] + P_j[i] -> row e2
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row_w + i * 32 + ((lane + 64 * u) >> 2);
+            const bool ok = row < M;
+            const int ni = ok ? pe.pair_i[row] : 0, nj = ok ? pe.pair_j[row] : 0;
+            h_a[i][u] = dir == 0 ? ni : nj;
+            h_b[i][u] = dir == 0 ? nj : ni;
+            h_gr[i][u] = ok ? pe.pair_graph[row] : 0;
+            h_e[i][u] = ok ? (dir == 0 ? pe.pair_e1[row] : pe.pair_e2[row]) : 0;
+        }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = row_w + i * 32, cb = col_w + j * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r] * os;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = lane + 64 * u, rl = q >> 2, c8 = (q & 3) * 8;
+                const int row = rb + rl, col = cb + c8;
+                if (row < M && col < N) {
+                    const f32x4 z0 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8), z1 = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c8 + 4);
+                    float v[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+                    auto ld8 = [&](float (&dst)[8], const float* src) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            dst[k] = a[k];
+                            dst[4 + k] = b[k];
+                        }
+                    };
+                    float pa[8], pb[8], gg[8], bb[8];
+                    ld8(pa, ep.row_bias + (size_t)h_a[i][u] * ep.ld_row_bias + col);
+                    ld8(pb, ep.row_bias2 + (size_t)h_b[i][u] * ep.ld_row_bias2 + col);
+                    ld8(gg, ep.row_bias3 + (size_t)h_gr[i][u] * ep.ld_row_bias3 + col);
+                    if (ep.bias) ld8(bb, ep.bias + col);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (ep.bias ? v[k] + bb[k] : v[k]) + ((pa[k] + pb[k]) + gg[k]);
+                    const int erow = h_e[i][u];
+                    if (ep.pre_act) {
+                        float* d = ep.pre_act + (size_t)erow * ep.ld_pre + col;
+                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                    if (ep.act == ACT_SILU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
+                    }
+                    u32x4 o[3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        unsigned pr[3];
+                        pl_split_pair_acc(v[2 * k], v[2 * k + 1], cps, pr, sat);
+                        o[0][k] = pr[0];
+                        o[1][k] = pr[1];
+                        o[2][k] = pr[2];
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    sat_report(sat);
+}
+
 // Pre-activation save of the result-layout epilogue (training forward of the second edge linear: Z2 = acc + bias is kept for the
 // backward pass while the activation and the fused segmented sum go on in registers).  Through the per-wave LDS patch so that the
 // stores are 16-byte row-major ones instead of 16 four-byte column stores per tile and lane.  No row-gathered addends here.

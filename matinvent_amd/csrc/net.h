@@ -33,6 +33,7 @@ struct mi_net {
     unsigned short* Waggpl = nullptr;  // (H x H):  node_mlp.0.weight[:, H:]  (multiplies the aggregated messages)
     unsigned short* Wn2pl = nullptr;   // (H x H):  node_mlp.2.weight
     unsigned short* Wffc = nullptr;    // [L] the pair-layout Fourier block of edge_mlp.0 in MFMA fragment order (edge_stage.hip: first edge GEMM)
+    unsigned short* Wffc2 = nullptr;   // [L] -2 x its sine block in the same order (the second pass of edge_gemm1e_kernel)
     unsigned short* Wnc = nullptr;     // [L] the three operands above in MFMA fragment order: [Wagg | Wn2 | Wln] (node_chain.hip; H = 128 / 256 / 512 with LayerNorm)
     float* wbounds = nullptr;          // [L][8] row-sum / bias bounds of the layer's weights (fp16 plane format: activation scales)
     // pair mode of the first edge GEMM (symmetric edge lists): K' = 2*Kh columns = [sin block | pad | cos block | pad],

@@ -335,11 +335,13 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         # 4 = form 3 AND the pair-mode first edge GEMM on the same form (weights in fragment order straight from L2); 5 = its 128 x 256-tile
         # variant (one workgroup per CU, 512 registers per lane; an ablation build only, otherwise form 4 again); 6 = its 2 x 2-wave variant
         # (a wave owns 64 pairs x 64 columns); 7 = form 3 with BOTH edge products and the edge -> node sums in one launch (edge_fused.hip: a
-        # workgroup owns 64 pairs, M1 stays in LDS; hidden_dim 512, fc; exists in ablation builds only -- the default library runs form 3 again)
-        for knob in (0, 1, 2, 3, 4, 5, 6, 7):
+        # workgroup owns 64 pairs, M1 stays in LDS; hidden_dim 512, fc; exists in ablation builds only -- the default library runs form 3 again);
+        # 8 = form 3 with the pair-mode first edge GEMM on ONE accumulator set (128 x 256 tiles, the sine half of K a second time against -2 Wsin:
+        # edge_gemm1e_kernel; widths that are multiples of 256, otherwise form 4's kernel)
+        for knob in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             lib.mi_debug_set_node_fused(1 if knob >= 3 else knob)
             lib.mi_debug_set_edge2_fused(1 if knob >= 3 else 0)
-            lib.mi_debug_set_edge1_fused(knob - 3 if 4 <= knob <= 6 else 0)
+            lib.mi_debug_set_edge1_fused(knob - 3 if 4 <= knob <= 6 else 4 if knob == 8 else 0)
             lib.mi_debug_set_edge_fused(1 if knob == 7 else 0)
             with torch.no_grad():
                 outs = [x.clone() for x in net(t_emb, at, fr, lat, None, batch=bt)]
@@ -355,7 +357,7 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         for a, b, w in zip(res[knob], res[3], ["pred_l", "pred_x", "pred_t"]):   # same epilogue, same k and term order: the same M1, bit for bit
             assert torch.equal(a, b), f"{w}: the first edge GEMM's forms differ (form {knob})"
     names = ["pred_l", "pred_x", "pred_t"] + [f"h after layer {l}" for l in range(L)]
-    for knob in (1, 2, 3, 4, 5, 6, 7):
+    for knob in (1, 2, 3, 4, 5, 6, 7, 8):
         for a, b, w in zip(res[knob], res[0], names):
             # (form 3 sums M2 rounded to the plane format's 22 bits: 1e-6 instead of a few ulp)
             _close(a, b, 2e-6 if knob < 3 else 5e-6, f"{w}: form {knob} vs seven launches")
@@ -363,6 +365,6 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         n2g = torch.repeat_interleave(torch.arange(B), na)
         with torch.no_grad():
             ref = O.cspnet_forward(P, hp, t_emb.cpu(), at.cpu(), fr.cpu(), lat.cpu(), na, n2g)
-        for knob in (1, 4, 7):
+        for knob in (1, 4, 7, 8):
             for a, b, w in zip(res[knob][:3], ref, names):
                 _close(a, b, 3e-5, f"{w} (form {knob}) vs oracle")
