@@ -8,6 +8,8 @@
 //   hipcc --offload-arch=gfx950 -O3 scripts/force_fwd_repro.hip -o /tmp/ffr && /tmp/ffr [launches] [mode] [busy streams] [busy kind] [head variant] [no memset]
 //   busy kind: 0 = matrix-pipe loop, 64 KiB LDS, 256 registers (two workgroups fill a CU); 1 = plain-fma VALU loop, no LDS, few registers;
 //              2 = matrix-pipe loop without LDS at <= 128 registers (the head's waves fit beside it)
+//              3 / 4 = kind 0 without its LDS + fp16 tail / with it at four accumulators; 5 = matrix pipe + LDS read only; 6 = matrix pipe + fp16 VALU only;
+//              7 = the head itself on the other streams; 8 = kind 6's fp16 VALU work without the matrix pipe; 9 = kind 6 with a fixed vector element
 //   head variant: 0 = as in the library (IEEE division in inv3); 1 = v_rcp_f32 instead of the division; 2 = no inverse (pos = force sums)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -152,6 +154,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s == 123.456f) out[0] = s;
 }
 
+// kinds 5 / 6 split kind 4's loop tail: 5 = matrix-pipe loop + an LDS read per iteration feeding an fp32 add (no fp16 VALU work);
+// 6 = matrix-pipe loop + the fp16 VALU work on a register value (no LDS traffic)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void busy_mfma4_ldsonly_kernel(float* out, int iters) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * (lane - i)); }
+    f32x16 acc[4];
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    lds[threadIdx.x] = (float)lane;
+    __syncthreads();
+    float t = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
+        t += lds[(threadIdx.x + it) & 255];
+    }
+    float s = t;
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += acc[m][r];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void busy_mfma4_f16valu_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * (lane - i)); }
+    f32x16 acc[4];
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    float x = 0.001f * lane;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
+        x = x * 1.0001f + 1e-7f;
+        a[it & 7] += (_Float16)x * (_Float16)1e-4f;
+    }
+    float s = x;
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += acc[m][r];
+    if (s == 123.456f) out[0] = s;
+}
+
+// kinds 8 / 9: kind 6's fp16 VALU work WITHOUT the matrix pipe (8), and kind 6 with a fixed vector element instead of the rotating one (9)
+__global__ __launch_bounds__(256) void busy_f16valu_only_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16x8 a;
+    for (int i = 0; i < 8; ++i) a[i] = (_Float16)(0.001f * (lane + i));
+    float x = 0.001f * lane;
+    for (int it = 0; it < 8 * iters; ++it) {
+        x = x * 1.0001f + 1e-7f;
+        a[it & 7] += (_Float16)x * (_Float16)1e-4f;
+    }
+    float s = x;
+    for (int i = 0; i < 8; ++i) s += (float)a[i];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void busy_mfma4_f16fixed_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * (lane - i)); }
+    f32x16 acc[4];
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    float x = 0.001f * lane;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
+        x = x * 1.0001f + 1e-7f;
+        a[0] += (_Float16)x * (_Float16)1e-4f;
+    }
+    float s = x;
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += acc[m][r];
+    if (s == 123.456f) out[0] = s;
+}
+
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 10000, mode = argc > 2 ? atoi(argv[2]) : 0, nbusy = argc > 3 ? atoi(argv[3]) : 3;
     const int busy_kind = argc > 4 ? atoi(argv[4]) : 0, head_var = argc > 5 ? atoi(argv[5]) : 0, no_memset = argc > 6 ? atoi(argv[6]) : 0;
@@ -167,11 +240,11 @@ int main(int argc, char** argv) {
     for (auto& x : V) x = rnd();
     for (int b = 0; b < B; ++b) for (int q = 0; q < 9; ++q) cell[b * 9 + q] = (q % 4 == 0 ? 7.f : 0.f) + 0.3f * rnd();
     int *d_rowptr, *d_n2g;
-    float *d_Fbase, *d_Fadd, *d_F, *d_V, *d_cell, *d_pos, *d_ref, *d_sink;
+    float *d_Fbase, *d_Fadd, *d_F, *d_V, *d_cell, *d_pos, *d_ref, *d_ref2, *d_sink;
     unsigned* d_bad;
     CK(hipMalloc(&d_rowptr, (N + 1) * 4)); CK(hipMalloc(&d_n2g, N * 4));
     CK(hipMalloc(&d_Fbase, E * 4)); CK(hipMalloc(&d_Fadd, E * 4)); CK(hipMalloc(&d_F, E * 4)); CK(hipMalloc(&d_V, (size_t)E * 12));
-    CK(hipMalloc(&d_cell, B * 36)); CK(hipMalloc(&d_pos, N * 12)); CK(hipMalloc(&d_ref, N * 12)); CK(hipMalloc(&d_bad, 128 * 4)); CK(hipMalloc(&d_sink, 64));
+    CK(hipMalloc(&d_cell, B * 36)); CK(hipMalloc(&d_pos, N * 12)); CK(hipMalloc(&d_ref, N * 12)); CK(hipMalloc(&d_ref2, N * 12)); CK(hipMalloc(&d_bad, 128 * 4)); CK(hipMalloc(&d_sink, 64));
     auto head = [&](hipStream_t s, float* out) {
         if (head_var == 1) hipLaunchKernelGGL(force_fwd_kernel<1>, dim3((N + 255) / 256), dim3(256), 0, s, d_F, d_V, d_rowptr, d_n2g, d_cell, out, N);
         else if (head_var == 2) hipLaunchKernelGGL(force_fwd_kernel<2>, dim3((N + 255) / 256), dim3(256), 0, s, d_F, d_V, d_rowptr, d_n2g, d_cell, out, N);
@@ -183,6 +256,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(d_bad, 0, 128 * 4));
     CK(hipFuncSetAttribute((const void*)busy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void*)busy_mfma4_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute((const void*)busy_mfma4_ldsonly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     hipStream_t s0;
     CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
     auto produce = [&](hipStream_t s) {
@@ -206,6 +280,11 @@ int main(int argc, char** argv) {
                 else if (busy_kind == 2) hipLaunchKernelGGL(busy_mfma_slim_kernel, dim3(1024), dim3(256), 0, s, d_sink, 3000);
                 else if (busy_kind == 3) hipLaunchKernelGGL(busy_mfma8_nolds_kernel, dim3(512), dim3(256), 0, s, d_sink, 1500);
                 else if (busy_kind == 4) hipLaunchKernelGGL(busy_mfma4_lds_kernel, dim3(512), dim3(256), 65536, s, d_sink, 3000);
+                else if (busy_kind == 5) hipLaunchKernelGGL(busy_mfma4_ldsonly_kernel, dim3(512), dim3(256), 65536, s, d_sink, 3000);
+                else if (busy_kind == 6) hipLaunchKernelGGL(busy_mfma4_f16valu_kernel, dim3(512), dim3(256), 0, s, d_sink, 3000);
+                else if (busy_kind == 7) head(s, d_ref2);   // the same kernel as the victim, on another stream
+                else if (busy_kind == 8) hipLaunchKernelGGL(busy_f16valu_only_kernel, dim3(2048), dim3(256), 0, s, d_sink, 3000);
+                else if (busy_kind == 9) hipLaunchKernelGGL(busy_mfma4_f16fixed_kernel, dim3(512), dim3(256), 0, s, d_sink, 3000);
                 else hipLaunchKernelGGL(busy_kernel, dim3(512), dim3(256), 65536, s, d_sink, 1500);
                 if ((++q & 7) == 0) CK(hipStreamSynchronize(s));
             }
