@@ -1101,6 +1101,10 @@ __global__ void copy_ld_kernel(const float* __restrict__ X, int ldx, float* __re
     if (i >= rows * cols) return;
     Y[(i / cols) * ldy + i % cols] = X[(i / cols) * ldx + i % cols];
 }
+__global__ void wrap_pos_kernel(float* x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = pymod1(x[i]);
+}
 __global__ void fill_kernel(float* p, float v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -2973,6 +2977,7 @@ int mi_mg_sampler_run(mi_gemnet* net, mi_gbatch* b, const mi_mg_corruption* c, i
     // capacity runs without edges from that evaluation on and keeps its flag: mi_gbatch_graph_status after the chain.
     const int fwd_flags = g_mg_nosync ? 2 : 0;
     MI_HIP(hipMemsetAsync(b->bad, 0, (size_t)B * sizeof(int), s));
+    hipLaunchKernelGGL(wrap_pos_kernel, dim3(nblk((int64_t)N * 3)), dim3(256), 0, s, pos, (int64_t)N * 3);   // (a resumed state may be unwrapped; in-library, not a torch op on a chain's stream)
     for (int i = i_start; i < i_stop; ++i) {
         TraceRange range("mi_mg_sampler_step");
         const float t = ts_host[i];

@@ -206,6 +206,13 @@ __global__ void wrap_copy_kernel(const float* __restrict__ x, float* __restrict_
     if (i < n) y[i] = pymod1(x[i]);
 }
 
+// x <- x mod 1 in place (the chain starts from the wrapped coordinates, diffusion.py:289): done here rather than by a torch op of the caller,
+// which on a chain's side stream would be a packed-fp32 kernel beside the other chains' GEMMs
+__global__ void wrap_inplace_kernel(float* x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = pymod1(x[i]);
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -265,6 +272,7 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
     }
 
     const size_t n3 = (size_t)N * 3, nA = (size_t)N * MI_NUM_TYPES, b9 = (size_t)B * 9;
+    hipLaunchKernelGGL(wrap_inplace_kernel, dim3(cdiv(n3, 256)), dim3(256), 0, s, frac, (int64_t)n3);
     if (rec) {  // traj[t_start] = current state (diffusion.py:287-293)
         if (rec->atom_types) MI_HIP(hipMemcpyAsync(rec->atom_types + t_start * nA, atom_types, nA * 4, hipMemcpyDeviceToDevice, s));
         if (rec->lattices) MI_HIP(hipMemcpyAsync(rec->lattices + t_start * b9, lattices, b9 * 4, hipMemcpyDeviceToDevice, s));

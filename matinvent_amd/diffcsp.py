@@ -313,7 +313,8 @@ class DiffCSPModule(nn.Module):
             _lib.check(lib.mi_sampler_init_state(cb._h, seed, T, _ptr(a), _ptr(x), _ptr(l), _stream()), "mi_sampler_init_state")
         else:
             x, l, a = (v.to(dev, torch.float32).contiguous().clone() for v in init)
-        x = x % 1.0  # traj[T]['frac_coords'] = x_T % 1 (diffusion.py:289)
+        # (traj[T]['frac_coords'] = x_T % 1, diffusion.py:289: mi_sampler_run wraps the coordinates in place before its first step -- no torch
+        #  arithmetic on a chain's stream)
         coef = self._coefficients(step_lr)
         _lib.check(lib.mi_sampler_set_keep(cb._h, int(self.keep_lattice), int(self.keep_coords)))
         nz = None

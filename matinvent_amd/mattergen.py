@@ -554,7 +554,8 @@ class MatterGenModule(nn.Module):
         if state is None:
             _lib.check(lib.mi_mg_sampler_init(gb._h, C.byref(corr), seed, _ptr(ip), _ptr(ic), _ptr(pos), _ptr(cell), _ptr(types), _stream()), "mi_mg_sampler_init")
         else:   # resume at grid point i_start from a given state (noise arrays are then indexed from i_start on)
-            pos, cell, types = f(state["pos"]) % 1.0, f(state["cell"]).clone(), state["atomic_numbers"].to(dev, torch.int32).contiguous().clone()
+            # (mi_mg_sampler_run wraps the positions in place before its first step: no torch arithmetic on a chain's stream)
+            pos, cell, types = f(state["pos"]).clone(), f(state["cell"]).clone(), state["atomic_numbers"].to(dev, torch.int32).contiguous().clone()
         ts = torch.linspace(self.T, eps_t, n_steps).float().contiguous()
         nzs, keep = None, None
         if noise is not None:
