@@ -912,12 +912,14 @@ def main():
                                                                     parity="self-consistent, PARITY-UNPINNED vs upstream", dense_layer_frac_of_mfma_peak=mg["roofline"]["frac"])
                 except Exception as e:   # (never let the secondary figure take the headline down)
                     out["extra"]["mattergen_shaped_sampler"] = {"error": repr(e)}
-                # BASELINE configs[2] in every driver-run record: a short fine-tune leg (B = 256, 20 timesteps + 3 warm-up, the Adam step
-                # that closes the window -- pipeline/mat_invent.py:150-177), with its own roofline and CPU baseline
+                # BASELINE configs[2] in every driver-run record: a short fine-tune leg (B = 256, ONE whole accumulation window -- 50 timesteps
+                # and the Adam step that closes it, the reference's own ratio: pipeline/mat_invent.py:150-177, configs/pipeline/mat_invent.yaml;
+                # rounds 2-3 timed 20 timesteps per Adam step, 2.5 x the reference's optimizer work per timestep -- + 3 warm-up), with its own
+                # roofline and CPU baseline
                 try:
                     del m
                     torch.cuda.empty_cache()
-                    ftl = measure_ft(args, 20, 3, ctx, cpu_budget_s=8.0)
+                    ftl = measure_ft(args, 50, 3, ctx, cpu_budget_s=8.0)
                     out["extra"]["fine_tune"] = {k: ftl[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline") if k in ftl}
                     out["extra"]["fine_tune"]["workload"] = ftl["config"]["workload"]
                     out["extra"]["fine_tune"]["adam_steps_in_timed_region"] = ftl["config"]["adam_steps_in_timed_region"]
