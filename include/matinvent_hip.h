@@ -378,6 +378,11 @@ int mi_debug_set_planes_dma(int mode);
  * projections LayerNorm(h) feeds: models/diffcsp/cspnet.py:79-91,61) as ONE launch per layer boundary (csrc/node_chain.hip):
  * 1 (default) = on for hidden_dim 128 / 256 / 512 with LayerNorm, 0 = the seven-launch form.  Returns the previous setting. */
 int mi_debug_set_node_fused(int on);
+/* The same launch in the TRAINING forward, which then also writes what the backward pass reads of it (the aggregated messages and
+ * LayerNorm(h) into the tape's cat rows, the two node-MLP pre-activations, the LayerNorm statistics): 1 (default) = on wherever the
+ * inference chain is, 0 = layernorm + PQ product + finalize_agg + two node-MLP products (seven launches per layer).  Returns the
+ * previous setting. */
+int mi_debug_set_node_train(int on);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
  * 1 (default) = on (inference forwards, next to the node-chain launch above; training forwards too, with the pre-activation kept

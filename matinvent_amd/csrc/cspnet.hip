@@ -19,6 +19,7 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
+int g_node_train = 1;             // the training forward's node-level work on the one-launch chain too (node_chain.hip writes the tape on the way); 0: seven launches per layer
 int g_edge2_train = 1;            // the training forward's second edge GEMM on the register-tile kernel too, its pre-activation written row-major through LDS patches
 int g_planes_rt = 2;              // register-tile kernel for every qualifying product (gemm_split.h / edge_stage.hip); 1 = only those with epilogue extensions
 int g_planes_rt_min_rows = 16384;
@@ -1000,7 +1001,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     const bool node_planes = g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && H % 32 == 0 && N >= g_node_planes_min_rows;
     // inference: everything between two edge stages -- aggregation, node MLP, residual, LayerNorm, the projections LayerNorm(h) feeds --
     // is ONE launch per layer boundary (node_chain.hip), for any batch size
-    const bool fused = !train && !use_hi && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 && node_chain_supported(net);
+    // training: the same launch, which then also writes what the backward pass reads (cat = [LayerNorm(h) | agg], the two pre-activations,
+    // the LayerNorm statistics) -- five launches per layer fewer than layernorm + PQ product + finalize_agg + the two node-MLP products
+    const bool fused = (!train || g_node_train) && !use_hi && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 && node_chain_supported(net);
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
@@ -1016,7 +1019,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const int ldpq = (node_planes || fused) ? 3 * H : 2 * H;
         MI_TRY(to(ns));
         if (fused) {
-            MI_TRY(node_chain(net, b, l, s));
+            MI_TRY(node_chain(net, b, l, s, train));
         } else {
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, ns, h_in, net->p(p + "layer_norm.weight"),
@@ -1110,7 +1113,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         pe1.diag_e = b->e_diag;
                         pe1.diag_nodes = N;
                     }
-                    const bool efused = fused && fold && MI_PLANES_FP16 && edge_fused_supported(net, b);
+                    const bool efused = !train && fused && fold && MI_PLANES_FP16 && edge_fused_supported(net, b);
                     if (efused) {   // both edge products and the edge -> node sums in one launch, M1 stays in LDS (edge_fused.hip)
                         MI_TRY(edge_fused(net, b, l, s));
                         b->seg_shift = -1;
@@ -1209,7 +1212,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     // ---- heads (cspnet.py:276-291) ----
     const float* h_last = b->h + (size_t)L * NH;
     if (fused) {
-        MI_TRY(node_chain(net, b, L, s));   // the last layer's node MLP + residual and the final LayerNorm -> b->hf
+        MI_TRY(node_chain(net, b, L, s, train));   // the last layer's node MLP + residual and the final LayerNorm -> b->hf
     } else if (net->cfg.ln) {
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, h_last, net->p("final_layer_norm.weight"),
                            net->p("final_layer_norm.bias"), b->hf, H, train ? tp.lnstat + (size_t)L * N * 2 : (float*)nullptr, N, H);

@@ -181,9 +181,10 @@ bool edge_gemm1_supported(const mi_net* net);
 int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
 extern int g_edge2_train;
+extern int g_node_train;
 int edge_fused(mi_net* net, mi_batch* b, int layer, hipStream_t s);   // edge_fused.hip: both edge products of a layer in one launch (M1 stays in LDS)
 bool edge_fused_supported(const mi_net* net, const mi_batch* b);
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2 = nullptr);   // Z2: optional pre-activation output (training forward)
-int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s);
+int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train = false);
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s);
 }  // namespace mi

@@ -78,6 +78,15 @@ struct NodeChainArgs {
     float* PQ = nullptr;            // [N][3H]
     unsigned* absmax = nullptr;     // atomicMax of the bit pattern of max |PQ|
     unsigned long long* clk = nullptr;  // optional phase clock: [workgroup][16] s_memtime stamps (mi_debug_node_chain_clock)
+    // optional (TRAINING forward): what the backward pass reads of this chain, written on the way -- the same values the seven-launch form
+    // keeps on its tape (cspnet.hip: finalize_agg / the two node-MLP products' pre-activations / layernorm_kernel)
+    float* t_agg = nullptr;     // phase A: the aggregated messages, rows of stride ld_agg (cat[:, H:2H] of layer l-1)
+    int ld_agg = 0;
+    float* t_xpre = nullptr;    // phase A: node_mlp.0's pre-activation [N][H]
+    float* t_ypre = nullptr;    // phase A: node_mlp.2's pre-activation [N][H]
+    float* t_ln = nullptr;      // LayerNorm output, rows of stride ld_ln (cat[:, 0:H] of layer l)
+    int ld_ln = 0;
+    float* t_lnstat = nullptr;  // LayerNorm statistics [N][2] = {mean, 1 / sqrt(var + eps)}
 };
 
 template <int H>
@@ -264,6 +273,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                         ys[k] = ys[k] / d;
                     }
                 }
+                if (a.t_agg && row0 + row < N) {
+                    float* o = a.t_agg + (size_t)(row0 + row) * a.ld_agg + c0;
+                    *reinterpret_cast<f32x4*>(o) = xs;
+                    *reinterpret_cast<f32x4*>(o + 4) = ys;
+                }
                 u32x4 pk[2];
                 unsigned pr[3];
                 pl_split_pair_acc(xs[0], xs[1], s_agg, pr, sat); pk[0][0] = pr[0]; pk[1][0] = pr[1];
@@ -321,8 +335,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 for (int q = 0; q < 4; ++q) {
                     const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
                     float v[4];
+                    f32x4 zpre;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = i < N ? silu_fast((acc[t][4 * q + k] * os + bq[t][q][k]) + xq[t][q][k]) : 0.f;
+                    for (int k = 0; k < 4; ++k) zpre[k] = (acc[t][4 * q + k] * os + bq[t][q][k]) + xq[t][q][k];
+                    if (a.t_xpre && i < N) *reinterpret_cast<f32x4*>(a.t_xpre + (size_t)i * H + c4) = zpre;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = i < N ? silu_fast(zpre[k]) : 0.f;
                     unsigned p01[3], p23[3];
                     pl_split_pair_acc(v[0], v[1], s_x, p01, sat);
                     pl_split_pair_acc(v[2], v[3], s_x, p23, sat);
@@ -354,9 +372,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c4 = wave * CW + t * 32 + 8 * q + 4 * kg;
-                    f32x4 o;
+                    f32x4 o, ypre;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = silu_fast(acc[t][4 * q + k] * os + bq[t][q][k]) + hq[t][q][k];
+                    for (int k = 0; k < 4; ++k) ypre[k] = acc[t][4 * q + k] * os + bq[t][q][k];
+                    if (a.t_ypre && i < N) *reinterpret_cast<f32x4*>(a.t_ypre + (size_t)i * H + c4) = ypre;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = silu_fast(ypre[k]) + hq[t][q][k];
                     *reinterpret_cast<f32x4*>(Hs + l31 * HLD + c4) = o;
                 }
         }
@@ -414,6 +435,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                     *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0) = o0;
                     *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0 + 4) = o1;
                 }
+                if (a.t_ln) {
+                    *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0) = o0;
+                    *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0 + 4) = o1;
+                }
+            }
+            if (a.t_lnstat && lane == 0 && i < N) {
+                a.t_lnstat[2 * (size_t)i] = mean;
+                a.t_lnstat[2 * (size_t)i + 1] = rstd;
             }
             if (act && phaseB) {
                 u32x4 pk[2];
@@ -497,12 +526,29 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
 }
 
 // The chain in front of layer l's edge stage (l = 0 .. L; l = L: finishes the last layer and applies the final LayerNorm into b->hf).
-int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
+int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     const int H = net->H, L = net->L, N = b->N;
     const size_t NH = (size_t)N * H;
     NodeChainArgs a;
     a.N = N;
     a.clk = g_node_clk;
+    if (train) {   // the training forward: this chain writes what the backward reads of it (see NodeChainArgs)
+        Tape& tp = b->tape;
+        auto cat_of = [&](int layer) {
+            return tp.wslots > 0 ? tp.w_cat + ((size_t)layer * tp.wslots * N + (size_t)tp.wcur * N) * 2 * H : tp.cat + (size_t)layer * N * 2 * H;
+        };
+        if (l > 0) {
+            a.t_agg = cat_of(l - 1) + H;
+            a.ld_agg = 2 * H;
+            a.t_xpre = tp.Xpre + (size_t)(l - 1) * NH;
+            a.t_ypre = tp.Ypre + (size_t)(l - 1) * NH;
+        }
+        if (l < L) {
+            a.t_ln = cat_of(l);
+            a.ld_ln = 2 * H;
+        }
+        a.t_lnstat = tp.lnstat + (size_t)l * N * 2;
+    }
     if (l > 0) {
         const std::string p = "csp_layer_" + std::to_string(l - 1) + ".";
         const u16* base = net->Wnc + (size_t)(l - 1) * node_chain_pack_elems(H);
@@ -550,7 +596,7 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s) {
 bool node_chain_supported(const mi_net*) { return false; }
 size_t node_chain_pack_elems(int) { return 0; }
 int node_chain_pack(mi_net*, int, const float*, const float*, const float*, const float*, hipStream_t) { return MI_OK; }
-int node_chain(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
+int node_chain(mi_net*, mi_batch*, int, hipStream_t, bool) { return MI_ESTATE; }
 
 #endif
 
@@ -559,6 +605,12 @@ int node_chain(mi_net*, mi_batch*, int, hipStream_t) { return MI_ESTATE; }
 extern "C" int mi_debug_node_chain_clock(void* dev_buffer) {
     mi::g_node_clk = (unsigned long long*)dev_buffer;
     return MI_OK;
+}
+
+extern "C" int mi_debug_set_node_train(int on) {
+    const int was = mi::g_node_train;
+    mi::g_node_train = on != 0;
+    return was;
 }
 
 extern "C" int mi_debug_set_node_fused(int on) {

@@ -149,9 +149,20 @@ def test_gradients_vs_oracle_autograd_ragged():
     assert torch.allclose(m.decoder.theta.grad, 2 * g1, rtol=1e-5, atol=1e-6)
 
 
-def test_gradients_vs_oracle_autograd_mid_size():
+@pytest.mark.parametrize("node_train", [1, 0], ids=["node-chain-writes-the-tape", "seven-launch-node-level"])
+def test_gradients_vs_oracle_autograd_mid_size(node_train):
     """The same check at a size where the large-problem kernels run in the training forward and the backward (B=96 x 20 atoms,
-    E=38 400, H=512, L=2, F=128: pair-mode Fourier GEMM and its pair-mode weight gradient, 256-row double-buffered GEMM)."""
+    E=38 400, H=512, L=2, F=128: pair-mode Fourier GEMM and its pair-mode weight gradient, 256-row double-buffered GEMM).  The node-level
+    work between two edge stages runs as the one-launch chain that also writes the backward's tape (default) and as the seven-launch form."""
+    from matinvent_amd import _lib
+    was = _lib.load().mi_debug_set_node_train(node_train)
+    try:
+        _mid_size_case()
+    finally:
+        _lib.load().mi_debug_set_node_train(was)
+
+
+def _mid_size_case():
     H, L, F = 512, 2, 128
     hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
     P = O.init_params(hp, seed=6)
