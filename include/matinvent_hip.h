@@ -345,6 +345,10 @@ int mi_debug_set_node_planes_min_rows(int n);
 int mi_debug_set_tn128(int on);
 /* Tuning knob: shortest row list (contraction length) for which the bf16-pipe weight-gradient kernel is used (default 4096). */
 int mi_debug_set_tn_split_min_rows(int n);
+/* Workgroups a long weight-gradient contraction C += A^T X (the backward of every linear layer over the edge / pair / node lists:
+ * pipeline/mat_invent.py:164 `loss.backward()`) is split into along its row list; every split writes a partial tile that a fixed-order
+ * reduction adds into C.  Default 768 (three per CU for a product that has the chip to itself).  Returns the previous value. */
+int mi_debug_set_tn_target_tiles(int n);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
 /* Plain plane-set products (row-major epilogue) with at least `min_rows` rows (default 65536; <= 0 keeps the limit) and N % 256 == 0

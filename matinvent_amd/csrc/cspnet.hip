@@ -31,6 +31,7 @@ int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per 
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile;
 int g_tn128 = 1;
+int g_tn_target_tiles = 768;      // three workgroups per CU for a contraction that has the chip to itself
 int g_tn_split = 1;
 int g_tn_split_min_rows = 4096;  // (at 5120 rows: 43 -> 39 us for 512 x 512, 71 -> 56 us for 512 x 1024; no gain below)
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
@@ -1778,6 +1779,12 @@ int mi_debug_set_tn128(int on) {
     g_bwd_pairs_tile = (on & 128) == 0;  // +128: the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
+}
+
+int mi_debug_set_tn_target_tiles(int n) {
+    const int was = g_tn_target_tiles;
+    if (n > 0) g_tn_target_tiles = n;
+    return was;
 }
 
 int mi_debug_set_tn_split_min_rows(int n) {

@@ -330,15 +330,65 @@ static __global__ __launch_bounds__(256) void gemm_tn128_kernel(const float* __r
             }
 }
 
+// (a thread owns four adjacent columns when the output allows 16-byte accesses -- V4 -- and keeps eight partial tiles' loads in flight;
+//  the sum runs over the splits in index order whatever the form, so the result does not depend on it)
+template <bool V4>
 static __global__ void tn_reduce_kernel(const float* __restrict__ P, int nsplit, int PN, int PK, float* __restrict__ C, int ldc, int Na,
                                  int Kx, float scale) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Na * Kx) return;
-    int n = idx / Kx, k = idx % Kx;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += P[((size_t)z * PN + n) * PK + k];
-    C[(size_t)n * ldc + k] += s * scale;
+    constexpr int W = V4 ? 4 : 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kw = Kx / W;
+    if (idx >= Na * kw) return;
+    const int n = idx / kw, k = (idx % kw) * W;
+    const float* p = P + (size_t)n * PK + k;
+    const size_t zs = (size_t)PN * PK;
+    float s[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) s[c] = 0.f;
+    int z = 0;
+    for (; z + 8 <= nsplit; z += 8) {
+        float v[8][W];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if constexpr (V4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(p + (size_t)(z + u) * zs);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[u][c] = q[c];
+            } else {
+                v[u][0] = p[(size_t)(z + u) * zs];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < W; ++c) s[c] += v[u][c];
+    }
+    for (; z < nsplit; ++z) {
+        if constexpr (V4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + (size_t)z * zs);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += q[c];
+        } else {
+            s[0] += p[(size_t)z * zs];
+        }
+    }
+    float* c = C + (size_t)n * ldc + k;
+    if constexpr (V4) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += s[i] * scale;
+        *reinterpret_cast<f32x4*>(c) = o;
+    } else {
+        c[0] += s[0] * scale;
+    }
 }
+inline void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, int Na, int Kx, hipStream_t s) {
+    if ((Kx & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0)
+        hipLaunchKernelGGL(tn_reduce_kernel<true>, dim3(cdiv((int64_t)Na * (Kx / 4), 256)), dim3(256), 0, s, P, nsplit, PN, PK, C, ldc, Na, Kx, 1.0f);
+    else
+        hipLaunchKernelGGL(tn_reduce_kernel<false>, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, P, nsplit, PN, PK, C, ldc, Na, Kx, 1.0f);
+}
+extern int g_tn_target_tiles;  // workgroups a long weight-gradient contraction is split into (over its row list); the partial tiles are summed by tn_reduce
 
 // C[Na,Kx] (ldc) += A^T X.  `scratch` must hold nsplit * ceil64(Na) * ceil64(Kx) floats.
 inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
@@ -346,14 +396,13 @@ inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* 
     if (M <= 0 || Na <= 0 || Kx <= 0) return MI_OK;
     if (g_tn128 && Na >= 128 && Kx >= 128 && M >= 8192) {  // the edge / pair-list contractions
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
-        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles, gx * gy)));
         while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
         MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
         nsplit = cdiv(M, rows);
         hipLaunchKernelGGL(gemm_tn128_kernel, dim3(gx * gy * ((nsplit + 7) / 8 * 8)), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc,
-                           Na, Kx, 1.0f);
+        tn_reduce(scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx, s);
         MI_KERNEL_CHECK();
         return MI_OK;
     }
@@ -364,8 +413,7 @@ inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* 
     int rows = cdiv(cdiv(M, nsplit), 32) * 32;
     nsplit = cdiv(M, rows);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, nsplit), dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 64, gx * 64, C, ldc,
-                       Na, Kx, 1.0f);
+    tn_reduce(scratch, nsplit, gy * 64, gx * 64, C, ldc, Na, Kx, s);
     MI_KERNEL_CHECK();
     return MI_OK;
 }

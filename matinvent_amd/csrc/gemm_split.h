@@ -1909,7 +1909,7 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
                         size_t scratch_floats, hipStream_t s, bool x_silu = false, const float* sa = nullptr, const float* sx = nullptr) {
     if (gemm_tn_is_split(A, lda, X, ldx, M, Na, Kx)) {
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
-        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(768, gx * gy)));
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles, gx * gy)));
         while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
         MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
@@ -1920,8 +1920,7 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
         else if (f16) hipLaunchKernelGGL((gemm_tn_split_kernel<false, true>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
         else if (x_silu) hipLaunchKernelGGL((gemm_tn_split_kernel<true, false>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
         else hipLaunchKernelGGL((gemm_tn_split_kernel<false, false>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx,
-                           1.0f);
+        tn_reduce(scratch, nsplit, gy * 128, gx * 128, C, ldc, Na, Kx, s);
         MI_KERNEL_CHECK();
         return MI_OK;
     }
