@@ -66,6 +66,12 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
+// silu(x) * s for a power-of-two s, given inv_s = 1 / s, at the cost of silu itself: (1 + e) / s = fma(e, inv_s, inv_s) rounds as 1 + e
+// does (scaling by a power of two commutes with rounding), v_rcp_f32 of a power-of-two multiple is the same multiple of the reciprocal
+// (it works on the mantissa), and so is the final product.  (The plane-set stores scale every activation: this saves their multiply.)
+__device__ __forceinline__ float silu_fast_scaled(float x, float inv_s) {
+    return x * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(x * -1.44269504088896340736f), inv_s, inv_s));
+}
 // d silu / dx given x
 __device__ __forceinline__ float silu_grad(float x) {
     float s = 1.0f / (1.0f + expf(-x));

@@ -1101,6 +1101,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                     pe1.pair_e1 = b->pair_e1;
                     pe1.pair_e2 = b->pair_e2;
                     pe1.pair_graph = b->pair_graph;
+                    pe1.pair_wide = !pairs_fit_32bit(N, ldpq, B, H, b->E, H);   // (sizes allowing, the epilogue addresses in 32 bits)
                     if (fold) {
                         if (MI_PLANES_FP16) {
                             pe1.sc_pq = b->absmax + 2 * l;

@@ -798,7 +798,7 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     }
     stamp();
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    planes_epilogue_pairs<MI, NJ>(pe, accS, acc, row0 + wm * MI * 32, qt * WGC + wn * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
+    planes_epilogue_pairs<MI, NJ, true>(pe, accS, acc, row0 + wm * MI * 32, qt * WGC + wn * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
     stamp();
 }
 

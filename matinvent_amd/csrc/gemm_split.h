@@ -128,17 +128,41 @@ __device__ __forceinline__ void pl_split_pair(float x, float y, float scale, uns
     split3_pair(x, y, p);
 #endif
 }
-// The same with the saturation test ACCUMULATED into `sat` (non-zero = some conversion clamped or met a NaN) instead of a branch with an
-// atomic per conversion: lets the compiler schedule a whole epilogue as straight-line code; the caller reports once with sat_report().
+// The same with the saturation test ACCUMULATED into `sat` instead of a branch with an atomic per conversion: lets the compiler schedule a
+// whole epilogue as straight-line code; the caller reports once with sat_report().  fp16 format, per element pair: clamp (2 x v_med3),
+// ONE packed conversion for the leading plane, the residuals x - (float)h straight from its halves (2 x v_fma_mix_f32: the compiler's own
+// form converted every element twice -- v_cvt_f16_f32 for the residual chain next to the v_cvt_pk_f16_f32 for the store -- and back with
+// v_cvt_f32_f16 + v_sub: 7 operations per element where this takes 4), one packed conversion for the second plane; and the saturation test
+// on the BITS of the leading plane: a half that was clamped (|h| = 65504 = 0x7BFF) or is a NaN (> 0x7C00) carries into bit 15 when 0x0401
+// is added to its magnitude -- and / add / or per PAIR instead of compare / select / or per element.  `sat` is meaningful in bits 15 and 31.
+__device__ __forceinline__ void pl_split_scaled_pair_acc(float xr, float yr, unsigned (&p)[3], unsigned& sat) {   // (xr, yr: already multiplied by the scale)
+#if MI_PLANES_FP16 && defined(MI_AB_SPLIT_R3)   // (A/B builds, scripts/gpu_epi_ab.sh: round 3's form of the split, the compiler's own instruction choice)
+    sat |= ((unsigned)(!(fabsf(xr) <= 65504.f)) | (unsigned)(!(fabsf(yr) <= 65504.f))) << 15;
+    const float xs0 = fminf(fmaxf(xr, -65504.f), 65504.f), ys0 = fminf(fmaxf(yr, -65504.f), 65504.f);
+    const f16x2 h0 = {(_Float16)xs0, (_Float16)ys0};
+    p[0] = __builtin_bit_cast(unsigned, h0);
+    p[1] = pack_f16(xs0 - (float)h0[0], ys0 - (float)h0[1]);
+    p[2] = 0u;
+#elif MI_PLANES_FP16
+    // (the instruction itself: fminf(fmaxf()) makes the compiler canonicalise -- v_max x, x -- a value that reaches it through a branch
+    //  merge; a NaN comes out as -65504 -- v_med3 returns the minimum of the non-NaN operands -- and is counted like a clamp)
+    const float xs = __builtin_amdgcn_fmed3f(xr, -65504.f, 65504.f), ys = __builtin_amdgcn_fmed3f(yr, -65504.f, 65504.f);
+    const unsigned hi = pack_f16(xs, ys);
+    sat |= (hi & 0x7fff7fffu) + 0x04010401u;   // (no carry between the halves: a masked half + 0x0401 < 0x10000)
+    float lx, ly;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lx) : "v"(hi), "v"(xs));   // xs - (float)hi.lo, exact
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ly) : "v"(hi), "v"(ys));   // ys - (float)hi.hi
+    p[0] = hi;
+    p[1] = pack_f16(lx, ly);
+    p[2] = 0u;
+#else
+    (void)sat;
+    split3_pair(xr, yr, p);
+#endif
+}
 __device__ __forceinline__ void pl_split_pair_acc(float x, float y, float scale, unsigned (&p)[3], unsigned& sat) {
 #if MI_PLANES_FP16
-    const float xr = x * scale, yr = y * scale;
-    sat |= (unsigned)(!(fabsf(xr) <= 65504.f)) | (unsigned)(!(fabsf(yr) <= 65504.f));
-    const float xs = fminf(fmaxf(xr, -65504.f), 65504.f), ys = fminf(fmaxf(yr, -65504.f), 65504.f);
-    const f16x2 h0 = {(_Float16)xs, (_Float16)ys};
-    p[0] = __builtin_bit_cast(unsigned, h0);
-    p[1] = pack_f16(xs - (float)h0[0], ys - (float)h0[1]);
-    p[2] = 0u;
+    pl_split_scaled_pair_acc(x * scale, y * scale, p, sat);
 #else
     (void)scale;
     (void)sat;
@@ -146,7 +170,7 @@ __device__ __forceinline__ void pl_split_pair_acc(float x, float y, float scale,
 #endif
 }
 __device__ __forceinline__ void sat_report(unsigned sat) {
-    if (sat) atomicAdd(&g_sat_events, 1u);
+    if (sat & 0x80008000u) atomicAdd(&g_sat_events, 1u);
 }
 __device__ __forceinline__ void pl_split(float x, float scale, u16& p0, u16& p1, u16& p2) {
 #if MI_PLANES_FP16
@@ -531,6 +555,10 @@ struct PlanesEpilogue {
     const float* sc_wb = nullptr;
     float* sc_dsc = nullptr;
     float* sc_dsc2 = nullptr;  // optional second copy (the training tape keeps each layer's scales for the backward pass)
+    // pair mode: true (the safe default) = 64-bit address arithmetic in the epilogue; false = every gathered array, the pre-activation
+    // array and the output plane set are addressed with 32-bit byte offsets off their (scalar) base -- the caller has checked the sizes
+    // (pairs_fit_32bit).  In pair-mode kernels the EXT template flag selects the form (the extended row epilogue does not exist there).
+    bool pair_wide = true;
     const float* diag_C0 = nullptr;
     const int* diag_node2graph = nullptr;
     const int* diag_e = nullptr;
@@ -687,6 +715,7 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
     const float os = pe.oscale(), cps = pe.Cp.base ? pe.Cp.s() : 1.f;
     const int l31 = lane & 31, kg = lane >> 5;
     float amax = 0.f;
+    unsigned sat = 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -773,7 +802,7 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned pr[3];
-                            pl_split_pair(v[2 * k], v[2 * k + 1], cps, pr);
+                            pl_split_pair_acc(v[2 * k], v[2 * k + 1], cps, pr, sat);
                             o[0][k] = pr[0];
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
@@ -798,6 +827,7 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
                 __builtin_amdgcn_wave_barrier();
             }
         }
+    sat_report(sat);
     if (pe.absmax) {  // max |output| of this wave's block: order-independent, so the atomic keeps the result deterministic
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -806,11 +836,18 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 }
 // PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major
 // through two per-wave LDS patches; each lane handles 8 consecutive columns of one pair and emits BOTH directed edges.
-template <int TM, int TN>
+// Instruction budget (this epilogue is 40 % of the kernel's issue slots and does not overlap other waves' MFMAs): per output element
+// one add / subtract of the raw accumulators and one FMA with the (power-of-two, hence exact) output scale; two adds for the gathered
+// addends; SiLU with the destination plane scale folded into the reciprocal's argument (silu_fast_scaled); the plane split at four
+// operations (pl_split_scaled_pair_acc).  Addresses: WIDE = false takes every gather / store offset in 32 bits off a scalar base
+// (v_mad_u32_u24 + the saddr form of the access: one operation per address where 64-bit pointer arithmetic took three to twelve);
+// the host picks WIDE = true when an operand is too large for that (pairs_fit_32bit).
+template <int TM, int TN, bool WIDE = false>
 __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, f32x16 (&accS)[TM][TN], f32x16 (&accC)[TM][TN], int row_w,
                                                       int col_w, int M, int N, int lane, float* stage, float cps_in = 0.f) {
     const GemmEpilogue& ep = pe.ep;
     const float os = pe.oscale(), cps = cps_in != 0.f ? cps_in : pe.Cp.base ? pe.Cp.s() : 1.f;
+    const float inv_cps = 1.0f / cps;   // (a power of two: exact)
     const int l31 = lane & 31, kg = lane >> 5;
     float* stS = stage;
     float* stC = stage + 1152;
@@ -831,16 +868,32 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
             h_e1[i][u] = ok ? pe.pair_e1[row] : 0;
             h_e2[i][u] = ok ? pe.pair_e2[row] : 0;
         }
+    // row r, column c of a row-major fp32 array / of the output plane set, as a pointer
+#ifdef MI_AB_PAIRS_R3   // (A/B builds: round 3's addressing and arithmetic)
+    constexpr bool W64 = true;
+#else
+    constexpr bool W64 = WIDE;
+#endif
+    auto frow = [&](const float* base, int r, int ld, int c) -> const float* {
+        if constexpr (W64) return base + (size_t)r * ld + c;
+        else return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (__umul24((unsigned)r, (unsigned)ld * 4u) + (unsigned)c * 4u));
+    };
+    const unsigned tile_stride_b = ((unsigned)pe.Cp.KT * 12288u + 2048u) * 2u;
+    auto prow = [&](int r, int c, int pl) -> u16* {
+        if constexpr (W64) return pe.Cp.base + pe.Cp.elem(r, c, pl);
+        else return reinterpret_cast<u16*>(reinterpret_cast<char*>(pe.Cp.base + pl * 4096) +
+                                           (__umul24((unsigned)r >> 7, tile_stride_b) + (((unsigned)r & 127u) << 6) + ((unsigned)(c >> 5) * 24576u + ((unsigned)c & 31u) * 2u)));
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rb = row_w + i * 32, cb = col_w + j * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; ++r) {   // (raw sums: the output scale is applied by the FMA that adds the gathered terms -- exact, it is a power of two)
                 const int o = ((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31;
-                stS[o] = accS[i][j][r] * os;
-                stC[o] = accC[i][j][r] * os;
+                stS[o] = accS[i][j][r];
+                stC[o] = accC[i][j][r];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -869,18 +922,17 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                             dst[4 + k] = b[k];
                         }
                     };
-                    float pii[8], pjj[8], pij[8], pji[8], gg[8], bb[8];
+                    float pii[8], pjj[8], pij[8], pji[8], gg[8];   // (no column bias in pair mode: the caller folds it into the per-crystal addend -- a run-time test of it cost a select per element)
 #if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 2)   // timing diagnostic (wrong results): no row gathers
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pii[k] = pjj[k] = pij[k] = pji[k] = gg[k] = 0.25f * (float)(ni + nj + gr);
 #else
-                    ld8(pii, ep.row_bias + (size_t)ni * ep.ld_row_bias + col);    // P_i[i]
-                    ld8(pjj, ep.row_bias2 + (size_t)nj * ep.ld_row_bias2 + col);  // P_j[j]
-                    ld8(pij, ep.row_bias + (size_t)nj * ep.ld_row_bias + col);    // P_i[j]
-                    ld8(pji, ep.row_bias2 + (size_t)ni * ep.ld_row_bias2 + col);  // P_j[i]
-                    ld8(gg, ep.row_bias3 + (size_t)gr * ep.ld_row_bias3 + col);
+                    ld8(pii, frow(ep.row_bias, ni, ep.ld_row_bias, col));     // P_i[i]
+                    ld8(pjj, frow(ep.row_bias2, nj, ep.ld_row_bias2, col));   // P_j[j]
+                    ld8(pij, frow(ep.row_bias, nj, ep.ld_row_bias, col));     // P_i[j]
+                    ld8(pji, frow(ep.row_bias2, ni, ep.ld_row_bias2, col));   // P_j[i]
+                    ld8(gg, frow(ep.row_bias3, gr, ep.ld_row_bias3, col));
 #endif
-                    if (ep.bias) ld8(bb, ep.bias + col);
 #pragma unroll
                     for (int dir = 0; dir < 2; ++dir) {
 #if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 16)  // (timing diagnostic, wrong results: every store lands in the first 1024 rows -- the same instructions, no HBM-side traffic)
@@ -895,24 +947,36 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
                         for (int k = 0; k < 8; ++k) {
                             const float acc = dir == 0 ? cv[k] + sv[k] : cv[k] - sv[k];
                             const float g = dir == 0 ? (pii[k] + pjj[k]) + gg[k] : (pij[k] + pji[k]) + gg[k];
-                            v[k] = (ep.bias ? acc + bb[k] : acc) + g;
+#ifdef MI_AB_PAIRS_R3
+                            v[k] = acc * os + g;
+#else
+                            v[k] = __builtin_fmaf(acc, os, g);   // = (acc os) + g: acc os is exact
+#endif
                         }
                         if (ep.pre_act) {
-                            float* d = ep.pre_act + (size_t)erow * ep.ld_pre + col;
+                            float* d = const_cast<float*>(frow(ep.pre_act, erow, ep.ld_pre, col));
                             *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                             *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
                         }
 #if !(defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 4))   // (timing diagnostic, wrong results: 4 = no SiLU)
                         if (ep.act == ACT_SILU) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]);
-                        }
+#ifdef MI_AB_PAIRS_R3
+                            for (int k = 0; k < 8; ++k) v[k] = silu_fast(v[k]) * cps;
+#else
+                            for (int k = 0; k < 8; ++k) v[k] = silu_fast_scaled(v[k], inv_cps);
 #endif
+                        } else
+#endif
+                        {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] *= cps;
+                        }
                         u32x4 o[3];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned pr[3];
-                            pl_split_pair_acc(v[2 * k], v[2 * k + 1], cps, pr, sat);
+                            pl_split_scaled_pair_acc(v[2 * k], v[2 * k + 1], pr, sat);
                             o[0][k] = pr[0];
                             o[1][k] = pr[1];
                             o[2][k] = pr[2];
@@ -923,7 +987,7 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) {
                             // (non-temporal stores measured equal: 44.4 / 48.9-50.6 against 44.6 / 49.8-50.6 structures/s on one / four chains)
-                            *reinterpret_cast<u32x4*>(pe.Cp.base + pe.Cp.elem(erow, col, pl)) = o[pl];
+                            *reinterpret_cast<u32x4*>(prow(erow, col, pl)) = o[pl];
                         }
                     }
                 }
@@ -979,13 +1043,12 @@ __device__ __forceinline__ void planes_epilogue_pairs_dir(const PlanesEpilogue& 
                             dst[4 + k] = b[k];
                         }
                     };
-                    float pa[8], pb[8], gg[8], bb[8];
+                    float pa[8], pb[8], gg[8];
                     ld8(pa, ep.row_bias + (size_t)h_a[i][u] * ep.ld_row_bias + col);
                     ld8(pb, ep.row_bias2 + (size_t)h_b[i][u] * ep.ld_row_bias2 + col);
                     ld8(gg, ep.row_bias3 + (size_t)h_gr[i][u] * ep.ld_row_bias3 + col);
-                    if (ep.bias) ld8(bb, ep.bias + col);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (ep.bias ? v[k] + bb[k] : v[k]) + ((pa[k] + pb[k]) + gg[k]);
+                    for (int k = 0; k < 8; ++k) v[k] = v[k] + ((pa[k] + pb[k]) + gg[k]);
                     const int erow = h_e[i][u];
                     if (ep.pre_act) {
                         float* d = ep.pre_act + (size_t)erow * ep.ld_pre + col;
@@ -1321,7 +1384,7 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
         }
         if constexpr (V == 1) {
             __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-            planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+            planes_epilogue_pairs<TM, TN, EXT>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
                                           cps_local);
             return;
         }
@@ -1370,7 +1433,7 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
                         }
                 }
             });
-            planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+            planes_epilogue_pairs<TM, TN, EXT>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
                                           cps_local);
             return;
         } else {
@@ -1404,7 +1467,7 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
         run(KT);
-        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
+        planes_epilogue_pairs<TM, TN, EXT>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304,
                                       cps_local);
         return;
     }
@@ -1727,7 +1790,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         advance(KT);
         __syncthreads();  // the staging patches overlay the operand tiles
-        planes_epilogue_pairs<TM, TN>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
+        planes_epilogue_pairs<TM, TN, true>(pe, accS, acc, row0 + wm * TM * 32, col0 + wn * TN * 32, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304);
         return;
     } else {
         advance(KT);
@@ -1933,6 +1996,15 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
 size_t frag_elems(int N, int K);
 int pack_frag_from_planes(const Planes& W, int N, int K, u16* dst, hipStream_t s);
 
+// whether the pair-mode epilogue may take its addresses in 32 bits (see PlanesEpilogue::pair_wide): `nodes` x ld_node floats and `graphs` x
+// ld_graph floats in the gathered arrays, `edges` rows of H columns in the pre-activation array and the output plane set
+inline bool pairs_fit_32bit(int64_t nodes, int ld_node, int64_t graphs, int ld_graph, int64_t edges, int H) {
+    const int64_t lim = (int64_t)1 << 32, u24 = (int64_t)1 << 24;
+    const int64_t plane_bytes = (int64_t)planes_elems(edges, H) * 2;
+    return nodes < u24 && graphs < u24 && edges < u24 && (int64_t)ld_node * 4 < u24 && (int64_t)ld_graph * 4 < u24 && (int64_t)H * 4 < u24 &&
+           nodes * ld_node * 4 < lim && graphs * ld_graph * 4 < lim && edges * H * 4 < lim && plane_bytes < lim && ((int64_t)((H + 31) / 32) * 12288 + 2048) * 2 < u24;
+}
+
 inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s) {
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
@@ -1944,8 +2016,8 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     const bool ext = pe.extended();
     MI_CHECK(!ext || (!pair && planes_epilogue_is_rows(pe, N) && (pe.ld_post_mul & 3) == 0 && (MI_PLANES_FP16 || g_planes_variant != 1)), MI_EINVAL,
              "gemm_planes: plane-set residuals / the second merge / the multiplicand exist in the row-major epilogue of the 128-row kernel only");
-    MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0), MI_EINVAL,
-             "gemm_planes: pair mode needs an even k-tile count, a plane-set output and the three gathered addends");
+    MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0 && !pe.ep.bias), MI_EINVAL,
+             "gemm_planes: pair mode needs an even k-tile count, a plane-set output, the three gathered addends and no column bias");
     const int nct = cdiv(N, 128);
 #if MI_PLANES_FP16
     {
@@ -1954,6 +2026,7 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
             MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
+            MI_HIP(hipFuncSetAttribute((const void*)gemm_planes_dma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLANES_DMA_LDS));
             dma_attr_set = true;
         }
     }
@@ -1984,9 +2057,15 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
             pe.diag_block0 = nblk;
             nblk += cdiv(pe.diag_nodes, 8);
         }
-        if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
-        else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
-        else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        if (pe.pair_wide) {
+            if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1, true>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
+            else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1, true>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+            else hipLaunchKernelGGL((gemm_planes_kernel<1, 2, true>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        } else {
+            if (dma) hipLaunchKernelGGL((gemm_planes_dma_kernel<1>), dim3(nblk), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
+            else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+            else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
+        }
     } else if (MI_PLANES_FP16 && W.frag && g_planes_rt && (g_planes_rt > 1 || ext) && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && M >= g_planes_rt_min_rows &&
                planes_epilogue_is_rows(pe, N)) {
         return gemm_rt(A, W.frag, M, N, K, pe, ext, s);
