@@ -408,6 +408,17 @@ int mi_debug_edge_fused_clock(void* dev_buffer);
  * -DMI_ABLATION_KERNELS build, otherwise 2 runs form 1); 3 = the 128 x 128 tile as 2 x 2 waves of 64 pairs x 64 columns (half the LDS reads,
  * twice the weight fetches; 12 % slower; ablation build only).  Same epilogue: bit-identical M1.  Returns the previous setting. */
 int mi_debug_set_edge1_fused(int on);
+/* Phase clock of ONE launch of the register-tile GEMM (csrc/edge_stage.hip gemm_rt_kernel: the dense layers of the MatterGen-shaped network,
+ * the dM1 data gradient of `loss.backward()`, pipeline/mat_invent.py:164): dev_buffer = [workgroups][8] uint64 -- s_memtime at entry / first
+ * k-tile in LDS / end of the main loop / exit, then s_memrealtime (100 MHz) at entry and exit.  ext = 0 / 1: the next launch with the plain /
+ * the extended epilogue after `skip` such launches (the clock then switches itself off); ext = -1: every launch (the last one stays) until
+ * called with a null buffer. */
+int mi_debug_rt_clock(void* dev_buffer, int ext, int skip);
+/* The lean epilogue of that kernel for the launches that only write a plane set (the dense layers of an inference forward of the
+ * MatterGen-shaped network, models/mattergen/pl_module.py:73: activation, plane-set residuals, multiplicand, exact max |y|): transposed
+ * accumulator tiles + v_permlane32_swap instead of the LDS patch, every scale folded into two constants.  1 (default) = on, 0 = the general
+ * row epilogue for every launch.  Returns the previous setting. */
+int mi_debug_set_rt_lean(int on);
 /* Phase clock of that kernel (measurement only): device buffer of [row tiles][8] 64-bit s_memtime stamps (start, first operand chunk
  * landed, main loop done, epilogue done); nullptr = off.  `on` = 2 above selects the variant with a two-deep weight ring and
  * double-buffered activation fragments (ablation). */

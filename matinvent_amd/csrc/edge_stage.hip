@@ -20,6 +20,8 @@
 // messages use anyway).
 #include <mutex>
 
+#include <cstdio>
+#include <cstdlib>
 #include "net.h"
 #include "gemm_split.h"
 
@@ -468,13 +470,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef MI_RT_PF_AT
 #define MI_RT_PF_AT 0   // k-tiles before the end of the loop at which the epilogue's operands are touched (0: never -- measured: no gain, see below)
 #endif
-template <bool EXT>
+template <bool EXT, bool LEAN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
-                                                                                                 PlanesEpilogue pe) {
+                                                                                                 PlanesEpilogue pe, unsigned long long* __restrict__ clk) {
     const int KS = K >> 4, KT = K >> 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     M = pe.rows(M);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // optional phase clock (mi_debug_rt_clock): per workgroup [8] = s_memtime at entry / first k-tile in LDS / end of the main loop / exit,
+    // s_memrealtime (100 MHz) at entry and exit
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (clk && tid == 0) clk[(size_t)blockIdx.x * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+    if (clk && tid == 0) clk[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int l31 = lane & 31, kg = lane >> 5;
     const int ncb = N >> 8;
     const int id = blockIdx.x, slot = id >> 3, cb = slot % ncb, tile = (slot / ncb) * 8 + (id & 7);
@@ -531,7 +542,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+                    if constexpr (LEAN)   // operands swapped: the tile arrives transposed, a lane holds one output ROW (planes_epilogue_lean)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), af[i][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
     // EXT (a recorded ablation, off: MI_RT_PF_AT = 0): the epilogue's row-wise operands -- the residual and the second merge as plane sets,
     // the multiplicand as fp32 rows; 128 KB per workgroup each -- are first touched in the epilogue (590 us against 454 us for the same
@@ -581,6 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             __syncthreads();
+            if (k == 0) stamp();
             // (extra loads only put more operations behind a k-tile's DMA pieces: the counted waits stay sufficient)
             if (MI_RT_PF_AT > 0 && k == KT - MI_RT_PF_AT) prefetch_epilogue_operands();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
@@ -595,7 +610,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();   // every wave is done with the stages: they become the epilogue's per-wave patches
-    planes_epilogue_rows<4, 2, EXT>(pe, acc, row0, cb * 256 + wave * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    stamp();
+    if constexpr (LEAN) planes_epilogue_lean<4, 2>(pe, acc, tile, cb * 256 + wave * 64, M, lane);
+    else planes_epilogue_rows<4, 2, EXT>(pe, acc, row0, cb * 256 + wave * 64, M, N, lane, reinterpret_cast<float*>(smem) + wave * 1152);
+    stamp();
+    if (clk && tid == 0) clk[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     if constexpr (EXT && MI_RT_PF_AT > 0) {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
@@ -1098,19 +1117,40 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
 
 bool edge_gemm2_supported(const mi_net* net) { return g_edge2_fused && net->H == 512 && net->Wnc != nullptr; }
 
+unsigned long long* g_rt_clk = nullptr;   // phase clock of gemm_rt launches (mi_debug_rt_clock): [workgroup][8]
+int g_rt_clk_ext = -1;                    // -1: every launch writes it (the last one stays); 0 / 1: launches of the plain / the extended epilogue only
+int g_rt_lean = 1;                        // the lean epilogue for the launches that qualify (planes_epilogue_is_lean); 0: the general one for all
+int g_rt_clk_skip = 0;                    // matching launches to let pass before the one that is clocked (then the clock switches itself off)
+
 int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const PlanesEpilogue& pe, bool ext, hipStream_t s) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
     });
     MI_HIP(attr_err);
     MI_CHECK(Wfrag && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && A.KT >= K / 32, MI_EINVAL, "gemm_rt: N % 256, K % 64, K >= 128 and a fragment-order W operand");
     if (M <= 0) return MI_OK;
     const dim3 grid((N >> 8) * ((cdiv(M, 128) + 7) / 8 * 8));
-    if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe);
-    else hipLaunchKernelGGL(gemm_rt_kernel<false>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe);
+    static const bool trace = getenv("MI_RT_TRACE") != nullptr;   // (debugging aid: which epilogue features each launch carries)
+    if (trace)
+        fprintf(stderr, "gemm_rt M=%d N=%d K=%d ext=%d act=%d bias=%d rb=%d%d%d pre_add=%d pre_act=%d res=%d res_pl=%d os=%g res2=%d res2_pl=%d rows2=%d post_mul=%d C=%d Cp=%d absmax=%d\n", M, N, K,
+                (int)ext, pe.ep.act, !!pe.ep.bias, !!pe.ep.row_bias, !!pe.ep.row_bias2, !!pe.ep.row_bias3, !!pe.ep.pre_add, !!pe.ep.pre_act, !!pe.ep.residual, !!pe.res_pl.base,
+                (double)pe.ep.out_scale, !!pe.residual2, !!pe.res2_pl.base, !!pe.res2_rows, !!pe.post_mul, !!pe.C, !!pe.Cp.base, !!pe.absmax);
+    unsigned long long* clk = nullptr;
+    if (g_rt_clk && (g_rt_clk_ext < 0 || g_rt_clk_ext == (int)ext)) {
+        if (g_rt_clk_skip > 0) {
+            --g_rt_clk_skip;
+        } else {
+            clk = g_rt_clk;
+            if (g_rt_clk_ext >= 0) g_rt_clk = nullptr;   // one launch
+        }
+    }
+    if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
+    else if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
+    else hipLaunchKernelGGL(gemm_rt_kernel<false>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -1140,6 +1180,28 @@ int g_edge1_fused = 0;
 #endif
 
 }  // namespace mi
+
+extern "C" int mi_debug_set_rt_lean(int on) {
+#if MI_PLANES_FP16
+    const int was = mi::g_rt_lean;
+    mi::g_rt_lean = on != 0;
+    return was;
+#else
+    (void)on;
+    return 0;
+#endif
+}
+
+extern "C" int mi_debug_rt_clock(void* dev_buffer, int ext, int skip) {
+#if MI_PLANES_FP16
+    mi::g_rt_clk = (unsigned long long*)dev_buffer;
+    mi::g_rt_clk_ext = ext;
+    mi::g_rt_clk_skip = skip;
+#else
+    (void)dev_buffer; (void)ext; (void)skip;
+#endif
+    return MI_OK;
+}
 
 extern "C" int mi_debug_edge2_clock(void* dev_buffer) {
 #if MI_PLANES_FP16

@@ -834,6 +834,134 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
         if (lane == 0) atomicMax(pe.absmax + (blockIdx.x & pe.absmax_mask), __float_as_uint(amax));
     }
 }
+// LEAN row epilogue of the register-tile GEMM (gemm_rt_kernel<EXT, true>, edge_stage.hip): the dense layers of an inference forward that only
+// write the plane set their consumer reads -- y = ((act(z) * post_mul + res) * scale + res2) * scale2 with res / res2 given as plane sets,
+// the exact max |y| recorded, nothing else (no bias, gathers, pre-activation or fp32 rows: those launches keep planes_epilogue_rows).
+// The kernel multiplies with its operands SWAPPED (acc = W A^T tile: a lane holds ONE ROW of the output and the sixteen columns
+// (r & 3) + 8 (r >> 2) + 4 kg), and eight v_permlane32_swap per 32 x 32 tile exchange column groups between the two lanes of a row, after which
+// lane (l31, kg) owns columns 16 kg .. 16 kg + 15 of row l31: the transposition that planes_epilogue_rows does through an LDS patch
+// (16 ds_write_b32 + 4 ds_read_b128 + two wave barriers per tile, and the tiles serialised behind them) costs eight VALU slots and no wait.
+// Every scale folds into two constants: with I = 1 / (os ga post) the scaled activation is a rcp(fma(e, I, I)) (silu_fast_scaled's identity;
+// os = accumulator scale, ga = 1 / 0.6 for ScaledSiLU, post = scale scale2 cps) straight from the raw accumulator a, and a plane-set residual
+// enters as two v_fma_mix_f32 per element.  Addresses: the row tile is the workgroup's, so every plane access is a scalar base + one per-lane
+// offset computed once.  Measured instruction count per element: ~10 against ~25 in the general epilogue, which under a partner wave's MFMAs
+// issue at ~16 cycles each (scripts/rt_phases.py: 29 k cycles of epilogue per workgroup, 60 k with the extensions).
+template <int TM, int TN>
+__device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int tile, int col_w, int M, int lane) {
+#if MI_PLANES_FP16
+    const GemmEpilogue& ep = pe.ep;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const float os = pe.oscale(), cps = pe.Cp.s();
+    const bool has_res = pe.res_pl.base != nullptr, has_res2 = pe.res2_pl.base != nullptr, has_pm = pe.post_mul != nullptr;
+    const float s1 = ep.out_scale, s2 = has_res2 ? pe.out_scale2 : 1.f;
+    const float post = s1 * s2 * cps;
+    const float ga = ep.act == ACT_SSILU ? 1.66666666666666667f : 1.f;
+    const float I = 1.0f / (os * ga * post), lin = os * post;          // activation / no activation
+    const float R1 = has_res ? (pe.res_pl.dscale ? pe.res_pl.dscale[1] : 1.f / pe.res_pl.scale) * post : 0.f;
+    const float R2 = has_res2 ? (pe.res2_pl.dscale ? pe.res2_pl.dscale[1] : 1.f / pe.res2_pl.scale) * (s2 * cps) : 0.f;
+    float amax = 0.f;
+    unsigned sat = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = tile * 128 + i * 32 + l31;
+        const bool row_ok = row < M;
+        const unsigned loff = (unsigned)((i * 32 + l31) * 32 + kg * 16);   // element offset of this lane's sixteen columns inside a (row tile, column tile, plane) block
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ct = (col_w >> 5) + j;
+            // column groups X_g = acc[4 g .. 4 g + 3]: swap (X0, X2) and (X1, X3) between the halves of the wave -> (X0, X2, X1, X3) = sixteen consecutive columns
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const auto a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][k]), __float_as_uint(acc[i][j][8 + k]), false, false);
+                const auto a13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][4 + k]), __float_as_uint(acc[i][j][12 + k]), false, false);
+                x[k] = __uint_as_float(a02[0]);
+                x[4 + k] = __uint_as_float(a02[1]);
+                x[8 + k] = __uint_as_float(a13[0]);
+                x[12 + k] = __uint_as_float(a13[1]);
+            }
+            if (row_ok) {
+                u32x4 rh[2][2], qh[2][2];   // residual planes [plane][half of the sixteen columns]
+                if (has_res) {
+                    const u16* rb = pe.res_pl.base + pe.res_pl.tile(tile, ct) + loff;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) rh[pl][h] = *reinterpret_cast<const u32x4*>(rb + pl * 4096 + h * 8);
+                }
+                if (has_res2) {
+                    const u16* qb = pe.res2_pl.base + pe.res2_pl.tile(tile, ct) + loff;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) qh[pl][h] = *reinterpret_cast<const u32x4*>(qb + pl * 4096 + h * 8);
+                }
+                f32x4 pm[4];
+                if (has_pm) {
+                    const float* pb = pe.post_mul + (size_t)row * pe.ld_post_mul + ct * 32 + kg * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pm[q] = *reinterpret_cast<const f32x4*>(pb + 4 * q);
+                }
+                float v[16];
+                if (ep.act == ACT_NONE) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = x[k] * lin;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        v[k] = x[k] * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(x[k] * (os * -1.44269504088896340736f)), I, I));
+                }
+                if (has_pm) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] *= pm[k >> 2][k & 3];
+                }
+                // v += (float)half * R for the two planes of a residual (smallest plane first): v_fma_mix_f32 reads the half in place
+                auto add_planes = [&](const u32x4 (&w)[2][2], float R) {
+#pragma unroll
+                    for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                        for (int k = 0; k < 16; k += 2) {
+                            const unsigned word = w[pl][k >> 3][(k >> 1) & 3];
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v[k]) : "v"(word), "v"(R));
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[k + 1]) : "v"(word), "v"(R));
+                        }
+                };
+                if (has_res) add_planes(rh, R1);
+                if (has_res2) add_planes(qh, R2);
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) amax = fmaxf(amax, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
+                u32x4 o[2][2];
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    unsigned pr[3];
+                    pl_split_scaled_pair_acc(v[k], v[k + 1], pr, sat);
+                    o[0][k >> 3][(k >> 1) & 3] = pr[0];
+                    o[1][k >> 3][(k >> 1) & 3] = pr[1];
+                }
+                u16* ob = pe.Cp.base + pe.Cp.tile(tile, ct) + loff;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4*>(ob + pl * 4096 + h * 8) = o[pl][h];
+            }
+        }
+    }
+    sat_report(sat);
+    if (pe.absmax) {  // max |y| of this wave's block (v is y cps: cps is a power of two)
+        amax *= 1.0f / cps;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) atomicMax(pe.absmax + (blockIdx.x & pe.absmax_mask), __float_as_uint(amax));
+    }
+#endif
+}
+// whether a launch's epilogue is the lean one's (host side, gemm_rt)
+inline bool planes_epilogue_is_lean(const PlanesEpilogue& pe) {
+    const GemmEpilogue& ep = pe.ep;
+    return MI_PLANES_FP16 && pe.Cp.base && !pe.C && !ep.bias && !ep.row_bias && !ep.row_bias2 && !ep.row_bias3 && !ep.pre_add && !ep.pre_act && !ep.residual &&
+           !pe.residual2 && !pe.res2_rows && !pe.seg_part && !pe.pair_i && (ep.act == ACT_NONE || ep.act == ACT_SILU || ep.act == ACT_SSILU);
+}
+
 // PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major
 // through two per-wave LDS patches; each lane handles 8 consecutive columns of one pair and emits BOTH directed edges.
 // Instruction budget (this epilogue is 40 % of the kernel's issue slots and does not overlap other waves' MFMAs): per output element

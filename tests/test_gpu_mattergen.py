@@ -427,14 +427,16 @@ def large_tile_case():
                 grads={k: v.grad.clone() for k, v in Pg.items()})
 
 
-@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
-                         ids=["pre-split-plane-sets", "pre-split-plane-sets-both-formats", "pre-split-plane-sets-lds-dma-256-tiles",
-                              "pre-split-plane-sets-forward-only", "fp32-operand-fp16-2plane", "fp32-operand-bf16-3plane"])
+@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (4, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
+                         ids=["pre-split-plane-sets", "pre-split-plane-sets-general-row-epilogue", "pre-split-plane-sets-both-formats",
+                              "pre-split-plane-sets-lds-dma-256-tiles", "pre-split-plane-sets-forward-only", "fp32-operand-fp16-2plane",
+                              "fp32-operand-bf16-3plane"])
 def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, large_tile_case):
     """110 crystals x 20 atoms at width 256 (>= 16k edges): the edge-level dense layers run on the pre-split plane-set kernel
     (default: operands split once where they are produced, scales from one-layer bounds on exact absmax values; inference keeps one
     format per edge-level tensor and folds the skip merges into the residual stacks -- `lean`, also run switched off) or on the
     fp32-operand kernel (three bf16 planes or two fp16 planes split on the fly); all against the oracle, outputs and per-block taps,
+    the register-tile kernel's launches that only write a plane set through its lean epilogue (default) or its general one;
     the plane-set variants also through the backward (whose edge-level data gradients run on the plane-set kernel too, dZ written as a
     plane set by the activation-gradient pass -- `planes` = 3 keeps them on the fp32-operand kernel)."""
     from matinvent_amd import _lib
@@ -444,6 +446,8 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, 
     _lib.check(_lib.load().mi_debug_set_mg_f16(f16))
     _lib.check(_lib.load().mi_debug_set_mg_planes(3 if planes == 3 else 1 if planes else 0))
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
+    if planes == 4:   # the register-tile kernel's general row epilogue (LDS patch) for the launches that by default take its lean one
+        _lib.load().mi_debug_set_rt_lean(0)
     if planes == 2:   # every qualifying product (epilogue extensions included) on the 256 x 256 LDS-DMA kernel, whatever its row count
         _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))   # (the other cases take the default route: the 128 x 256 register-tile
         _lib.check(_lib.load().mi_debug_set_planes_rt(0, 0))    #  kernel of csrc/edge_stage.hip for these products)
@@ -471,6 +475,7 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, 
         _lib.check(_lib.load().mi_debug_set_mg_lean(1))
         _lib.check(_lib.load().mi_debug_set_planes_big(1, 65536))
         _lib.check(_lib.load().mi_debug_set_planes_rt(2, 0))
+        _lib.load().mi_debug_set_rt_lean(1)
 
 
 # ---- the network at the size the benchmark times it: GemNetHParams() defaults (512 / 512 / 64 / 16 / 16, 4 blocks, 28.3 M parameters),
