@@ -623,6 +623,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// The lean launches as a PERSISTENT grid (two workgroups per CU, each walking virtual block ids blockIdx.x, + gridDim.x, ...; the id -> (row tile,
+// column block) map is gemm_rt_kernel's, and the stride is a multiple of 8, so a workgroup stays on its XCD's row tiles): the lean epilogue
+// uses no LDS, so the NEXT tile's first three k-tiles (LDS-DMA from HBM) are requested before the epilogue starts -- a workgroup of
+// gemm_rt_kernel waits ~8 k cycles for those at its start (scripts/rt_phases.py).  The first wait of a tile is vmcnt(0) as before; it now also
+// covers the previous tile's plane stores, which were issued after the requests.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_lean_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
+                                                                                                      PlanesEpilogue pe, unsigned long long* __restrict__ clk, int nvb) {
+    const int KS = K >> 4, KT = K >> 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    M = pe.rows(M);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int stamp_i = 0;   // phase clock: the FIRST tile's phases (entry / first k-tile in LDS / end of the main loop / end of the epilogue), [5] = exit, [6] = tiles done
+    auto stamp = [&]() {
+        if (clk && tid == 0 && stamp_i < 4) clk[(size_t)blockIdx.x * 8 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+    if (clk && tid == 0) clk[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int ncb = N >> 8;
+    int vid = blockIdx.x, tile, cb;
+    auto decode = [&](int v) {
+        const int slot = v >> 3;
+        cb = slot % ncb;
+        tile = (slot / ncb) * 8 + (v & 7);
+    };
+    if (vid >= nvb) return;
+    decode(vid);
+    if (tile * 128 >= M) return;   // (a workgroup's tiles ascend: nothing behind an empty one)
+
+    __amdgpu_buffer_rsrc_t rsa;
+    const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(Wf, N * K * 4);
+    int voffw[2];
+    u32x4 ring[4][2][2];
+    auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+    };
+    // the first three k-tiles of (tile, cb) -- from HBM, into LDS: no registers -- and its first four weight slices (from L2, 64 registers: those
+    // are requested AFTER the epilogue; live across it they spilled 83 registers)
+    auto request_a = [&]() {
+        rsa = uniform_rsrc(A.base + A.tile(tile, 0), A.KT * 24576);
+        dma_tile(0, 0);
+        dma_tile(1, 1);
+        dma_tile(2, 2);
+    };
+    auto request_w = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * cb + 2 * wave + t) * KS) * 2048;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ring_load(d, ring[d]);
+    };
+    request_a();
+    request_w();
+
+    f32x16 acc[4][2];
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {   // operands swapped: transposed tiles (planes_epilogue_lean)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), af[i][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+    };
+    int done = 0;
+#pragma unroll 1
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < KT; kt += 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int k = kt + h2;
+                if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                __syncthreads();
+                if (k == 0) stamp();
+                if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
+                f16x8 af[4][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    read_a(k & 3, s2, af);
+                    mma(ring[2 * h2 + s2], af);
+                    if (2 * k + s2 + 4 < KS) ring_load(2 * k + s2 + 4, ring[2 * h2 + s2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();   // every wave is done with the stages: the next tile's k-tiles may land in them
+        stamp();
+        const int cur_tile = tile, cur_cb = cb;
+        vid += gridDim.x;
+        bool more = vid < nvb;
+        if (more) {
+            decode(vid);
+            more = tile * 128 < M;
+        }
+        if (more) request_a();
+        __builtin_amdgcn_sched_barrier(0);   // (the requests go out before the epilogue's first instruction)
+        planes_epilogue_lean<4, 2>(pe, acc, cur_tile, cur_cb * 256 + wave * 64, M, lane);
+        stamp();
+        ++done;
+        if (!more) break;
+        __builtin_amdgcn_sched_barrier(0);
+        request_w();
+    }
+    if (clk && tid == 0) {
+        clk[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        clk[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)done;
+        clk[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+    }
+}
+
 // plane set [N x K] -> fragment order (exact copy): one thread per (row, 8-k chunk)
 __global__ void pack_frag_from_planes_kernel(Planes W, int N, int K, u16* __restrict__ dst) {
     const int KS = K / 16;
@@ -1119,6 +1257,7 @@ bool edge_gemm2_supported(const mi_net* net) { return g_edge2_fused && net->H ==
 
 unsigned long long* g_rt_clk = nullptr;   // phase clock of gemm_rt launches (mi_debug_rt_clock): [workgroup][8]
 int g_rt_clk_ext = -1;                    // -1: every launch writes it (the last one stays); 0 / 1: launches of the plain / the extended epilogue only
+int g_rt_lean_grid = 512;                 // workgroups of the persistent form (two per CU; a multiple of 8)
 int g_rt_lean = 1;                        // the lean epilogue for the launches that qualify (planes_epilogue_is_lean); 0: the general one for all
 int g_rt_clk_skip = 0;                    // matching launches to let pass before the one that is clocked (then the clock switches itself off)
 
@@ -1129,6 +1268,8 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
         attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+        if (const char* e = getenv("MI_RT_LEAN")) g_rt_lean = atoi(e) & 3;   // (A/B runs of whole test files: scripts/gpu_rt_lean_ab.sh)
     });
     MI_HIP(attr_err);
     MI_CHECK(Wfrag && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && A.KT >= K / 32, MI_EINVAL, "gemm_rt: N % 256, K % 64, K >= 128 and a fragment-order W operand");
@@ -1148,7 +1289,9 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
             if (g_rt_clk_ext >= 0) g_rt_clk = nullptr;   // one launch
         }
     }
-    if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
+    if (g_rt_lean >= 2 && planes_epilogue_is_lean(pe))
+        hipLaunchKernelGGL(gemm_rt_lean_kernel, dim3(std::min<unsigned>(grid.x, (unsigned)g_rt_lean_grid)), dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk, (int)grid.x);
+    else if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     else if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     else hipLaunchKernelGGL(gemm_rt_kernel<false>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     MI_KERNEL_CHECK();
@@ -1184,7 +1327,8 @@ int g_edge1_fused = 0;
 extern "C" int mi_debug_set_rt_lean(int on) {
 #if MI_PLANES_FP16
     const int was = mi::g_rt_lean;
-    mi::g_rt_lean = on != 0;
+    mi::g_rt_lean = on & 3;                                  // 2: the persistent grid (gemm_rt_lean_kernel)
+    if ((on >> 2) > 0) mi::g_rt_lean_grid = (on >> 2) * 8;   // (optional: its size in units of 8 workgroups, in the bits above)
     return was;
 #else
     (void)on;

@@ -31,6 +31,10 @@ with torch.no_grad():
     lib.mi_debug_rt_clock(None, -1, 0)
 c = clk.cpu().numpy().reshape(nwg, 8)
 c = c[c[:, 3] > 0]
+if c[:, 6].max() > 0:   # the persistent form: [0..3] = the FIRST tile's stamps, [6] = tiles done, [7] = s_memtime at exit
+    tiles = c[:, 6].astype(np.float64)
+    whole = (c[:, 7] - c[:, 0]).astype(np.float64)
+    print(f"persistent grid: {len(c)} workgroups, {int(tiles.sum())} tiles, {tiles.mean():.2f} per workgroup; cycles per tile (whole workgroup / its tiles): mean {np.mean(whole / tiles):.0f}")
 d = np.diff(c[:, :4], axis=1).astype(np.float64)
 rt = (c[:, 5] - c[:, 4]).astype(np.float64)
 ok = rt > 0

@@ -427,8 +427,8 @@ def large_tile_case():
                 grads={k: v.grad.clone() for k, v in Pg.items()})
 
 
-@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (4, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
-                         ids=["pre-split-plane-sets", "pre-split-plane-sets-general-row-epilogue", "pre-split-plane-sets-both-formats",
+@pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (4, 0, 1), (5, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
+                         ids=["pre-split-plane-sets", "pre-split-plane-sets-general-row-epilogue", "pre-split-plane-sets-persistent-lean-grid", "pre-split-plane-sets-both-formats",
                               "pre-split-plane-sets-lds-dma-256-tiles", "pre-split-plane-sets-forward-only", "fp32-operand-fp16-2plane",
                               "fp32-operand-bf16-3plane"])
 def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, large_tile_case):
@@ -448,6 +448,8 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, 
     _lib.check(_lib.load().mi_debug_set_mg_lean(lean))
     if planes == 4:   # the register-tile kernel's general row epilogue (LDS patch) for the launches that by default take its lean one
         _lib.load().mi_debug_set_rt_lean(0)
+    if planes == 5:   # the lean launches as a persistent grid (a recorded ablation: equal on four chains, 1.7 % slower on one)
+        _lib.load().mi_debug_set_rt_lean(2)
     if planes == 2:   # every qualifying product (epilogue extensions included) on the 256 x 256 LDS-DMA kernel, whatever its row count
         _lib.check(_lib.load().mi_debug_set_planes_big(2, 1))   # (the other cases take the default route: the 128 x 256 register-tile
         _lib.check(_lib.load().mi_debug_set_planes_rt(0, 0))    #  kernel of csrc/edge_stage.hip for these products)
