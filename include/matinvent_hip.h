@@ -349,6 +349,10 @@ int mi_debug_set_tn_split_min_rows(int n);
  * pipeline/mat_invent.py:164 `loss.backward()`) is split into along its row list; every split writes a partial tile that a fixed-order
  * reduction adds into C.  Default 768 (three per CU for a product that has the chip to itself).  Returns the previous value. */
 int mi_debug_set_tn_target_tiles(int n);
+/* The pair-mode first edge GEMM's epilogue (models/diffcsp/cspnet.py:59-79) addresses its gathered operands and its output plane set with
+ * 32-bit offsets off scalar bases when their sizes allow (below ~1.38 M edges per chain) and with 64-bit pointers otherwise, same results:
+ * 1 = the 64-bit form whatever the sizes (tests), 0 (default) = by size.  Returns the previous setting. */
+int mi_debug_set_pair_wide(int on);
 /* Tuning knob: plain plane GEMMs with fewer 128x128 output tiles than this run on 64-row tiles (more, shorter workgroups); default 0 = never. */
 int mi_debug_set_planes_small_tiles(int n);
 /* Plain plane-set products (row-major epilogue) with at least `min_rows` rows (default 65536; <= 0 keeps the limit) and N % 256 == 0

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mi_debug_set_tn128": (_I, [_I]),
     "mi_debug_set_tn_split_min_rows": (_I, [_I]),
     "mi_debug_set_tn_target_tiles": (_I, [_I]),
+    "mi_debug_set_pair_wide": (_I, [_I]),
     "mi_debug_set_planes_small_tiles": (_I, [_I]),
     "mi_debug_set_planes_big": (_I, [_I, _I]),
     "mi_debug_set_planes_rt": (_I, [_I, _I]),

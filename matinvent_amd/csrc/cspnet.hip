@@ -19,6 +19,7 @@ int g_pair_kernel = 0;
 int g_fold_pair_extras = 1;  // pair mode: activation scales and self edges ride in the launch of the Fourier-block GEMM (0: separate launches)
 int g_planes_big = 1;             // large-M plain products on the 256 x 256 LDS-DMA kernel (gemm_split.h); the pinned path's launches are below the row limit
 int g_planes_big_min_rows = 65536;
+int g_pair_wide_force = 0;         // tests: the pair-mode epilogue's 64-bit addressing whatever the operand sizes (it is otherwise taken beyond 4 GB only)
 int g_node_train = 1;             // the training forward's node-level work on the one-launch chain too (node_chain.hip writes the tape on the way); 0: seven launches per layer
 int g_edge2_train = 1;            // the training forward's second edge GEMM on the register-tile kernel too, its pre-activation written row-major through LDS patches
 int g_planes_rt = 2;              // register-tile kernel for every qualifying product (gemm_split.h / edge_stage.hip); 1 = only those with epilogue extensions
@@ -1101,7 +1102,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                     pe1.pair_e1 = b->pair_e1;
                     pe1.pair_e2 = b->pair_e2;
                     pe1.pair_graph = b->pair_graph;
-                    pe1.pair_wide = !pairs_fit_32bit(N, ldpq, B, H, b->E, H);   // (sizes allowing, the epilogue addresses in 32 bits)
+                    pe1.pair_wide = g_pair_wide_force || !pairs_fit_32bit(N, ldpq, B, H, b->E, H);   // (sizes allowing, the epilogue addresses in 32 bits)
                     if (fold) {
                         if (MI_PLANES_FP16) {
                             pe1.sc_pq = b->absmax + 2 * l;
@@ -1780,6 +1781,12 @@ int mi_debug_set_tn128(int on) {
     g_bwd_pairs_tile = (on & 128) == 0;  // +128: the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
+}
+
+int mi_debug_set_pair_wide(int on) {
+    const int was = g_pair_wide_force;
+    g_pair_wide_force = on != 0;
+    return was;
 }
 
 int mi_debug_set_tn_target_tiles(int n) {

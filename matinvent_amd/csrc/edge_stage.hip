@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (more) request_a();
         __builtin_amdgcn_sched_barrier(0);   // (the requests go out before the epilogue's first instruction)
-        planes_epilogue_lean<4, 2>(pe, acc, cur_tile, cur_cb * 256 + wave * 64, M, lane);
+        planes_epilogue_lean<4, 2, false>(pe, acc, cur_tile, cur_cb * 256 + wave * 64, M, lane);
         stamp();
         ++done;
         if (!more) break;
@@ -1289,7 +1289,7 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
             if (g_rt_clk_ext >= 0) g_rt_clk = nullptr;   // one launch
         }
     }
-    if (g_rt_lean >= 2 && planes_epilogue_is_lean(pe))
+    if (g_rt_lean >= 2 && planes_epilogue_is_lean(pe, false))
         hipLaunchKernelGGL(gemm_rt_lean_kernel, dim3(std::min<unsigned>(grid.x, (unsigned)g_rt_lean_grid)), dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk, (int)grid.x);
     else if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     else if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);

@@ -835,8 +835,9 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
     }
 }
 // LEAN row epilogue of the register-tile GEMM (gemm_rt_kernel<EXT, true>, edge_stage.hip): the dense layers of an inference forward that only
-// write the plane set their consumer reads -- y = ((act(z) * post_mul + res) * scale + res2) * scale2 with res / res2 given as plane sets,
-// the exact max |y| recorded, nothing else (no bias, gathers, pre-activation or fp32 rows: those launches keep planes_epilogue_rows).
+// write the plane set their consumer reads -- y = ((act(z + G1[g1[row]] + G2[g2[row]]) * post_mul + res) * scale + res2[rows2[row]]) * scale2 with
+// res / res2 given as plane sets or fp32 rows, the exact max |y| recorded, nothing else (no column bias, third gather, pre-activation or
+// fp32 output rows: those launches keep planes_epilogue_rows).
 // The kernel multiplies with its operands SWAPPED (acc = W A^T tile: a lane holds ONE ROW of the output and the sixteen columns
 // (r & 3) + 8 (r >> 2) + 4 kg), and eight v_permlane32_swap per 32 x 32 tile exchange column groups between the two lanes of a row, after which
 // lane (l31, kg) owns columns 16 kg .. 16 kg + 15 of row l31: the transposition that planes_epilogue_rows does through an LDS patch
@@ -846,17 +847,22 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
 // enters as two v_fma_mix_f32 per element.  Addresses: the row tile is the workgroup's, so every plane access is a scalar base + one per-lane
 // offset computed once.  Measured instruction count per element: ~10 against ~25 in the general epilogue, which under a partner wave's MFMAs
 // issue at ~16 cycles each (scripts/rt_phases.py: 29 k cycles of epilogue per workgroup, 60 k with the extensions).
-template <int TM, int TN>
+// (FULL = false: without the gathered addends and the fp32 residual rows -- the persistent ablation kernel's budget, see planes_epilogue_is_lean)
+template <int TM, int TN, bool FULL = true>
 __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f32x16 (&acc)[TM][TN], int tile, int col_w, int M, int lane) {
 #if MI_PLANES_FP16
     const GemmEpilogue& ep = pe.ep;
     const int l31 = lane & 31, kg = lane >> 5;
     const float os = pe.oscale(), cps = pe.Cp.s();
     const bool has_res = pe.res_pl.base != nullptr, has_res2 = pe.res2_pl.base != nullptr, has_pm = pe.post_mul != nullptr;
-    const float s1 = ep.out_scale, s2 = has_res2 ? pe.out_scale2 : 1.f;
+    const bool has_g = FULL && ep.row_bias != nullptr, has_g2 = FULL && ep.row_bias2 != nullptr, has_rf = FULL && ep.residual != nullptr,
+               has_rf2 = FULL && pe.residual2 != nullptr;
+    const float s1 = ep.out_scale, s2 = (has_res2 || has_rf2) ? pe.out_scale2 : 1.f;
     const float post = s1 * s2 * cps;
     const float ga = ep.act == ACT_SSILU ? 1.66666666666666667f : 1.f;
-    const float I = 1.0f / (os * ga * post), lin = os * post;          // activation / no activation
+    // activation / no activation; with gathered addends the pre-activation is formed first (x = a os + g) and os leaves the constants
+    const float osx = has_g ? 1.f : os;
+    const float I = 1.0f / (osx * ga * post), lin = osx * post;
     const float R1 = has_res ? (pe.res_pl.dscale ? pe.res_pl.dscale[1] : 1.f / pe.res_pl.scale) * post : 0.f;
     const float R2 = has_res2 ? (pe.res2_pl.dscale ? pe.res2_pl.dscale[1] : 1.f / pe.res2_pl.scale) * (s2 * cps) : 0.f;
     float amax = 0.f;
@@ -866,6 +872,12 @@ __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f
         const int row = tile * 128 + i * 32 + l31;
         const bool row_ok = row < M;
         const unsigned loff = (unsigned)((i * 32 + l31) * 32 + kg * 16);   // element offset of this lane's sixteen columns inside a (row tile, column tile, plane) block
+        int g1 = 0, g2 = 0, r2row = row;   // this row's gather / row-map indices: one load each per row block
+        if (row_ok) {
+            if (has_g) g1 = ep.row_group[row];
+            if (has_g2) g2 = ep.row_group2[row];
+            if (has_rf2 && pe.res2_rows) r2row = pe.res2_rows[row];
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ct = (col_w >> 5) + j;
@@ -902,6 +914,19 @@ __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f
 #pragma unroll
                     for (int q = 0; q < 4; ++q) pm[q] = *reinterpret_cast<const f32x4*>(pb + 4 * q);
                 }
+                if (has_g) {   // x = a os + G1[g1] (+ G2[g2])
+                    const float* gp = ep.row_bias + (size_t)g1 * ep.ld_row_bias + ct * 32 + kg * 16;
+                    f32x4 ga4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ga4[q] = *reinterpret_cast<const f32x4*>(gp + 4 * q);
+                    if (has_g2) {
+                        const float* gq = ep.row_bias2 + (size_t)g2 * ep.ld_row_bias2 + ct * 32 + kg * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ga4[q] += *reinterpret_cast<const f32x4*>(gq + 4 * q);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = __builtin_fmaf(x[k], os, ga4[k >> 2][k & 3]);
+                }
                 float v[16];
                 if (ep.act == ACT_NONE) {
 #pragma unroll
@@ -909,7 +934,7 @@ __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f
                 } else {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
-                        v[k] = x[k] * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(x[k] * (os * -1.44269504088896340736f)), I, I));
+                        v[k] = x[k] * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(x[k] * (osx * -1.44269504088896340736f)), I, I));
                 }
                 if (has_pm) {
 #pragma unroll
@@ -927,7 +952,26 @@ __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f
                         }
                 };
                 if (has_res) add_planes(rh, R1);
+                if (has_rf) {   // fp32 residual rows: v += r post
+                    const float* rp = ep.residual + (size_t)row * ep.ld_res + ct * 32 + kg * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(rp + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[4 * q + k] = __builtin_fmaf(r[k], post, v[4 * q + k]);
+                    }
+                }
                 if (has_res2) add_planes(qh, R2);
+                if (has_rf2) {   // fp32 second merge, optionally through its row map: v += r2 (scale2 cps)
+                    const float* rp = pe.residual2 + (size_t)r2row * pe.ld_res2 + ct * 32 + kg * 16;
+                    const float c2 = s2 * cps;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(rp + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[4 * q + k] = __builtin_fmaf(r[k], c2, v[4 * q + k]);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 16; k += 2) amax = fmaxf(amax, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
                 u32x4 o[2][2];
@@ -955,11 +999,14 @@ __device__ __forceinline__ void planes_epilogue_lean(const PlanesEpilogue& pe, f
     }
 #endif
 }
-// whether a launch's epilogue is the lean one's (host side, gemm_rt)
-inline bool planes_epilogue_is_lean(const PlanesEpilogue& pe) {
+// whether a launch's epilogue is the lean one's (host side, gemm_rt); full = false: its form without gathers and fp32 residual rows
+inline bool planes_epilogue_is_lean(const PlanesEpilogue& pe, bool full = true) {
     const GemmEpilogue& ep = pe.ep;
-    return MI_PLANES_FP16 && pe.Cp.base && !pe.C && !ep.bias && !ep.row_bias && !ep.row_bias2 && !ep.row_bias3 && !ep.pre_add && !ep.pre_act && !ep.residual &&
-           !pe.residual2 && !pe.res2_rows && !pe.seg_part && !pe.pair_i && (ep.act == ACT_NONE || ep.act == ACT_SILU || ep.act == ACT_SSILU);
+    if (!full && (ep.row_bias || ep.row_bias2 || ep.residual || pe.residual2)) return false;
+    return MI_PLANES_FP16 && pe.Cp.base && !pe.C && !ep.bias && (ep.row_bias || !ep.row_bias2) && !ep.row_bias3 && !ep.pre_add && !ep.pre_act &&
+           !(ep.residual && pe.res_pl.base) && !(pe.residual2 && pe.res2_pl.base) && (pe.residual2 || !pe.res2_rows) && !pe.seg_part && !pe.pair_i &&
+           (ep.ld_row_bias & 3) == 0 && (ep.ld_row_bias2 & 3) == 0 && (ep.ld_res & 3) == 0 && (pe.ld_res2 & 3) == 0 && (pe.ld_post_mul & 3) == 0 &&
+           (ep.act == ACT_NONE || ep.act == ACT_SILU || ep.act == ACT_SSILU);
 }
 
 // PAIR-mode epilogue (see PlanesEpilogue): accS / accC = the sine-half and cosine-half sums of one wave's tiles.  Row-major

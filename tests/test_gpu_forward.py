@@ -338,7 +338,9 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         # workgroup owns 64 pairs, M1 stays in LDS; hidden_dim 512, fc; exists in ablation builds only -- the default library runs form 3 again);
         # 8 = form 3 with the pair-mode first edge GEMM on ONE accumulator set (128 x 256 tiles, the sine half of K a second time against -2 Wsin:
         # edge_gemm1e_kernel; widths that are multiples of 256, otherwise form 4's kernel)
-        for knob in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        # 9 = form 3 with the pair-mode epilogue's 64-bit addressing (taken by itself only beyond 4 GB of operands)
+        for knob in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+            lib.mi_debug_set_pair_wide(1 if knob == 9 else 0)
             lib.mi_debug_set_node_fused(1 if knob >= 3 else knob)
             lib.mi_debug_set_edge2_fused(1 if knob >= 3 else 0)
             lib.mi_debug_set_edge1_fused(knob - 3 if 4 <= knob <= 6 else 4 if knob == 8 else 0)
@@ -352,8 +354,9 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         lib.mi_debug_set_edge2_fused(1)
         lib.mi_debug_set_edge1_fused(0)
         lib.mi_debug_set_edge_fused(0)
+        lib.mi_debug_set_pair_wide(0)
     assert _lib.saturation_events(reset=True) == 0
-    for knob in (4, 5, 6):
+    for knob in (4, 5, 6, 9):
         for a, b, w in zip(res[knob], res[3], ["pred_l", "pred_x", "pred_t"]):   # same epilogue, same k and term order: the same M1, bit for bit
             assert torch.equal(a, b), f"{w}: the first edge GEMM's forms differ (form {knob})"
     names = ["pred_l", "pred_x", "pred_t"] + [f"h after layer {l}" for l in range(L)]
