@@ -17,6 +17,7 @@ int g_tn_xsilu = 1;          // M1 = silu(Z1) inside the weight-gradient product
 int g_bwd_pairs_tile = 1;   // crystals of at most 24 atoms: the LDS-tile form of the fused pass (0: the thread-per-column form, ablation)
 int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
 int g_bwd_dz2_planes = 1;   // fp16 plane format: dZ2 also as a plane set, its data gradient on the pre-split plane GEMM (0: on-the-fly bf16 split)
+int g_bwd_wgrad_planes = 1; // fp16 plane format: edge_mlp.2's weight gradient from the plane sets of M1 (kept per layer by the training forward) and dZ2 (0: fp32 rows re-split on the way into LDS)
 int g_bwd_wgrad_f16 = 1;    // fp16 plane format: edge-level weight gradients on two fp16 planes / three terms (0: three bf16 planes / six)
 }
 
@@ -248,18 +249,25 @@ __global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* _
                                                                   const int* __restrict__ node_off, const int* __restrict__ rowptr,
                                                                   const int* __restrict__ pair_off, float* __restrict__ Dm, float* __restrict__ Dp,
                                                                   float* __restrict__ dPQ, float* __restrict__ dG, float* __restrict__ dsum_part,
-                                                                  int H, const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
+                                                                  int H, const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr,
+                                                                  Planes DmP = Planes(), Planes DpP = Planes()) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // dZ1 [n * n][32] | row sums [n][32]   (16-byte pieces: the base must be 16-aligned behind the static table)
     __shared__ unsigned short pij[PAIRS_NMAX * (PAIRS_NMAX - 1) / 2];   // pair k -> (i << 8) | j
-    if (dsc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (scales of the weight-gradient operands: see the kernel above)
+    float pl_scale = 1.f;   // scale of the pair differences / sums (every block computes it: the plane-set form below needs it before block 0 has published it)
+    if (amax) {
         const float bnd = 2.2f * __uint_as_float(amax[0]);
         int ex = 14 - (int)ceilf(log2f(fmaxf(bnd, 1e-30f)));
         if (!(bnd == bnd) || bnd > 3e38f) ex = -100;
         ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
-        dsc_out[0] = exp2f((float)ex);
-        dsc_out[1] = exp2f(-(float)ex);
-        dsc_out[2] = 16384.f;
-        dsc_out[3] = 1.f / 16384.f;
+        pl_scale = exp2f((float)ex);
+        if (dsc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (scales of the weight-gradient operands: see the kernel above)
+            dsc_out[0] = pl_scale;
+            dsc_out[1] = exp2f(-(float)ex);
+            dsc_out[2] = 16384.f;
+            dsc_out[3] = 1.f / 16384.f;
+            dsc_out[4] = PL_S_UNIT;          // (the forward's pair-mode Fourier plane set, read as it is by gemm_tn_planes)
+            dsc_out[5] = 1.f / PL_S_UNIT;
+        }
     }
     const int g = blockIdx.x, tid = threadIdx.x, lc = tid & (PAIRS_W - 1), w = tid >> 5, c = blockIdx.y * PAIRS_W + lc;
     const int o = node_off[g], n = node_off[g + 1] - o;
@@ -315,7 +323,19 @@ __global__ __launch_bounds__(256) void edge_bwd_pairs_tile_kernel(const float* _
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + (i * n + j) * PAIRS_W + c4), v2 = *reinterpret_cast<const f32x4*>(tile + (j * n + i) * PAIRS_W + c4);
         const f32x4 dm = v1 - v2, dp = v1 + v2;
         const size_t a = (size_t)(p0 + k) * H + cq;
-        if (vec) {
+        if (DmP.base) {   // as plane sets (H % 32 == 0: the four columns lie in one 32-column tile): the weight gradient reads them as they are
+            unsigned m01[3], m23[3], s01[3], s23[3];
+            pl_split_pair(dm[0], dm[1], pl_scale, m01);
+            pl_split_pair(dm[2], dm[3], pl_scale, m23);
+            pl_split_pair(dp[0], dp[1], pl_scale, s01);
+            pl_split_pair(dp[2], dp[3], pl_scale, s23);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                *reinterpret_cast<u32x2*>(DmP.base + DmP.elem((int)(p0 + k), cq, pl)) = u32x2{m01[pl], m23[pl]};
+                *reinterpret_cast<u32x2*>(DpP.base + DpP.elem((int)(p0 + k), cq, pl)) = u32x2{s01[pl], s23[pl]};
+            }
+        } else if (vec) {
             *reinterpret_cast<f32x4*>(Dm + a) = dm;
             *reinterpret_cast<f32x4*>(Dp + a) = dp;
         } else {
@@ -516,6 +536,163 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] -= lr_over_bc1 * (mi_ / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+
+#if MI_PLANES_FP16
+// ------------------------------------------------------------------------------------------------------------------------------------
+// C[Na x Kx] += A^T X over a long row list, both operands given as the PLANE SETS their producers wrote (A = dZ2, X = M1 of the layer: the
+// weight gradient of edge_mlp.2, `loss.backward()` of pipeline/mat_invent.py:164).  gemm_tn_split_kernel reads fp32 rows and splits -- and, for
+// M1 = silu(Z1), re-evaluates the activation of -- every operand element in each of the four column tiles that read it, transposing on the way
+// into LDS: measured VALU-bound, 0.58 PF/s issued.  Here a 32-row slab of both operands goes to LDS by LDS-DMA exactly as it lies
+// in memory ([column tile][plane][32 rows][32 columns], 2 KiB pieces), and the k-strided MFMA operands are gathered by the hardware's
+// transposing read: ds_read_b64_tr_b16 hands lane i of a 16-lane group element (i & 3) of the 8-byte chunk that lane 4 j + (i >> 2) of the
+// group addressed (j = 0..3, probed on the device: scripts/probes/tr_probe.hip) -- so with lane 4 j + c pointing at row k0 + j, columns m0 + 4 c ..,
+// lane i receives A[k0 .. k0 + 3][m0 + i]: four consecutive k of its own column, two reads per 8-deep operand.  No VALU work on the operands.
+// 256 (A columns) x 128 (X columns) output tile, eight waves (4 x 2, a wave owns 64 x 64), three 48 KiB stages two slabs ahead, one
+// workgroup per CU; the row list is split as in gemm_tn_split_kernel (XCD-aware tile order, partial tiles summed in fixed order by tn_reduce).
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int TNP_STAGE = 49152, TNP_NST = 3;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_planes_kernel(Planes A, int a_col0, Planes X, int x_col0,
+                                                                                                        float* __restrict__ P, int M, int rows_per_split, int gx,
+                                                                                                        int gy, int nsplit, const float* __restrict__ sa,
+                                                                                                        const float* __restrict__ sx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int id_ = blockIdx.x, slot_ = id_ >> 3, tile_ = slot_ % (gx * gy), bz = (slot_ / (gx * gy)) * 8 + (id_ & 7);
+    if (bz >= nsplit) return;
+    const int bx = tile_ % gx, by = tile_ / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kg = lane >> 5;
+    const int m_begin = bz * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int nslab = (m_end - m_begin + 31) >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // LDS-DMA: a slab = 16 pieces of A (8 column tiles x 2 planes) + 8 of X, 2 KiB each = two 1 KiB instructions; a wave issues four of A's and two of X's
+    const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base, 0x7ffffff0), rsx = uniform_rsrc(X.base, 0x7ffffff0);
+    const unsigned a_stride = ((unsigned)A.KT * 12288u + 2048u) * 2u, x_stride = ((unsigned)X.KT * 12288u + 2048u) * 2u;
+    const int a_ct0 = (a_col0 + by * 256) >> 5, x_ct0 = (x_col0 + bx * 128) >> 5;
+    auto issue = [&](int r0, int st) {
+        const unsigned ra = (unsigned)(r0 >> 7) * a_stride + (unsigned)(r0 & 127) * 64u, rx = (unsigned)(r0 >> 7) * x_stride + (unsigned)(r0 & 127) * 64u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = wave * 4 + t, pc = q >> 1, half = q & 1;   // piece pc = column tile (pc >> 1), plane (pc & 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * TNP_STAGE + pc * 2048 + half * 1024), 16, lane * 16,
+                                                     ra + (unsigned)(a_ct0 + (pc >> 1)) * 24576u + (unsigned)(pc & 1) * 8192u + (unsigned)half * 1024u, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = wave * 2 + t, pc = q >> 1, half = q & 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(smem + st * TNP_STAGE + 32768 + pc * 2048 + half * 1024), 16,
+                                                     lane * 16, rx + (unsigned)(x_ct0 + (pc >> 1)) * 24576u + (unsigned)(pc & 1) * 8192u + (unsigned)half * 1024u, 0, 0);
+        }
+    };
+    // transposing reads: lane = 16 g + 4 j + c addresses row 8 (g >> 1) + j (+ 4 for the second half of an operand), columns 16 (g & 1) + 4 c of a 32 x 32 piece.
+    // As inline asm with their own lgkmcnt waits: written as the compiler's builtin, every read was preceded by s_waitcnt vmcnt(0) -- the compiler
+    // cannot tell that the LDS-DMA in flight targets another stage -- which serialised each slab behind the slab requested two ahead of it
+    // (227 us for edge_mlp.2's gradient at 102 k edges); __syncthreads() likewise drains every counter, the bare s_barrier does not.
+    const int g = lane >> 4, jj = (lane >> 2) & 3, cc = lane & 3;
+    const unsigned lane_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (unsigned)((8 * (g >> 1) + jj) * 64 + (16 * (g & 1) + 4 * cc) * 2);
+    typedef unsigned long long u64;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#define TNP_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    issue(m_begin, 0);
+    if (nslab > 1) issue(m_begin + 32, 1);
+#pragma unroll 1
+    for (int it = 0; it < nslab; ++it) {
+        if (it + 1 < nslab) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (this wave's six pieces of slab it + 1 may still be in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // slab `it` is in LDS for every wave; everyone is done with the stage slab it + 2 goes to (read in iteration it - 1)
+        if (it + 2 < nslab) issue(m_begin + (it + 2) * 32, (it + 2) % TNP_NST);
+        const unsigned ab = lane_base + (unsigned)(it % TNP_NST) * TNP_STAGE + (unsigned)(wm * 2) * 4096u;            // this wave's two A pieces (x 2 planes)
+        const unsigned xb = lane_base + (unsigned)(it % TNP_NST) * TNP_STAGE + 32768u + (unsigned)(wn * 2) * 4096u;   // and its two X pieces
+        u64 fa[2][8], fb[2][8];   // [k16 step][tile * 4 + plane * 2 + half]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            TNP_RD(fa[ks][0], ab, ks * 1024 + 0 * 2048 + 0);   TNP_RD(fa[ks][1], ab, ks * 1024 + 0 * 2048 + 256);
+            TNP_RD(fa[ks][2], ab, ks * 1024 + 1 * 2048 + 0);   TNP_RD(fa[ks][3], ab, ks * 1024 + 1 * 2048 + 256);
+            TNP_RD(fa[ks][4], ab, ks * 1024 + 2 * 2048 + 0);   TNP_RD(fa[ks][5], ab, ks * 1024 + 2 * 2048 + 256);
+            TNP_RD(fa[ks][6], ab, ks * 1024 + 3 * 2048 + 0);   TNP_RD(fa[ks][7], ab, ks * 1024 + 3 * 2048 + 256);
+            TNP_RD(fb[ks][0], xb, ks * 1024 + 0 * 2048 + 0);   TNP_RD(fb[ks][1], xb, ks * 1024 + 0 * 2048 + 256);
+            TNP_RD(fb[ks][2], xb, ks * 1024 + 1 * 2048 + 0);   TNP_RD(fb[ks][3], xb, ks * 1024 + 1 * 2048 + 256);
+            TNP_RD(fb[ks][4], xb, ks * 1024 + 2 * 2048 + 0);   TNP_RD(fb[ks][5], xb, ks * 1024 + 2 * 2048 + 256);
+            TNP_RD(fb[ks][6], xb, ks * 1024 + 3 * 2048 + 0);   TNP_RD(fb[ks][7], xb, ks * 1024 + 3 * 2048 + 256);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // LDS reads return in order: with the second step's sixteen still in flight the first step's are complete.  The fragments ride through the
+            // wait as read-write operands, so that no consumer can be scheduled in front of it.
+            if (ks == 0)
+                asm volatile("s_waitcnt lgkmcnt(15)\n s_nop 0" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[0][4]), "+v"(fa[0][5]), "+v"(fa[0][6]), "+v"(fa[0][7]),
+                             "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[0][4]), "+v"(fb[0][5]), "+v"(fb[0][6]), "+v"(fb[0][7]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 0" : "+v"(acc[1][1]), "+v"(fa[1][0]),   // (behind the first step's last product: its reads overlap those MFMAs) "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fa[1][4]), "+v"(fa[1][5]), "+v"(fa[1][6]), "+v"(fa[1][7]),
+                             "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]), "+v"(fb[1][4]), "+v"(fb[1][5]), "+v"(fb[1][6]), "+v"(fb[1][7]));
+            f16x8 a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    a[i][pl] = __builtin_bit_cast(f16x8, u64x2{fa[ks][i * 4 + pl * 2], fa[ks][i * 4 + pl * 2 + 1]});
+                    b[i][pl] = __builtin_bit_cast(f16x8, u64x2{fb[ks][i * 4 + pl * 2], fb[ks][i * 4 + pl * 2 + 1]});
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#undef TNP_RD
+    const float sc_out = sa[1] * sx[1];
+    const int PK = gx * 128;
+    float* Pt = P + (size_t)bz * (gy * 256) * PK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = by * 256 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, k = bx * 128 + wn * 64 + j * 32 + l31;
+                Pt[(size_t)n * PK + k] = acc[i][j][r] * sc_out;
+            }
+}
+
+// whether the product can run there: whole 256 / 128-column tiles starting on 32-column boundaries, rows beyond M inside the operands' (zero) row padding
+static bool gemm_tn_planes_ok(const Planes& A, int a_col0, const Planes& X, int x_col0, int64_t M, int Na, int Kx) {
+    return A.base && X.base && (Na & 255) == 0 && (Kx & 127) == 0 && (a_col0 & 31) == 0 && (x_col0 & 31) == 0 && M >= 4096 &&
+           (int64_t)planes_elems(M, (a_col0 + Na)) * 2 < 0x7ffffff0 && (int64_t)planes_elems(M, (x_col0 + Kx)) * 2 < 0x7ffffff0 &&
+           A.KT * 32 >= a_col0 + Na && X.KT * 32 >= x_col0 + Kx;
+}
+extern int g_tn_target_tiles;
+// C[Na, Kx] (ldc) += A[:, a_col0 : a_col0 + Na]^T X[:, x_col0 : x_col0 + Kx] / (sa sx); sa / sx = device-side {scale, 1 / scale} of the two plane sets
+static int gemm_tn_planes(const Planes& A, int a_col0, const Planes& X, int x_col0, float* C, int ldc, int M, int Na, int Kx, const float* sa, const float* sx,
+                          float* scratch, size_t scratch_floats, hipStream_t s) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)gemm_tn_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TNP_NST * TNP_STAGE); });
+    MI_HIP(attr_err);
+    const int gy = Na / 256, gx = Kx / 128;
+    int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles * 2 / 3, gx * gy)));   // (one workgroup per CU: two rounds of the chip)
+    while (nsplit > 1 && (size_t)nsplit * Na * Kx > scratch_floats) --nsplit;
+    MI_CHECK((size_t)nsplit * Na * Kx <= scratch_floats, MI_ENOMEM, "gemm_tn_planes scratch too small");
+    const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
+    nsplit = cdiv(M, rows);
+    hipLaunchKernelGGL(gemm_tn_planes_kernel, dim3(gx * gy * ((nsplit + 7) / 8 * 8)), dim3(512), TNP_NST * TNP_STAGE, s, A, a_col0, X, x_col0, scratch, M, rows, gx, gy,
+                       nsplit, sa, sx);
+    tn_reduce(scratch, nsplit, Na, Kx, C, ldc, Na, Kx, s);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+#endif
+
 static int alloc_tape(mi_net* net, mi_batch* b) {
     if (b->tape.allocated) return MI_OK;
     const size_t N = b->N, B = b->B, E = (size_t)b->E_cap, H = net->H, L = net->L, F = net->F, TD = net->TD;
@@ -546,6 +723,17 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
     T_(dlo, B * 12);
     T_(dtproj, B * H);
     T_(M1, E * H);
+    if (MI_PLANES_FP16 && g_bwd_wgrad_planes && H % 256 == 0 && b->M1pl && E >= 8192) {   // every layer's M1 plane set (see Tape::M1pl_l); row padding zero
+        t.m1pl_stride = planes_elems(E, H);
+        T_(M1pl_l, L * t.m1pl_stride);
+        if (rc == MI_OK && hipMemset(t.M1pl_l, 0, L * t.m1pl_stride * sizeof(unsigned short)) != hipSuccess) rc = MI_EHIP;
+    }
+    if (t.M1pl_l && b->Np >= 4096 && H % 256 == 0) {   // the pair differences / sums of dZ1 as plane sets (see Tape::DmPl)
+        const size_t ne = planes_elems(b->Np, H);
+        T_(DmPl, ne);
+        T_(DpPl, ne);
+        if (rc == MI_OK && (hipMemset(t.DmPl, 0, ne * sizeof(unsigned short)) != hipSuccess || hipMemset(t.DpPl, 0, ne * sizeof(unsigned short)) != hipSuccess)) rc = MI_EHIP;
+    }
     T_(dM1, E * H);
     T_(FF, E * 6 * F);
     T_(nz_lat, B * 9);
@@ -741,6 +929,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             if (g_tn_xsilu && gemm_tn_is_split(Z2, H, Z1, H, (int)E, H, H)) {  // M1 = silu(Z1) formed inside the product's operand load
                 // (fp16 plane format: dZ2's scale was published by the dZ2 kernel, M1's by this layer's training forward)
                 const bool w2_f16 = dz2_planes && t.dsc_layers_valid && g_bwd_wgrad_f16;
+#if MI_PLANES_FP16
+                // (both operands exist as plane sets: dZ2 just written above, M1 kept by this layer's training forward)
+                const Planes m1l = t.M1pl_l ? make_planes(t.M1pl_l + (size_t)l * t.m1pl_stride, H, 1.f, t.dsc_layers + (size_t)l * 8) : Planes();
+                if (w2_f16 && g_bwd_wgrad_planes && t.M1pl_l && gemm_tn_planes_ok(dzp, 0, m1l, 0, E, H, H)) {
+                    MI_TRY(gemm_tn_planes(dzp, 0, m1l, 0, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, b->dsc + 6, t.dsc_layers + (size_t)l * 8, sc, scf, s));
+                } else
+#endif
                 MI_TRY(gemm_tn_auto(Z2, H, Z1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s, true, w2_f16 ? b->dsc + 6 : nullptr,
                                     w2_f16 ? t.dsc_layers + (size_t)l * 8 : nullptr));
             } else {
@@ -772,8 +967,24 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
                 MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
                 const bool wff_f16 = dz2_planes && fused_pairs && g_bwd_wgrad_f16;  // two-plane fp16 operands for the Fourier-block weight gradient
+                bool wff_planes = false;   // ... and from plane sets: the pass below writes Dm / Dp as such, the Fourier operand is the forward's pair-mode plane set
+#if MI_PLANES_FP16
+                Planes dmp, dpp, ffp;
+                if (wff_f16 && g_bwd_wgrad_planes && t.DmPl && b->nmax_fc <= PAIRS_NMAX && g_bwd_pairs_tile && g_edge_pairs && b->FFpl) {
+                    dmp = make_planes(t.DmPl, H, 1.f, b->dsc + 8);
+                    dpp = make_planes(t.DpPl, H, 1.f, b->dsc + 8);
+                    ffp = make_planes(b->FFpl, 2 * net->Kh, PL_S_UNIT);
+                    wff_planes = gemm_tn_planes_ok(dmp, 0, ffp, 0, Np, H, 3 * F) && gemm_tn_planes_ok(dpp, 0, ffp, net->Kh, Np, H, 3 * F);
+                }
+#endif
                 if (fused_pairs && b->nmax_fc <= PAIRS_NMAX && g_bwd_pairs_tile) {
                     const size_t sh = ((size_t)b->nmax_fc * b->nmax_fc + b->nmax_fc) * PAIRS_W * sizeof(float);
+#if MI_PLANES_FP16
+                    if (wff_planes)
+                        hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
+                                           Dp, dPQ, t.dG, sc, H, b->absmax + 2 * L + 1, b->dsc + 8, dmp, dpp);
+                    else
+#endif
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
                                        Dp, dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
@@ -793,6 +1004,12 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 }
                 hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
                 MI_KERNEL_CHECK();
+#if MI_PLANES_FP16
+                if (Np > 0 && wff_planes) {
+                    MI_TRY(gemm_tn_planes(dmp, 0, ffp, 0, gWff, net->edge_in, (int)Np, H, 3 * F, b->dsc + 8, b->dsc + 12, sc, scf - H, s));
+                    MI_TRY(gemm_tn_planes(dpp, 0, ffp, net->Kh, gWff + 3 * F, net->edge_in, (int)Np, H, 3 * F, b->dsc + 8, b->dsc + 12, sc, scf - H, s));
+                } else
+#endif
                 if (Np > 0) {
                     MI_TRY(gemm_tn_auto(Dm, H, t.FF, 6 * F, gWff, net->edge_in, (int)Np, H, 3 * F, sc, scf - H, s, false, wff_f16 ? b->dsc + 8 : nullptr,
                                         wff_f16 ? b->dsc + 10 : nullptr));

@@ -30,7 +30,7 @@ int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
-extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile;
+extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile, g_bwd_wgrad_planes;
 int g_tn128 = 1;
 int g_tn_target_tiles = 768;      // three workgroups per CU for a contraction that has the chip to itself
 int g_tn_split = 1;
@@ -1088,7 +1088,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             if (g_gemm_mode == MI_GEMM_SPLIT) {  // operands pre-split into bf16 planes: pure bf16 GEMMs
                 Planes ffp = make_planes(b->FFpl, F6, PL_S_UNIT);
                 Planes wffp = make_planes(net->Wffpl + (size_t)l * planes_elems(H, F6), F6);
-                Planes m1p = make_planes(b->M1pl, H, PL_S_ACT, b->dsc);
+                b->m1_cur = (train && tp.M1pl_l) ? tp.M1pl_l + (size_t)l * tp.m1pl_stride : b->M1pl;
+                Planes m1p = make_planes(b->m1_cur, H, PL_S_ACT, b->dsc);
                 Planes w2p = make_planes(net->W2pl + (size_t)l * planes_elems(H, H), H);
                 PlanesEpilogue pe1;
                 pe1.ep = g1e;
@@ -1579,7 +1580,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(lnpl, planes_elems(N, H));
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
-    A_(dsc, 12);
+    A_(dsc, 16);
     A_(absmax, 2 * L + 2);
     A_(X, NH);
     A_(x1, NH);
@@ -1779,6 +1780,7 @@ int mi_debug_set_tn128(int on) {
     g_bwd_pairs_fused = (on & 8) == 0;  // +8: the separate dZ1 consumers instead of the fused pair-mode backward pass  // 0: 64x64 f32, 1: 128x128 f32, 3 (default): bf16 three-plane split on the split path
     g_bwd_dz2_planes = (on & 32) == 0;  // +32: dM1 data gradient on the on-the-fly three-plane bf16 split instead of the fp16 plane GEMM
     g_bwd_pairs_tile = (on & 128) == 0;  // +128: the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form
+    g_bwd_wgrad_planes = (on & 256) == 0;   // +256: edge_mlp.2's weight gradient from fp32 rows (split, SiLU and transposition on the way into LDS) instead of from the M1 / dZ2 plane sets
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
 }

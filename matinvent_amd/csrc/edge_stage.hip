@@ -1229,7 +1229,7 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     MI_HIP(attr_err);
     const int H = net->H;
     EdgeGemm2Args a;
-    a.A = make_planes(b->M1pl, H, PL_S_ACT, b->dsc);
+    a.A = make_planes(b->m1_cur ? b->m1_cur : b->M1pl, H, PL_S_ACT, b->dsc);
     a.W2f = net->Wnc + (size_t)layer * node_chain_pack_elems(H) + (size_t)5 * H * H * 2;
     a.b2 = net->p("csp_layer_" + std::to_string(layer) + ".edge_mlp.2.bias");
     a.dsc = b->dsc;

@@ -716,6 +716,36 @@ __device__ __forceinline__ void planes_epilogue_rows(const PlanesEpilogue& pe, f
     const int l31 = lane & 31, kg = lane >> 5;
     float amax = 0.f;
     unsigned sat = 0;
+    // products that only write fp32 rows (the data gradients of the backward pass): the scaled tile goes through the patch once and leaves as
+    // whole 128-byte lines -- none of the general path's per-element feature tests, second patch round trip or plane conversion
+    if (pe.C && !pe.Cp.base && !ep.bias && !ep.row_bias && !ep.pre_add && !ep.pre_act && ep.act == ACT_NONE && !ep.residual && ep.out_scale == 1.f && !pe.extended()) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int rb = row_w + i * 32, cb = col_w + j * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = acc[i][j][r] * os;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int row = rb + rl, col = cb + c4;
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(stage + rl * 36 + c4);
+                    if (row < M && col < N) {
+                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
+                        *reinterpret_cast<f32x4*>(pe.C + (size_t)row * pe.ldc + col) = z;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        if (pe.absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            if (lane == 0) atomicMax(pe.absmax + (blockIdx.x & pe.absmax_mask), __float_as_uint(amax));
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

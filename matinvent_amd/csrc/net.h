@@ -75,6 +75,12 @@ struct Tape {
     float *nz_lat = nullptr, *nz_frac = nullptr, *nz_types = nullptr, *tar_x = nullptr, *rnd_l = nullptr, *rnd_t = nullptr, *d_l = nullptr,
           *d_x = nullptr, *d_t = nullptr, *Lb = nullptr, *KLb = nullptr;
     float* dsc_layers = nullptr;  // [L][8] each layer's activation scales of the training forward (fp16 plane format, folded launch)
+    // fp16 plane format: every layer's M1 plane set of the training forward, kept for edge_mlp.2's weight gradient (gemm_tn_planes, backward.hip:
+    // the product reads both operands as the plane sets their producers wrote instead of re-splitting -- and re-evaluating SiLU on -- fp32 rows)
+    unsigned short* M1pl_l = nullptr;
+    size_t m1pl_stride = 0;       // elements per layer
+    // and the pair differences / sums of dZ1 (the A operands of the Fourier block's weight gradient) as plane sets, written by the fused pair pass
+    unsigned short *DmPl = nullptr, *DpPl = nullptr;
     bool dsc_layers_valid = false;
     size_t scratch_floats = 0;
     // Deferred node-level weight gradients (mi_batch_set_wgrad_window).  Between two optimizer steps the weights do not change, so the
@@ -130,6 +136,7 @@ struct mi_batch {
     float* M2 = nullptr;     // [E][H]
     unsigned short* FFpl = nullptr;  // [3][E][ld(6F)] bf16 planes of the Fourier features
     unsigned short* M1pl = nullptr;  // [3][E][H]      bf16 planes of M1
+    unsigned short* m1_cur = nullptr;  // the plane set this layer's edge products write / read: M1pl, or the layer's slot of Tape::M1pl_l in a training forward
     unsigned short* lnpl = nullptr;  // plane sets of LayerNorm(h) and of the aggregated messages (N x H each)
     unsigned short* aggpl = nullptr;
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)

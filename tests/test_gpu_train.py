@@ -149,17 +149,19 @@ def test_gradients_vs_oracle_autograd_ragged():
     assert torch.allclose(m.decoder.theta.grad, 2 * g1, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("node_train", [1, 0], ids=["node-chain-writes-the-tape", "seven-launch-node-level"])
-def test_gradients_vs_oracle_autograd_mid_size(node_train):
+@pytest.mark.parametrize("node_train,tn", [(1, 3), (0, 3), (1, 3 + 256)], ids=["node-chain-writes-the-tape", "seven-launch-node-level", "edge-weight-gradients-from-fp32-rows"])
+def test_gradients_vs_oracle_autograd_mid_size(node_train, tn):
     """The same check at a size where the large-problem kernels run in the training forward and the backward (B=96 x 20 atoms,
     E=38 400, H=512, L=2, F=128: pair-mode Fourier GEMM and its pair-mode weight gradient, 256-row double-buffered GEMM).  The node-level
     work between two edge stages runs as the one-launch chain that also writes the backward's tape (default) and as the seven-launch form."""
     from matinvent_amd import _lib
     was = _lib.load().mi_debug_set_node_train(node_train)
+    _lib.check(_lib.load().mi_debug_set_tn128(tn))   # (+256: edge_mlp.2's weight gradient from fp32 rows instead of the M1 / dZ2 plane sets)
     try:
         _mid_size_case()
     finally:
         _lib.load().mi_debug_set_node_train(was)
+        _lib.check(_lib.load().mi_debug_set_tn128(3))
 
 
 def _mid_size_case():
