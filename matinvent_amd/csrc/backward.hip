@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void absmax_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __restrict__ dcat, const int* __restrict__ src,
                                                               const int* __restrict__ rowptr, float* __restrict__ Z2, float* __restrict__ part,
                                                               int64_t E, int H, int rows, Planes dzp = Planes(),
-                                                              const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr) {
+                                                              const unsigned* __restrict__ amax = nullptr, float* __restrict__ dsc_out = nullptr,
+                                                              int store_f32 = 1) {   // (0: every consumer of dZ2 reads the plane set -- its fp32 rows are not written)
     const int q = H / 4;                                     // column quads per row
     // optional: dZ2 also as an fp16 plane set (the A operand of the dM1 data gradient on the pre-split plane GEMM).  Its
     // power-of-two scale follows from a rigorous bound, |dZ2| <= max|d cat| * max|silu'| (degrees are >= 1, |silu'| < 1.1):
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void edge_dz2_colsum_kernel(const float* __res
                 // (the mean's 1 / deg stays an IEEE division -- it is exact for the powers of two and shared by a row; silu' on the hardware transcendentals)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = (d[k] / deg) * silu_grad_fast(z[k]);
-                *reinterpret_cast<f32x4*>(zp) = v;
+                if (store_f32) *reinterpret_cast<f32x4*>(zp) = v;
                 if (dzp.base) {
                     unsigned lo[3], hi[3];
                     pl_split_pair(v[0], v[1], ps, lo);
@@ -919,23 +920,27 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 hipLaunchKernelGGL(absmax_bwd_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 1024))), dim3(256), 0, s, t.dcat, (int64_t)N * 2 * H,
                                    b->absmax + 2 * L);
             }
+            // (both consumers of dZ2 on its plane set -- the data gradient below and edge_mlp.2's weight gradient: its fp32 rows are dead)
+            bool w2_planes = false;
+#if MI_PLANES_FP16
+            const Planes m1l = t.M1pl_l ? make_planes(t.M1pl_l + (size_t)l * t.m1pl_stride, H, 1.f, t.dsc_layers + (size_t)l * 8) : Planes();
+            w2_planes = dz2_planes && t.dsc_layers_valid && g_bwd_wgrad_f16 && g_bwd_wgrad_planes && t.M1pl_l && g_tn_xsilu && gemm_tn_planes_ok(dzp, 0, m1l, 0, E, H, H);
+#endif
             if (dz2_sums) {
                 hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(1, nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H, crows, dzp,
-                                   b->absmax + 2 * L, b->dsc + 6);
+                                   b->absmax + 2 * L, b->dsc + 6, w2_planes ? 0 : 1);
                 hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
             } else {
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
             }
+#if MI_PLANES_FP16
+            if (w2_planes) {   // (both operands exist as plane sets: dZ2 just written above, M1 kept by this layer's training forward)
+                MI_TRY(gemm_tn_planes(dzp, 0, m1l, 0, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, b->dsc + 6, t.dsc_layers + (size_t)l * 8, sc, scf, s));
+            } else
+#endif
             if (g_tn_xsilu && gemm_tn_is_split(Z2, H, Z1, H, (int)E, H, H)) {  // M1 = silu(Z1) formed inside the product's operand load
                 // (fp16 plane format: dZ2's scale was published by the dZ2 kernel, M1's by this layer's training forward)
                 const bool w2_f16 = dz2_planes && t.dsc_layers_valid && g_bwd_wgrad_f16;
-#if MI_PLANES_FP16
-                // (both operands exist as plane sets: dZ2 just written above, M1 kept by this layer's training forward)
-                const Planes m1l = t.M1pl_l ? make_planes(t.M1pl_l + (size_t)l * t.m1pl_stride, H, 1.f, t.dsc_layers + (size_t)l * 8) : Planes();
-                if (w2_f16 && g_bwd_wgrad_planes && t.M1pl_l && gemm_tn_planes_ok(dzp, 0, m1l, 0, E, H, H)) {
-                    MI_TRY(gemm_tn_planes(dzp, 0, m1l, 0, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, b->dsc + 6, t.dsc_layers + (size_t)l * 8, sc, scf, s));
-                } else
-#endif
                 MI_TRY(gemm_tn_auto(Z2, H, Z1, H, G(p + "edge_mlp.2.weight"), H, (int)E, H, H, sc, scf, s, true, w2_f16 ? b->dsc + 6 : nullptr,
                                     w2_f16 ? t.dsc_layers + (size_t)l * 8 : nullptr));
             } else {
