@@ -24,6 +24,30 @@
 #include <cstdlib>
 #include "net.h"
 #include "gemm_split.h"
+// The k-loops of edge_gemm2b_kernel and gemm_rt_kernel with EVERY memory operation under manual control (2, default): LDS fragment reads and
+// the weight ring as inline asm with counted lgkmcnt / vmcnt waits, bare s_barrier.  With compiler-visible LDS reads and __syncthreads() (0) the
+// compiler drains the LDS-DMA in flight in front of every barrier (`s_waitcnt vmcnt(1)`: it cannot tell that the k-tiles requested two and
+// three iterations ahead target other stages than the one being read); with the reads hidden but the ring loads visible (1) it waits for the
+// ring with vmcnt(1) / vmcnt(0), i.e. for the LDS-DMA just issued.  Measured, builds alternating on one box (scripts/gpu_asm_lds_ab.sh):
+// 2 vs 0 = 51.8 / 51.3 vs 51.2 / 51.3 structures/s on four chains, 46.1 / 46.4 vs 45.9 / 45.9 on one, MatterGen-shaped sampler 3.12 / 3.16
+// vs 3.04 / 2.99; 1 is slower than both.
+#ifndef MI_ASM_LDS
+#define MI_ASM_LDS 2
+#endif
+#if MI_ASM_LDS
+#define MI_LOOP_BARRIER() __builtin_amdgcn_s_barrier()
+#else
+#define MI_LOOP_BARRIER() __syncthreads()
+#endif
+#if MI_ASM_LDS >= 2
+// Weight slice of a k-step: requested four steps ahead; the vector-memory operations this wave issues after it and before its use are the
+// other three slices in flight (12) and the LDS-DMA pieces of the two k-tile heads in between (8) -- vector loads retire in order, so at most
+// 20 outstanding means it has arrived.  (The last three k-tiles and the first drain the counter at their head: fewer operations behind a slice
+// there.)  The slice rides through the wait as read-write operands, so that no MFMA can be scheduled in front of it.
+#define MI_RING_WAIT(w) asm volatile("s_waitcnt vmcnt(20)" : "+v"((w)[0][0]), "+v"((w)[0][1]), "+v"((w)[1][0]), "+v"((w)[1][1]))
+#else
+#define MI_RING_WAIT(w) (void)0
+#endif
 
 namespace mi {
 
@@ -291,12 +315,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * half + 2 * wave + t) * KS) * 2048;
     u32x4 ring[D][2][2];
+#if MI_ASM_LDS >= 2
+    // (the weight ring as inline asm too, with a counted wait in front of every step's MFMAs: see MI_RING_WAIT)
+    const u32x4 rsw_s = rsrc_words(a.W2f, H * H * 4);
+    auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+        const int soff = __builtin_amdgcn_readfirstlane(ks * 2048);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[t][0]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(w[t][1]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+        }
+    };
+#else
     auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
     };
+#endif
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
 
@@ -316,6 +353,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if MI_ASM_LDS
+    // The fragment reads as inline asm with their own lgkmcnt wait, and the bare s_barrier instead of __syncthreads(): the compiler cannot tell
+    // that the LDS-DMA in flight targets other stages than the one being read, so it drains it -- in this loop `s_waitcnt vmcnt(1)` in front of
+    // every barrier, i.e. the k-tiles requested two and three iterations ahead had to LAND before the current one was used (found in
+    // gemm_tn_planes_kernel, backward.hip, where the same cost 30 %).  The fragments ride through the wait as read-write operands, so that no
+    // MFMA can be scheduled in front of it.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned rd_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) rd_off[s2] = lds0 + (unsigned)(l31 * 64 + (((2 * s2 + kg) ^ ((l31 >> 2) & 3)) * 16));
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+        const unsigned va = rd_off[s2] + (unsigned)st * EG2B_STAGE;
+#define MI_RD128(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(off))
+        MI_RD128(af[0][0], 0 * 2048);        MI_RD128(af[0][1], 0 * 2048 + 8192);
+        MI_RD128(af[1][0], 1 * 2048);        MI_RD128(af[1][1], 1 * 2048 + 8192);
+        MI_RD128(af[2][0], 2 * 2048);        MI_RD128(af[2][1], 2 * 2048 + 8192);
+        MI_RD128(af[3][0], 3 * 2048);        MI_RD128(af[3][1], 3 * 2048 + 8192);
+#undef MI_RD128
+        // (no wait here: MI_AF_WAIT in front of the MFMAs that read the fragments -- LDS reads return in order, so the first two row blocks' four
+        //  reads are complete when at most four are outstanding)
+    };
+#else
     auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -324,6 +383,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
         }
     };
+#endif
+#if MI_ASM_LDS
+    auto mma = [&](const u32x4 (&w)[2][2], f16x8 (&af)[4][2]) {   // two row blocks at a time, each pair behind the wait for its own fragments (same term order per accumulator)
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+        }
+    };
+#else
     auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
@@ -333,6 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
+#endif
     static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
     // vector loads retire in order.  Per k-tile this wave issues 4 DMA pieces (k-tile kt + 3) and then 8 ring loads; k-tile kt's pieces were
     // issued three iterations ago, i.e. at least 8 + 12 + 12 operations ago: vmcnt(24) leaves the younger ones in flight.
@@ -344,13 +421,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (the last three k-tiles have fewer loads behind them -- no further DMA, the ring runs dry: drain)
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            __syncthreads();   // k-tile k has landed for every wave; every wave is done with the stage k-tile k + 3 goes to (= that of k - 1)
+            MI_LOOP_BARRIER();   // k-tile k has landed for every wave; every wave is done with the stage k-tile k + 3 goes to (= that of k - 1)
             if (k == 0) stamp();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
             f16x8 af[4][2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 read_a(k & 3, s2, af);
+                MI_RING_WAIT(ring[2 * h2 + s2]);
                 mma(ring[2 * h2 + s2], af);
                 if (2 * k + s2 + D < KS) ring_load(2 * k + s2 + D, ring[2 * h2 + s2]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -511,12 +589,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * cb + 2 * wave + t) * KS) * 2048;
     u32x4 ring[4][2][2];
+#if MI_ASM_LDS >= 2
+    // (the weight ring as inline asm too, with a counted wait in front of every step's MFMAs: see MI_RING_WAIT)
+    const u32x4 rsw_s = rsrc_words(Wf, N * K * 4);
+    auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+        const int soff = __builtin_amdgcn_readfirstlane(ks * 2048);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[t][0]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(w[t][1]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+        }
+    };
+#else
     auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
     };
+#endif
 #pragma unroll
     for (int d = 0; d < 4; ++d) ring_load(d, ring[d]);
 
@@ -527,6 +618,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if MI_ASM_LDS
+    // The fragment reads as inline asm with their own lgkmcnt wait, and the bare s_barrier instead of __syncthreads(): the compiler cannot tell
+    // that the LDS-DMA in flight targets other stages than the one being read, so it drains it -- in this loop `s_waitcnt vmcnt(1)` in front of
+    // every barrier, i.e. the k-tiles requested two and three iterations ahead had to LAND before the current one was used (found in
+    // gemm_tn_planes_kernel, backward.hip, where the same cost 30 %).  The fragments ride through the wait as read-write operands, so that no
+    // MFMA can be scheduled in front of it.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned rd_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) rd_off[s2] = lds0 + (unsigned)(l31 * 64 + (((2 * s2 + kg) ^ ((l31 >> 2) & 3)) * 16));
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+        const unsigned va = rd_off[s2] + (unsigned)st * EG2B_STAGE;
+#define MI_RD128(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(off))
+        MI_RD128(af[0][0], 0 * 2048);        MI_RD128(af[0][1], 0 * 2048 + 8192);
+        MI_RD128(af[1][0], 1 * 2048);        MI_RD128(af[1][1], 1 * 2048 + 8192);
+        MI_RD128(af[2][0], 2 * 2048);        MI_RD128(af[2][1], 2 * 2048 + 8192);
+        MI_RD128(af[3][0], 3 * 2048);        MI_RD128(af[3][1], 3 * 2048 + 8192);
+#undef MI_RD128
+        // (no wait here: MI_AF_WAIT in front of the MFMAs that read the fragments -- LDS reads return in order, so the first two row blocks' four
+        //  reads are complete when at most four are outstanding)
+    };
+#else
     auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -535,17 +648,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
         }
     };
-    auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {
+#endif
+    auto mma = [&](const u32x4 (&w)[2][2], f16x8 (&af)[4][2]) {   // (MI_ASM_LDS: two row blocks at a time, each pair behind the wait for its own fragments)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int ip = 0; ip < 2; ++ip) {
+#if MI_ASM_LDS
+            if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
+#endif
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if constexpr (LEAN)   // operands swapped: the tile arrives transposed, a lane holds one output ROW (planes_epilogue_lean)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), af[i][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+                for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if constexpr (LEAN)   // operands swapped: the tile arrives transposed, a lane holds one output ROW (planes_epilogue_lean)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), af[i][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+        }
     };
     // EXT (a recorded ablation, off: MI_RT_PF_AT = 0): the epilogue's row-wise operands -- the residual and the second merge as plane sets,
     // the multiplicand as fp32 rows; 128 KB per workgroup each -- are first touched in the epilogue (590 us against 454 us for the same
@@ -594,7 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int k = kt + h2;
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            __syncthreads();
+            MI_LOOP_BARRIER();
             if (k == 0) stamp();
             // (extra loads only put more operations behind a k-tile's DMA pieces: the counted waits stay sufficient)
             if (MI_RT_PF_AT > 0 && k == KT - MI_RT_PF_AT) prefetch_epilogue_operands();
@@ -603,6 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 read_a(k & 3, s2, af);
+                MI_RING_WAIT(ring[2 * h2 + s2]);
                 mma(ring[2 * h2 + s2], af);
                 if (2 * k + s2 + 4 < KS) ring_load(2 * k + s2 + 4, ring[2 * h2 + s2]);
                 __builtin_amdgcn_sched_barrier(0);

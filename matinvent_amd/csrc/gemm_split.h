@@ -500,6 +500,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// the same descriptor as four scalar words (an operand of inline-asm buffer loads)
+__device__ __forceinline__ u32x4 rsrc_words(const void* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((uint32_t)a), (unsigned)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu,
+                 (unsigned)__builtin_amdgcn_readfirstlane(bytes), 0x00020000u};
+}
+
 struct PlanesEpilogue {
     GemmEpilogue ep;       // bias / gathers / pre_act / act / residual as for the fp32 kernels
     float out_scale = 1.f; // 1 / (A.scale * W.scale), set by gemm_planes: applied to the accumulator first
