@@ -406,8 +406,9 @@ int mi_debug_set_edge_fused(int on);
  * pair epilogue / second product of column chunk c, 13 exit), NULL = off. */
 int mi_debug_edge_fused_clock(void* dev_buffer);
 /* The pair-mode first edge GEMM (Fourier block over unordered atom pairs, models/diffcsp/cspnet.py:59-74) on the same form -- 128 x 128
- * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 1 = on for hidden_dim
- * multiples of 128, 0 (default: the two measure equal, this product is bound by its epilogue) = the plane GEMM; 2 = 128 x 256 tiles, one
+ * tiles per four-wave workgroup, the Fourier operand by LDS-DMA, the weights in fragment order straight from L2: 9 (default) = that form
+ * for hidden_dim multiples of 128 and launches beyond the plane GEMM's small-launch forms (with its k-loop under manual control it is
+ * 3-6 % ahead end to end: DESIGN 18.4e), 1 = that form whatever the size, 0 = the plane GEMM always; 2 = 128 x 256 tiles, one
  * workgroup per CU with 512 registers per lane (half the LDS reads per MFMA; measured 11-13 % slower end to end; exists only in a
  * -DMI_ABLATION_KERNELS build, otherwise 2 runs form 1); 3 = the 128 x 128 tile as 2 x 2 waves of 64 pairs x 64 columns (half the LDS reads,
  * twice the weight fetches; 12 % slower; ablation build only).  Same epilogue: bit-identical M1.  Returns the previous setting. */

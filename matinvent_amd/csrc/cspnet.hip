@@ -1124,7 +1124,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         MI_TRY(prof_end(net, s, ps));
                         continue;   // (fused: the rest of the layer runs in node_chain(l + 1))
                     }
-                    if (b->Np > 0 && fold && edge_gemm1_supported(net))   // 128 x 128 tiles, weights straight from L2 in fragment order (edge_stage.hip)
+                    if (b->Np > 0 && fold && edge_gemm1_supported(net, b->Np))   // 128 x 128 tiles, weights straight from L2 in fragment order (edge_stage.hip)
                         MI_TRY(edge_gemm1(net, make_planes(b->FFpl, Kp, PL_S_UNIT), l, (int)b->Np, pe1, s));
                     else if (b->Np > 0)
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp, PL_S_UNIT), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,

@@ -904,7 +904,9 @@ __global__ void pack_frag_from_planes_kernel(Planes W, int N, int K, u16* __rest
 // k-tile for 96 MFMAs): its main loop ran at 42 % of the matrix pipe's floor.  Epilogue, folded-in activation scales and self-edge
 // workgroups are the plane GEMM's (planes_epilogue_pairs / act_scales_eval), so M1 is bit-identical to its output.
 // ------------------------------------------------------------------------------------------------------------------------------------
-int g_edge1_fused = 0;   // off: measured equal to the plane GEMM (191.8 vs 186.6 us at B = 256) -- this product is bound by its epilogue, not by its loop
+int g_edge1_fused = 9;   // 9 = form b (edge_gemm1b_kernel) for launches beyond the plane GEMM's latency forms, 0 = the plane GEMM always, 1 .. 4 = a form whatever the size.
+                         // (Round 3 measured form b equal to the plane GEMM, 191.8 vs 186.6 us at B = 256, and concluded "bound by its epilogue, not by its
+                         //  loop"; its loop was being drained by compiler-inserted waits -- MI_ASM_LDS -- and with those gone it is 3-6 % ahead end to end.)
 
 // fragment-order pack of the Fourier block of edge_mlp.0 in the pair-mode column layout [sin block | pad | cos block | pad] (2 Kh columns)
 __global__ void pack_frag_wff_pair_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int Kh, u16* __restrict__ dst) {
@@ -938,7 +940,7 @@ __global__ void pack_frag_wff_pair_kernel(const float* __restrict__ W1, int edge
 // MI: 32-row MFMA tiles per wave.  4: a wave owns all 128 pairs of the tile; 2 (with NJ = 2): the four waves are 2 x 2 -- a wave owns 64 pairs x 64
 // columns, the same 128 accumulator registers and the same 128 x 128 workgroup tile as (4, 1), but each activation fragment feeds TWO column
 // tiles (4 LDS reads per 12 MFMAs instead of 8) at the price of each weight fragment being fetched by two waves (L2 -> CU traffic doubles).
-template <int D, int MI, int NJ>
+template <int D, int MI, int NJ, bool WIDE = true>
 __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __restrict__ Wf, int M, int N, int K, PlanesEpilogue& pe, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -970,6 +972,10 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
                 const float* G = pe.ep.row_bias3 + (size_t)g * pe.ep.ld_row_bias3;
                 const float v0 = c0 + ((PQ[(size_t)i * ldpq + f] + PQ[(size_t)i * ldpq + N + f]) + G[f]);
                 const float v1 = c1 + ((PQ[(size_t)i * ldpq + f + 1] + PQ[(size_t)i * ldpq + N + f + 1]) + G[f + 1]);
+                if (pe.ep.pre_act) {   // (training forward: the self edges' pre-activation is on the tape too)
+                    pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f] = v0;
+                    pe.ep.pre_act[(size_t)e * pe.ep.ld_pre + f + 1] = v1;
+                }
                 unsigned p[3];
                 pl_split_pair(silu_fast(v0), silu_fast(v1), cps, p);
 #pragma unroll
@@ -1007,11 +1013,21 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 #pragma unroll
     for (int t = 0; t < NJ; ++t) voffw[t] = lane * 16 + (((WN * qt + wn) * NJ + t) * KS) * 2048;
     u32x4 ring[D][NJ][2];
+    // (MI_ASM_LDS >= 2, the 4 x 1 form: every memory operation of the k-loop under manual control, as in edge_gemm2b_kernel -- a weight slice is two
+    //  loads here, so 6 ring loads and 8 LDS-DMA pieces are issued behind one before its use: vmcnt(14))
+    constexpr bool MAN = MI_ASM_LDS >= 2 && MI == 4 && NJ == 1;
+    const u32x4 rsw_s = rsrc_words(Wf, N * K * 4);
     auto ring_load = [&](int ks, u32x4 (&w)[NJ][2]) {
+        if constexpr (MAN) {
+            const int soff = __builtin_amdgcn_readfirstlane(ks * 2048);
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[0][0]) : "v"(voffw[0]), "s"(rsw_s), "s"(soff));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(w[0][1]) : "v"(voffw[0]), "s"(rsw_s), "s"(soff));
+        } else {
 #pragma unroll
-        for (int t = 0; t < NJ; ++t)
+            for (int t = 0; t < NJ; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+                for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
+        }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
@@ -1023,22 +1039,50 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned rd_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) rd_off[s2] = lds0 + (unsigned)(l31 * 64 + (((2 * s2 + kg) ^ ((l31 >> 2) & 3)) * 16));
     auto read_a = [&](int st, int s2, f16x8 (&af)[MI][2]) {
+        if constexpr (MAN) {
+            const unsigned va = rd_off[s2] + (unsigned)st * EG2B_STAGE;
+#define MI_RD128(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(off))
+            MI_RD128(af[0][0], 0 * 2048);        MI_RD128(af[0][1], 0 * 2048 + 8192);
+            MI_RD128(af[1][0], 1 * 2048);        MI_RD128(af[1][1], 1 * 2048 + 8192);
+            MI_RD128(af[2][0], 2 * 2048);        MI_RD128(af[2][1], 2 * 2048 + 8192);
+            MI_RD128(af[3][0], 3 * 2048);        MI_RD128(af[3][1], 3 * 2048 + 8192);
+#undef MI_RD128
+        } else {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = (wm * MI + i) * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
+            for (int i = 0; i < MI; ++i) {
+                const int r = (wm * MI + i) * 32 + l31, c = (2 * s2 + kg) ^ ((r >> 2) & 3);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+                for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + st * EG2B_STAGE + pl * 8192 + r * 64 + c * 16);
+            }
         }
     };
-    auto mma = [&](const u32x4 (&w)[NJ][2], const f16x8 (&af)[MI][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+    auto mma = [&](u32x4 (&w)[NJ][2], f16x8 (&af)[MI][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
+        if constexpr (MAN) {
+            asm volatile("s_waitcnt vmcnt(14)" : "+v"(w[0][0]), "+v"(w[0][1]));
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+            for (int ip = 0; ip < 2; ++ip) {
+                if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+                    for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[0][term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+        }
     };
     static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
     const int khalf = KT / 2;
@@ -1062,7 +1106,8 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
             if (k == 0 || k >= KT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (NJ == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (4 DMA pieces + 8 ring loads per k-tile, as in edge_gemm2b_kernel)
-            __syncthreads();
+            if constexpr (MAN) __builtin_amdgcn_s_barrier();
+            else __syncthreads();
             if (k == 0) stamp();
             if (k + 3 < KT) dma_tile(k + 3, (k + 3) & 3);
             f16x8 af[MI][2];
@@ -1077,14 +1122,14 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     }
     stamp();
     __syncthreads();   // the epilogue's per-wave patches overlay the operand stages
-    planes_epilogue_pairs<MI, NJ, true>(pe, accS, acc, row0 + wm * MI * 32, qt * WGC + wn * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
+    planes_epilogue_pairs<MI, NJ, WIDE>(pe, accS, acc, row0 + wm * MI * 32, qt * WGC + wn * 32 * NJ, M, N, lane, reinterpret_cast<float*>(smem) + wave * 2304, cps_local);
     stamp();
 }
 
-template <int D>
+template <int D, bool WIDE = true>   // (WIDE: the pair epilogue's 64-bit addressing, see PlanesEpilogue::pair_wide)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1b_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
                                                                                                      PlanesEpilogue pe, unsigned long long* clk) {
-    edge_gemm1_body<D, 4, 1>(A, Wf, M, N, K, pe, clk);
+    edge_gemm1_body<D, 4, 1, WIDE>(A, Wf, M, N, K, pe, clk);
 }
 #if MI_HAVE_ABLATION_KERNELS   // (2 x 2 waves of 64 x 64: 256 registers and 64 bytes of scratch; measured 12 % SLOWER end to end -- every weight fragment is fetched by two waves)
 template <int D>
@@ -1179,6 +1224,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if MI_ASM_LDS >= 2   // (every memory operation of the k-loop under manual control, as in edge_gemm2b_kernel: see MI_ASM_LDS)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned rd_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) rd_off[s2] = lds0 + (unsigned)(l31 * 64 + (((2 * s2 + kg) ^ ((l31 >> 2) & 3)) * 16));
+    auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
+        const unsigned va = rd_off[s2] + (unsigned)st * EG2B_STAGE;
+#define MI_RD128(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(off))
+        MI_RD128(af[0][0], 0 * 2048);        MI_RD128(af[0][1], 0 * 2048 + 8192);
+        MI_RD128(af[1][0], 1 * 2048);        MI_RD128(af[1][1], 1 * 2048 + 8192);
+        MI_RD128(af[2][0], 2 * 2048);        MI_RD128(af[2][1], 2 * 2048 + 8192);
+        MI_RD128(af[3][0], 3 * 2048);        MI_RD128(af[3][1], 3 * 2048 + 8192);
+#undef MI_RD128
+    };
+    auto mma = [&](const u32x4 (&w)[2][2], f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0); two row blocks at a time behind the wait for their fragments
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+        }
+    };
+#else
     auto read_a = [&](int st, int s2, f16x8 (&af)[4][2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1196,6 +1270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[j][term == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
     };
+#endif
     static_assert(D == 4, "two k-tiles of ring per unrolled pair of iterations");
     // one pass over the k-tiles 0 .. KTp - 1 of the Fourier operand against the fragment-order weights Wp (KSp = 2 KTp k-steps per column tile);
     // the pipeline of edge_gemm2b_kernel: DMA three k-tiles ahead, four-deep weight ring, counted waits
@@ -1206,12 +1281,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < 2; ++t) voffw[t] = lane * 16 + ((8 * qt + 2 * wave + t) * KSp) * 2048;
         u32x4 ring[D][2][2];
+#if MI_ASM_LDS >= 2
+        const u32x4 rsw_s = rsrc_words(Wp, N * KSp * 16 * 4);
+        auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
+            const int soff = __builtin_amdgcn_readfirstlane(ks * 2048);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[t][0]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(w[t][1]) : "v"(voffw[t]), "s"(rsw_s), "s"(soff));
+            }
+        };
+#else
         auto ring_load = [&](int ks, u32x4 (&w)[2][2]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) w[t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffw[t] + pl * 1024, ks * 2048, 0);
         };
+#endif
         dma_tile(0, 0);
         dma_tile(1, 1);
         dma_tile(2, 2);
@@ -1224,12 +1311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int k = kt + h2;
                 if (k == 0 || k >= KTp - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (4 DMA pieces + 8 ring loads per k-tile, as in edge_gemm2b_kernel)
-                __syncthreads();
+                MI_LOOP_BARRIER();
                 if (k + 3 < KTp) dma_tile(k + 3, (k + 3) & 3);
                 f16x8 af[4][2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     read_a(k & 3, s2, af);
+                    MI_RING_WAIT(ring[2 * h2 + s2]);
                     mma(ring[2 * h2 + s2], af);
                     if (2 * k + s2 + D < KSp) ring_load(2 * k + s2 + D, ring[2 * h2 + s2]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1284,6 +1372,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1b_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
 #if MI_HAVE_ABLATION_KERNELS
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1d_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm1c_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
@@ -1319,12 +1408,19 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     else if (g_edge1_fused == 3) hipLaunchKernelGGL((edge_gemm1d_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);   // 2 x 2 waves of 64 x 64
     else
 #endif
-    hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
+    if (pe.pair_wide) hipLaunchKernelGGL((edge_gemm1b_kernel<4>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
+    else hipLaunchKernelGGL((edge_gemm1b_kernel<4, false>), dim3(nblk), dim3(256), EG2B_LDS, s, A, Wf, M, H, K, pe, g_edge1_clk);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
 
-bool edge_gemm1_supported(const mi_net* net) { return g_edge1_fused && net->H % 128 == 0 && net->Wffc != nullptr && (2 * net->Kh) % 64 == 0; }
+// whether layer launches of M pair rows take edge_gemm1: a forced form (1 .. 4: tests, ablations) whatever the size; by default (9) form b for the
+// launches beyond the plane GEMM's latency forms -- with its k-loop under manual control it beats the plane GEMM there
+bool edge_gemm1_supported(const mi_net* net, int64_t M) {
+    if (!(net->H % 128 == 0 && net->Wffc != nullptr && (2 * net->Kh) % 64 == 0) || g_edge1_fused == 0) return false;
+    if (g_edge1_fused != 9) return true;
+    return (int64_t)(net->H / 128) * ((cdiv(M, 128) + 7) / 8 * 8) > g_planes_lat_max_blocks;
+}
 
 int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s) {
     const int H = net->H, K = 2 * net->Kh;
@@ -1438,7 +1534,7 @@ int pack_frag_from_planes(const Planes&, int, int, u16*, hipStream_t) { return M
 int edge_gemm2(mi_net*, mi_batch*, int, hipStream_t, float*) { return MI_ESTATE; }
 bool edge_gemm2_supported(const mi_net*) { return false; }
 int edge_gemm1(mi_net*, const Planes&, int, int, PlanesEpilogue, hipStream_t) { return MI_ESTATE; }
-bool edge_gemm1_supported(const mi_net*) { return false; }
+bool edge_gemm1_supported(const mi_net*, int64_t) { return false; }
 int edge_gemm1_pack(mi_net*, int, const float*, hipStream_t) { return MI_OK; }
 int g_edge1_fused = 0;
 

@@ -184,7 +184,7 @@ bool node_chain_supported(const mi_net* net);
 size_t node_chain_pack_elems(int H);
 int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, const float* W2, hipStream_t s);
 // edge_stage.hip: the second edge GEMM + edge -> node reduction on 128-row x H-column register tiles (inference, hidden_dim 512)
-bool edge_gemm1_supported(const mi_net* net);
+bool edge_gemm1_supported(const mi_net* net, int64_t M);
 int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
 extern int g_edge2_train;
