@@ -294,7 +294,7 @@ def measure_ft(args, K, W, ctx, cpu_budget_s=15.0):
                       "batch_per_gpu": B, "atoms_per_cell": NATOM, "accum_steps": 50, "concurrent_groups": groups,
                       "adam_steps_in_timed_region": K // 50 + (1 if K % 50 else 0),
                       "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world},
-           "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + gemm_planes_kernel (agent forward, edge MLP of one layer; the "
+           "roofline": {"bound": "mfma", "kernel": "edge_gemm1b_kernel / gemm_planes_kernel<pair> + edge_gemm2b_kernel (agent forward, edge MLP of one layer; the "
                                                       "largest single kernel of the micro-step)",
                         "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS,
                         "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": tot_ms.value / max(1, n_launch.value),
@@ -331,7 +331,7 @@ def _edge_stage_roofline(lib, module, edges_total, pairs_total, evals):
     fp32_flops = evals * L * (pairs_total * 2 * (6 * F) * H + edges_total * 2 * H * H)   # Fourier block over pairs + second linear over edges
     busy_ms = max(union_ms.value, 1e-9)
     issued = terms * fp32_flops / (busy_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_planes_kernel<pair> + edge_gemm2b_kernel / gemm_planes_kernel (edge MLP of one layer over one crystal group; the second GEMM on the register-tile kernel in inference forwards at hidden_dim 512)", "achieved": issued,
+    return {"bound": "mfma", "kernel": "edge_gemm1b_kernel (pair mode; gemm_planes_kernel<pair> for small launches) + edge_gemm2b_kernel (edge MLP of one layer over one crystal group; the second GEMM on the register-tile kernel in inference forwards at hidden_dim 512)", "achieved": issued,
             "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "launches": int(n_launch.value),
             "avg_launch_ms": tot_ms.value / max(1, n_launch.value), "stage_busy_ms": busy_ms, "achieved_fp32_equivalent": issued / terms,
             "note": "flops of all bracketed launches / union of their execution intervals (concurrent groups overlap); small ragged sets are "
@@ -574,7 +574,7 @@ def measure_mg(args, K, W, ctx=None):
                        "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "concurrent_chains": chains, "edges_first_step": E0, "edges_last_step": E,
                        "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
                        "parameters": nparams, "final_state_finite": finite, "fp16_plane_saturation_events": sat},
-            "roofline": {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers of the interaction / output blocks)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_rt_kernel<lean> (edge-level dense layers of the interaction / output blocks)",
                          "achieved": terms * flops_eval * 2 * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": terms * flops_eval * 2 * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "per_gpu": True,
                          "achieved_fp32_equivalent": flops_eval * 2 * K / elapsed / 1e12, "flops_per_evaluation": flops_eval,
@@ -645,7 +645,7 @@ def main_mg_ft(args):
     Eset = E64 * Bm / min(Bm, 64)
     f_eval = mg_flops_eval(agent.decoder.hp, Bm * NATOM, Eset)
     terms = 3 if _lib.load().mi_plane_format() == 2 else 6
-    out["roofline"] = {"bound": "mfma", "kernel": "gemm_planes_kernel<0, 2> (edge-level dense layers: forward, data gradients) + gemm_tn_split_kernel (weight gradients)",
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm_rt_kernel / gemm_planes_kernel<0, 2> (edge-level dense layers: forward, data gradients) + gemm_tn_split_kernel (weight gradients)",
                        "achieved": terms * 4 * f_eval * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": terms * 4 * f_eval * K / elapsed / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                        "achieved_fp32_equivalent": 4 * f_eval * K / elapsed / 1e12, "flops_per_evaluation": f_eval, "edges": Eset,
@@ -844,7 +844,7 @@ def main():
             # every fp32 product is issued as THREE fp16 MFMA products (two-plane fp16 operands; six bf16 products in the three-plane
             # bf16 build): price the matrix pipe with what it executes (fp16 and bf16 MFMA have the same dense peak)
             terms = 3 if lib.mi_plane_format() == 2 else 6
-            kernel, issued, peak = "gemm_planes_kernel<pair> + edge_gemm2b_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges with the edge -> node sum)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
+            kernel, issued, peak = "edge_gemm1b_kernel (pair mode) + edge_gemm2b_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges with the edge -> node sum)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
             dtype = "f32 via 2-plane fp16 split (3 fp16 MFMA terms, f32 accumulate)" if terms == 3 else "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
