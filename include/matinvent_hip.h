@@ -391,6 +391,11 @@ int mi_debug_set_node_fused(int on);
  * inference chain is, 0 = layernorm + PQ product + finalize_agg + two node-MLP products (seven launches per layer).  Returns the
  * previous setting. */
 int mi_debug_set_node_train(int on);
+/* The same chain as TWO launches for small and medium batches (at most 85 row blocks of 32 atoms per chain): phase A, then LayerNorm + the
+ * three projection passes on three workgroups per row block -- the chain is bound by the weight planes a workgroup streams through its CU's
+ * L2 port, and the passes are independent given LayerNorm(h') (models/diffcsp/cspnet.py:87-88,61).  1 (default) = on, 0 = one launch.
+ * Returns the previous setting. */
+int mi_debug_set_node_split(int on);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
  * 1 (default) = on (inference forwards, next to the node-chain launch above; training forwards too, with the pre-activation kept

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mi_debug_node_chain_clock": (_I, [_P]),
     "mi_debug_set_edge2_fused": (_I, [_I]),
     "mi_debug_set_node_train": (_I, [_I]),
+    "mi_debug_set_node_split": (_I, [_I]),
     "mi_debug_rt_clock": (_I, [_P, _I, _I]),
     "mi_debug_set_rt_lean": (_I, [_I]),
     "mi_debug_set_edge_fused": (_I, [_I]),

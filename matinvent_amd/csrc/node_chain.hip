@@ -27,6 +27,8 @@ namespace mi {
 
 unsigned long long* g_node_clk = nullptr;
 int g_node_fused = 1;  // inference forwards: the node-level chain as one launch per layer boundary (0: the seven-launch form)
+int g_node_split = 1;  // small / medium batches: phase A and LayerNorm + projections as two launches, the second on three workgroups per row block (0: one launch)
+int g_node_split_max_blocks = 256;   // ... while those fit the chip in one round (one workgroup per CU)
 
 #if MI_PLANES_FP16
 
@@ -87,6 +89,9 @@ struct NodeChainArgs {
     float* t_ln = nullptr;      // LayerNorm output, rows of stride ld_ln (cat[:, 0:H] of layer l)
     int ld_ln = 0;
     float* t_lnstat = nullptr;  // LayerNorm statistics [N][2] = {mean, 1 / sqrt(var + eps)}
+    // the chain as TWO launches (node_chain(): small and medium batches): `a_only` = phase A, h' written, nothing else; `split_b` = a launch of
+    // LayerNorm + phase B with gridDim.y = 3, a workgroup running the projection pass blockIdx.y only (the passes are independent given y)
+    int a_only = 0, split_b = 0;
 };
 
 template <int H>
@@ -384,8 +389,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         __syncthreads();
         stamp();
     } else if (phaseB) {
-        ring_fill(uniform_rsrc(a.Wln, 3 * wsz), wave * TW);
+        ring_fill(uniform_rsrc(a.Wln, 3 * wsz), ((a.split_b ? (int)blockIdx.y : 0) * H + wave * CW) / 32);
     }
+    if (a.a_only) {   // (the first of two launches: h' leaves, LayerNorm and the projections follow on three times the CUs)
+        const int c0 = lane * 8;
+        if (c0 < H)
+#pragma unroll 2
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, i = row0 + row;
+                if (i < N) {
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)i * H + c0) = *reinterpret_cast<const f32x4*>(Hs + row * HLD + c0);
+                    *reinterpret_cast<f32x4*>(a.h_out + (size_t)i * H + c0 + 4) = *reinterpret_cast<const f32x4*>(Hs + row * HLD + c0 + 4);
+                }
+            }
+        return;
+    }
+    const int pass_lo = a.split_b ? (int)blockIdx.y : 0, pass_hi = a.split_b ? (int)blockIdx.y + 1 : 3;
+    const bool tape_w = !a.split_b || blockIdx.y == 0;   // (the three workgroups of a row block compute the same LayerNorm: one writes the tape)
     // ---- LayerNorm (layernorm_kernel's arithmetic: a wave per row, a lane owns eight consecutive columns) ----
     unsigned sat_ln = 0;
     {
@@ -435,12 +455,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                     *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0) = o0;
                     *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0 + 4) = o1;
                 }
-                if (a.t_ln) {
+                if (a.t_ln && tape_w) {
                     *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0) = o0;
                     *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0 + 4) = o1;
                 }
             }
-            if (a.t_lnstat && lane == 0 && i < N) {
+            if (a.t_lnstat && tape_w && lane == 0 && i < N) {
                 a.t_lnstat[2 * (size_t)i] = mean;
                 a.t_lnstat[2 * (size_t)i + 1] = rstd;
             }
@@ -466,11 +486,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         constexpr float os = 1.f / (PL_S_LN * PL_SW);
         float m = 0.f;
 #pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int pass = pass_lo; pass < pass_hi; ++pass) {
             const int ct0 = (pass * H + wave * CW) / 32;
             run(TRf{}, rs_ln, ct0);
             stamp();
-            if (pass < 2) ring_fill(rs_ln, ((pass + 1) * H + wave * CW) / 32);
+            if (pass + 1 < pass_hi) ring_fill(rs_ln, ((pass + 1) * H + wave * CW) / 32);
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
                 const int col = pass * H + wave * CW + t * 32 + l31;
@@ -500,7 +520,7 @@ static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_chain_kernel<H, NW, D>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeChainCfg<H>::LDS); });
     MI_HIP(attr_err);
-    hipLaunchKernelGGL((node_chain_kernel<H, NW, D>), dim3(cdiv(a.N, 32)), dim3(64 * NW), NodeChainCfg<H>::LDS, s, a);
+    hipLaunchKernelGGL((node_chain_kernel<H, NW, D>), dim3(cdiv(a.N, 32), a.split_b ? 3 : 1), dim3(64 * NW), NodeChainCfg<H>::LDS, s, a);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -586,9 +606,32 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
 #if MI_HAVE_ABLATION_KERNELS   // (the deeper weight ring spills registers: an ablation instantiation, see gemm_split.h)
     if (H == 512 && g_node_fused == 2) return node_chain_launch<512, 8, 8>(a, s);
 #endif
-    if (H == 512) return node_chain_launch<512, 8, 4>(a, s);
-    if (H == 256) return node_chain_launch<256, 8, 4>(a, s);
-    return node_chain_launch<128, 4, 4>(a, s);
+    auto launch = [&](const NodeChainArgs& x) {
+        if (H == 512) return node_chain_launch<512, 8, 4>(x, s);
+        if (H == 256) return node_chain_launch<256, 8, 4>(x, s);
+        return node_chain_launch<128, 4, 4>(x, s);
+    };
+    // The chain is bound by the weight planes each workgroup streams through ITS CU's L2 port (1 MB per product: DESIGN 18.6); the three
+    // projection passes are independent given LayerNorm(h'), so when three workgroups per row block still fit the chip in one round they
+    // run as a second launch on three times the CUs (each recomputes the LayerNorm of its 32 rows).  Larger batches keep the one launch.
+    const int nblk = cdiv(N, 32);
+    if (g_node_split && l < L && 3 * nblk <= g_node_split_max_blocks) {
+        if (l > 0) {
+            NodeChainArgs a1 = a;
+            a1.a_only = 1;
+            a1.Wln = nullptr;
+            a1.t_ln = nullptr;
+            a1.t_lnstat = nullptr;
+            MI_TRY(launch(a1));
+        }
+        NodeChainArgs a2 = a;
+        a2.part = nullptr;                       // no phase A: the chain starts at h' (l = 0: at the embedding's output, as before)
+        a2.h_in = b->h + (size_t)l * NH;
+        a2.t_agg = a2.t_xpre = a2.t_ypre = nullptr;
+        a2.split_b = 1;
+        return launch(a2);
+    }
+    return launch(a);
 }
 
 #else  // three-plane bf16 build: the chain stays on the plane GEMMs
@@ -605,6 +648,12 @@ int node_chain(mi_net*, mi_batch*, int, hipStream_t, bool) { return MI_ESTATE; }
 extern "C" int mi_debug_node_chain_clock(void* dev_buffer) {
     mi::g_node_clk = (unsigned long long*)dev_buffer;
     return MI_OK;
+}
+
+extern "C" int mi_debug_set_node_split(int on) {
+    const int was = mi::g_node_split;
+    mi::g_node_split = on != 0;
+    return was;
 }
 
 extern "C" int mi_debug_set_node_train(int on) {
