@@ -653,6 +653,7 @@ extern "C" int mi_debug_node_chain_clock(void* dev_buffer) {
 extern "C" int mi_debug_set_node_split(int on) {
     const int was = mi::g_node_split;
     mi::g_node_split = on != 0;
+    if (on > 1) mi::g_node_split_max_blocks = on;   // (experiments: the largest 3 x row-block count that still takes the two-launch form; default 256)
     return was;
 }
 
