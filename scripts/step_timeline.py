@@ -4,7 +4,7 @@ import csv, glob, os, subprocess, sys, collections
 out = "/tmp/step_tl"
 subprocess.run(["rm", "-rf", out])
 env = dict(os.environ, TMPDIR="/tmp")
-subprocess.run(["rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--streams", "1",
+subprocess.run(["rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable, "bench.py"] + (sys.argv[1:] if len(sys.argv) > 1 else ["--steps", "6", "--warmup", "2", "--streams", "1"]) + [
                 "--no-cpu-baseline", "--no-counters"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
 f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
