@@ -316,7 +316,9 @@ int mi_plane_format(void);
 /* Diagnostics: C[M,N] = A[M,K] W[N,K]^T through the node-level GEMM kernels.  kind 0 = f32-input MFMA,
  * kind 1 = three-plane bf16 split (six product terms, fp32-class) on the bf16 matrix pipe; kinds 2 / 3 = the same on pre-split
  * tile-blocked plane sets (128-row / 256-row double-buffered kernel); kind 4 = the weight-gradient form C[M,N] += A^T W with
- * A [K,M] and W [K,N] (contraction over rows, f32 MFMA, deterministic split reduction). */
+ * A [K,M] and W [K,N] (contraction over rows, f32 MFMA, deterministic split reduction); kind 5 = the same product from fp16 plane
+ * sets of both operands (split here with scale 2^6; LDS-DMA slabs + transposing LDS reads: the edge-level weight gradients of
+ * `loss.backward()`, pipeline/mat_invent.py:164; M % 256 == 0, N % 128 == 0, K >= 4096). */
 int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M,
                   int N, int K, void* stream);
 /* bench.py's roofline hook: HIP events bracket the dominant stage (the per-edge MLP of one layer) on the stream it is

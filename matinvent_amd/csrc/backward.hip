@@ -1454,6 +1454,30 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
         g_planes_variant = saved;
         return rc;
     }
+#if MI_PLANES_FP16
+    if (kind == 5) {  // the same product from PLANE SETS (gemm_tn_planes_kernel): both operands split here with scale 2^6 (|x| < 1023), M % 256 == 0, N % 128 == 0
+        hipStream_t s = (hipStream_t)stream;
+        MI_CHECK(M % 256 == 0 && N % 128 == 0 && K >= 4096, MI_EINVAL, "kind 5: the plane-set weight-gradient form needs M % 256 == 0, N % 128 == 0, K >= 4096");
+        static u16 *pa = nullptr, *pw = nullptr;
+        static float *sc = nullptr, *dsc = nullptr;
+        static size_t na = 0, nw = 0;
+        const size_t ea = planes_elems(K, M), ew = planes_elems(K, N), scf = (size_t)1 << 25;
+        if (ea > na) { if (pa) (void)hipFree(pa); na = ea; MI_HIP(hipMalloc((void**)&pa, na * 2)); }
+        if (ew > nw) { if (pw) (void)hipFree(pw); nw = ew; MI_HIP(hipMalloc((void**)&pw, nw * 2)); }
+        if (!sc) MI_HIP(hipMalloc((void**)&sc, scf * sizeof(float)));
+        if (!dsc) {
+            MI_HIP(hipMalloc((void**)&dsc, 2 * sizeof(float)));
+            const float h[2] = {64.f, 1.f / 64.f};
+            MI_HIP(hipMemcpy(dsc, h, sizeof(h), hipMemcpyHostToDevice));
+        }
+        Planes PA = make_planes(pa, M, 64.f), PW = make_planes(pw, N, 64.f);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, K, M, PA);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, K, N, PW);
+        MI_KERNEL_CHECK();
+        MI_CHECK(gemm_tn_planes_ok(PA, 0, PW, 0, K, M, N), MI_EINVAL, "kind 5: shape outside the plane-set form");
+        return gemm_tn_planes(PA, 0, PW, 0, C, ldc, K, M, N, dsc, dsc, sc, scf, s);
+    }
+#endif
     if (kind == 4) {  // weight-gradient form: C[M][N] += A^T W with A [K][M], W [K][N] (contraction over rows)
         static float* sc = nullptr;
         const size_t scf = (size_t)1 << 24;

@@ -96,6 +96,25 @@ def test_weight_gradient_gemm_vs_fp64(M, N, K):
         _lib.check(lib.mi_debug_set_tn128(3))
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 25600), (256, 384, 12163), (512, 128, 4099)])
+def test_weight_gradient_from_plane_sets_vs_fp64(M, N, K):
+    """C[M, N] += A^T W over a long row list with both operands given as fp16 plane sets (csrc/backward.hip gemm_tn_planes_kernel: LDS-DMA slabs,
+    the k-strided MFMA operands through ds_read_b64_tr_b16): against the fp64 product, at the plane format's accuracy; row counts that are not
+    multiples of the 32-row slab (the tail reads the plane sets' zero row padding) and both tile counts per operand."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g).cuda()
+    W = torch.randn(K, N, generator=g).cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+    ref = C0.double() + A.double().t() @ W.double()
+    scale = ref.abs().max().item()
+    out = C0.clone()
+    _lib.check(lib.mi_debug_gemm(5, C.c_void_p(A.data_ptr()), M, C.c_void_p(W.data_ptr()), N, C.c_void_p(out.data_ptr()), N, M, N, K, None))
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() / scale < 3e-6   # (the fp32-row forms' bound in the test above)
+
+
 @pytest.mark.parametrize("M,N,K", [(3000, 512, 512), (300, 256, 96), (1031, 768, 64), (256, 512, 16), (70000, 512, 512)])
 def test_plane_gemm_lds_dma_256_tiles_bit_identical(M, N, K):
     """Large plain products run on 256 x 256 tiles whose operands arrive by LDS-DMA into two LDS stages; the k order and the order
