@@ -30,7 +30,8 @@ extern "C" {
 #define MI_OK 0
 #define MI_EINVAL (-1)   /* bad argument / unsupported hyper-parameter */
 #define MI_EHIP (-2)     /* a HIP runtime call failed */
-#define MI_ENOMEM (-3)
+#define MI_ENOMEM (-3)    /* a device allocation failed or a caller-provided scratch / arena is too small */
+#define MI_ECAPACITY (-5) /* a periodic neighbour graph exceeded the capacity it was created with (the caller may drop the batch) */
 #define MI_ESTATE (-4)   /* call order violated (e.g. forward before mi_net_set_params) */
 
 #define MI_NUM_TYPES 100
@@ -94,7 +95,7 @@ int mi_batch_create(const mi_net* net, const int* num_atoms_host, int B, int64_t
  * (frac, lattices) -- CSPNet.gen_edges knn branch (cspnet.py:243-257) -> radius_graph_pbc (utils.py:335-514, 27 images,
  * cutoff = smallest inter-plane spacing + 0.01) + get_max_neighbors_mask (utils.py:517-601, `max_neighbors` with the
  * +0.01 band on d^2) + reorder_symmetric_edges (cspnet.py:159-234).  `edge_cap_per_node` bounds the kept, mask-selected
- * neighbours per centre atom (buffers are sized for 2 * N * cap edges; exceeding it is an MI_ENOMEM error, never a
+ * neighbours per centre atom (buffers are sized for 2 * N * cap edges; exceeding it is an MI_ECAPACITY error, never a
  * silent truncation).  At most 64 atoms per crystal. */
 int mi_batch_create_knn(const mi_net* net, const int* num_atoms_host, int B, int64_t node_offset, int64_t graph_offset,
                         int max_neighbors, int edge_cap_per_node, mi_batch** out);

@@ -169,11 +169,11 @@ def load():
     return lib
 
 
-MI_EINVAL, MI_EHIP, MI_ENOMEM, MI_ESTATE = -1, -2, -3, -4   # include/matinvent_hip.h
+MI_EINVAL, MI_EHIP, MI_ENOMEM, MI_ESTATE, MI_ECAPACITY = -1, -2, -3, -4, -5   # include/matinvent_hip.h
 
 
 class MIError(RuntimeError):
-    """A failed library call; `code` is the C ABI's return value (MI_EINVAL / MI_EHIP / MI_ENOMEM / MI_ESTATE)."""
+    """A failed library call; `code` is the C ABI's return value (MI_EINVAL / MI_EHIP / MI_ENOMEM / MI_ESTATE / MI_ECAPACITY)."""
 
     def __init__(self, code: int, message: str):
         super().__init__(message)

@@ -32,9 +32,18 @@ def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), __file__]
 
 
+def _flags_tag() -> str:
+    return " ".join(ARCH + CFLAGS + os.environ.get("MI_EXTRA_FLAGS", "").split())
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    """Missing, older than a source, or LINKED UNDER OTHER FLAGS than the ones in force now (the tag written next to the library): a
+    library built with MI_ALLOW_PACKED_FP32=1 or MI_EXTRA_FLAGS must not keep being loaded once the variable is gone."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".flags"):
         return True
+    with open(LIB + ".flags") as f:
+        if f.read() != _flags_tag():
+            return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -65,7 +74,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 return LIB
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
-            tag = " ".join(ARCH + CFLAGS + extra)
+            tag = _flags_tag()
 
             def compile_one(name: str) -> str:
                 src, obj = os.path.join(CSRC, name), os.path.join(OBJ, name.replace(".hip", ".o"))
@@ -93,6 +102,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             try:
                 subprocess.run(cmd, check=True)
                 os.replace(tmp, LIB)
+                with open(LIB + ".flags", "w") as f:
+                    f.write(tag)
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)

@@ -2109,9 +2109,9 @@ static int graph_build(mi_gemnet* net, mi_gbatch* b, const float* pos, const flo
     int meta[4];
     MI_HIP(hipMemcpyAsync(meta, b->meta, sizeof(meta), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
-    MI_CHECK(meta[2] == 0, MI_ENOMEM, "periodic graph: capacity exceeded (flags %d: 1 = more than max_neighbors kept pairs of one atom, 2 = more than %d atoms "
+    MI_CHECK(meta[2] == 0, MI_ECAPACITY, "periodic graph: capacity exceeded (flags %d: 1 = more than max_neighbors kept pairs of one atom, 2 = more than %d atoms "
              "inside the cutoff even after shrinking it, 4 = in-degree above %d)", meta[2], GN_CAND, GN_DEG);
-    MI_CHECK((int64_t)meta[0] <= b->E_cap, MI_ENOMEM, "periodic graph: %d edges exceed the capacity %lld", meta[0], (long long)b->E_cap);
+    MI_CHECK((int64_t)meta[0] <= b->E_cap, MI_ECAPACITY, "periodic graph: %d edges exceed the capacity %lld", meta[0], (long long)b->E_cap);
     b->E = meta[0];
     b->deg_max = std::max(1, std::min(meta[1], GN_DEG));
     return MI_OK;

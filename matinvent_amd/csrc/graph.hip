@@ -373,7 +373,7 @@ int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t
     int meta[4];
     MI_HIP(hipMemcpyAsync(meta, b->kn_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
-    MI_CHECK(meta[2] == 0 && meta[0] <= b->E_cap && meta[1] <= b->deg_cap, MI_ENOMEM,
+    MI_CHECK(meta[2] == 0 && meta[0] <= b->E_cap && meta[1] <= b->deg_cap, MI_ECAPACITY,
              "knn graph exceeds its capacity (edges %d of %lld, max degree %d of %d): raise edge_cap_per_node", meta[0], (long long)b->E_cap,
              meta[1], b->deg_cap);
     b->E = meta[0];

@@ -610,8 +610,9 @@ class MatterGenSampler:
                 invalid = model.last_sample_invalid()
             except _lib.MIError as e:
                 # (only the synchronising form of the forward -- mi_debug_set_mg_nosync(0) -- refuses a batch: there a crystal over a
-                #  graph capacity fails the whole call, MI_ENOMEM, and nothing of the batch can be kept)
-                if e.code != _lib.MI_ENOMEM:
+                #  graph capacity fails the whole call, MI_ECAPACITY, and nothing of the batch can be kept.  A real allocation failure --
+                #  MI_ENOMEM -- and every other error are re-raised: they must not shrink the RL step's list silently.)
+                if e.code != _lib.MI_ECAPACITY:
                     raise
                 import logging
                 logging.getLogger(__name__).warning("MatterGenSampler.generate: batch %d discarded (%s)", bi, e)

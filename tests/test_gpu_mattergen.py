@@ -286,7 +286,7 @@ def test_sampler_without_a_host_round_trip_equals_the_synchronising_form():
 
 def test_a_crystal_over_a_graph_capacity_is_dropped_alone():
     """A crystal with an in-degree above the graph's capacity (128 in-edges, the triplet kernels' LDS image; lowered to 24 here so that a
-    dense cell exceeds it -- a collapsed cell is what would do it in a chain) fails the synchronising forward as a whole (MI_ENOMEM).
+    dense cell exceeds it -- a collapsed cell is what would do it in a chain) fails the synchronising forward as a whole (MI_ECAPACITY).
     The chain's forwards take that ONE crystal out of the graph on the device, remember its flag, and go on: the other crystals'
     samples are those of a batch that never held it, up to the plane format's batch-composition rounding (the reference drops
     collapsed crystals one by one after sampling, pipeline/filters/opt_filter.py:49-61)."""
@@ -306,7 +306,7 @@ def test_a_crystal_over_a_graph_capacity_is_dropped_alone():
         lib.mi_debug_set_mg_deg_cap(24)
         with pytest.raises(_lib.MIError) as ei, torch.no_grad():
             m.decoder(state["pos"], state["cell"], state["atomic_numbers"], t, m.decoder.make_batch(torch.tensor(na)))
-        assert ei.value.code == _lib.MI_ENOMEM and "periodic graph" in str(ei.value)
+        assert ei.value.code == _lib.MI_ECAPACITY and "periodic graph" in str(ei.value)
         s_all, m_all = m.sample(na, state={k: v.clone() for k, v in state.items()}, **kw)
         inv = m.last_sample_invalid()
         assert inv.tolist() == [True, False, False]
