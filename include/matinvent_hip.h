@@ -399,6 +399,14 @@ int mi_debug_set_node_train(int on);
  * L2 port, and the passes are independent given LayerNorm(h') (models/diffcsp/cspnet.py:87-88,61).  1 (default) = on, 0 = one launch.
  * Returns the previous setting. */
 int mi_debug_set_node_split(int on);
+/* The chain with every product's COLUMNS split over workgroups (csrc/node_chain.hip, node_cols_kernel: 32 rows x 128 columns of one product
+ * per 4-wave workgroup, the intermediates' slices exchanged through L2): 1 = one launch per stage (agg + node_mlp.0, node_mlp.2 +
+ * residual, LayerNorm + projections), 2 = one launch per layer boundary with agent-scope flag hand-overs between the stages, 0 (default) = the
+ * row-block forms above.  Bit-identical to them (models/diffcsp/cspnet.py:79-91,61).  Returns the previous setting, MI_EINVAL for others. */
+int mi_debug_set_node_cols(int mode);
+/* TIMING ABLATIONS ONLY -- the results of a forward are garbage while a bit is set: 1 = skip the node chain's launches, 2 = the first edge GEMM,
+ * 4 = the second (what a chain's serial path and the chip's occupancy cost each other: DESIGN 19.1).  Returns the previous mask. */
+int mi_debug_set_skip(int mask);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
  * 1 (default) = on (inference forwards, next to the node-chain launch above; training forwards too, with the pre-activation kept

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmatinvent_hip.so")
+LIB_PATH = os.environ.get("MI_LIB_PATH") or os.path.join(HERE, "lib", "libmatinvent_hip.so")   # (MI_LIB_PATH: an A/B build of scripts/build_variant.py)
 
 NCOEF = 16
 NUM_TYPES = 100
@@ -81,6 +81,8 @@ SIGNATURES = {
     "mi_debug_set_edge2_fused": (_I, [_I]),
     "mi_debug_set_node_train": (_I, [_I]),
     "mi_debug_set_node_split": (_I, [_I]),
+    "mi_debug_set_node_cols": (_I, [_I]),
+    "mi_debug_set_skip": (_I, [_I]),
     "mi_debug_rt_clock": (_I, [_P, _I, _I]),
     "mi_debug_set_rt_lean": (_I, [_I]),
     "mi_debug_set_edge_fused": (_I, [_I]),

@@ -973,6 +973,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
         MI_HIP(hipMemsetAsync(b->absmax, 0, 2 * L * sizeof(unsigned), s));
+        if (g_node_cols == 2 && b->nc_flags) MI_HIP(hipMemsetAsync(b->nc_flags, 0, (size_t)(L + 1) * 2 * cdiv(N, 32) * sizeof(unsigned), s));
         hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
     }
@@ -1582,6 +1583,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(Xpl, planes_elems(N, H));
     A_(dsc, 16);
     A_(absmax, 2 * L + 2);
+    A_(nc_flags, (size_t)(L + 1) * 2 * cdiv(N, 32));
     A_(X, NH);
     A_(x1, NH);
     A_(tproj, (size_t)B * H);

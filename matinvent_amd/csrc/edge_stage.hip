@@ -1368,6 +1368,7 @@ __global__ void pack_frag_wff_sin_neg2_kernel(const float* __restrict__ W1, int 
 unsigned long long* g_edge1_clk = nullptr;
 
 int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe, hipStream_t s) {
+    if (g_ablate_skip & 2) return MI_OK;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -1436,6 +1437,7 @@ int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s) {
 unsigned long long* g_edge2_clk = nullptr;
 
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
+    if (g_ablate_skip & 4) return MI_OK;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {

@@ -142,6 +142,7 @@ struct mi_batch {
     unsigned short* Xpl = nullptr;   // plane set of the node MLP's hidden activation (N x H)
     float* dsc = nullptr;            // [6][2] {scale, 1/scale}: this layer's M1 / agg / X plane sets; backward pass: dZ2, the pair differences, the Fourier features (fp16 plane format)
     unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation); [2L], [2L + 1] = max |d cat|, max |dM1| of the layer the backward pass is in
+    unsigned* nc_flags = nullptr;    // [L + 1][2 x row blocks] arrival counters of node_cols_kernel's in-launch hand-overs (zeroed per evaluation)
     float* X = nullptr;      // [N][H] node-MLP hidden
     float* x1 = nullptr;     // [N][H] node_embedding output
     float* tproj = nullptr;  // [B][H]
@@ -189,6 +190,8 @@ int edge_gemm1_pack(mi_net* net, int l, const float* W1, hipStream_t s);
 bool edge_gemm2_supported(const mi_net* net);
 extern int g_edge2_train;
 extern int g_node_train;
+extern int g_node_cols;
+extern int g_ablate_skip;
 int edge_fused(mi_net* net, mi_batch* b, int layer, hipStream_t s);   // edge_fused.hip: both edge products of a layer in one launch (M1 stays in LDS)
 bool edge_fused_supported(const mi_net* net, const mi_batch* b);
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2 = nullptr);   // Z2: optional pre-activation output (training forward)

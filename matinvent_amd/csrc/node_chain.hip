@@ -29,6 +29,10 @@ unsigned long long* g_node_clk = nullptr;
 int g_node_fused = 1;  // inference forwards: the node-level chain as one launch per layer boundary (0: the seven-launch form)
 int g_node_split = 1;  // small / medium batches: phase A and LayerNorm + projections as two launches, the second on three workgroups per row block (0: one launch)
 int g_node_split_max_blocks = 256;   // ... while those fit the chip in one round (one workgroup per CU)
+int g_ablate_skip = 0;   // TIMING ABLATIONS ONLY (results are garbage): bit 0 = skip the node chain's launches, 1 = the first edge GEMM, 2 = the second (mi_debug_set_skip)
+int g_node_cols = 0;   // the column-split form of the chain (node_cols_kernel): 0 = off (default: measured 7 % SLOWER on the headline), 1 = one launch per stage, 2 = one launch per layer boundary with in-launch hand-overs
+int g_node_cols_b_max = 512;       // LayerNorm + projections: one 128-column group per workgroup up to this many workgroups, three above
+int g_node_cols_fused_max = 256;   // the one-launch form only while every workgroup of the launch is resident at once (a waiting workgroup holds its slot)
 
 #if MI_PLANES_FP16
 
@@ -92,6 +96,13 @@ struct NodeChainArgs {
     // the chain as TWO launches (node_chain(): small and medium batches): `a_only` = phase A, h' written, nothing else; `split_b` = a launch of
     // LayerNorm + phase B with gridDim.y = 3, a workgroup running the projection pass blockIdx.y only (the passes are independent given y)
     int a_only = 0, split_b = 0;
+    // the COLUMN-SPLIT form (node_cols_kernel): `stages` = which of {1: agg + node_mlp.0 -> X planes, 2: node_mlp.2 + residual -> h', 4: LayerNorm
+    // + projections} this launch runs, on `gy` workgroups per 32-row block (each owning 128-column groups gy apart); the X planes and h' cross
+    // from one stage to the next through `xpl` / `h_out` -- at a kernel boundary (one launch per stage) or, with `flags`, inside ONE launch
+    // behind an agent-scope release / acquire hand-over (all gy workgroups of a row block arrive at flags[2 rb + seam])
+    int stages = 0, gy = 1, npad = 0;
+    u16* xpl = nullptr;             // [2 planes][npad][H] X = SiLU(node_mlp.0) as fp16 planes, row-major
+    unsigned* flags = nullptr;
 };
 
 template <int H>
@@ -525,6 +536,412 @@ static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
     return MI_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The same chain with every product's COLUMNS split over workgroups.  The one-launch kernel above is bound by what ONE CU's L2
+// port delivers: a workgroup owning 32 rows streams each product's whole weight operand (1 MB at H = 512, five times per layer) and, at 8
+// waves x 228 registers + 133 KB of LDS, needs a CU to itself -- beside other chains' edge GEMMs (two 4-wave workgroups per CU) it waits for
+// one to drain completely.  Here a workgroup is 4 waves x one 32 x 32 tile = 32 rows x 128 columns of ONE product: a quarter of the weight
+// bytes per CU, 1 / NCG of the time per product, 67 KB of LDS and < 128 registers, so it is placed next to a running edge-GEMM workgroup.  The
+// price is the exchange of the intermediates' column slices between the workgroups of a row block (X planes, h'): through L2, either at a
+// kernel boundary (three launches per layer boundary: ~1.5 us each, MI355X guide "boundary") or inside one launch behind an agent-scope
+// flag hand-over (`flags`; the group sits on one XCD by block-id arithmetic, so the slices are served by the L2 they were written to).
+// Arithmetic, k order and term order per output element are those of node_chain_kernel: results are bit-identical.
+template <int H>
+struct NodeColsCfg {
+    static constexpr int KS = H / 16, ROWB = 2 * H + 16, PLB = 32 * ROWB, NCG = H / 128;
+    static constexpr int LDS = 2 * PLB;
+};
+
+template <int H, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void node_cols_kernel(NodeChainArgs a) {
+    using C = NodeColsCfg<H>;
+    constexpr int KS = C::KS, ROWB = C::ROWB, PLB = C::PLB, NCG = C::NCG, RPW = 8;
+    static_assert(KS % D == 0 && KS >= 2 * D && D % 2 == 0 && H % 128 == 0, "ring depth / column groups");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* P = smem;                                    // activation planes [2][32][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int N = a.N, nblk = (N + 31) >> 5, gy = a.gy;
+    // block id -> (row block, column-group worker) with the gy workgroups of a row block on ONE XCD (dispatch is round-robin over the 8 XCDs)
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int cgw = j % gy, rb = (j / gy) * 8 + xcd;
+    if (rb >= nblk) return;
+    const int row0 = rb * 32;
+
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.clk && tid == 0) a.clk[(size_t)bid * 16 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+    u32x4 ring[D][2];
+    f32x16 acc;
+    const int voff = lane * 16;
+    auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, int ct, int ks, u32x4 (&w)[2]) {
+        const int so = (ct * KS + ks) * 2048;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + pl * 1024, so, 0);
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rs, int ct) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ring_load(rs, ct, d, ring[d]);
+    };
+    auto read_act = [&](int ks, f16x8 (&af)[2]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[pl] = *reinterpret_cast<const f16x8*>(P + pl * PLB + l31 * ROWB + (2 * ks + kg) * 16);
+    };
+    // term order of the plane GEMMs: (a1, b0), (a0, b1), (a0, b0) with a = activation, b = weight
+    auto mma_step = [&](auto tr, const u32x4 (&w)[2], const f16x8 (&af)[2]) {
+        constexpr bool TR = decltype(tr)::value;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            const f16x8 wv = __builtin_bit_cast(f16x8, w[term == 1 ? 1 : 0]);
+            const f16x8 av = af[term == 0 ? 1 : 0];
+            if constexpr (TR) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, av, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc, 0, 0, 0);
+        }
+    };
+    auto run = [&](auto tr, const __amdgpu_buffer_rsrc_t& rs, int ct) {   // the ring holds k-steps 0 .. D-1 on entry, nothing on exit
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        f16x8 af[2][2];
+        read_act(0, af[0]);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS - D; ks0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                read_act(ks0 + d + 1, af[(d + 1) & 1]);
+                mma_step(tr, ring[d], af[d & 1]);
+                ring_load(rs, ct, ks0 + d + D, ring[d]);
+                __builtin_amdgcn_sched_barrier(0);   // (pins the refill behind its slot's use: see node_chain_kernel)
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d + 1 < D) read_act(KS - D + d + 1, af[(d + 1) & 1]);
+            mma_step(tr, ring[d], af[d & 1]);
+        }
+    };
+    using TRt = std::true_type;
+    using TRf = std::false_type;
+    // hand-over between two stages of ONE launch: every workgroup of the row block has published its slice (MI355X guide, Guideline 16:
+    // plain stores -> barrier -> one lane's agent-scope release -> drained -> relaxed arrive; ONE relaxed poll loop -> agent acquire -> barrier)
+    auto handover = [&](int seam) {
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned* f = a.flags + 2 * rb + seam;
+            __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)gy) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    };
+
+    const int wsz = H * H * 4;  // bytes of one packed H x H operand
+    const int cg = cgw;         // stages 1 and 2: this workgroup's 128-column group (gy == NCG)
+    const int ct_a = cg * 4 + wave;
+    const int ccol = cg * 128 + wave * 32;   // first column of the wave's tile
+    if (a.stages & 1) {
+        const __amdgpu_buffer_rsrc_t rs_agg = uniform_rsrc(a.Wagg, wsz);
+        // ---- A1: agg = (sum of the node's slots) / degree -> planes, all H columns (every workgroup of the row block needs the whole K) ----
+        const float s_agg = a.dsc[2];
+        unsigned sat = 0;
+        {
+            const int c0 = lane * 8;
+            const bool act = c0 < H;
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {   // (two rounds of four rows: the gathers of a round in flight together, 64 registers)
+                constexpr int RH = RPW / 2;
+                int e0[RH], e1[RH];
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const int i = row0 + wave * RPW + half * RH + r;
+                    e0[r] = i < N ? a.rowptr[i] : 0;
+                    e1[r] = i < N ? a.rowptr[i + 1] : 0;
+                }
+                f32x4 x[RH], y[RH], x1[RH], y1[RH];
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const int i = row0 + wave * RPW + half * RH + r;
+                    const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
+                    x[r] = y[r] = x1[r] = y1[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (act && ns > 0) {
+                        const float* p = a.part + (size_t)i * H + c0;
+                        x[r] = *reinterpret_cast<const f32x4*>(p);
+                        y[r] = *reinterpret_cast<const f32x4*>(p + 4);
+                        if (ns > 1) {
+                            x1[r] = *reinterpret_cast<const f32x4*>(p + (size_t)N * H);
+                            y1[r] = *reinterpret_cast<const f32x4*>(p + (size_t)N * H + 4);
+                        }
+                    }
+                }
+                if (half == 1) ring_fill(rs_agg, ct_a);   // behind the last gathers (vector loads return in order), in flight under the arithmetic
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const int row = wave * RPW + half * RH + r, i = row0 + row;
+                    const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
+                    f32x4 xs = x[r], ys = y[r];
+                    if (act && ns > 1) {
+                        xs += x1[r];
+                        ys += y1[r];
+                        for (int sl = 2; sl < ns; ++sl) {
+                            const float* p = a.part + ((size_t)sl * N + i) * H + c0;
+                            xs += *reinterpret_cast<const f32x4*>(p);
+                            ys += *reinterpret_cast<const f32x4*>(p + 4);
+                        }
+                    }
+                    if (!act) continue;
+                    if (ns > 0) {
+                        const float d = (float)(e1[r] - e0[r]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            xs[k] = xs[k] / d;
+                            ys[k] = ys[k] / d;
+                        }
+                    }
+                    if (a.t_agg && cgw == 0 && i < N) {
+                        float* o = a.t_agg + (size_t)i * a.ld_agg + c0;
+                        *reinterpret_cast<f32x4*>(o) = xs;
+                        *reinterpret_cast<f32x4*>(o + 4) = ys;
+                    }
+                    u32x4 pk[2];
+                    unsigned pr[3];
+                    pl_split_pair_acc(xs[0], xs[1], s_agg, pr, sat); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                    pl_split_pair_acc(xs[2], xs[3], s_agg, pr, sat); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                    pl_split_pair_acc(ys[0], ys[1], s_agg, pr, sat); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                    pl_split_pair_acc(ys[2], ys[3], s_agg, pr, sat); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
+                }
+            }
+        }
+        __syncthreads();
+        stamp();
+        f32x4 xq[4];   // the epilogue's row addends, requested in front of the product
+        {
+            const int i = row0 + l31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < N) xq[q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + ccol + 8 * q + 4 * kg);
+            }
+        }
+        // ---- A2: Z = agg W0b^T (transposed), this workgroup's 128 columns ----
+        run(TRt{}, rs_agg, ct_a);
+        stamp();
+        // ---- A3: X = SiLU(Z + b0 + X_part) -> planes, to the exchange buffer ----
+        {
+            const float os = a.dsc[3] * (1.f / PL_SW), s_x = a.dsc[4];
+            const int i = row0 + l31;
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(a.b0 + ccol + 8 * q + 4 * kg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = ccol + 8 * q + 4 * kg;
+                float v[4];
+                f32x4 zpre;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) zpre[k] = (acc[4 * q + k] * os + bq[q][k]) + xq[q][k];
+                if (a.t_xpre && i < N) *reinterpret_cast<f32x4*>(a.t_xpre + (size_t)i * H + c4) = zpre;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = i < N ? silu_fast(zpre[k]) : 0.f;
+                unsigned p01[3], p23[3];
+                pl_split_pair_acc(v[0], v[1], s_x, p01, sat);
+                pl_split_pair_acc(v[2], v[3], s_x, p23, sat);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(a.xpl + ((size_t)pl * a.npad + i) * H + c4) = make_uint2(p01[pl], p23[pl]);
+            }
+            sat_report(sat);
+        }
+        stamp();
+        if (a.stages & 2) handover(0);
+    }
+    if (a.stages & 2) {
+        const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
+        // ---- the row block's X planes (all H columns) -> LDS: 2 x 32 rows of 2H bytes, 16-byte pieces ----
+        {
+            constexpr int PPR = H / 8, NP = 32 * PPR / 256;   // pieces per row, pieces per thread and plane
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {   // (a plane at a time: 32 registers of staging next to the weight ring)
+                u32x4 v[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int pc = tid + 256 * k, r = pc / PPR, c = pc % PPR;
+                    v[k] = *reinterpret_cast<const u32x4*>(a.xpl + ((size_t)pl * a.npad + row0 + r) * H + c * 8);
+                }
+                if (pl == 1) ring_fill(rs_n2, ct_a);   // behind the last piece loads (vector loads return in order)
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int pc = tid + 256 * k, r = pc / PPR, c = pc % PPR;
+                    *reinterpret_cast<u32x4*>(P + pl * PLB + r * ROWB + c * 16) = v[k];
+                }
+            }
+        }
+        f32x4 hq[4];   // the residual rows of A5
+        {
+            const int i = row0 + l31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < N) hq[q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + ccol + 8 * q + 4 * kg);
+            }
+        }
+        __syncthreads();
+        stamp();
+        // ---- A4: Y = X W2^T (transposed) ----
+        run(TRt{}, rs_n2, ct_a);
+        stamp();
+        // ---- A5: h' = h + SiLU(Y + b2) -> h_out ----
+        {
+            const float os = a.dsc[5] * (1.f / PL_SW);
+            const int i = row0 + l31;
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(a.b2 + ccol + 8 * q + 4 * kg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = ccol + 8 * q + 4 * kg;
+                f32x4 o, ypre;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ypre[k] = acc[4 * q + k] * os + bq[q][k];
+                if (a.t_ypre && i < N) *reinterpret_cast<f32x4*>(a.t_ypre + (size_t)i * H + c4) = ypre;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = silu_fast(ypre[k]) + hq[q][k];
+                if (i < N) *reinterpret_cast<f32x4*>(a.h_out + (size_t)i * H + c4) = o;
+            }
+        }
+        stamp();
+        if (a.stages & 4) handover(1);
+    }
+    if (!(a.stages & 4)) return;
+    const bool phaseB = a.Wln != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_ln = uniform_rsrc(a.Wln, 3 * wsz);
+    const float* hsrc = (a.stages & 2) ? a.h_out : a.h_in;   // (a launch of this stage alone is handed h' as h_in)
+    const bool tape_w = cgw == 0;   // (the gy workgroups of a row block compute the same LayerNorm: one writes the tape / the final rows)
+    // ---- LayerNorm (layernorm_kernel's arithmetic: a wave per row, a lane owns eight consecutive columns) ----
+    unsigned sat_ln = 0;
+    {
+        const int c0 = lane * 8;
+        const bool act = c0 < H;
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, b0 = w0, b1 = w0;
+        if (act) {
+            w0 = *reinterpret_cast<const f32x4*>(a.ln_w + c0);
+            w1 = *reinterpret_cast<const f32x4*>(a.ln_w + c0 + 4);
+            b0 = *reinterpret_cast<const f32x4*>(a.ln_b + c0);
+            b1 = *reinterpret_cast<const f32x4*>(a.ln_b + c0 + 4);
+        }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+        constexpr int RH = RPW / 2;
+        f32x4 xr[RH], yr[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {   // four rows of the wave requested at once
+            const int i = row0 + wave * RPW + half * RH + r;
+            xr[r] = yr[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (act && i < N) {
+                xr[r] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)i * H + c0);
+                yr[r] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)i * H + c0 + 4);
+            }
+        }
+        if (phaseB && half == 1) ring_fill(rs_ln, cgw * 4 + wave);   // behind the last row loads, in flight under the arithmetic
+#pragma unroll 2
+        for (int r = 0; r < RH; ++r) {
+            const int row = wave * RPW + half * RH + r, i = row0 + row;
+            const f32x4 x = xr[r], y = yr[r];
+            const float mean = wave_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3]))) / (float)H;
+            float q = 0.f;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float da = x[k] - mean, db = y[k] - mean;
+                    q += da * da + db * db;
+                }
+            }
+            const float var = wave_sum(q) / (float)H;
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            if (act && i < N) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o0[k] = (x[k] - mean) * rstd * w0[k] + b0[k];
+                    o1[k] = (y[k] - mean) * rstd * w1[k] + b1[k];
+                }
+                if (a.hf && tape_w) {
+                    *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0) = o0;
+                    *reinterpret_cast<f32x4*>(a.hf + (size_t)i * H + c0 + 4) = o1;
+                }
+                if (a.t_ln && tape_w) {
+                    *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0) = o0;
+                    *reinterpret_cast<f32x4*>(a.t_ln + (size_t)i * a.ld_ln + c0 + 4) = o1;
+                }
+            }
+            if (a.t_lnstat && tape_w && lane == 0 && i < N) {
+                a.t_lnstat[2 * (size_t)i] = mean;
+                a.t_lnstat[2 * (size_t)i + 1] = rstd;
+            }
+            if (act && phaseB) {
+                u32x4 pk[2];
+                unsigned pr[3];
+                pl_split_pair_acc(o0[0], o0[1], PL_S_LN, pr, sat_ln); pk[0][0] = pr[0]; pk[1][0] = pr[1];
+                pl_split_pair_acc(o0[2], o0[3], PL_S_LN, pr, sat_ln); pk[0][1] = pr[0]; pk[1][1] = pr[1];
+                pl_split_pair_acc(o1[0], o1[1], PL_S_LN, pr, sat_ln); pk[0][2] = pr[0]; pk[1][2] = pr[1];
+                pl_split_pair_acc(o1[2], o1[3], PL_S_LN, pr, sat_ln); pk[0][3] = pr[0]; pk[1][3] = pr[1];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(P + pl * PLB + row * ROWB + c0 * 2) = pk[pl];
+            }
+        }
+        }
+    }
+    sat_report(sat_ln);
+    if (!phaseB) return;
+    __syncthreads();
+    stamp();
+    // ---- phase B: [P_i | P_j | X_part] = y Wln^T: the 128-column groups cgw, cgw + gy, ... of the 3H columns (lane = column, registers = rows) ----
+    {
+        constexpr float os = 1.f / (PL_S_LN * PL_SW);
+        float m = 0.f;
+#pragma unroll 1
+        for (int g = cgw; g < 3 * NCG; g += gy) {
+            const int ct = g * 4 + wave;
+            run(TRf{}, rs_ln, ct);
+            if (g + gy < 3 * NCG) ring_fill(rs_ln, (g + gy) * 4 + wave);
+            const int col = ct * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float v = acc[r] * os;
+                if (i < N) {
+                    a.PQ[(size_t)i * (3 * H) + col] = v;
+                    m = fmaxf(m, fabsf(v));
+                }
+            }
+        }
+        if (a.absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) atomicMax(a.absmax, __float_as_uint(m));
+        }
+        stamp();
+    }
+}
+
+template <int H, int D>
+static int node_cols_launch(const NodeChainArgs& a, hipStream_t s) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_cols_kernel<H, D>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeColsCfg<H>::LDS); });
+    MI_HIP(attr_err);
+    const int nblk = cdiv(a.N, 32);
+    hipLaunchKernelGGL((node_cols_kernel<H, D>), dim3(8 * a.gy * cdiv(nblk, 8)), dim3(256), NodeColsCfg<H>::LDS, s, a);
+    MI_KERNEL_CHECK();
+    return MI_OK;
+}
+
 bool node_chain_supported(const mi_net* net) { return g_node_fused && net->cfg.ln && (net->H == 128 || net->H == 256 || net->H == 512) && net->Wnc != nullptr; }
 
 size_t node_chain_pack_elems(int H) { return (size_t)6 * H * H * 2; }  // per layer: [Wagg | Wn2 | Wln (3H rows) | W2 (edge_mlp.2, edge_stage.hip)] x two planes (u16 elements)
@@ -547,6 +964,7 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
 
 // The chain in front of layer l's edge stage (l = 0 .. L; l = L: finishes the last layer and applies the final LayerNorm into b->hf).
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
+    if (g_ablate_skip & 1) return MI_OK;
     const int H = net->H, L = net->L, N = b->N;
     const size_t NH = (size_t)N * H;
     NodeChainArgs a;
@@ -611,6 +1029,46 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
         if (H == 256) return node_chain_launch<256, 8, 4>(x, s);
         return node_chain_launch<128, 4, 4>(x, s);
     };
+    // The column-split form (mi_debug_set_node_cols; node_cols_kernel): three launches per layer boundary -- or one with in-launch hand-overs -- of light
+    // workgroups that own 32 rows x 128 columns of one product each.
+    if (g_node_cols && !a.slotmask && b->Xpl != nullptr) {   // (H = 128 / 256 / 512: node_chain_supported)
+        constexpr int NCGmax = 4;
+        const int nblk = cdiv(N, 32), NCG = H / 128;
+        (void)NCGmax;
+        auto launch_cols = [&](const NodeChainArgs& x) {
+            if (H == 512) return node_cols_launch<512, 8>(x, s);
+            if (H == 256) return node_cols_launch<256, 8>(x, s);
+            return node_cols_launch<128, 4>(x, s);
+        };
+        a.xpl = b->Xpl;
+        a.npad = nblk * 32;
+        // workgroups per row block of the LayerNorm + projection stage: one 128-column group each while the launch still fits the chip at two
+        // workgroups per CU, otherwise NCG (three groups each)
+        const int gyB = l < L ? (nblk * 3 * NCG <= g_node_cols_b_max ? 3 * NCG : NCG) : 1;
+        const bool one_launch = g_node_cols == 2 && l > 0 && l < L && b->nc_flags != nullptr && nblk * NCG <= g_node_cols_fused_max;
+        if (one_launch) {   // stages 1 | 2 | 4 behind two hand-overs; the row block's arrival counters were zeroed with the absmax slots
+            a.stages = 7;
+            a.gy = NCG;
+            a.flags = b->nc_flags + (size_t)l * 2 * nblk;
+            return launch_cols(a);
+        }
+        if (l > 0) {
+            NodeChainArgs a1 = a;
+            a1.stages = 1;
+            a1.gy = NCG;
+            a1.Wln = nullptr;
+            MI_TRY(launch_cols(a1));
+            a1.stages = 2;
+            MI_TRY(launch_cols(a1));
+        }
+        NodeChainArgs a2 = a;
+        a2.stages = 4;
+        a2.gy = gyB;
+        a2.part = nullptr;
+        a2.h_in = b->h + (size_t)l * NH;
+        a2.t_agg = a2.t_xpre = a2.t_ypre = nullptr;
+        return launch_cols(a2);
+    }
     // The chain is bound by the weight planes each workgroup streams through ITS CU's L2 port (1 MB per product: DESIGN 18.6); the three
     // projection passes are independent given LayerNorm(h'), so when three workgroups per row block still fit the chip in one round they
     // run as a second launch on three times the CUs (each recomputes the LayerNorm of its 32 rows).  Larger batches keep the one launch.
@@ -654,6 +1112,19 @@ extern "C" int mi_debug_set_node_split(int on) {
     const int was = mi::g_node_split;
     mi::g_node_split = on != 0;
     if (on > 1) mi::g_node_split_max_blocks = on;   // (experiments: the largest 3 x row-block count that still takes the two-launch form; default 256)
+    return was;
+}
+
+extern "C" int mi_debug_set_skip(int mask) {
+    const int was = mi::g_ablate_skip;
+    mi::g_ablate_skip = mask;
+    return was;
+}
+
+extern "C" int mi_debug_set_node_cols(int mode) {
+    const int was = mi::g_node_cols;
+    if (mode < 0 || mode > 2) return MI_EINVAL;
+    mi::g_node_cols = mode;
     return was;
 }
 

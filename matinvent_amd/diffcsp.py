@@ -231,7 +231,6 @@ class DiffCSPModule(nn.Module):
         streams = max(1, min(int(streams), len(na)))
         if streams == 1:
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
-        import threading
         key = ("split", streams, tuple(na))
         parts = getattr(batch, "_mi_split", {}).get(key)
         if parts is None:  # contiguous crystal groups, cached on the batch object like its CrystalBatch
@@ -250,30 +249,20 @@ class DiffCSPModule(nn.Module):
         self._coefficients(step_lr)
         cur = torch.cuda.current_stream()
         ready = cur.record_event()
-        from .streams import concurrent_streams
-        pool = concurrent_streams(streams, self.device)
-        out, err = [None] * streams, [None] * streams
+        # long-lived worker threads, one per stream (streams.ChainWorkers): a call hands each its chain and waits -- no thread start per call
+        from .streams import ChainWorkers
+        workers = ChainWorkers.get(streams, self.device)
 
-        def run(k):
-            try:
-                with torch.cuda.stream(pool[k]):
-                    pool[k].wait_event(ready)
-                    ini = None if init is None else (init[0][n0[k]:n0[k + 1]], init[1][g0[k]:g0[k + 1]], init[2][n0[k]:n0[k + 1]])
-                    nz = None if noise is None else {"corr_x": noise["corr_x"][:, n0[k]:n0[k + 1]], "pred_x": noise["pred_x"][:, n0[k]:n0[k + 1]],
-                                                     "pred_t": noise["pred_t"][:, n0[k]:n0[k + 1]], "pred_l": noise["pred_l"][:, g0[k]:g0[k + 1]]}
-                    out[k] = self._sample_one(parts[k], step_lr, seed, nz, ini, record, t_start, t_stop, node_offset + n0[k], graph_offset + g0[k])
-                    cur.wait_event(pool[k].record_event())
-            except BaseException as e:  # re-raised on the caller's thread
-                err[k] = e
+        def run(k, stream):
+            stream.wait_event(ready)
+            ini = None if init is None else (init[0][n0[k]:n0[k + 1]], init[1][g0[k]:g0[k + 1]], init[2][n0[k]:n0[k + 1]])
+            nz = None if noise is None else {"corr_x": noise["corr_x"][:, n0[k]:n0[k + 1]], "pred_x": noise["pred_x"][:, n0[k]:n0[k + 1]],
+                                             "pred_t": noise["pred_t"][:, n0[k]:n0[k + 1]], "pred_l": noise["pred_l"][:, g0[k]:g0[k + 1]]}
+            r = self._sample_one(parts[k], step_lr, seed, nz, ini, record, t_start, t_stop, node_offset + n0[k], graph_offset + g0[k])
+            cur.wait_event(stream.record_event())
+            return r
 
-        th = [threading.Thread(target=run, args=(k,)) for k in range(streams)]
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
-        for e in err:
-            if e is not None:
-                raise e
+        out = workers.run(run, streams)
 
         def merge(ds):
             m = {}

@@ -339,7 +339,10 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
         # 8 = form 3 with the pair-mode first edge GEMM on ONE accumulator set (128 x 256 tiles, the sine half of K a second time against -2 Wsin:
         # edge_gemm1e_kernel; widths that are multiples of 256, otherwise form 4's kernel)
         # 9 = form 3 with the pair-mode epilogue's 64-bit addressing (taken by itself only beyond 4 GB of operands)
-        for knob in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+        # 10 / 11 = form 3 with the chain's products COLUMN-SPLIT over workgroups (node_cols_kernel: 32 rows x 128 columns of one product per
+        # workgroup) as one launch per stage / as one launch per layer boundary with agent-scope flag hand-overs; forms 1 .. 9 keep the row-block chain
+        for knob in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            lib.mi_debug_set_node_cols(knob - 9 if knob >= 10 else 0)
             lib.mi_debug_set_pair_wide(1 if knob == 9 else 0)
             lib.mi_debug_set_node_fused(1 if knob >= 3 else knob)
             lib.mi_debug_set_edge2_fused(1 if knob >= 3 else 0)
@@ -351,6 +354,7 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
             assert all(torch.isfinite(x).all() for x in res[knob])
     finally:
         lib.mi_debug_set_node_fused(1)
+        lib.mi_debug_set_node_cols(0)
         lib.mi_debug_set_edge2_fused(1)
         lib.mi_debug_set_edge1_fused(9)   # (the default: the register-tile form for launches beyond the plane GEMM's small-launch forms)
         lib.mi_debug_set_edge_fused(0)
@@ -359,6 +363,9 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
     for knob in (4, 5, 6, 9):
         for a, b, w in zip(res[knob], res[3], ["pred_l", "pred_x", "pred_t"]):   # same epilogue, same k and term order: the same M1, bit for bit
             assert torch.equal(a, b), f"{w}: the first edge GEMM's forms differ (form {knob})"
+    for knob in (10, 11):   # the column-split chain: same arithmetic, same k and term order per output element -- every layer's features, bit for bit
+        for a, b, w in zip(res[knob], res[3], ["pred_l", "pred_x", "pred_t"] + [f"h after layer {l}" for l in range(L)]):
+            assert torch.equal(a, b), f"{w}: the column-split node chain (form {knob}) differs from the row-block launch"
     names = ["pred_l", "pred_x", "pred_t"] + [f"h after layer {l}" for l in range(L)]
     for knob in (1, 2, 3, 4, 5, 6, 7, 8):
         for a, b, w in zip(res[knob], res[0], names):
