@@ -29,23 +29,33 @@ if not os.environ.get("MI_ALLOW_PACKED_FP32"):   # (ablation only: rebuilds the 
 
 
 def _headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), __file__]
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), os.path.join(HERE, "..", "include", "matinvent_hip_debug.h"), __file__]
 
 
-def _flags_tag() -> str:
-    return " ".join(ARCH + CFLAGS + os.environ.get("MI_EXTRA_FLAGS", "").split())
+# Library variants: "" = the product library; "tf32" = the TF32-CLASS build (every plane-set product keeps its leading fp16 x fp16 term only:
+# csrc/gemm_split.h MI_TF32_CLASS) behind bench.py's labelled `extra.tf32_class_path` line and tests/test_gpu_tf32_class.py -- never loaded by default.
+VARIANTS = {"": [], "tf32": ["-DMI_TF32_CLASS=1"]}
 
 
-def _stale() -> bool:
+def lib_path(variant: str = "") -> str:
+    return LIB if not variant else os.path.join(HERE, "lib", f"libmatinvent_hip_{variant}.so")
+
+
+def _flags_tag(variant: str = "") -> str:
+    return " ".join(ARCH + CFLAGS + VARIANTS[variant] + os.environ.get("MI_EXTRA_FLAGS", "").split())
+
+
+def _stale(variant: str = "") -> bool:
     """Missing, older than a source, or LINKED UNDER OTHER FLAGS than the ones in force now (the tag written next to the library): a
     library built with MI_ALLOW_PACKED_FP32=1 or MI_EXTRA_FLAGS must not keep being loaded once the variable is gone."""
-    if not os.path.exists(LIB) or not os.path.exists(LIB + ".flags"):
+    lib = lib_path(variant)
+    if not os.path.exists(lib) or not os.path.exists(lib + ".flags"):
         return True
-    with open(LIB + ".flags") as f:
-        if f.read() != _flags_tag():
+    with open(lib + ".flags") as f:
+        if f.read() != _flags_tag(variant):
             return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), __file__]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "matinvent_hip.h"), os.path.join(HERE, "..", "include", "matinvent_hip_debug.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -59,25 +69,27 @@ def _obj_stale(src: str, obj: str, flags_tag: str) -> bool:
     return any(os.path.getmtime(d) > t for d in [src] + _headers())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     """Compile the library if it is missing or older than its sources.  Safe to call from several processes at once (one rank
     per GPU): an exclusive file lock serialises them, the linker writes to a temporary file that is renamed into place, and a
     process that waited for the lock re-checks before compiling again."""
-    if not force and not _stale():
-        return LIB
+    lib = lib_path(variant)
+    if not force and not _stale(variant):
+        return lib
     import fcntl
-    os.makedirs(OBJ, exist_ok=True)
-    with open(LIB + ".lock", "w") as lock:
+    objdir = OBJ if not variant else OBJ + "_" + variant
+    os.makedirs(objdir, exist_ok=True)
+    with open(lib + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not _stale():
-                return LIB
+            if not force and not _stale(variant):
+                return lib
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-            extra = os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
-            tag = _flags_tag()
+            extra = VARIANTS[variant] + os.environ.get("MI_EXTRA_FLAGS", "").split()  # tuning experiments (e.g. -DMI_UG=2 -DMI_RING=4)
+            tag = _flags_tag(variant)
 
             def compile_one(name: str) -> str:
-                src, obj = os.path.join(CSRC, name), os.path.join(OBJ, name.replace(".hip", ".o"))
+                src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace(".hip", ".o"))
                 if force or _obj_stale(src, obj, tag):
                     cmd = [hipcc] + ARCH + CFLAGS + extra + ["-c", src, "-o", obj]
                     if verbose:
@@ -95,23 +107,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
             with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
                 objs = list(pool.map(compile_one, SOURCES))
-            tmp = f"{LIB}.tmp{os.getpid()}"
+            tmp = f"{lib}.tmp{os.getpid()}"
             cmd = [hipcc] + ARCH + ["-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd), flush=True)
             try:
                 subprocess.run(cmd, check=True)
-                os.replace(tmp, LIB)
-                with open(LIB + ".flags", "w") as f:
+                os.replace(tmp, lib)
+                with open(lib + ".flags", "w") as f:
                     f.write(tag)
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    variants = [""] + (["tf32"] if "--tf32" in sys.argv or "--all" in sys.argv else [])
+    for v in variants:
+        print(build(force="--force" in sys.argv, variant=v))

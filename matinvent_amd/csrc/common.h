@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/matinvent_hip.h"
+#include "../../include/matinvent_hip_debug.h"
 
 namespace mi {
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 
+#define MI_GEMM_OWNER   // this unit defines the GEMM launchers of gemm.h / gemm_split.h (and therefore carries their kernels); the others see prototypes
 #include "edge_mlp.h"
 #include "gemm_split.h"
 #include "net.h"
@@ -1376,7 +1377,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         MI_HIP(hipMalloc((void**)&n->wbounds, (size_t)n->L * 8 * sizeof(float)));
         if (node_chain_pack_elems(H) && cfg_ln_and_wide(n)) MI_HIP(hipMalloc((void**)&n->Wnc, (size_t)n->L * node_chain_pack_elems(H) * sizeof(u16)));
         if (MI_PLANES_FP16 && H % 128 == 0) MI_HIP(hipMalloc((void**)&n->Wffc, (size_t)n->L * H * 2 * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));
-        if (MI_PLANES_FP16 && H % 256 == 0) MI_HIP(hipMalloc((void**)&n->Wffc2, (size_t)n->L * H * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));   // -2 x the sine block (edge_gemm1e_kernel)
+        if (MI_PLANES_FP16 && MI_HAVE_ABLATION_KERNELS && H % 256 == 0) MI_HIP(hipMalloc((void**)&n->Wffc2, (size_t)n->L * H * ((3 * n->F + 31) / 32 * 32) * 2 * sizeof(u16)));   // -2 x the sine block (edge_gemm1e_kernel)
         n->Kh = (3 * n->F + 31) / 32 * 32;
         MI_HIP(hipMalloc((void**)&n->Wffpl_pair, (size_t)n->L * planes_elems(H, 2 * n->Kh) * sizeof(u16)));
         MI_HIP(hipMalloc((void**)&n->C0, (size_t)n->L * H * sizeof(float)));
@@ -1774,6 +1775,7 @@ int mi_debug_set_planes_dma(int mode) {
 }
 
 int mi_plane_format(void) { return NPL; }
+int mi_terms_per_product(void) { return MI_TF32_CLASS ? 1 : 3; }
 
 int mi_debug_set_tn128(int on) {
     g_tn128 = (on & 1) != 0;

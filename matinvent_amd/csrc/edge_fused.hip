@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const f16x8*>(smem + EF_M1 + pl * EF_PLB + r * EF_ROWB + (16 * s + 8 * kg) * 2);
                 }
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
+                for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -73,6 +73,7 @@ constexpr int EG2_CHUNK = 2 * 128 * 256;            // bytes of one k-chunk in L
 constexpr int EG2_LDS = 2 * EG2_CHUNK + 128 * 4 + 128 * 4;   // two chunks + per-row local source + per-local-node slot base
 
 // D: depth of the weight ring in k-steps; AFB: 2 = the activation fragments of k-step s + 1 are read while k-step s multiplies
+#if MI_HAVE_ABLATION_KERNELS   // (the eight-wave 128 x 512 form: superseded by edge_gemm2b_kernel, kept for the recorded A/B)
 template <int D, int AFB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm2_kernel(EdgeGemm2Args a) {
     constexpr int H = 512, KS = H / 16;   // 32 k-steps of 16
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0): the plane GEMM's order
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stamp();
     sat_report(sat);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Form B (default): 128 rows x 256 columns per FOUR-wave workgroup, TWO workgroups per CU.  A wave does the same work as in the form
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                 for (int i = 2 * ip; i < 2 * ip + 2; ++i)
 #pragma unroll
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
     auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #endif
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                 for (int i = 2 * ip; i < 2 * ip + 2; ++i)
 #pragma unroll
@@ -750,6 +752,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // uses no LDS, so the NEXT tile's first three k-tiles (LDS-DMA from HBM) are requested before the epilogue starts -- a workgroup of
 // gemm_rt_kernel waits ~8 k cycles for those at its start (scripts/rt_phases.py).  The first wait of a tile is vmcnt(0) as before; it now also
 // covers the previous tile's plane stores, which were issued after the requests.
+#if MI_HAVE_ABLATION_KERNELS   // (the persistent form of the lean launch: did not recover its tail)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_rt_lean_kernel(Planes A, const u16* __restrict__ Wf, int M, int N, int K,
                                                                                                       PlanesEpilogue pe, unsigned long long* __restrict__ clk, int nvb) {
     const int KS = K >> 4, KT = K >> 5;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {   // operands swapped: transposed tiles (planes_epilogue_lean)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -882,6 +885,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         clk[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
     }
 }
+#endif
 
 // plane set [N x K] -> fragment order (exact copy): one thread per (row, 8-k chunk)
 __global__ void pack_frag_from_planes_kernel(Planes W, int N, int K, u16* __restrict__ dst) {
@@ -1069,14 +1073,14 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
                 if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
+                for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                     for (int i = 2 * ip; i < 2 * ip + 2; ++i)
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[0][term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1156,6 +1160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // 1 x at 1.7 x its floor; the epilogue work per emitted edge is unchanged.  Same products up to the order of the fp32 accumulation: M1
 // agrees with the two-set forms to fp32 round-off, not bit for bit.
 // ------------------------------------------------------------------------------------------------------------------------------------
+#if MI_HAVE_ABLATION_KERNELS   // (form E -- one accumulator set, the sine half twice: measured no faster than form b)
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void edge_gemm1e_kernel(Planes A, const u16* __restrict__ Wf, const u16* __restrict__ Wf2, int M,
                                                                                                      int N, int K, PlanesEpilogue pe, unsigned long long* clk) {
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
                 for (int i = 2 * ip; i < 2 * ip + 2; ++i)
 #pragma unroll
@@ -1263,7 +1268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto mma = [&](const u32x4 (&w)[2][2], const f16x8 (&af)[4][2]) {   // terms (a1, b0), (a0, b1), (a0, b0)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1339,6 +1344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     planes_epilogue_pairs_dir<4, 2>(pe, acc, 1, row0, qt * 256 + wave * 64, M, N, lane, patch, cps_local);
     stamp();
 }
+#endif
 
 // fragment-order pack of -2 x the SINE block of the Fourier weights (Kh columns): the second pass of edge_gemm1e_kernel
 __global__ void pack_frag_wff_sin_neg2_kernel(const float* __restrict__ W1, int edge_in, int H, int F, int Kh, u16* __restrict__ dst) {
@@ -1382,6 +1388,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     MI_HIP(attr_err);
     const int H = net->H, K = 2 * net->Kh;
     pe.out_scale = 1.f / (A.scale * PL_SW);
+#if MI_HAVE_ABLATION_KERNELS
     if (g_edge1_fused == 4 && H % 256 == 0 && net->Wffc2 && (K / 32) % 4 == 0) {   // form E: one accumulator set, 128 x 256 tiles, the sine half twice
         static std::once_flag once_e;
         static hipError_t attr_e = hipSuccess;
@@ -1397,6 +1404,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
         MI_KERNEL_CHECK();
         return MI_OK;
     }
+#endif
     const bool wide = MI_HAVE_ABLATION_KERNELS && g_edge1_fused == 2 && H % 256 == 0;   // 128 x 256 tiles, one four-wave workgroup per CU with 512 registers per lane
     int nblk = (H / (wide ? 256 : 128)) * ((cdiv(M, 128) + 7) / 8 * 8);
     if (pe.diag_C0) {
@@ -1441,8 +1449,10 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
+#if MI_HAVE_ABLATION_KERNELS
         attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2_LDS);
+#endif
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)edge_gemm2b_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_LDS);
     });
@@ -1466,9 +1476,12 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
         return MI_OK;
     }
     // 1 (default): form B -- 128 x 256 tiles, four waves, two workgroups per CU; 2 / 3: the eight-wave 128 x 512 form (ablations)
+#if MI_HAVE_ABLATION_KERNELS
     if (g_edge2_fused == 2) hipLaunchKernelGGL((edge_gemm2_kernel<2, 2>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
     else if (g_edge2_fused == 3) hipLaunchKernelGGL((edge_gemm2_kernel<4, 1>), dim3(cdiv(b->E, 128)), dim3(512), EG2_LDS, s, a);
-    else hipLaunchKernelGGL((edge_gemm2b_kernel<4>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
+    else
+#endif
+    hipLaunchKernelGGL((edge_gemm2b_kernel<4>), dim3(2 * ((cdiv(b->E, 128) + 7) / 8 * 8)), dim3(256), EG2B_LDS, s, a);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -1488,7 +1501,9 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
         attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+#if MI_HAVE_ABLATION_KERNELS
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)gemm_rt_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EG2B_NST * EG2B_STAGE);
+#endif
         if (const char* e = getenv("MI_RT_LEAN")) g_rt_lean = atoi(e) & 3;   // (A/B runs of whole test files: scripts/gpu_rt_lean_ab.sh)
     });
     MI_HIP(attr_err);
@@ -1509,9 +1524,12 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
             if (g_rt_clk_ext >= 0) g_rt_clk = nullptr;   // one launch
         }
     }
+#if MI_HAVE_ABLATION_KERNELS
     if (g_rt_lean >= 2 && planes_epilogue_is_lean(pe, false))
         hipLaunchKernelGGL(gemm_rt_lean_kernel, dim3(std::min<unsigned>(grid.x, (unsigned)g_rt_lean_grid)), dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk, (int)grid.x);
-    else if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
+    else
+#endif
+    if (g_rt_lean && planes_epilogue_is_lean(pe)) hipLaunchKernelGGL((gemm_rt_kernel<false, true>), grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     else if (ext) hipLaunchKernelGGL(gemm_rt_kernel<true>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     else hipLaunchKernelGGL(gemm_rt_kernel<false>, grid, dim3(256), EG2B_NST * EG2B_STAGE, s, A, Wfrag, M, N, K, pe, clk);
     MI_KERNEL_CHECK();

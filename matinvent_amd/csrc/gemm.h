@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 }
 
 // host launcher.  Requirements: K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, 16-byte aligned bases.
-inline int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                        const GemmEpilogue& ep, hipStream_t s) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt: K/lda/ldw must be multiples of 4 (%d,%d,%d)", K, lda, ldw);
     MI_CHECK((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, MI_EINVAL, "gemm_nt: operands must be 16-byte aligned");
@@ -181,6 +182,10 @@ inline int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* 
     MI_KERNEL_CHECK();
     return MI_OK;
 }
+#else
+int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                       const GemmEpilogue& ep, hipStream_t s);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM ("TN"):  C[Na, Kx] (+)= sum_m A[m, Na] * X[m, Kx]   (contraction over rows).
@@ -382,16 +387,21 @@ static __global__ void tn_reduce_kernel(const float* __restrict__ P, int nsplit,
         c[0] += s[0] * scale;
     }
 }
-inline void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, int Na, int Kx, hipStream_t s) {
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, int Na, int Kx, hipStream_t s) {
     if ((Kx & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0)
         hipLaunchKernelGGL(tn_reduce_kernel<true>, dim3(cdiv((int64_t)Na * (Kx / 4), 256)), dim3(256), 0, s, P, nsplit, PN, PK, C, ldc, Na, Kx, 1.0f);
     else
         hipLaunchKernelGGL(tn_reduce_kernel<false>, dim3(cdiv((int64_t)Na * Kx, 256)), dim3(256), 0, s, P, nsplit, PN, PK, C, ldc, Na, Kx, 1.0f);
 }
+#else
+void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, int Na, int Kx, hipStream_t s);
+#endif
 extern int g_tn_target_tiles;  // workgroups a long weight-gradient contraction is split into (over its row list); the partial tiles are summed by tn_reduce
 
 // C[Na,Kx] (ldc) += A^T X.  `scratch` must hold nsplit * ceil64(Na) * ceil64(Kx) floats.
-inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
                        size_t scratch_floats, hipStream_t s) {
     if (M <= 0 || Na <= 0 || Kx <= 0) return MI_OK;
     if (g_tn128 && Na >= 128 && Kx >= 128 && M >= 8192) {  // the edge / pair-list contractions
@@ -417,6 +427,10 @@ inline int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* 
     MI_KERNEL_CHECK();
     return MI_OK;
 }
+#else
+int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+                       size_t scratch_floats, hipStream_t s);
+#endif
 
 // out[c] += sum_z P[z][c]  (P row stride ldp): the second stage of the column-sum style reductions.  32 columns (one 128-byte line
 // per row) x 8 row groups per block, four independent chains per thread, combined through LDS in a fixed order (deterministic);
@@ -458,7 +472,8 @@ static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restr
     if (rg == 0 && c < Nc) P[(size_t)blockIdx.y * (gridDim.x * 64) + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s,
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s,
                       const int* row_idx = nullptr) {
     if (M <= 0 || Nc <= 0) return MI_OK;
     const int gx = cdiv(Nc, 64);
@@ -471,5 +486,9 @@ inline int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float*
     MI_KERNEL_CHECK();
     return MI_OK;
 }
+#else
+int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratch, size_t scratch_floats, hipStream_t s,
+                      const int* row_idx = nullptr);
+#endif
 
 }  // namespace mi

@@ -71,6 +71,15 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned (&p)[3]) 
 // four-waves-per-SIMD build of the 128-row loop: 15-16 spilled registers) are compiled only with -DMI_ABLATION_KERNELS: the default library
 // ships no kernel with scratch on any path, and the switches that select them (mi_debug_set_planes_big_seg, mi_debug_set_planes_dma(4))
 // return MI_EINVAL without it.
+// TF32-CLASS BUILD (-DMI_TF32_CLASS=1 -> lib/libmatinvent_hip_tf32.so, `python -m matinvent_amd.build --tf32`; never the default, never the
+// headline): every product of two PLANE SETS keeps its leading term only -- fp16(s a) x fp16(s b), i.e. 11-bit significands with f32
+// accumulation, the arithmetic class the reference itself runs after torch.set_float32_matmul_precision("high") (pipeline/mat_invent.py:127,
+// TF32 on its hardware) -- a third of the matrix-pipe work.  Plane sets, scales, saturation accounting, the fp32 sums (segmented means,
+// reductions) and the fp32-operand products that split on the fly are unchanged.
+#ifndef MI_TF32_CLASS
+#define MI_TF32_CLASS 0
+#endif
+#define MI_TERM0 (MI_TF32_CLASS ? 2 : 0)   // first term of the (a1 b0), (a0 b1), (a0 b0) sequences
 #ifdef MI_ABLATION_KERNELS
 #define MI_HAVE_ABLATION_KERNELS 1
 #else
@@ -331,8 +340,10 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (F16) {
+#if !MI_TF32_CLASS   // (the TF32-class build keeps the leading term only: 11-bit operands, f32 accumulate)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
+#endif
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
                         continue;
                     }
@@ -388,7 +399,8 @@ static __global__ void splitk_reduce_kernel(const float* __restrict__ part, int 
     C[(size_t)row * ldc + col] = apply_epilogue(ep, v, row, col);
 }
 
-inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
                          hipStream_t s, const SplitK* sk = nullptr, const unsigned* amax_a = nullptr, const unsigned* amax_w = nullptr) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt_split: K/lda/ldw must be multiples of 4");
     if (M <= 0 || N <= 0) return MI_OK;
@@ -418,6 +430,10 @@ inline int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float
     MI_KERNEL_CHECK();
     return MI_OK;
 }
+#else
+int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
+                         hipStream_t s, const SplitK* sk = nullptr, const unsigned* amax_a = nullptr, const unsigned* amax_w = nullptr);
+#endif
 
 // Which matrix path the node- and edge-level GEMMs take (process-wide; set by mi_set_gemm_mode).
 //   MI_GEMM_SPLIT (default): three-plane bf16 split, six terms -- fp32-class accuracy, bf16 matrix pipe
@@ -1464,8 +1480,10 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // the two residual cross terms first, the leading term last
+#if !MI_TF32_CLASS   // (the TF32-class build keeps the leading term only: 11-bit operands, f32 accumulate)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
 #else
@@ -1536,8 +1554,10 @@ __device__ __forceinline__ void gemm_planes_body(Planes A, Planes W, int M, int 
             for (int pl = 0; pl < 2; ++pl) f.b[j][pl] = *reinterpret_cast<const f16x8*>(st + (2 + pl) * 8192 + r * 64 + c * 16);
         };
         auto mma3 = [&](const Frag& f, int i, int j) {   // the three terms in the register-staged loop's order
+#if !MI_TF32_CLASS   // (the TF32-class build keeps the leading term only: 11-bit operands, f32 accumulate)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
         };
         f32x16 accS[V == 1 ? TM : 1][V == 1 ? TN : 1];
@@ -1815,8 +1835,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int pl = 0; pl < 2; ++pl) f.a[i][pl] = *reinterpret_cast<const f16x8*>(Ab + pl * 8192 + r * 64 + c * 16);
     };
     auto mma3 = [&](const Frag& f, int i, int j) {   // the three terms of one accumulator tile, in the 128 x 128 kernel's order
+#if !MI_TF32_CLASS   // (the TF32-class build keeps the leading term only: 11-bit operands, f32 accumulate)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+#endif
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
     };
     auto dma_piece = [&](int kt, int stage, int sub) {
@@ -2124,8 +2146,10 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+#if !MI_TF32_CLASS   // (the TF32-class build keeps the leading term only: 11-bit operands, f32 accumulate)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+#endif
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                     }
 #endif
@@ -2180,7 +2204,8 @@ inline bool gemm_tn_is_split(const float* A, int lda, const float* X, int ldx, i
            ((((uintptr_t)A) | ((uintptr_t)X)) & 7) == 0;
 }
 // sa / sx (fp16 plane format): optional device-side {scale, 1 / scale} of the two operands -> two-plane fp16 split, three terms
-inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
                         size_t scratch_floats, hipStream_t s, bool x_silu = false, const float* sa = nullptr, const float* sx = nullptr) {
     if (gemm_tn_is_split(A, lda, X, ldx, M, Na, Kx)) {
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
@@ -2202,6 +2227,10 @@ inline int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float*
     MI_CHECK(!x_silu, MI_EINVAL, "gemm_tn_auto: silu on the X operand needs the bf16-pipe kernel (check gemm_tn_is_split first)");
     return gemm_tn_acc(A, lda, X, ldx, C, ldc, M, Na, Kx, scratch, scratch_floats, s);
 }
+#else
+int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
+                        size_t scratch_floats, hipStream_t s, bool x_silu = false, const float* sa = nullptr, const float* sx = nullptr);
+#endif
 
 // edge_stage.hip: C = A W^T on 128-row x 256-column register tiles (four waves, W in fragment order from L2, A by LDS-DMA), row-major epilogue
 int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const PlanesEpilogue& pe, bool ext, hipStream_t s);
@@ -2217,7 +2246,8 @@ inline bool pairs_fit_32bit(int64_t nodes, int ld_node, int64_t graphs, int ld_g
            nodes * ld_node * 4 < lim && graphs * ld_graph * 4 < lim && edges * H * 4 < lim && plane_bytes < lim && ((int64_t)((H + 31) / 32) * 12288 + 2048) * 2 < u24;
 }
 
-inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s) {
+#ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
+int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s) {
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
@@ -2326,5 +2356,8 @@ inline int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, co
     MI_KERNEL_CHECK();
     return MI_OK;
 }
+#else
+int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const PlanesEpilogue& pe_in, hipStream_t s);
+#endif
 
 }  // namespace mi

@@ -30,8 +30,12 @@ int g_node_fused = 1;  // inference forwards: the node-level chain as one launch
 int g_node_split = 1;  // small / medium batches: phase A and LayerNorm + projections as two launches, the second on three workgroups per row block (0: one launch)
 int g_node_split_max_blocks = 256;   // ... while those fit the chip in one round (one workgroup per CU)
 int g_ablate_skip = 0;   // TIMING ABLATIONS ONLY (results are garbage): bit 0 = skip the node chain's launches, 1 = the first edge GEMM, 2 = the second (mi_debug_set_skip)
-int g_node_cols = 0;   // the column-split form of the chain (node_cols_kernel): 0 = off (default: measured 7 % SLOWER on the headline), 1 = one launch per stage, 2 = one launch per layer boundary with in-launch hand-overs
-int g_node_cols_b_max = 512;       // LayerNorm + projections: one 128-column group per workgroup up to this many workgroups, three above
+int g_node_cols = 3;   // the column-split form of the chain (node_cols_kernel): 3 = automatic (default: one launch per stage for chains of at most g_node_cols_auto_blocks
+                       // row blocks -- the reference's default sampling batch, +3 %; the row-block forms above for larger ones -- the headline's chains measured equal, one
+                       // chain of 256 crystals 2.5 % slower: DESIGN 19.1), 1 = one launch per stage always, 2 = one launch per layer boundary with in-launch hand-overs, 0 = off
+int g_node_cols_auto_blocks = 36;
+int g_node_cols_b_max = 0;         // LayerNorm + projections: one 128-column group per workgroup up to this many workgroups, NCG groups each above (0: always NCG -- 3 x NCG workgroups
+                                   // per row block each re-reading h' and recomputing its LayerNorm measured 85 against 62 us per launch under four chains)
 int g_node_cols_fused_max = 256;   // the one-launch form only while every workgroup of the launch is resident at once (a waiting workgroup holds its slot)
 
 #if MI_PLANES_FP16
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     auto mma_step = [&](auto tr, const u32x4 (&w)[TW][2], const f16x8 (&af)[2]) {
         constexpr bool TR = decltype(tr)::value;
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = MI_TERM0; term < 3; ++term)
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
                 const f16x8 wv = __builtin_bit_cast(f16x8, w[t][term == 1 ? 1 : 0]);
@@ -550,10 +554,10 @@ static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
 template <int H>
 struct NodeColsCfg {
     static constexpr int KS = H / 16, ROWB = 2 * H + 16, PLB = 32 * ROWB, NCG = H / 128;
-    static constexpr int LDS = 2 * PLB;
+    static constexpr int LDS = 2 * PLB + 32;   // (+ 32: the fragment read one k-step ahead of the last row's last step lands here)
 };
 
-template <int H, int D>
+template <int H, int D, int ST>   // ST: the stages this instantiation runs (1, 2, 4: one per launch; 7: all three behind hand-overs)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void node_cols_kernel(NodeChainArgs a) {
     using C = NodeColsCfg<H>;
     constexpr int KS = C::KS, ROWB = C::ROWB, PLB = C::PLB, NCG = C::NCG, RPW = 8;
@@ -578,14 +582,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32x4 ring[D][2];
     f32x16 acc;
     const int voff = lane * 16;
-    auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, int ct, int ks, u32x4 (&w)[2]) {
-        const int so = (ct * KS + ks) * 2048;
+    // One descriptor per (operand, column tile): exactly the tile's KS k-steps.  The k-loop has no tail -- every step refills its ring slot D
+    // steps ahead, and the refills past the tile's end are out of range: they return zeros without a memory access (the k-step offset sits in
+    // the VECTOR offset, which the range check covers), so the loop body is one uniform block whatever D is.
+    auto tile_rsrc = [&](const u16* W, int ct) { return uniform_rsrc(W + (size_t)ct * KS * 1024, KS * 2048); };
+    // (ks = kv + d: the part that can run past the tile's end, kv, in the vector offset -- ONE register per D steps --, the slot d in the scalar offset)
+    auto ring_load = [&](const __amdgpu_buffer_rsrc_t& rs, int vo, int d, u32x4 (&w)[2]) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + pl * 1024, so, 0);
+        for (int pl = 0; pl < 2; ++pl) w[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + pl * 1024, d * 2048, 0);
     };
-    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rs, int ct) {
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rs) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) ring_load(rs, ct, d, ring[d]);
+        for (int d = 0; d < D; ++d) ring_load(rs, voff, d, ring[d]);
     };
     auto read_act = [&](int ks, f16x8 (&af)[2]) {
 #pragma unroll
@@ -595,32 +603,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto mma_step = [&](auto tr, const u32x4 (&w)[2], const f16x8 (&af)[2]) {
         constexpr bool TR = decltype(tr)::value;
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
+        for (int term = MI_TERM0; term < 3; ++term) {
             const f16x8 wv = __builtin_bit_cast(f16x8, w[term == 1 ? 1 : 0]);
             const f16x8 av = af[term == 0 ? 1 : 0];
             if constexpr (TR) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, av, acc, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc, 0, 0, 0);
         }
     };
-    auto run = [&](auto tr, const __amdgpu_buffer_rsrc_t& rs, int ct) {   // the ring holds k-steps 0 .. D-1 on entry, nothing on exit
+    auto run = [&](auto tr, const __amdgpu_buffer_rsrc_t& rs) {   // the ring holds k-steps 0 .. D-1 on entry
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         f16x8 af[2][2];
         read_act(0, af[0]);
 #pragma unroll 1
-        for (int ks0 = 0; ks0 < KS - D; ks0 += D) {
+        for (int ks0 = 0; ks0 < KS; ks0 += D) {
+            const int vo = voff + (ks0 + D) * 2048;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 read_act(ks0 + d + 1, af[(d + 1) & 1]);
                 mma_step(tr, ring[d], af[d & 1]);
-                ring_load(rs, ct, ks0 + d + D, ring[d]);
+                ring_load(rs, vo, d, ring[d]);
                 __builtin_amdgcn_sched_barrier(0);   // (pins the refill behind its slot's use: see node_chain_kernel)
             }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (d + 1 < D) read_act(KS - D + d + 1, af[(d + 1) & 1]);
-            mma_step(tr, ring[d], af[d & 1]);
         }
     };
     using TRt = std::true_type;
@@ -640,12 +644,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
     };
 
-    const int wsz = H * H * 4;  // bytes of one packed H x H operand
     const int cg = cgw;         // stages 1 and 2: this workgroup's 128-column group (gy == NCG)
     const int ct_a = cg * 4 + wave;
     const int ccol = cg * 128 + wave * 32;   // first column of the wave's tile
-    if (a.stages & 1) {
-        const __amdgpu_buffer_rsrc_t rs_agg = uniform_rsrc(a.Wagg, wsz);
+    if constexpr ((ST & 1) != 0) {
+        const __amdgpu_buffer_rsrc_t rs_agg = tile_rsrc(a.Wagg, ct_a);
         // ---- A1: agg = (sum of the node's slots) / degree -> planes, all H columns (every workgroup of the row block needs the whole K) ----
         const float s_agg = a.dsc[2];
         unsigned sat = 0;
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                     }
                 }
-                if (half == 1) ring_fill(rs_agg, ct_a);   // behind the last gathers (vector loads return in order), in flight under the arithmetic
+                if (half == 1) ring_fill(rs_agg);   // behind the last gathers (vector loads return in order), in flight under the arithmetic
 #pragma unroll
                 for (int r = 0; r < RH; ++r) {
                     const int row = wave * RPW + half * RH + r, i = row0 + row;
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         // ---- A2: Z = agg W0b^T (transposed), this workgroup's 128 columns ----
-        run(TRt{}, rs_agg, ct_a);
+        run(TRt{}, rs_agg);
         stamp();
         // ---- A3: X = SiLU(Z + b0 + X_part) -> planes, to the exchange buffer ----
         {
@@ -759,10 +762,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             sat_report(sat);
         }
         stamp();
-        if (a.stages & 2) handover(0);
+        if constexpr ((ST & 2) != 0) handover(0);
     }
-    if (a.stages & 2) {
-        const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
+    if constexpr ((ST & 2) != 0) {
+        const __amdgpu_buffer_rsrc_t rs_n2 = tile_rsrc(a.Wn2, ct_a);
         // ---- the row block's X planes (all H columns) -> LDS: 2 x 32 rows of 2H bytes, 16-byte pieces ----
         {
             constexpr int PPR = H / 8, NP = 32 * PPR / 256;   // pieces per row, pieces per thread and plane
@@ -774,12 +777,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int pc = tid + 256 * k, r = pc / PPR, c = pc % PPR;
                     v[k] = *reinterpret_cast<const u32x4*>(a.xpl + ((size_t)pl * a.npad + row0 + r) * H + c * 8);
                 }
-                if (pl == 1) ring_fill(rs_n2, ct_a);   // behind the last piece loads (vector loads return in order)
+                if (pl == 1) ring_fill(rs_n2);   // behind the last piece loads (vector loads return in order)
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     const int pc = tid + 256 * k, r = pc / PPR, c = pc % PPR;
                     *reinterpret_cast<u32x4*>(P + pl * PLB + r * ROWB + c * 16) = v[k];
                 }
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the second plane's loads behind the first plane's LDS writes: both in registers at once spill)
             }
         }
         f32x4 hq[4];   // the residual rows of A5
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         stamp();
         // ---- A4: Y = X W2^T (transposed) ----
-        run(TRt{}, rs_n2, ct_a);
+        run(TRt{}, rs_n2);
         stamp();
         // ---- A5: h' = h + SiLU(Y + b2) -> h_out ----
         {
@@ -816,12 +820,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         stamp();
-        if (a.stages & 4) handover(1);
+        if constexpr ((ST & 4) != 0) handover(1);
     }
-    if (!(a.stages & 4)) return;
+    if constexpr ((ST & 4) == 0) return;
     const bool phaseB = a.Wln != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_ln = uniform_rsrc(a.Wln, 3 * wsz);
-    const float* hsrc = (a.stages & 2) ? a.h_out : a.h_in;   // (a launch of this stage alone is handed h' as h_in)
+    const float* hsrc = (ST & 2) ? a.h_out : a.h_in;   // (a launch of this stage alone is handed h' as h_in)
     const bool tape_w = cgw == 0;   // (the gy workgroups of a row block compute the same LayerNorm: one writes the tape / the final rows)
     // ---- LayerNorm (layernorm_kernel's arithmetic: a wave per row, a lane owns eight consecutive columns) ----
     unsigned sat_ln = 0;
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 yr[r] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)i * H + c0 + 4);
             }
         }
-        if (phaseB && half == 1) ring_fill(rs_ln, cgw * 4 + wave);   // behind the last row loads, in flight under the arithmetic
+        if (phaseB && half == 1) ring_fill(tile_rsrc(a.Wln, cgw * 4 + wave));   // behind the last row loads, in flight under the arithmetic
 #pragma unroll 2
         for (int r = 0; r < RH; ++r) {
             const int row = wave * RPW + half * RH + r, i = row0 + row;
@@ -908,8 +911,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
         for (int g = cgw; g < 3 * NCG; g += gy) {
             const int ct = g * 4 + wave;
-            run(TRf{}, rs_ln, ct);
-            if (g + gy < 3 * NCG) ring_fill(rs_ln, (g + gy) * 4 + wave);
+            run(TRf{}, tile_rsrc(a.Wln, ct));
+            if (g + gy < 3 * NCG) ring_fill(tile_rsrc(a.Wln, (g + gy) * 4 + wave));
             const int col = ct * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -930,16 +933,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int H, int D>
-static int node_cols_launch(const NodeChainArgs& a, hipStream_t s) {
+template <int H, int D, int ST>
+static int node_cols_launch_st(const NodeChainArgs& a, hipStream_t s) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_cols_kernel<H, D>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeColsCfg<H>::LDS); });
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_cols_kernel<H, D, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeColsCfg<H>::LDS); });
     MI_HIP(attr_err);
     const int nblk = cdiv(a.N, 32);
-    hipLaunchKernelGGL((node_cols_kernel<H, D>), dim3(8 * a.gy * cdiv(nblk, 8)), dim3(256), NodeColsCfg<H>::LDS, s, a);
+    hipLaunchKernelGGL((node_cols_kernel<H, D, ST>), dim3(8 * a.gy * cdiv(nblk, 8)), dim3(256), NodeColsCfg<H>::LDS, s, a);
     MI_KERNEL_CHECK();
     return MI_OK;
+}
+template <int H, int D>
+static int node_cols_launch(const NodeChainArgs& a, hipStream_t s) {
+    switch (a.stages) {
+        case 1: return node_cols_launch_st<H, D, 1>(a, s);
+        case 2: return node_cols_launch_st<H, D, 2>(a, s);
+        case 4: return node_cols_launch_st<H, D, 4>(a, s);
+        case 7: return node_cols_launch_st<H, D, 7>(a, s);
+    }
+    return MI_EINVAL;
 }
 
 bool node_chain_supported(const mi_net* net) { return g_node_fused && net->cfg.ln && (net->H == 128 || net->H == 256 || net->H == 512) && net->Wnc != nullptr; }
@@ -1031,12 +1044,12 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     };
     // The column-split form (mi_debug_set_node_cols; node_cols_kernel): three launches per layer boundary -- or one with in-launch hand-overs -- of light
     // workgroups that own 32 rows x 128 columns of one product each.
-    if (g_node_cols && !a.slotmask && b->Xpl != nullptr) {   // (H = 128 / 256 / 512: node_chain_supported)
+    if (g_node_cols && (g_node_cols != 3 || cdiv(N, 32) <= g_node_cols_auto_blocks) && !a.slotmask && b->Xpl != nullptr) {   // (H = 128 / 256 / 512: node_chain_supported)
         constexpr int NCGmax = 4;
         const int nblk = cdiv(N, 32), NCG = H / 128;
         (void)NCGmax;
         auto launch_cols = [&](const NodeChainArgs& x) {
-            if (H == 512) return node_cols_launch<512, 8>(x, s);
+            if (H == 512) return node_cols_launch<512, 16>(x, s);
             if (H == 256) return node_cols_launch<256, 8>(x, s);
             return node_cols_launch<128, 4>(x, s);
         };
@@ -1123,8 +1136,9 @@ extern "C" int mi_debug_set_skip(int mask) {
 
 extern "C" int mi_debug_set_node_cols(int mode) {
     const int was = mi::g_node_cols;
-    if (mode < 0 || mode > 2) return MI_EINVAL;
-    mi::g_node_cols = mode;
+    if (mode < 0 || (mode & 255) > 3) return MI_EINVAL;
+    mi::g_node_cols = mode & 255;
+    if (mode >> 8) mi::g_node_cols_b_max = (mode >> 8) - 1;   // (experiments: the workgroup count up to which LayerNorm + projections take one column group per workgroup)
     return was;
 }
 

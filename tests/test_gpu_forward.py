@@ -354,7 +354,7 @@ def test_node_chain_launch_vs_the_seven_launch_form(H, L, F, num_atoms, style):
             assert all(torch.isfinite(x).all() for x in res[knob])
     finally:
         lib.mi_debug_set_node_fused(1)
-        lib.mi_debug_set_node_cols(0)
+        lib.mi_debug_set_node_cols(3)
         lib.mi_debug_set_edge2_fused(1)
         lib.mi_debug_set_edge1_fused(9)   # (the default: the register-tile form for launches beyond the plane GEMM's small-launch forms)
         lib.mi_debug_set_edge_fused(0)

@@ -134,3 +134,82 @@ def test_baseline_config0_shape_vs_oracle(tmp_path):
         assert np.minimum(dx, 1 - dx).max() < 5e-3
         np.testing.assert_allclose(d.lengths.numpy()[0], o_len[i].numpy(), rtol=5e-3)
         np.testing.assert_allclose(d.angles.numpy()[0], o_ang[i].numpy(), rtol=5e-3, atol=0.5)
+
+
+def test_config4_rehearsal_two_property_reward_with_replay_on_one_gpu(tmp_path):
+    """BASELINE configs[4] on ONE GPU: pipeline=mat_invent model=diffcsp with a MULTI-OBJECTIVE reward (two property columns reduced by
+    `mean`, rewards/reward.py:102-103) and the replay buffer enabled, through dropin/main.py.  From the second loop on the fine-tune set
+    is top-k + replayed crystals -- ragged, and larger than finetune_cfg.batch_size x topk_ratio (configs/pipeline/mat_invent.yaml:19-21).
+    That loop's update is checked against the oracle's restatement of pipeline/mat_invent.py:125-189 on the SAME set: the pipeline's own
+    call is re-run from the parameters it started from with injected noise, next to O.ft_step consuming that noise."""
+    from oracle import diffcsp_oracle as O
+    from matinvent_amd import finetune
+    from matinvent_amd import pipeline as PL
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    calls = []
+    real = PL.MatInvent.ft_step
+
+    def spy(self, data_list, rewards, baseline=None):
+        calls.append(dict(data=list(data_list), rewards=np.asarray(rewards, dtype=float).copy(), theta=self.agent.decoder.theta.detach().clone()))
+        return real(self, data_list, rewards, baseline)
+
+    PL.MatInvent.ft_step = spy
+    try:
+        import main as dropin_main
+        np.random.seed(0)
+        H, L, F, T = 64, 2, 8, 20
+        tiny = [f"+model.hparams.decoder.hidden_dim={H}", f"+model.hparams.decoder.num_layers={L}", f"+model.hparams.decoder.num_freqs={F}",
+                f"+model.hparams.beta_scheduler.timesteps={T}", f"+model.hparams.sigma_scheduler.timesteps={T}", "model.head_scale=0.1"]
+        rl = dropin_main.main(["expname=cfg4", "eval_size=8", "rl_epoch=3", "model.finetune_cfg.timesteps=4", "pipeline.finetune_cfg.accum_steps=2",
+                               "pipeline.finetune_cfg.epochs=1", "device=cuda:0", "+sample_cfg.geometric_filter=false",
+                               "reward.mode=uniform", "+reward.n_props=2", "+reward.reduce=mean",            # two objectives, reduced by mean
+                               "pipeline.replay=True", "pipeline.replay_args.sample_size=5", "pipeline.replay_args.reward_cutoff=0.0"] + tiny)
+        rows = (tmp_path / "exp_res" / "cfg4" / "metrics.csv").read_text().strip().splitlines()
+        assert len(rows) == 4 and "synthetic mean" in rows[0] and "synthetic_1 mean" in rows[0] and "reward mean" in rows[0]
+        assert len(calls) == 3 and len(rl.replay) > 0
+        topk = int(8 * 0.5)
+        assert len(calls[0]["data"]) == topk                     # first loop: nothing to replay yet
+        c = calls[1]
+        assert topk < len(c["data"]) <= topk + 5                 # top-k + replayed crystals
+        na = [int(d.num_atoms) for d in c["data"]]
+        assert len(set(na)) > 1                                  # ragged
+        # ---- that fine-tune set, from the parameters the pipeline started it with, against the oracle ----
+        agent, prior = rl.agent, rl.prior
+        with torch.no_grad():
+            agent.decoder.theta.data.copy_(c["theta"])
+        agent.decoder.mark_dirty()
+        P0 = {"decoder." + k: v.detach().cpu().clone() for k, v in agent.decoder.views().items()}
+        Q0 = {"decoder." + k: v.detach().cpu().clone() for k, v in prior.decoder.views().items()}
+        gen = torch.Generator().manual_seed(5)
+        B, N, TS = len(na), sum(na), 2
+        noises = {(0, t): (torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen)) for t in range(TS)}
+        cfg = dict(lr=1e-4, accum_steps=TS, epochs=1, timesteps=TS, sigma=0.025)
+        stats = finetune.ft_step(agent, prior, c["data"], c["rewards"], cfg, noise_fn=lambda e, t: noises[(e, t)], fused=True)
+        hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+        sch = O.Schedules.make(T, sigmas_norm=agent.sigma_scheduler.sigmas_norm.cpu())
+        sch.beta = {k: getattr(agent.beta_scheduler, k).cpu() for k in ("betas", "alphas", "alphas_cumprod", "sigmas")}
+        batch = dict(num_atoms=torch.tensor(na), lengths=torch.cat([d.lengths for d in c["data"]]), angles=torch.cat([d.angles for d in c["data"]]),
+                     frac_coords=torch.cat([d.frac_coords for d in c["data"]]), atom_types=torch.cat([d.atom_types for d in c["data"]]))
+        A = {k: v.clone() for k, v in P0.items()}
+        rec = {}
+        O.ft_step(A, Q0, hp, sch, O.Costs(), batch, torch.from_numpy(c["rewards"]).float(),
+                  lambda e, t: dict(zip(("rand_l", "rand_x", "rand_t"), noises[(e, t)])), lr=1e-4, timesteps=TS, accum_steps=TS, sigma=0.025,
+                  epochs=1, record=rec)
+        ref_loss = float(torch.stack(rec["loss"][:TS]).sum())
+        assert abs(stats[0]["loss"] - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (stats[0]["loss"], ref_loss)
+        rw = torch.from_numpy(c["rewards"]).float()
+        ref_diff = float(sum((rw * l).sum() for l in rec["sample_loss"][:TS]) / TS / B)   # the GLOBAL count of the ragged set (mat_invent.py:163)
+        assert abs(stats[0]["loss_diff"] - ref_diff) <= 1e-4 * max(1.0, abs(ref_diff))
+        bad = tot = 0
+        for k, w in agent.decoder.views().items():
+            d = (w.detach().cpu() - A["decoder." + k]).abs()
+            assert float(d.max()) <= 2.1e-4, f"{k}: {float(d.max())}"   # one Adam step of lr 1e-4: a sign flip of a near-zero gradient moves 2 lr
+            bad += int((d > 1e-5).sum())
+            tot += d.numel()
+        assert bad <= 0.02 * tot
+    finally:
+        PL.MatInvent.ft_step = real
+        os.chdir(cwd)
+        sys.path.remove(os.path.join(ROOT, "dropin"))

@@ -384,11 +384,12 @@ def test_stacked_timesteps_reproduce_the_sequential_update_with_device_noise():
         assert abs(sa[0][key] - sb[0][key]) <= 1e-5 * max(1.0, abs(sa[0][key])), key
 
 
-def test_ft_step_benchmark_hparams_concurrent_groups_vs_oracle():
+@pytest.mark.parametrize("ncrys", [192, 256], ids=["192-crystals-4x48", "benchmark-256-crystals-4x64"])
+def test_ft_step_benchmark_hparams_concurrent_groups_vs_oracle(ncrys):
     """The route `bench.py --mode ft` takes at B = 256 (four concurrent crystal groups on separate streams with separate gradient
     buffers, summed before the optimizer step; the node-level weight gradients of the window's micro-steps contracted together) at the
-    BENCHMARK network H=512, L=6, F=128: 192 crystals x 20 atoms = 76 800 edges in four groups of 48 (each group's kernels are the
-    large-list ones), one accumulation window of two timesteps with injected noise, against the oracle's restatement of
+    BENCHMARK network H=512, L=6, F=128: 192 crystals x 20 atoms = 76 800 edges in four groups of 48, and the benchmark's own 256 crystals
+    in four groups of 64 (BASELINE configs[2]: each group's kernels are the large-list ones), one accumulation window of two timesteps with injected noise, against the oracle's restatement of
     pipeline/mat_invent.py:125-189."""
     from matinvent_amd.data import CrystalData
     from matinvent_amd.finetune import auto_groups, ft_step
@@ -402,7 +403,7 @@ def test_ft_step_benchmark_hparams_concurrent_groups_vs_oracle():
     sn = torch.cat([torch.ones(1), 0.5 + torch.rand(1000, generator=gen)])
     agent, prior = make_module(H, L, F, 1000, P0, sigmas_norm=sn), make_module(H, L, F, 1000, Q0, sigmas_norm=sn)
     prior.requires_grad_(False)
-    na = [20] * 192
+    na = [20] * ncrys
     data = [CrystalData(torch.rand(n, 3, generator=gen), torch.randint(1, 95, (n,), generator=gen), 4 + 6 * torch.rand(1, 3, generator=gen),
                         70 + 40 * torch.rand(1, 3, generator=gen)) for n in na]
     rewards = torch.rand(len(na), generator=gen).numpy()
