@@ -744,6 +744,22 @@ def _self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def tf32_class_leg(args, K, W):
+    """extra.tf32_class_path: `bench.py --path tf32-class` as a child process (another library build cannot be loaded beside the product one)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--path", "tf32-class", "--steps", str(K), "--warmup", str(W), "--streams", str(args.streams),
+           "--no-cpu-baseline", "--no-counters"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
+                "terms_per_product": 1, "tolerance": "stated and tested in tests/test_gpu_tf32_class.py: 5e-4 of max|ref| on a benchmark-width forward (measured 1.6e-4), 5e-4 on accumulated gradients; the product path: 2e-5 (measured 7e-7 / 6e-6)",
+                "note": "labelled secondary line, never the headline: north_star's tolerance is fp32"}
+    except Exception as e:   # (never let the secondary figure take the headline down)
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -753,10 +769,12 @@ def main():
     ap.add_argument("--ft-groups", type=int, default=None, help="--mode ft: crystal groups fine-tuned concurrently (default: automatic)")
     ap.add_argument("--streams", type=int, default=4, help="crystal groups of the batch sampled concurrently on separate HIP "
                     "streams (same samples: the noise is indexed by global ids)")
-    ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused"], default="split-gemm",
+    ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused", "tf32-class"], default="split-gemm",
                     help="arithmetic path: split-gemm (default) = fp32 products on the fp16 matrix pipe from two pre-split fp16 planes per operand "
                          "(three MFMA terms, f32 accumulate; a -DMI_PLANES_FP16=0 build uses three bf16 planes / six terms), fp32-class accuracy; "
-                         "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage")
+                         "f32-gemm / f32-fused = f32-input MFMA with the GEMM or the register-chained edge stage; tf32-class = split-gemm's kernels in the "
+                         "TF32-CLASS library build (ONE fp16 x fp16 term per plane-set product, 11-bit operands: the class the reference runs after "
+                         "pipeline/mat_invent.py:127) -- a labelled secondary line with its own tolerance (tests/test_gpu_tf32_class.py), never the headline")
     ap.add_argument("--mg-batch", type=int, default=256, help="--mode mg-sample: crystals per batch")
     ap.add_argument("--mg-free-chain", action="store_true", help="--mode mg-sample: time the free-running random-init chain (emptying graph) instead of "
                     "steps that each start from the physical-density state")
@@ -779,6 +797,11 @@ def main():
         return main_mg_ft(args)
     if args.mode in ("sample-default", "ft-default"):
         return main_reference_defaults(args)
+    tf32 = args.path == "tf32-class"
+    if tf32:   # the same command on the TF32-class library build (selected before anything loads the library)
+        from matinvent_amd import build as _b
+        os.environ["MI_LIB_PATH"] = _b.build(verbose=False, variant="tf32")
+        args.path = "split-gemm"
     K, W = args.steps, args.warmup
     assert 1 <= K <= T and 0 <= W <= T, f"steps and warmup must be <= T = {T}"
 
@@ -789,6 +812,7 @@ def main():
     from matinvent_amd import _lib, build as _build
     _build.build(verbose=False)
     lib = _lib.load()
+    assert (lib.mi_terms_per_product() == 1) == tf32, "bench.py: the loaded library is not the arithmetic class this line is labelled with"
     _apply_env_knobs(lib)
     from matinvent_amd.cspnet import set_gemm_mode
     set_gemm_mode("split" if args.path == "split-gemm" else "f32")
@@ -843,9 +867,11 @@ def main():
         if args.path == "split-gemm":
             # every fp32 product is issued as THREE fp16 MFMA products (two-plane fp16 operands; six bf16 products in the three-plane
             # bf16 build): price the matrix pipe with what it executes (fp16 and bf16 MFMA have the same dense peak)
-            terms = 3 if lib.mi_plane_format() == 2 else 6
+            terms = lib.mi_terms_per_product() if lib.mi_plane_format() == 2 else 6
             kernel, issued, peak = "edge_gemm1b_kernel (pair mode) + edge_gemm2b_kernel (edge MLP of one layer: Fourier-block GEMM over atom pairs + second-linear GEMM over edges with the edge -> node sum)", terms * fp32_equiv, PEAK_BF16_MFMA_TFLOPS
-            dtype = "f32 via 2-plane fp16 split (3 fp16 MFMA terms, f32 accumulate)" if terms == 3 else "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)"
+            dtype = ("f32 via 2-plane fp16 split (3 fp16 MFMA terms, f32 accumulate)" if terms == 3 else
+                     "TF32-CLASS: fp16 x fp16 leading term only (11-bit operands, f32 accumulate) -- NOT the headline arithmetic" if terms == 1 else
+                     "f32 via 3-plane bf16 split (6 bf16 MFMA terms, f32 accumulate)")
         else:
             kernel = "edge_mlp_fwd_kernel<512>" if args.path == "f32-fused" else "gemm_nt_kernel<128,64> x2 (edge MLP of one layer)"
             issued, peak, dtype = fp32_equiv, PEAK_F32_MFMA_TFLOPS, "f32"
@@ -903,6 +929,10 @@ def main():
                                                     "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
                 set_gemm_mode("split")
                 m.decoder.set_edge_mode("gemm")
+                # the arithmetic class the REFERENCE runs after its first fine-tune step (torch.set_float32_matmul_precision("high"),
+                # pipeline/mat_invent.py:127: TF32 on its hardware), as a LABELLED secondary line: the same command on the TF32-class library
+                # build (one term per plane-set product; its own tolerance is stated and tested in tests/test_gpu_tf32_class.py), in a child process
+                out["extra"]["tf32_class_path"] = tf32_class_leg(args, min(K, 20), W)
                 # the MatterGen-LABELLED form of the same config (self-consistent, parity-unpinned vs upstream): a short run of its own
                 # sampler, outside the timed region, so that every driver-run record carries it next to the pinned headline
                 try:

@@ -1001,7 +1001,11 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 
     const __amdgpu_buffer_rsrc_t rsa = uniform_rsrc(A.base + A.tile(tile, 0), A.KT * 24576);
     const int voffa = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+#ifndef MI_DBG_E1_LOOP
+#define MI_DBG_E1_LOOP 0   // timing diagnostics (wrong results): 1 = no MFMAs, 2 = no LDS-DMA of the Fourier operand, 4 = no weight ring loads, 8 = no LDS fragment reads
+#endif
     auto dma_tile = [&](int kt, int st) {
+        if constexpr ((MI_DBG_E1_LOOP & 2) != 0) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int piece = wave * 4 + q;
@@ -1022,6 +1026,10 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     constexpr bool MAN = MI_ASM_LDS >= 2 && MI == 4 && NJ == 1;
     const u32x4 rsw_s = rsrc_words(Wf, N * K * 4);
     auto ring_load = [&](int ks, u32x4 (&w)[NJ][2]) {
+        if constexpr ((MI_DBG_E1_LOOP & 4) != 0) {
+            asm volatile("" : "+v"(w[0][0]), "+v"(w[0][1]));
+            return;
+        }
         if constexpr (MAN) {
             const int soff = __builtin_amdgcn_readfirstlane(ks * 2048);
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[0][0]) : "v"(voffw[0]), "s"(rsw_s), "s"(soff));
@@ -1048,6 +1056,11 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) rd_off[s2] = lds0 + (unsigned)(l31 * 64 + (((2 * s2 + kg) ^ ((l31 >> 2) & 3)) * 16));
     auto read_a = [&](int st, int s2, f16x8 (&af)[MI][2]) {
+        if constexpr ((MI_DBG_E1_LOOP & 8) != 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(af[i][0]), "+v"(af[i][1]));
+            return;
+        }
         if constexpr (MAN) {
             const unsigned va = rd_off[s2] + (unsigned)st * EG2B_STAGE;
 #define MI_RD128(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(off))
@@ -1073,7 +1086,7 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
                 if (ip == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]));
 #pragma unroll
-                for (int term = MI_TERM0; term < 3; ++term)
+                for (int term = (MI_DBG_E1_LOOP & 1) ? 3 : MI_TERM0; term < 3; ++term)
 #pragma unroll
                     for (int i = 2 * ip; i < 2 * ip + 2; ++i)
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[0][term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
