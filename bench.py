@@ -953,6 +953,14 @@ def main():
                     out["extra"]["fine_tune"] = {k: ftl[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline") if k in ftl}
                     out["extra"]["fine_tune"]["workload"] = ftl["config"]["workload"]
                     out["extra"]["fine_tune"]["adam_steps_in_timed_region"] = ftl["config"]["adam_steps_in_timed_region"]
+                    # the same leg on rounds 2-3's protocol (20 timesteps per Adam step), so that the records stay comparable across rounds
+                    saved = args.no_cpu_baseline
+                    args.no_cpu_baseline = True
+                    try:
+                        ft20 = measure_ft(args, 20, 3, ctx)
+                        out["extra"]["fine_tune"]["value_20step"] = ft20["value"]
+                    finally:
+                        args.no_cpu_baseline = saved
                 except Exception as e:
                     out["extra"]["fine_tune"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline()

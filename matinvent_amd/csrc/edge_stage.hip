@@ -992,6 +992,12 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     const int slot = id >> 3, qt = slot % nq, tile = (slot / nq) * 8 + (id & 7);
     const int row0 = tile * 128;
     if (row0 >= M) return;
+#ifdef MI_E1_STAGGER   // (experiment: the workgroups that fill the CUs' SECOND slots start this many cycles late, so that co-resident workgroups are out of phase)
+    if ((id >> 8) & 1) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)(MI_E1_STAGGER)) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     int stamp_i = 0;
     auto stamp = [&]() {
         if (clk && tid == 0) clk[(size_t)(tile * nq + qt) * 8 + stamp_i] = __builtin_amdgcn_s_memtime();

@@ -1216,6 +1216,7 @@ struct mi_gbatch {
     int take_idx = 0;
     std::set<int> mat_ord;
     std::map<const float*, int> ord_of;
+    std::set<const float*> placeholder;   // tensors of THIS forward that got a 1-float placeholder instead of rows (compact arena): materialising one is MI_ESTATE, never a write
     uint64_t dry_key = 0;
     size_t dry_need = 0;
     int64_t node_offset = 0, graph_offset = 0;
@@ -1312,8 +1313,10 @@ struct Ctx {
     // a tensor gets a 256-byte placeholder (its address is still the key of the per-forward tables) unless a consumer materialises it
     float* take_y(size_t n, bool plane_only) {
         const int ord = b->take_idx;
-        float* y = take((plane_only && b->compact && !b->collect && !b->mat_ord.count(ord)) ? 1 : n);
+        const bool ph = plane_only && b->compact && !b->collect && !b->mat_ord.count(ord);
+        float* y = take(ph ? 1 : n);
         if (b->collect) b->ord_of[y] = ord;
+        if (ph && !dry) b->placeholder.insert(y);
         return y;
     }
     // device-side row count of an edge-level launch (NULL: the host's count is exact)
@@ -1327,15 +1330,16 @@ struct Ctx {
     }
     bool pm() const { return b->planes_mode; }
     // the exact absmax slot of a tensor: the producer's if it tracked one, otherwise one extra pass over the tensor (node-level tensors)
-    unsigned* amax(const float* x, int64_t n) {
+    unsigned* amax(const float* x, int64_t rows, int64_t cols) {   // (rows given explicitly: "edge-level" is rows == E, never inferred from the element count)
+        const int64_t n = rows * cols;
         unsigned*& slot = b->amax_of[x];
         if (!slot && b->amax_used < AMAX_SLOTS) {
             need_f32(x);
             slot = b->amax_pool + (size_t)AMAX_W * b->amax_used++;
-            const bool edge_rows = b->nosync && b->E > 0 && n % b->E == 0;
+            const bool edge_rows = b->nosync && b->E > 0 && rows == b->E;
             if (!dry && n > 0)
                 hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1,
-                                   edge_rows ? b->meta : (const int*)nullptr, edge_rows ? (int)(n / b->E) : 0);
+                                   edge_rows ? b->meta : (const int*)nullptr, edge_rows ? (int)cols : 0);
         }
         return slot;
     }
@@ -1363,9 +1367,13 @@ struct Ctx {
     const int* gidx(int kind) const { return kind == GK_SRC ? b->src : kind == GK_DST ? b->dst : b->node2graph; }
 };
 
-static void materialize_f32(mi_gbatch* b, const float* X, hipStream_t s) {
+static int materialize_f32(mi_gbatch* b, const float* X, hipStream_t s) {
     auto it = b->absent.find(X);
-    if (it == b->absent.end()) return;
+    if (it == b->absent.end()) return MI_OK;
+    // (a tensor the cached dry passes left without rows: the program's shape changed behind the cache key -- fail, do not write rows x cols
+    //  floats over the neighbouring tensors of the compact arena)
+    MI_CHECK(!b->placeholder.count(X), MI_ESTATE, "MatterGen-shaped forward: a plane-only tensor without reserved rows is being materialised "
+             "(a kernel-selection knob changed between two forwards of one batch handle without the dry passes being redone)");
     const mi_gbatch::Dims d = it->second;
     const mi_gbatch::PlInfo& pi = b->pl_of.at(X);
     if (d.rows > 0)
@@ -1373,6 +1381,7 @@ static void materialize_f32(mi_gbatch* b, const float* X, hipStream_t s) {
                            Src{nullptr, make_planes(pi.pl, d.cols, pi.scale, pi.dsc)}, const_cast<float*>(X), d.rows, d.cols,
                            (b->nosync && d.rows == b->E) ? b->meta : (const int*)nullptr);
     b->absent.erase(it);
+    return MI_OK;
 }
 void Ctx::need_f32(const float* X) {
     if (!X || !is_absent(X)) return;
@@ -1383,7 +1392,8 @@ void Ctx::need_f32(const float* X) {
         }
         b->absent.erase(X);
     } else {
-        materialize_f32(b, X, s);
+        const int r = materialize_f32(b, X, s);
+        if (r != MI_OK && rc == MI_OK) rc = r;
     }
 }
 
@@ -1606,10 +1616,10 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         if (Ypl) {   // scale of the output plane set from the one-layer bound on the exact absmax of everything that enters
             float* dsc = c.new_dsc();
             const int rows_g = gk1 == GK_NODE ? c.b->B : c.b->N;
-            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(X, M * K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
-                               G1 ? c.amax(G1, (int64_t)rows_g * N) : (const unsigned*)nullptr, G2 ? c.amax(G2, (int64_t)c.b->N * N) : (const unsigned*)nullptr,
-                               res ? c.amax(res, M * N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc,
-                               res2 ? c.amax(res2, M * N) : (const unsigned*)nullptr, scale2, ex.post_mul ? c.amax(ex.post_mul, M * N) : (const unsigned*)nullptr);
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(X, M, K), wp.rowsum, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+                               G1 ? c.amax(G1, rows_g, N) : (const unsigned*)nullptr, G2 ? c.amax(G2, c.b->N, N) : (const unsigned*)nullptr,
+                               res ? c.amax(res, M, N) : (const unsigned*)nullptr, act == ACT_SSILU ? GN_ACT : 1.f, scale, dsc,
+                               res2 ? c.amax(res2, M, N) : (const unsigned*)nullptr, scale2, ex.post_mul ? c.amax(ex.post_mul, M, N) : (const unsigned*)nullptr);
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));   // the k-padding of the next product must be zero
             pe.Cp = make_planes(Ypl, N, 1.f, dsc);
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1727,7 +1737,7 @@ static float* op_mul(Ctx& c, const float* A, const float* Bm, int64_t M, int N, 
     if (c.dry || !CTX_OK(c) || M == 0) return Y;
     if (pl) {
         float* dsc = c.new_dsc();
-        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M * N), (const float*)nullptr, c.amax(Bm, M * N), (const int*)nullptr, 1.f,
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M, N), (const float*)nullptr, c.amax(Bm, M, N), (const int*)nullptr, 1.f,
                            (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, 1.f, 1.f, dsc);
         if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
         c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
@@ -1767,8 +1777,8 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
         float* dsc = nullptr;
         if (Ypl) {
             dsc = c.new_dsc();
-            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M * N), (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
-                               (const unsigned*)nullptr, (const unsigned*)nullptr, c.amax(Bm, M * N), 1.f, GN_ISQ2, dsc);
+            hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(A, M, N), (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
+                               (const unsigned*)nullptr, (const unsigned*)nullptr, c.amax(Bm, M, N), 1.f, GN_ISQ2, dsc);
             if (N % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(M, N) * sizeof(u16), c.s));
             c.b->pl_of[Y] = mi_gbatch::PlInfo{Ypl, dsc, 1.f};
         }
@@ -1844,7 +1854,7 @@ static float* op_triplet(Ctx& c, const float* xd, const float* cbfW) {
     unsigned* ymax = nullptr;
     if (pl) {   // |Tm| <= max|cbfW| max|xd| S max|Y_l| deg_max
         float* dsc = c.new_dsc();
-        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(cbfW, E * g.num_spherical * g.emb_cbf), (const float*)nullptr, c.amax(xd, E * g.emb_trip),
+        hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, c.s, c.amax(cbfW, E, (int64_t)g.num_spherical * g.emb_cbf), (const float*)nullptr, c.amax(xd, E, g.emb_trip),
                            (const int*)(c.b->meta + 1), 1.1f * (float)g.num_spherical, (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr,
                            1.f, 1.f, dsc);
         if (NT % 32 != 0) MI_HIP_VOID(hipMemsetAsync(Ypl, 0, planes_elems(E, NT) * sizeof(u16), c.s));
@@ -1962,6 +1972,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
     b->amax_used = 0;
     b->pl_of.clear();
     b->absent.clear();
+    b->placeholder.clear();
     b->dsc_used = 0;
     b->planes_mode = g_mg_planes && g_gemm_mode != 0 && E >= MG_PLANES_MIN_ROWS;
     if (!c.dry && CTX_OK(c)) MI_HIP_VOID(hipMemsetAsync(b->amax_pool, 0, (size_t)AMAX_SLOTS * AMAX_W * sizeof(unsigned), c.s));
@@ -2131,7 +2142,16 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
     size_t need = 0;
     b->compact = nosync;
     b->collect = false;
-    const uint64_t key = nosync ? (((uint64_t)b->E << 8) | (uint64_t)(g_mg_lean & 63) | 0x80u) : 0;
+    // (the cached dry passes are valid for ONE program shape: the capacity, the network, and every knob that selects a kernel form or a tensor's format)
+    uint64_t key = 0;
+    if (nosync) {
+        const uint64_t parts[] = {(uint64_t)b->E, (uint64_t)(uintptr_t)net, (uint64_t)g_mg_lean, (uint64_t)g_mg_f16, (uint64_t)g_gemm_mode, (uint64_t)g_planes_rt,
+                                  (uint64_t)g_planes_rt_min_rows, (uint64_t)g_planes_big, (uint64_t)g_planes_big_min_rows, (uint64_t)g_planes_dma,
+                                  (uint64_t)g_planes_lat_max_blocks, (uint64_t)g_planes_variant, (uint64_t)g_mg_planes};
+        key = 0xcbf29ce484222325ull;
+        for (uint64_t v : parts) key = (key ^ v) * 0x100000001b3ull;   // FNV-1a over the words
+        key |= 1;
+    }
     if (nosync && b->dry_key == key) {
         need = b->dry_need;   // (same program as the last such forward of this handle: its dry passes are on file)
     } else {
@@ -2747,7 +2767,7 @@ int mi_gemnet_tap(mi_gbatch* b, const char* name, float* out, int64_t capacity, 
     if (numel) *numel = it->second.second;
     if (out) {
         MI_CHECK(capacity >= it->second.second, MI_EINVAL, "tap %s needs %lld floats", name, (long long)it->second.second);
-        mi::materialize_f32(b, it->second.first, (hipStream_t)stream);   // (a lean inference forward kept this tensor as a plane set only)
+        MI_TRY(mi::materialize_f32(b, it->second.first, (hipStream_t)stream));   // (a lean inference forward kept this tensor as a plane set only)
         MI_HIP(hipMemcpyAsync(out, it->second.first, (size_t)it->second.second * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return MI_OK;

@@ -567,6 +567,8 @@ class MatterGenModule(nn.Module):
                                          C.byref(nzs) if nzs is not None else None, _ptr(pos), _ptr(cell), _ptr(types), _ptr(mean_pos), _ptr(mean_cell),
                                          _stream()), "mi_mg_sampler_run")
         del keep
+        if i_start >= stop:   # a zero-step resume: no predictor ran, the mean IS the state -- which the library has wrapped in place meanwhile
+            mean_pos, mean_cell = pos.clone(), cell.clone()
         sample = dict(pos=pos, cell=cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
         mean = dict(pos=mean_pos, cell=mean_cell, atomic_numbers=types.long(), num_atoms=gb.num_atoms)
         return sample, mean, gb

@@ -90,15 +90,17 @@ def test_free_running_chain(golden):
     assert (final["atom_types"].argmax(-1).cpu().numpy() == g["traj_0_atom_types"].argmax(-1)).all()
 
 
-def test_philox_chain_vs_oracle_and_sharding():
+@pytest.mark.parametrize("H", [64, 192], ids=["H64", "H192-not-a-power-of-two"])
+def test_philox_chain_vs_oracle_and_sharding(H):
     """Built-in counter-based noise: the oracle consumes the same stream (restated in numpy).
-    Also: a 2-way crystal shard with global offsets reproduces the single-batch samples."""
+    Also: a 2-way crystal shard with global offsets reproduces the single-batch samples.  (H = 192: the sampler's heads and chain at a width
+    that is a multiple of 64 but not a power of two.)"""
     T, seed = 12, 4242
-    hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8)
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=2, num_freqs=8)
     P = O.init_params(hp, seed=1, head_scale=0.1)
     Pd = {k: v for k, v in P.items()}
     torch.manual_seed(99)
-    m = make_module(64, 2, 8, T, Pd, sigmas_norm=None)
+    m = make_module(H, 2, 8, T, Pd, sigmas_norm=None)
     sn = torch.cat([torch.ones(1), 0.5 + torch.rand(T)])
     m.sigma_scheduler.sigmas_norm.copy_(sn)
     sch = O.Schedules.make(T, sigmas_norm=sn)

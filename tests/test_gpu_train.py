@@ -118,16 +118,18 @@ def test_ft_gradients_and_adam_golden(golden):
     assert nstep == 2
 
 
-def test_gradients_vs_oracle_autograd_ragged():
+@pytest.mark.parametrize("H", [64, 192], ids=["H64", "H192-not-a-power-of-two"])
+def test_gradients_vs_oracle_autograd_ragged(H):
     """Backward kernels vs torch autograd through the oracle on a ragged batch (incl. a 1-atom
-    crystal and runs spanning tile boundaries), random upstream gradients on all three heads."""
-    hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=10)
+    crystal and runs spanning tile boundaries), random upstream gradients on all three heads.  H = 192: the widths mi_net_create accepts
+    since round 4 (any multiple of 64) through the TRAINING forward and the backward too, not only the inference forward."""
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=2, num_freqs=10)
     P = O.init_params(hp, seed=5)
     gen = torch.Generator().manual_seed(2)
     for k in P:
         if "layer_norm" in k:
             P[k] = P[k] + 0.1 * torch.randn(P[k].shape, generator=gen)
-    m = make_module(64, 2, 10, 20, P)
+    m = make_module(H, 2, 10, 20, P)
     na = torch.tensor([1, 7, 20, 3, 13])
     B, N = len(na), int(na.sum())
     n2g = torch.repeat_interleave(torch.arange(B), na)
