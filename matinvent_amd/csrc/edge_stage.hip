@@ -65,9 +65,30 @@ struct EdgeGemm2Args {
     const int* rowptr;        // [N + 1]
     float* part;              // [nslots][N][H], slot = tile - (first row of the node >> 7)
     int E, N;
+    const int* tab = nullptr; // [tiles][EG2_TAB] per-tile tables {first node, local nodes, srcl[128], slotb[128]} (edge2_tables_kernel; edge_gemm2b_kernel)
     float* Z2 = nullptr;      // optional (training forward): the pre-activation M1 W2^T + b2, fp32 [E][H], kept for the backward pass
     unsigned long long* clk;  // optional phase clock: [tile][8] s_memtime stamps (mi_debug_edge2_clock)
 };
+
+// Per-tile tables of the second edge GEMM (a 128-row tile's first source node, its number of local nodes, each row's local source index and each
+// local node's slot): a function of the edge list alone, so they are built ONCE per graph (fc: once per batch; knn: once per forward) instead of
+// by every workgroup of every layer -- where they were a chain of three dependent loads, each behind an s_waitcnt vmcnt(0) that also waited for
+// the twelve LDS-DMA pieces and the weight ring issued in front of it, plus one more at the head of the epilogue (ISA).
+constexpr int EG2_TAB = 2 + 128 + 128;
+__global__ __launch_bounds__(128) void edge2_tables_kernel(const int* __restrict__ src, const int* __restrict__ rowptr, int E, int N, int* __restrict__ tab) {
+    const int tile = blockIdx.x, tid = threadIdx.x, row0 = tile * 128;
+    if (row0 >= E) return;
+    const int nrows = E - row0 < 128 ? E - row0 : 128;
+    const int node_first = src[row0];
+    int* t = tab + (size_t)tile * EG2_TAB;
+    const int r = row0 + tid, node = node_first + tid;
+    t[2 + tid] = r < E ? src[r] - node_first : -1;
+    t[130 + tid] = node < N ? tile - (rowptr[node] >> 7) : 0;
+    if (tid == 0) {
+        t[0] = node_first;
+        t[1] = src[row0 + nrows - 1] - node_first + 1;
+    }
+}
 
 constexpr int EG2_CHUNK = 2 * 128 * 256;            // bytes of one k-chunk in LDS: [plane][row 128][k 128 halfs], 16-byte pieces XOR-swizzled by row
 constexpr int EG2_LDS = 2 * EG2_CHUNK + 128 * 4 + 128 * 4;   // two chunks + per-row local source + per-local-node slot base
@@ -291,6 +312,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stamp();
     if (a.clk && tid == 0) a.clk[(size_t)(tile * 2 + half) * 8 + 4] = __builtin_amdgcn_s_memrealtime();   // (100 MHz: stamps 4 / 5 give the shader clock the other four ran at)
 
+    // per-tile tables (edge2_tables_kernel), requested FIRST: independent loads that land under the operand stream; consumed after it is issued
+    const int* tab = a.tab + (size_t)tile * EG2_TAB;
+    int t_srcl = -1, t_slotb = 0;
+    if (tid < 128) {
+        t_srcl = tab[2 + tid];
+        t_slotb = tab[130 + tid];
+    }
+    const int node_first = tab[0], cnt_tab = tab[1];
+
     // ---- A operand: k-tile kt = one 16 KiB block [plane][128 rows][64 B] of the plane set, 16 pieces of 1 KiB, four per wave ----
     // LDS image of a stage = the plane GEMM's: 64-byte rows, 16-byte piece c of row r at position c ^ ((r >> 2) & 3)
 #if defined(MI_DBG_PAIRS_SKIP) && (MI_DBG_PAIRS_SKIP & 32)   // (timing diagnostic, wrong results: M1 is READ from its first eight row tiles -- with bit 16, the whole M1 round trip stays inside the L2s)
@@ -339,12 +369,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_load(d, ring[d]);
 
-    const int node_first = a.src[row0];
-    if (tid < 128) {
-        const int r = row0 + tid;
-        srcl[tid] = r < a.E ? a.src[r] - node_first : -1;
-        const int node = node_first + tid;
-        slotb[tid] = node < a.N ? tile - (a.rowptr[node] >> 7) : 0;
+    if (tid < 128) {   // (the tables were requested before the operand loads: this waits for them alone)
+        srcl[tid] = t_srcl;
+        slotb[tid] = t_slotb;
     }
     const float os = a.dsc[1] * (1.f / PL_SW), s_m2 = a.dsc[2], inv_m2 = a.dsc[3];
 
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // ---- epilogue (as in the eight-wave form): SiLU -> two fp16 planes -> part = S x M2 on the matrix pipe ----
-    const int cnt = (nrows > 0 ? a.src[row0 + nrows - 1] - node_first + 1 : 0);
+    const int cnt = nrows > 0 ? cnt_tab : 0;
     u16* sfr = reinterpret_cast<u16*>(smem);
     unsigned sat = 0;
     const int nlb = (cnt + 31) >> 5;
@@ -955,15 +982,20 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
     const int id = blockIdx.x;
     // this layer's M1 scale from the absmax slots and the weight bounds; workgroup 0 publishes all six scales (as the plane GEMM does)
     float cps_local = 0.f;
-    if (pe.sc_pq) {
-        float dsc[6];
-        act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
-        cps_local = dsc[0];
-        if (id == 0 && tid < 6) {
-            pe.sc_dsc[tid] = dsc[tid];
-            if (pe.sc_dsc2) pe.sc_dsc2[tid] = dsc[tid];
+    auto eval_scales = [&]() {
+        if (pe.sc_pq) {
+            float dsc[6];
+            act_scales_eval(__uint_as_float(pe.sc_pq[0]), __uint_as_float(pe.sc_gmax[0]), pe.sc_wb, dsc);
+            cps_local = dsc[0];
+            if (id == 0 && tid < 6) {
+                pe.sc_dsc[tid] = dsc[tid];
+                if (pe.sc_dsc2) pe.sc_dsc2[tid] = dsc[tid];
+            }
         }
-    }
+    };
+    // (evaluated in front of the operand loads: behind them -- so that its four dependent scalar loads would run under the LDS-DMA latency --
+    //  measured 2 k cycles SLOWER per workgroup, 4.9 k -> 6.9 k to the first barrier: profiles/r5_index_loads_ab.log)
+    eval_scales();
     if (pe.diag_C0 && id >= pe.diag_block0) {  // self edges: eight nodes per workgroup, a thread per column pair (d = 0: the Fourier term is C0)
         const float cps = cps_local != 0.f ? cps_local : pe.Cp.s();
         const int n0 = (id - pe.diag_block0) * 8, n1 = n0 + 8 < pe.diag_nodes ? n0 + 8 : pe.diag_nodes;
@@ -1096,6 +1128,9 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 #pragma unroll
                     for (int i = 2 * ip; i < 2 * ip + 2; ++i)
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[0][term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
+#ifdef MI_E1_PIN   // (experiment: keep the second pair's wait + MFMAs BEHIND the first pair's six MFMAs -- left alone, the scheduler rotates all four accumulators and waits for every fragment after ONE MFMA)
+                if (ip == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         } else {
 #pragma unroll
@@ -1487,6 +1522,16 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     a.part = b->part;
     a.E = (int)b->E;
     a.N = b->N;
+    {   // the per-tile tables of this graph (fc: built once per batch handle; knn: the forward that rebuilt the edge list bumped graph_epoch)
+        const int tiles_cap = cdiv(b->E_cap, 128);
+        if (!b->e2_tab) MI_TRY(dev_alloc(b, &b->e2_tab, (size_t)tiles_cap * EG2_TAB));
+        if (b->e2_tab_epoch != b->graph_epoch) {
+            hipLaunchKernelGGL(edge2_tables_kernel, dim3(cdiv(b->E, 128)), dim3(128), 0, s, b->src, b->rowptr, (int)b->E, b->N, b->e2_tab);
+            MI_KERNEL_CHECK();
+            b->e2_tab_epoch = b->graph_epoch;
+        }
+        a.tab = b->e2_tab;
+    }
     a.Z2 = Z2;
     a.clk = g_edge2_clk;
     if (Z2) {   // the training forward: form B with the pre-activation kept (written row-major through per-wave LDS patches)

@@ -635,12 +635,17 @@ __device__ __forceinline__ void planes_epilogue(const PlanesEpilogue& pe, f32x16
         if (pe.seg_part) {
             const int rb = row_w + i * 32;
             h_nvalid[i] = M - rb < 32 ? (M - rb > 0 ? M - rb : 0) : 32;
-            h_srcv[i] = h_nvalid[i] > 0 ? pe.seg_src[rb + (l31 < h_nvalid[i] ? l31 : h_nvalid[i] - 1)] : 0;
+            // (unconditional loads of clamped rows -- `nvalid > 0 ? table[..] : 0` compiles to a branch per block with its own s_waitcnt vmcnt(0):
+            //  TM dependent latencies instead of the one chain of two this block is written for; an empty block's values are unused)
+            int r = rb + (l31 < h_nvalid[i] ? l31 : h_nvalid[i] - 1);
+            r = r < M ? r : M - 1;
+            r = r > 0 ? r : 0;   // (M may be a device-side count of 0: the tables are capacity-sized)
+            h_srcv[i] = pe.seg_src[r];
         }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-        if (pe.seg_part) h_rpv[i] = h_nvalid[i] > 0 ? pe.seg_rowptr[h_srcv[i]] : 0;
+        if (pe.seg_part) h_rpv[i] = pe.seg_rowptr[h_srcv[i]];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rb = row_w + i * 32;  // first row of this 32-row block
@@ -1088,13 +1093,16 @@ __device__ __forceinline__ void planes_epilogue_pairs(const PlanesEpilogue& pe, 
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // (UNCONDITIONAL loads of a clamped row: `ok ? table[row] : 0` compiled to one exec-masked branch per (i, u) with its own
+            //  s_waitcnt vmcnt(0) inside -- eight dependent memory latencies at the head of every epilogue, 10-15 k cycles of the 33 k
+            //  (found in the ISA); rows past M are masked where they are used)
             const int row = row_w + i * 32 + ((lane + 64 * u) >> 2);
-            const bool ok = row < M;
-            h_ni[i][u] = ok ? pe.pair_i[row] : 0;
-            h_nj[i][u] = ok ? pe.pair_j[row] : 0;
-            h_gr[i][u] = ok ? pe.pair_graph[row] : 0;
-            h_e1[i][u] = ok ? pe.pair_e1[row] : 0;
-            h_e2[i][u] = ok ? pe.pair_e2[row] : 0;
+            const int rc = row < M ? row : (M > 0 ? M - 1 : 0);
+            h_ni[i][u] = pe.pair_i[rc];
+            h_nj[i][u] = pe.pair_j[rc];
+            h_gr[i][u] = pe.pair_graph[rc];
+            h_e1[i][u] = pe.pair_e1[rc];
+            h_e2[i][u] = pe.pair_e2[rc];
         }
     // row r, column c of a row-major fp32 array / of the output plane set, as a pointer
 #ifdef MI_AB_PAIRS_R3   // (A/B builds: round 3's addressing and arithmetic)

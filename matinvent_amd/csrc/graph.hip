@@ -377,6 +377,7 @@ int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t
              "knn graph exceeds its capacity (edges %d of %lld, max degree %d of %d): raise edge_cap_per_node", meta[0], (long long)b->E_cap,
              meta[1], b->deg_cap);
     b->E = meta[0];
+    ++b->graph_epoch;   // (tables derived from the edge list -- edge_stage.hip's per-tile tables -- are rebuilt at their next use)
     return MI_OK;
 }
 

@@ -212,11 +212,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             const int c0 = lane * 8;
             const bool act = c0 < H;
             int e0[RPW], e1[RPW];
+            int rp;
+            {
+                const int idx = row0 + wave * RPW + lane;
+                rp = a.rowptr[idx < N ? idx : N];   // (lanes 0 .. RPW hold rowptr[i0 .. i0 + RPW]; the table has N + 1 entries)
+            }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
+                // (the wave's RPW + 1 consecutive row pointers come from ONE lane-parallel load, `rp`, below: `i < N ? rowptr[i] : 0` per row
+                //  compiled to RPW wave-uniform loads, each with its own s_waitcnt vmcnt(0) + v_readfirstlane -- RPW dependent memory
+                //  latencies in front of everything else)
                 const int i = row0 + wave * RPW + r;
-                e0[r] = i < N ? a.rowptr[i] : 0;
-                e1[r] = i < N ? a.rowptr[i + 1] : 0;
+                e0[r] = i < N ? __builtin_amdgcn_readlane(rp, r) : 0;
+                e1[r] = i < N ? __builtin_amdgcn_readlane(rp, r + 1) : 0;
             }
             f32x4 xsum[RPW], ysum[RPW];
             bool any[RPW];
@@ -655,15 +663,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const int c0 = lane * 8;
             const bool act = c0 < H;
+            int rp;
+            {
+                const int idx = row0 + wave * RPW + lane;
+                rp = a.rowptr[idx < N ? idx : N];   // (lanes 0 .. RPW hold the wave's RPW + 1 consecutive row pointers)
+            }
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {   // (two rounds of four rows: the gathers of a round in flight together, 64 registers)
                 constexpr int RH = RPW / 2;
                 int e0[RH], e1[RH];
 #pragma unroll
                 for (int r = 0; r < RH; ++r) {
-                    const int i = row0 + wave * RPW + half * RH + r;
-                    e0[r] = i < N ? a.rowptr[i] : 0;
-                    e1[r] = i < N ? a.rowptr[i + 1] : 0;
+                    const int i = row0 + wave * RPW + half * RH + r;   // (from the one lane-parallel load `rp`: see node_chain_kernel)
+                    e0[r] = i < N ? __builtin_amdgcn_readlane(rp, half * RH + r) : 0;
+                    e1[r] = i < N ? __builtin_amdgcn_readlane(rp, half * RH + r + 1) : 0;
                 }
                 f32x4 x[RH], y[RH], x1[RH], y1[RH];
 #pragma unroll
