@@ -1128,9 +1128,6 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
 #pragma unroll
                     for (int i = 2 * ip; i < 2 * ip + 2; ++i)
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][term == 0 ? 1 : 0], __builtin_bit_cast(f16x8, w[0][term == 1 ? 1 : 0]), acc[i][0], 0, 0, 0);
-#ifdef MI_E1_PIN   // (experiment: keep the second pair's wait + MFMAs BEHIND the first pair's six MFMAs -- left alone, the scheduler rotates all four accumulators and waits for every fragment after ONE MFMA)
-                if (ip == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         } else {
 #pragma unroll

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             for (int r = 0; r < RPW; ++r) {
                 const int i = row0 + wave * RPW + r;
                 const int ns = e1[r] > e0[r] ? ((e1[r] - 1) >> a.seg_shift) - (e0[r] >> a.seg_shift) + 1 : 0;
+                // (these stay conditional: loading both slots of every row unconditionally and masking afterwards measured SLOWER -- A1 8.6 k -> 10.3 k
+                //  cycles, profiles/r5_node_a1_ab.log: twice the bytes for the rows that have one slot)
                 x[r] = y[r] = x1[r] = y1[r] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (act && ns > 0) {
                     const float* p = a.part + (size_t)i * H + c0;
@@ -323,12 +325,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         f32x4 xq[TW][4];
         {
             const int i = row0 + l31;
+            const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    xq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (i < N) xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + wave * CW + t * 32 + 8 * q + 4 * kg);
+                    xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)ic * a.ld_xpart + wave * CW + t * 32 + 8 * q + 4 * kg);
                 }
         }
         // ---- A2: Z = agg W0b^T (transposed) ----
@@ -338,12 +340,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         f32x4 hq[TW][4];   // the residual rows of A5, requested here for the same reason
         {
             const int i = row0 + l31;
+            const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    hq[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (i < N) hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + wave * CW + t * 32 + 8 * q + 4 * kg);
+                    hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)ic * H + wave * CW + t * 32 + 8 * q + 4 * kg);
                 }
         }
         __syncthreads();                // every wave has read the agg planes
@@ -739,10 +741,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x4 xq[4];   // the epilogue's row addends, requested in front of the product
         {
             const int i = row0 + l31;
+            const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                xq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < N) xq[q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)i * a.ld_xpart + ccol + 8 * q + 4 * kg);
+                xq[q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)ic * a.ld_xpart + ccol + 8 * q + 4 * kg);
             }
         }
         // ---- A2: Z = agg W0b^T (transposed), this workgroup's 128 columns ----
@@ -802,10 +804,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x4 hq[4];   // the residual rows of A5
         {
             const int i = row0 + l31;
+            const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                hq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < N) hq[q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)i * H + ccol + 8 * q + 4 * kg);
+                hq[q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)ic * H + ccol + 8 * q + 4 * kg);
             }
         }
         __syncthreads();
