@@ -848,7 +848,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 8 * H * sizeof(float), s, dy, ld_dy, x, stats, net->p(wname + ".weight"),
                            dx, accumulate, sc, N, H, rows_per_block);
         // part[blk][0:H] -> dw, [H:2H] -> db ; weight and bias are adjacent in theta (weight first)
-        hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(2 * H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nblk, 2 * H, G(wname + ".weight"), 2 * H);
+        hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(2 * H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nblk, 2 * H, G(wname + ".weight"), 2 * H);
         MI_KERNEL_CHECK();
         return MI_OK;
     };
@@ -931,7 +931,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             if (dz2_sums) {
                 hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(1, nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H, crows, dzp,
                                    b->absmax + 2 * L, b->dsc + 6, w2_planes ? 0 : 1);
-                hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
+                hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
             } else {
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
             }
@@ -994,13 +994,13 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 #endif
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
                                        Dp, dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
-                    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
+                    hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
                 } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
                                        Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, dPQ, t.dG, sc, H,
                                        wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
-                    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
+                    hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
                 } else {
                     if (Np > 0) {
@@ -1155,7 +1155,7 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
         hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p(p + "edge_mlp.2.weight"), H, H, H, n->W2T + (size_t)l * H * H);
         if (n->W2Tpl) {
             Planes wp = make_planes(n->W2Tpl + (size_t)l * planes_elems(H, H), H);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((H + 127) / 128 * 128) * wp.KT * 16, 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)((H + 127) / 128 * 128) * wp.KT * 16, 256)), dim3(256), 0, s,
                                n->W2T + (size_t)l * H * H, H, H, H, wp, 0);
             if (n->W2Tf) MI_TRY(pack_frag_from_planes(wp, H, H, n->W2Tf + (size_t)l * frag_elems(H, H), s));
         }
@@ -1437,8 +1437,8 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
         if (planes_elems(N, K) > nw) { if (pw) (void)hipFree(pw); nw = planes_elems(N, K); MI_HIP(hipMalloc((void**)&pw, nw * 2)); }
         Planes PA = make_planes(pa, K, PL_S_LN), PW = make_planes(pw, K, PL_SW);
         if (ldc >= 0) {
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((M + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, M, K, PA);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((N + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, N, K, PW);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)((M + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, M, K, PA);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)((N + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, N, K, PW);
         }
         if (MI_PLANES_FP16 && (N & 255) == 0 && (K & 63) == 0 && K >= 128) {   // + the fragment-order copy the register-tile form reads (mi_debug_set_planes_rt)
             static u16* pf = nullptr;
@@ -1473,8 +1473,8 @@ int mi_debug_gemm(int kind, const float* A, int lda, const float* W, int ldw, fl
             MI_HIP(hipMemcpy(dsc, h, sizeof(h), hipMemcpyHostToDevice));
         }
         Planes PA = make_planes(pa, M, 64.f), PW = make_planes(pw, N, 64.f);
-        hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, K, M, PA);
-        hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, K, N, PW);
+        hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PA.KT * 16, 256)), dim3(256), 0, s, A, lda, K, M, PA);
+        hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)((K + 127) / 128 * 128) * PW.KT * 16, 256)), dim3(256), 0, s, W, ldw, K, N, PW);
         MI_KERNEL_CHECK();
         MI_CHECK(gemm_tn_planes_ok(PA, 0, PW, 0, K, M, N), MI_EINVAL, "kind 5: shape outside the plane-set form");
         return gemm_tn_planes(PA, 0, PW, 0, C, ldc, K, M, N, dsc, dsc, sc, scf, s);

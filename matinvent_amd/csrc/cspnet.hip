@@ -1403,9 +1403,9 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
         {
             const int F6 = 6 * n->F, Hp = (H + 127) / 128 * 128;
             Planes wffp = make_planes(n->Wffpl + (size_t)l * planes_elems(H, F6), F6);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wffp.KT * 16, 256)), dim3(256), 0, s, W1 + 2 * H + 9, n->edge_in, H, F6, wffp);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)Hp * wffp.KT * 16, 256)), dim3(256), 0, s, W1 + 2 * H + 9, n->edge_in, H, F6, wffp);
             Planes w2p = make_planes(n->W2pl + (size_t)l * planes_elems(H, H), H);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * w2p.KT * 16, 256)), dim3(256), 0, s, W2, H, H, H, w2p);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)Hp * w2p.KT * 16, 256)), dim3(256), 0, s, W2, H, H, H, w2p);
             Planes wpp = make_planes(n->Wffpl_pair + (size_t)l * planes_elems(H, 2 * n->Kh), 2 * n->Kh);
             hipLaunchKernelGGL(pack_wff_pair_planes_kernel, dim3(cdiv((int64_t)Hp * n->Kh, 256)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->Kh, wpp);
             hipLaunchKernelGGL(wff_cos_rowsum_kernel, dim3(cdiv(H, 4)), dim3(256), 0, s, W1, n->edge_in, H, n->F, n->C0 + (size_t)l * H);
@@ -1414,12 +1414,12 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
             const float* Wn0 = n->p(p + "node_mlp.0.weight");
             const int H3p = (3 * H + 127) / 128 * 128;
             Planes wlnp = make_planes(n->Wlnpl + (size_t)l * planes_elems(3 * H, H), H);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, n->Whh + l * n->whh_stride(), H, 2 * H, H, wlnp, 0);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, Wn0, 2 * H, H, H, wlnp, 2 * H);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, n->Whh + l * n->whh_stride(), H, 2 * H, H, wlnp, 0);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)H3p * wlnp.KT * 16, 256)), dim3(256), 0, s, Wn0, 2 * H, H, H, wlnp, 2 * H);
             Planes waggp = make_planes(n->Waggpl + (size_t)l * planes_elems(H, H), H);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)Hp * waggp.KT * 16, 256)), dim3(256), 0, s, Wn0 + H, 2 * H, H, H, waggp, 0);
             Planes wn2p = make_planes(n->Wn2pl + (size_t)l * planes_elems(H, H), H);
-            hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
+            hipLaunchKernelGGL(split_planes_kernel<>, dim3(cdiv((int64_t)Hp * wn2p.KT * 16, 256)), dim3(256), 0, s, n->p(p + "node_mlp.2.weight"), H, H, H, wn2p);
             if (n->Wnc) MI_TRY(node_chain_pack(n, l, W1, Wn0, n->p(p + "node_mlp.2.weight"), W2, s));
             if (n->Wffc) MI_TRY(edge_gemm1_pack(n, l, W1, s));  // the same weights in fragment order (node_chain.hip)
         }

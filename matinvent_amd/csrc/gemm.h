@@ -195,6 +195,7 @@ int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int 
 // buffer; tn_reduce_kernel adds them in fixed order into the destination (deterministic; gradients
 // ACCUMULATE across micro-steps, so the destination is always += ).
 // ------------------------------------------------------------------------------------------------
+#ifdef MI_GEMM_OWNER   // (launched by the owning unit's launchers only: a static kernel is emitted by EVERY unit that sees its definition)
 static __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
                                                       float* __restrict__ P, int M, int Na, int Kx, int rows_per_split) {
     constexpr int BM = 32, LD = 68;
@@ -248,10 +249,12 @@ static __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __rest
         Pt[(size_t)n * PK + k] = acc[r];
     }
 }
+#endif
 
 // The same product on 128 x 128 output tiles (each wave a 64 x 64 quadrant = four accumulator tiles): half the LDS reads and a
 // quarter of the operand re-reads per MFMA of the 64 x 64 kernel, next 32-row slab prefetched into registers during the MFMAs.
 // Used for the large weight-gradient products (contraction over the edge or pair list).
+#ifdef MI_GEMM_OWNER   // (launched by the owning unit's launchers only: a static kernel is emitted by EVERY unit that sees its definition)
 static __global__ __launch_bounds__(256) void gemm_tn128_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
                                                                 float* __restrict__ P, int M, int Na, int Kx, int rows_per_split, int gx,
                                                                 int gy, int nsplit) {
@@ -334,6 +337,7 @@ static __global__ __launch_bounds__(256) void gemm_tn128_kernel(const float* __r
                 Pt[(size_t)n * PK + k] = acc[i][j][r];
             }
 }
+#endif
 
 // (a thread owns four adjacent columns when the output allows 16-byte accesses -- V4 -- and keeps eight partial tiles' loads in flight;
 //  the sum runs over the splits in index order whatever the form, so the result does not depend on it)
@@ -438,6 +442,7 @@ int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int 
 // for the LayerNorm weight gradients), and 64 columns x 4 row groups took 55 us over the 1600 partial rows of the dZ2 column sums.
 // Launch with cdiv(Nc, PART_REDUCE_COLS) blocks of 256 threads.
 constexpr int PART_REDUCE_COLS = 32;
+template <int MI_UNUSED = 0>   // (a template so that only the units that launch it emit it)
 static __global__ __launch_bounds__(256) void part_reduce_kernel(const float* __restrict__ P, int nsplit, int ldp, float* __restrict__ out, int Nc) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, rg = threadIdx.x >> 5;
@@ -459,6 +464,7 @@ static __global__ __launch_bounds__(256) void part_reduce_kernel(const float* __
 }
 
 // out[c] += sum_m A[m][c]   (bias gradients), two stages through `scratch` like gemm_tn_acc
+template <int MI_UNUSED = 0>   // (a template so that only the units that launch it emit it)
 static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ P, int M, int Nc,
                                                      int rows_per_split, const int* __restrict__ row_idx = nullptr) {
     __shared__ float red[4][64];
@@ -481,8 +487,8 @@ int colsum_acc(const float* A, int lda, float* out, int M, int Nc, float* scratc
     MI_CHECK((size_t)nsplit * gx * 64 <= scratch_floats, MI_ENOMEM, "colsum scratch too small");
     int rows = cdiv(M, nsplit);
     nsplit = cdiv(M, rows);
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows, row_idx);
-    hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(Nc, PART_REDUCE_COLS)), dim3(256), 0, s, scratch, nsplit, gx * 64, out, Nc);
+    hipLaunchKernelGGL(colsum_kernel<>, dim3(gx, nsplit), dim3(256), 0, s, A, lda, scratch, M, Nc, rows, row_idx);
+    hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(Nc, PART_REDUCE_COLS)), dim3(256), 0, s, scratch, nsplit, gx * 64, out, Nc);
     MI_KERNEL_CHECK();
     return MI_OK;
 }

@@ -209,6 +209,7 @@ __device__ __forceinline__ float f16_scale_from_absmax(unsigned bits) {
 // (spread_mask: the waves' atomics go to out[blockIdx & mask] -- same-address atomics serialise at ~8.5 ns each in the L2, so a
 // launch of thousands of waves spreads them over a power-of-two row of sub-slots that the reader folds; 0 = one slot)
 // (mdev / per_row: optional device-side row count -- the tensor has *mdev rows of per_row elements, n is the capacity)
+template <int MI_UNUSED = 0>   // (a template so that only the units that launch it emit it)
 static __global__ void absmax_bits_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out, int spread_mask = 0,
                                           const int* __restrict__ mdev = nullptr, int per_row = 0) {
     float m = 0.f;
@@ -366,6 +367,10 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
         step(k0 + BK, ra[1], rw[1]);
     }
 
+    // (Recorded ablation, round 5: issuing every optional addend load of the tile before the arithmetic -- the element-by-element form below cannot move
+    //  element r + 1's loads above element r's store, C may alias the addend arrays: 129 tight `s_waitcnt vmcnt(0)` in the 64 x 64 instantiation -- measured
+    //  +0.2 % on the fine-tune line and -2 % on the MatterGen-shaped sampler, profiles/r5_nt_split_epi_ab.log: the launches that carry addends are
+    //  split-K ones, whose epilogue runs in splitk_reduce_kernel.  Not kept.)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -389,15 +394,27 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
         }
 }
 
+#ifdef MI_GEMM_OWNER   // (launched by the owning unit's launchers only: a static kernel is emitted by EVERY unit that sees its definition)
 static __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpilogue ep) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * N) return;
     const int row = (int)(idx / N), col = (int)(idx % N);
     float v = 0.f;
-    for (int z = 0; z < S; ++z) v += part[(size_t)z * M * N + idx];
+    int z = 0;
+    const size_t MN = (size_t)M * N;
+    for (; z + 4 <= S; z += 4) {   // (four slices requested together, added in slice order: one memory latency per four slices instead of one per slice)
+        const float p0 = part[(size_t)z * MN + idx], p1 = part[(size_t)(z + 1) * MN + idx], p2 = part[(size_t)(z + 2) * MN + idx],
+                    p3 = part[(size_t)(z + 3) * MN + idx];
+        v += p0;
+        v += p1;
+        v += p2;
+        v += p3;
+    }
+    for (; z < S; ++z) v += part[(size_t)z * MN + idx];
     v += ep.bias ? ep.bias[col] : 0.f;
     C[(size_t)row * ldc + col] = apply_epilogue(ep, v, row, col);
 }
+#endif
 
 #ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
 int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
@@ -494,6 +511,7 @@ static inline Planes make_planes(u16* base, int cols, float scale = PL_SW, const
 // fp32 [rows][cols] (row stride ld_src) -> plane set (pads written as zero); one thread per column pair
 // (row0: first destination row -- lets several matrices share one plane set; the zero row padding then runs to the next
 // multiple of 128 destination rows, so stack them in increasing row order)
+template <int MI_UNUSED = 0>   // (a template so that only the units that launch it emit it)
 static __global__ void split_planes_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, Planes dst, int row0 = 0) {
     const int cp = dst.KT * 16;  // column pairs per padded row
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

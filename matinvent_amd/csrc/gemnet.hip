@@ -1338,7 +1338,7 @@ struct Ctx {
             slot = b->amax_pool + (size_t)AMAX_W * b->amax_used++;
             const bool edge_rows = b->nosync && b->E > 0 && rows == b->E;
             if (!dry && n > 0)
-                hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1,
+                hipLaunchKernelGGL(absmax_bits_kernel<>, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, s, x, n, slot, AMAX_W - 1,
                                    edge_rows ? b->meta : (const int*)nullptr, edge_rows ? (int)cols : 0);
         }
         return slot;
@@ -1477,7 +1477,7 @@ static int get_wplanes(Ctx& c, int pidx, int wcol0, int K, mi_gemnet::WPl* out) 
     net->warena_top += need;
     Planes P = make_planes(e.pl, K, e.scale);
     const int64_t nthr = (int64_t)((w.rows + 127) / 128 * 128) * P.KT * 16;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, P, 0);
+    hipLaunchKernelGGL(split_planes_kernel<>, dim3(nblk(nthr)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, P, 0);
     MI_HIP(hipMemsetAsync(e.rowsum, 0, sizeof(float), c.s));
     hipLaunchKernelGGL(rowsum_max_kernel, dim3((unsigned)std::min(64, (w.rows + 3) / 4)), dim3(256), 0, c.s, net->wptr(w) + wcol0, w.cols, w.rows, K, e.rowsum);
     MI_KERNEL_CHECK();
@@ -1514,7 +1514,7 @@ static int get_wtplanes(mi_gemnet* net, hipStream_t s, int pidx, int wcol0, int 
     net->warena_top += need;
     Planes P = make_planes(e.pl, w.rows, e.scale);
     const int64_t nthr = (int64_t)((K + 127) / 128 * 128) * P.KT * 16;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nblk(nthr)), dim3(256), 0, s, net->thetaT + w.toff + (size_t)wcol0 * w.ldt, w.ldt, K, w.rows, P, 0);
+    hipLaunchKernelGGL(split_planes_kernel<>, dim3(nblk(nthr)), dim3(256), 0, s, net->thetaT + w.toff + (size_t)wcol0 * w.ldt, w.ldt, K, w.rows, P, 0);
     MI_KERNEL_CHECK();
     if (MI_PLANES_FP16 && (K & 255) == 0 && (w.rows & 63) == 0 && w.rows >= 128) {   // (this product's N is K, its contraction length w.rows)
         net->warena_top = (net->warena_top + 7) & ~(size_t)7;
@@ -1685,7 +1685,7 @@ static float* op_dense(Ctx& c, const float* X, int64_t M, int K, const std::stri
         unsigned*& slot = c.b->amax_of[X];
         if (!slot) {   // the operand's exact absmax, once per tensor and forward (one extra read of it; the product then issues half the MFMA work)
             slot = c.b->amax_pool + (size_t)AMAX_W * c.b->amax_used++;
-            hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot, AMAX_W - 1);
+            hipLaunchKernelGGL(absmax_bits_kernel<>, dim3((unsigned)std::min<int64_t>(2048, cdiv(M * K, 1024))), dim3(256), 0, c.s, X, M * K, slot, AMAX_W - 1);
         }
         hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(AMAX_W), 0, c.s, slot);   // (the kernel reads one word)
         CTX_TRY(c, gemm_nt_split(X, K, c.net->wptr(w) + wcol0, w.cols, Y, ldy, (int)M, N, K, ep, c.s, nullptr, slot, c.net->wamax + c.net->index.at(wname)));
@@ -2264,7 +2264,7 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 Planes dzp;
                 if (bwd_pl) {
                     MI_HIP(hipMemsetAsync(b->bwd_amax, 0, AMAX_W * sizeof(unsigned), s));
-                    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(2048, cdiv(o.M * o.N, 1024))), dim3(256), 0, s, dY, o.M * o.N, b->bwd_amax,
+                    hipLaunchKernelGGL(absmax_bits_kernel<>, dim3((unsigned)std::min<int64_t>(2048, cdiv(o.M * o.N, 1024))), dim3(256), 0, s, dY, o.M * o.N, b->bwd_amax,
                                        AMAX_W - 1);
                     hipLaunchKernelGGL(mg_scale_kernel, dim3(1), dim3(AMAX_W), 0, s, b->bwd_amax, (const float*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, 1.f,
                                        (const unsigned*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, o.act != ACT_NONE ? 1.1f * GN_ACT : 1.f, fabsf(o.s),
@@ -2357,7 +2357,7 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
                 const int rows_per = (int)((o.M + chunks - 1) / chunks);
                 chunks = (int)((o.M + rows_per - 1) / rows_per);
                 hipLaunchKernelGGL(rowdot_dw_kernel, dim3(nblk(o.K), chunks), dim3(256), 0, s, o.X, o.X2, dY, red, o.M, o.K, rows_per);
-                hipLaunchKernelGGL(part_reduce_kernel, dim3(cdiv(o.K, PART_REDUCE_COLS)), dim3(256), 0, s, red, chunks, o.K, grad + w.off, o.K);
+                hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(o.K, PART_REDUCE_COLS)), dim3(256), 0, s, red, chunks, o.K, grad + w.off, o.K);
                 break;
             }
             case OP_EMBED:
@@ -2518,7 +2518,7 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
     MI_HIP(hipMemsetAsync(net->wamax, 0, net->params.size() * sizeof(unsigned), s));
     for (size_t i = 0; i < net->params.size(); ++i) {
         const GParam& p = net->params[i];
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, net->wptr(p), p.numel, net->wamax + i);
+        hipLaunchKernelGGL(absmax_bits_kernel<>, dim3((unsigned)std::min<int64_t>(256, cdiv(p.numel, 1024))), dim3(256), 0, s, net->wptr(p), p.numel, net->wamax + i);
     }
     {   // per-tensor plane scales on the host (2^floor(log2(16384 / absmax))); the lazily built weight plane sets are stale now
         std::vector<unsigned> bits(net->params.size());
