@@ -154,11 +154,13 @@ def test_the_shipped_library_has_no_packed_fp32_instructions_and_records_its_fla
     subprocess.run([objdump, "--offloading", str(lib)], check=True, cwd=tmp_path, stdout=subprocess.DEVNULL)
     objs = [p for p in os.listdir(tmp_path) if p.endswith("gfx950")]
     assert objs
+    with_code = 0
     for o in objs:
         asm = subprocess.run([objdump, "-d", o], check=True, cwd=tmp_path, capture_output=True, text=True).stdout
-        assert "s_endpgm" in asm
+        with_code += "s_endpgm" in asm          # (a unit whose kernels are all ablation-only ships an empty code object)
         bad = [ln for ln in asm.splitlines() if any(k in ln for k in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32"))]
         assert not bad, bad[:3]
+    assert with_code >= 5
 
 
 def test_a_library_linked_under_other_flags_is_stale(monkeypatch, tmp_path):
