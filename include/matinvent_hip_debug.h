@@ -105,6 +105,11 @@ int mi_debug_set_node_split(int on);
  * launch per stage always; 2 = one launch per layer boundary with agent-scope flag hand-overs between the stages; 0 = off.  Bit-identical to
  * the row-block forms (models/diffcsp/cspnet.py:79-91,61).  Returns the previous setting, MI_EINVAL for other values. */
 int mi_debug_set_node_cols(int mode);
+/* Row-block chain launches of at least `min_blocks` 32-row blocks first warm the L2 with their weight operands (one dword per 128-byte line, shared
+ * out among the workgroups of an XCD): between two node-chain launches the edge GEMMs stream > 100 MB through the L2s, so the weight rings otherwise
+ * run at the miss latency.  Default 64 (one chain of 256 crystals: +4.3 %; chains of 64 crystals measured -1 % and stay off); 0 = never.  Returns the
+ * previous setting. */
+int mi_debug_set_node_touch(int min_blocks);
 /* TIMING ABLATIONS ONLY -- the results of a forward are garbage while a bit is set: 1 = skip the node chain's launches, 2 = the first edge GEMM,
  * 4 = the second (what a chain's serial path and the chip's occupancy cost each other: DESIGN 19.1).  Returns the previous mask. */
 int mi_debug_set_skip(int mask);

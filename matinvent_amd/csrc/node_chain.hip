@@ -30,6 +30,9 @@ int g_node_fused = 1;  // inference forwards: the node-level chain as one launch
 int g_node_split = 1;  // small / medium batches: phase A and LayerNorm + projections as two launches, the second on three workgroups per row block (0: one launch)
 int g_node_split_max_blocks = 256;   // ... while those fit the chip in one round (one workgroup per CU)
 int g_ablate_skip = 0;   // TIMING ABLATIONS ONLY (results are garbage): bit 0 = skip the node chain's launches, 1 = the first edge GEMM, 2 = the second (mi_debug_set_skip)
+int g_node_touch_min_blocks = 64;   // row blocks from which a row-block chain launch warms the L2 with its weights first: measured +4.3 % on one chain of 256 crystals
+                                    // (160 row blocks: node chain 88 -> 74 us), -1 % on four chains of 64 (40 row blocks: each workgroup then touches a fifth of the
+                                    // operands and waits for it, A1 8.7 k -> 17 k cycles, while the products -- bound by the CU's L2 port -- barely gain); profiles/r5_node_chain_l2_touch_ab.log
 int g_node_cols = 3;   // the column-split form of the chain (node_cols_kernel): 3 = automatic (default: one launch per stage for chains of at most g_node_cols_auto_blocks
                        // row blocks -- the reference's default sampling batch, +3 %; the row-block forms above for larger ones -- the headline's chains measured equal, one
                        // chain of 256 crystals 2.5 % slower: DESIGN 19.1), 1 = one launch per stage always, 2 = one launch per layer boundary with in-launch hand-overs, 0 = off
@@ -100,6 +103,7 @@ struct NodeChainArgs {
     // the chain as TWO launches (node_chain(): small and medium batches): `a_only` = phase A, h' written, nothing else; `split_b` = a launch of
     // LayerNorm + phase B with gridDim.y = 3, a workgroup running the projection pass blockIdx.y only (the passes are independent given y)
     int a_only = 0, split_b = 0;
+    int touch = 0;                  // node_chain_kernel: warm the L2 with this launch's weight operands first (large launches: see the kernel)
     // the COLUMN-SPLIT form (node_cols_kernel): `stages` = which of {1: agg + node_mlp.0 -> X planes, 2: node_mlp.2 + residual -> h', 4: LayerNorm
     // + projections} this launch runs, on `gy` workgroups per 32-row block (each owning 128-column groups gy apart); the X planes and h' cross
     // from one stage to the next through `xpl` / `h_out` -- at a kernel boundary (one launch per stage) or, with `flags`, inside ONE launch
@@ -117,7 +121,9 @@ struct NodeChainCfg {
 
 // NW waves (4 or 8) share the H output columns of a product: wave w owns columns [w CW, (w + 1) CW), CW = H / NW = TW tiles of 32.
 // D = depth of the weight ring in 16-deep k-steps.
-template <int H, int NW, int D>
+// PQ: the epilogues' row addends (X_part, the residual h) requested IN FRONT of their product (true) or behind it (false: 64 registers fewer, which a ring of
+// depth 8 needs -- twice the weight bytes in flight per CU)
+template <int H, int NW, int D, bool PQ = true>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void node_chain_kernel(NodeChainArgs a) {
     using C = NodeChainCfg<H>;
     constexpr int KS = C::KS, ROWB = C::ROWB, PLB = C::PLB, HLD = C::HLD, CW = H / NW, TW = CW / 32, RPW = 32 / NW;
@@ -135,6 +141,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         ++stamp_i;
     };
     stamp();
+    // L2 warm-up of THIS launch's weight operands (NodeChainArgs::touch: launches of at least g_node_touch_min_blocks row blocks).  Between two node-chain launches the edge GEMMs stream > 100 MB through the L2s, so every
+    // product's weight ring runs at the miss latency (the same launch twice in a row: 90 -> 66 us at 5 120 nodes,
+    // profiles/r5_node_chain_cold_vs_warm_l2.log).  The workgroups of an XCD (block b runs on XCD b % 8 -- for speed only) share out the lines of all
+    // operands and touch one dword per 128-byte line, fire and forget, before anything else: the later products then find their weights in L2.
+    float touch_dummy = 0.f;
+    if (a.touch) {
+        const int bl = (int)(blockIdx.x + gridDim.x * blockIdx.y), nb = (int)(gridDim.x * gridDim.y);
+        const int part = bl >> 3, nparts = (nb - (bl & 7) + 7) >> 3;
+        auto touch = [&](const void* base, int bytes) {
+            const int nlines = bytes >> 7;
+            for (int l0 = part * (64 * NW); l0 < nlines; l0 += nparts * (64 * NW)) {
+                const int line = l0 + tid;
+                if (line < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(touch_dummy) : "v"(reinterpret_cast<const char*>(base) + (size_t)line * 128));
+            }
+        };
+        const int wbytes = H * H * 4;
+        if (a.part != nullptr) {
+            touch(a.Wagg, wbytes);
+            touch(a.Wn2, wbytes);
+        }
+        if (a.Wln != nullptr && !a.a_only) touch(a.Wln + (size_t)(a.split_b ? blockIdx.y : 0) * H * H * 2, (a.split_b ? 1 : 3) * wbytes);
+    }
     u32x4 ring[D][TW][2];
     f32x16 acc[TW];
     // ---- weight ring: k-steps ks .. ks + D - 1 of the wave's TW column tiles (first tile ct0) in flight ----
@@ -323,7 +351,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         // (the epilogue's row gathers do not depend on the product: requested BEFORE it, they land under its MFMAs instead of costing one
         //  exposed memory latency per phase -- the phase clock put A3 at 18k cycles against 12k for the product itself)
         f32x4 xq[TW][4];
-        {
+        auto load_xq = [&]() {
             const int i = row0 + l31;
             const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
@@ -332,13 +360,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 for (int q = 0; q < 4; ++q) {
                     xq[t][q] = *reinterpret_cast<const f32x4*>(a.xpart + (size_t)ic * a.ld_xpart + wave * CW + t * 32 + 8 * q + 4 * kg);
                 }
-        }
+        };
+        if constexpr (PQ) load_xq();
         // ---- A2: Z = agg W0b^T (transposed) ----
         run(TRt{}, rs_agg, wave * TW);
         stamp();
+        if constexpr (!PQ) load_xq();
         const __amdgpu_buffer_rsrc_t rs_n2 = uniform_rsrc(a.Wn2, wsz);
         f32x4 hq[TW][4];   // the residual rows of A5, requested here for the same reason
-        {
+        auto load_hq = [&]() {
             const int i = row0 + l31;
             const int ic = i < N ? i : N - 1;   // (clamped, UNCONDITIONAL gathers: `if (i < N) x = load` compiled to a branch per load and, through a register copy, an s_waitcnt vmcnt(0) in the middle of them -- DESIGN 19.3; rows past N are masked where they are stored)
 #pragma unroll
@@ -347,7 +377,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 for (int q = 0; q < 4; ++q) {
                     hq[t][q] = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)ic * H + wave * CW + t * 32 + 8 * q + 4 * kg);
                 }
-        }
+        };
+        if constexpr (PQ) load_hq();
         __syncthreads();                // every wave has read the agg planes
         // ---- A3: X = SiLU(Z + b0 + X_part) -> planes ----
         {
@@ -387,6 +418,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         // ---- A4: Y = X W2^T (transposed) ----
         run(TRt{}, rs_n2, wave * TW);
         stamp();
+        if constexpr (!PQ) load_hq();
         // ---- A5: h' = h + SiLU(Y + b2) -> Hs ----
         {
             const float os = a.dsc[5] * (1.f / PL_SW);
@@ -416,6 +448,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     } else if (phaseB) {
         ring_fill(uniform_rsrc(a.Wln, 3 * wsz), ((a.split_b ? (int)blockIdx.y : 0) * H + wave * CW) / 32);
     }
+    if (a.touch) asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch_dummy));   // (the touches have landed long ago: this only ends the register's reservation)
     if (a.a_only) {   // (the first of two launches: h' leaves, LayerNorm and the projections follow on three times the CUs)
         const int c0 = lane * 8;
         if (c0 < H)
@@ -539,13 +572,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
 }
 
-template <int H, int NW, int D>
+template <int H, int NW, int D, bool PQ = true>
 static int node_chain_launch(const NodeChainArgs& a, hipStream_t s) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_chain_kernel<H, NW, D>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeChainCfg<H>::LDS); });
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)node_chain_kernel<H, NW, D, PQ>, hipFuncAttributeMaxDynamicSharedMemorySize, NodeChainCfg<H>::LDS); });
     MI_HIP(attr_err);
-    hipLaunchKernelGGL((node_chain_kernel<H, NW, D>), dim3(cdiv(a.N, 32), a.split_b ? 3 : 1), dim3(64 * NW), NodeChainCfg<H>::LDS, s, a);
+    hipLaunchKernelGGL((node_chain_kernel<H, NW, D, PQ>), dim3(cdiv(a.N, 32), a.split_b ? 3 : 1), dim3(64 * NW), NodeChainCfg<H>::LDS, s, a);
     MI_KERNEL_CHECK();
     return MI_OK;
 }
@@ -991,8 +1024,13 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
 }
 
 // The chain in front of layer l's edge stage (l = 0 .. L; l = L: finishes the last layer and applies the final LayerNorm into b->hf).
+static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train);
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     if (g_ablate_skip & 1) return MI_OK;
+    if (g_ablate_skip & 8) MI_TRY(node_chain_once(net, b, l, s, train));   // (timing experiment: every chain launched TWICE -- the second finds its weights in L2)
+    return node_chain_once(net, b, l, s, train);
+}
+static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     const int H = net->H, L = net->L, N = b->N;
     const size_t NH = (size_t)N * H;
     NodeChainArgs a;
@@ -1101,6 +1139,7 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     // projection passes are independent given LayerNorm(h'), so when three workgroups per row block still fit the chip in one round they
     // run as a second launch on three times the CUs (each recomputes the LayerNorm of its 32 rows).  Larger batches keep the one launch.
     const int nblk = cdiv(N, 32);
+    a.touch = g_node_touch_min_blocks > 0 && nblk >= g_node_touch_min_blocks;
     if (g_node_split && l < L && 3 * nblk <= g_node_split_max_blocks) {
         if (l > 0) {
             NodeChainArgs a1 = a;
@@ -1140,6 +1179,12 @@ extern "C" int mi_debug_set_node_split(int on) {
     const int was = mi::g_node_split;
     mi::g_node_split = on != 0;
     if (on > 1) mi::g_node_split_max_blocks = on;   // (experiments: the largest 3 x row-block count that still takes the two-launch form; default 256)
+    return was;
+}
+
+extern "C" int mi_debug_set_node_touch(int min_blocks) {
+    const int was = mi::g_node_touch_min_blocks;
+    mi::g_node_touch_min_blocks = min_blocks;
     return was;
 }
 
