@@ -111,7 +111,8 @@ def mg_flops_eval(hp, N, E):
     Ed, A = hp["emb_edge"], hp["emb_atom"]
     per_edge_block = 2 * Ed * (Ed * (2 + 2 * hp["num_before_skip"] + 2 * hp["num_after_skip"] + 1 + 2 * hp["num_concat"]) + hp["emb_rbf"] * 2
                                + hp["emb_trip"] + 2 * hp["emb_bil"]) + 2 * hp["emb_cbf"] * hp["emb_trip"] * hp["emb_bil"]
-    per_edge_out = 2 * Ed * (Ed * 4 + 2 * hp["emb_rbf"])
+    # (output blocks: the force path's Dense + num_atom residual layers and the lattice head's Dense; the energy path is not evaluated -- E_t feeds no output)
+    per_edge_out = 2 * Ed * (Ed * (2 + 2 * hp["num_atom"]) + 2 * hp["emb_rbf"])
     per_node_block = 2 * A * (Ed + A * 2 * hp["num_atom"] + 2 * Ed)
     return E * (hp["num_blocks"] * (per_edge_block + per_edge_out) + per_edge_out + 2 * hp["num_radial"] * (Ed + 3 * hp["emb_rbf"] + hp["num_spherical"] * hp["emb_cbf"])) \
         + N * (hp["num_blocks"] * per_node_block + 2 * A * (A + 2 * Ed + 101))
@@ -470,7 +471,7 @@ def cpu_baseline_mg_ft(budget_s=20.0):
             pp = MO.gemnet_forward(Q, hp, noisy["pos"], noisy["cell"], noisy["atomic_numbers"], na, t)
         sl, _ = MO.sample_loss(corr, ob, aux, pa)
         kl = MO.calc_kl_reg(pa, pp, aux["node2graph"], Bc)
-        torch.autograd.grad((rw * sl + 0.025 * kl * (1.1 - rw)).mean(), list(A.values()))
+        MO.param_grads((rw * sl + 0.025 * kl * (1.1 - rw)).mean(), A)
         t_total += time.perf_counter() - t0
         done += 1
     return {"value": Bc * done / t_total, "unit": "crystal-timesteps/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -480,7 +481,7 @@ def cpu_baseline_mg_ft(budget_s=20.0):
 
 def measure_mg(args, K, W, ctx=None):
     """The MatterGen-LABELLED form of BASELINE configs[1]: the predictor-corrector reverse sampler of the MatterGen-shaped network
-    (GemNet-T shape: 4 blocks at 512 / 512 / 64 / 16 / 16, cutoff 7 A, <= 50 neighbours, triplet basis; 28.3 M parameters), batch 256 x
+    (GemNet-T shape: 4 blocks at 512 / 512 / 64 / 16 / 16, cutoff 7 A, <= 50 neighbours, triplet basis; 42.7 M parameters), batch 256 x
     20 atoms, 1000-point grid, two denoiser evaluations per step.  SELF-CONSISTENT, PARITY-UNPINNED vs upstream (the reference's
     MatterGen arithmetic is an un-vendored dependency).  Returns the fields of a bench line."""
     ctx = ctx or (1, 0, torch.cuda.current_device(), False, None)

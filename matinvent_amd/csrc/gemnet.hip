@@ -462,6 +462,15 @@ __global__ void mul_bwd_kernel(const float* __restrict__ a, const float* __restr
     if (da) da[i] += g * b[i];
     if (db) db[i] += g * a[i];
 }
+// y = sf[0] * x and its gradient (GemNet's ScalingFactor with a fitted value: op_scale; identity factors launch nothing)
+__global__ void scale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sf, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * sf[0];
+}
+__global__ void scale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ sf, float* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] += dy[i] * sf[0];
+}
 // y = (a + b[perm]) * s   (perm: row permutation of b, or NULL)
 __global__ void axpby_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ perm, float s, float* __restrict__ y,
                                  int64_t rows, int cols) {
@@ -1160,6 +1169,12 @@ struct mi_gemnet {
     float* wrowsum = nullptr;          // [1024] device floats handed out with the blocks
     int wrowsum_used = 0;
     std::vector<float> wscale_h;       // per tensor, from its absmax (host copy refreshed by set_params)
+    // GemNet's ScalingFactor entries of the parameter list (`*.scale_factor`, 1 x 1, never trained): host copies refreshed by set_params.  A factor
+    // equal to one costs nothing (op_scale returns its input); any other value runs as an elementwise pass and switches the sampler's forwards to
+    // the synchronising form (sf_all_unit: the plane-only program has no such pass).  sf_pattern = which factors differ from one (program shape).
+    std::vector<float> sf_h;           // per tensor (1.f for everything that is not a scale factor)
+    bool sf_all_unit = true;
+    uint64_t sf_pattern = 0;
     const GParam& P(const std::string& n) const {
         auto it = index.find(n);
         if (it == index.end()) {
@@ -1170,7 +1185,7 @@ struct mi_gemnet {
     }
 };
 
-enum { OP_DENSE = 1, OP_MUL, OP_AXPBY, OP_SEGSUM, OP_TRIPLET, OP_ROWDOT, OP_EMBED, OP_FORCE, OP_STRESS };
+enum { OP_DENSE = 1, OP_MUL, OP_AXPBY, OP_SEGSUM, OP_TRIPLET, OP_ROWDOT, OP_EMBED, OP_FORCE, OP_STRESS, OP_SCALE };
 enum { GK_NONE = 0, GK_SRC = 1, GK_DST = 2, GK_NODE = 3 };
 
 struct GOp {
@@ -1802,6 +1817,33 @@ static float* op_axpby(Ctx& c, const float* A, const float* Bm, int64_t M, int N
     }
     return Y;
 }
+// GemNet's ScalingFactor `name`.scale_factor applied to X [M, N]: the input itself while the factor is one (the identity-initialised case: no launch,
+// no tape entry), otherwise one elementwise pass on fp32 rows (its result carries no plane set: the consumer splits on the fly)
+static float* op_scale(Ctx& c, float* X, int64_t M, int N, const std::string& name) {
+    const int idx = c.net->index.at(name + ".scale_factor");
+    if (c.net->sf_h.empty() || c.net->sf_h[idx] == 1.f) return X;
+    OpTimer optimer(c, "scale " + name, M, N, 0);
+    float* Y = c.take((size_t)M * N);
+    c.need_f32(X);
+    if (c.dry || !CTX_OK(c) || M == 0) return Y;
+    if (c.mdev(M)) {   // (forward_impl keeps such networks off the no-round-trip form)
+        c.rc = MI_ESTATE;
+        return Y;
+    }
+    const float* sf = c.net->theta + c.net->params[idx].off;
+    hipLaunchKernelGGL(scale_fwd_kernel, dim3(nblk(M * N)), dim3(256), 0, c.s, X, sf, Y, M * N);
+    if (c.train) {
+        GOp o;
+        o.type = OP_SCALE;
+        o.X = X;
+        o.Y = Y;
+        o.M = M;
+        o.N = N;
+        o.widx = idx;
+        c.b->tape.push_back(o);
+    }
+    return Y;
+}
 // edges -> atoms by target with the per-edge weights Wt multiplied in on the way (inference: the weighted messages are never written)
 static float* op_segsum_mul(Ctx& c, const float* X, const float* Wt, int cols) {
     OpTimer optimer(c, "segsum_mul", c.b->E, cols, 0);
@@ -1940,8 +1982,10 @@ static void out_block(Ctx& c, int i, const float* m, const float* rbf_out, bool 
     const std::string p = "out_blocks." + std::to_string(i);
     float* t1 = op_dense(c, m, E, Ed, p + ".dense_F.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
     const int Rb = g.emb_rbf;
+    // (the energy path -- dense_rbf, scale_sum, seq_energy, out_energy -- is not evaluated: E_t feeds no output, see the parameter list)
     if (c.lean_heads() && (Rb & (Rb - 1)) == 0 && Rb <= 64) {   // (see mi_gemnet::dtheta: the heads through the derived [emb_rbf, emb_edge] tensors)
-        float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed, true);
+        float* xF = res_stack(c, p + ".res_F", g.num_atom, t1, E, Ed, true);
+        xF = op_scale(c, xF, E, Ed, p + ".scale_rbf_F");
         float* pF = op_dense(c, xF, E, Ed, p + ".q_F");
         op_rowdot_short(c, rbf_out, pF, c.b->Fe, Rb, !first);
         float* xS = op_dense(c, m, E, Ed, p + ".dense_S.weight", 0, ACT_SSILU, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
@@ -1949,7 +1993,8 @@ static void out_block(Ctx& c, int i, const float* m, const float* rbf_out, bool 
         op_rowdot_short(c, rbf_out, pS, c.b->Se, Rb, !first);
         return;
     }
-    float* xF = res_stack(c, p + ".res_F", 1, t1, E, Ed);
+    float* xF = res_stack(c, p + ".res_F", g.num_atom, t1, E, Ed);
+    xF = op_scale(c, xF, E, Ed, p + ".scale_rbf_F");
     float* rF = op_dense(c, rbf_out, E, g.emb_rbf, p + ".rbf_F.weight");
     op_rowdot(c, xF, rF, p + ".out_F.weight", c.b->Fe, Ed, !first);
     float* xS = op_dense(c, m, E, Ed, p + ".dense_S.weight", 0, ACT_SSILU);
@@ -2031,9 +2076,11 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
             float* tb = op_dense(c, m, E, Ed, p + ".dense_ba.weight", 0, ACT_SSILU);
             x_ba = op_mul(c, tb, rr, E, Ed, true);
         }
+        x_ba = op_scale(c, x_ba, E, Ed, p + ".scale_rbf");
         float* xd = op_dense(c, x_ba, E, Ed, p + ".down_projection.weight");
         float* Tm = op_triplet(c, xd, cbfW);
         float* x3 = op_dense(c, Tm, E, Cb * Tr, p + ".bilinear.weight", 0, ACT_NONE, true, "", nullptr, GK_NONE, nullptr, GK_NONE, 0, nullptr, 1.f, true);
+        x3 = op_scale(c, x3, E, g.emb_bil, p + ".scale_cbf_sum");
         b->taps["x3_" + std::to_string(i)] = {x3, E * g.emb_bil};
         float* x;
         if (c.lean_mul()) {
@@ -2063,6 +2110,7 @@ static void run_program(Ctx& c, const float* pos, const float* cell, const int* 
             float* mm = op_mul(c, m, ru, E, Ed);
             h2 = op_segsum(c, mm, Ed);
         }
+        h2 = op_scale(c, h2, N, Ed, p + ".atom_update.scale_sum");
         h2 = op_dense(c, h2, N, Ed, p + ".atom_update.dense.weight", 0, ACT_SSILU);
         h2 = res_stack(c, p + ".atom_update.res", g.num_atom, h2, N, A);
         h = op_axpby(c, h, h2, N, A);
@@ -2136,7 +2184,8 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
                         bool nosync = false) {
     MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_gemnet_forward before mi_gemnet_set_params");
     b->tape_valid = false;
-    nosync = nosync && !train && MI_PLANES_FP16 && g_mg_planes && g_gemm_mode != 0 && (g_mg_lean & 63) == 63 && b->E_cap >= MG_PLANES_MIN_ROWS && !g_optime;
+    nosync = nosync && !train && MI_PLANES_FP16 && g_mg_planes && g_gemm_mode != 0 && (g_mg_lean & 63) == 63 && b->E_cap >= MG_PLANES_MIN_ROWS && !g_optime &&
+             net->sf_all_unit;   // (a ScalingFactor other than one is an elementwise pass on fp32 rows: op_scale)
     MI_TRY(graph_build(net, b, pos, cell, s, nosync));
     char* const real_base = b->fwd.base;
     size_t need = 0;
@@ -2147,7 +2196,7 @@ static int forward_impl(mi_gemnet* net, mi_gbatch* b, const float* pos, const fl
     if (nosync) {
         const uint64_t parts[] = {(uint64_t)b->E, (uint64_t)(uintptr_t)net, (uint64_t)g_mg_lean, (uint64_t)g_mg_f16, (uint64_t)g_gemm_mode, (uint64_t)g_planes_rt,
                                   (uint64_t)g_planes_rt_min_rows, (uint64_t)g_planes_big, (uint64_t)g_planes_big_min_rows, (uint64_t)g_planes_dma,
-                                  (uint64_t)g_planes_lat_max_blocks, (uint64_t)g_planes_variant, (uint64_t)g_mg_planes};
+                                  (uint64_t)g_planes_lat_max_blocks, (uint64_t)g_planes_variant, (uint64_t)g_mg_planes, net->sf_pattern};
         key = 0xcbf29ce484222325ull;
         for (uint64_t v : parts) key = (key ^ v) * 0x100000001b3ull;   // FNV-1a over the words
         key |= 1;
@@ -2328,6 +2377,9 @@ static int backward_impl(mi_gemnet* net, mi_gbatch* b, const float* d_pos, const
             case OP_AXPBY:
                 hipLaunchKernelGGL(axpby_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, o.perm ? b->swap : (const int*)nullptr, o.s, G(o.X), G(o.X2), o.M, o.N);
                 break;
+            case OP_SCALE:
+                if (o.M > 0) hipLaunchKernelGGL(scale_bwd_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, net->theta + net->params[o.widx].off, G(o.X), o.M * o.N);
+                break;
             case OP_SEGSUM:
                 if (o.M > 0) hipLaunchKernelGGL(gather_add_kernel, dim3(nblk(o.M * o.N)), dim3(256), 0, s, dY, b->dst, G(o.X), o.M, o.N);
                 break;
@@ -2420,10 +2472,19 @@ int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out) {
         }
     };
     auto outb = [&](int i) {
+        // GemNet-T's OutputBlock with direct forces [UPSTREAM-UNVERIFIED] (oracle/mattergen_oracle.py::param_list): the ENERGY path's tensors are part
+        // of the flat vector (the upstream denoiser evaluates E_t and never reads it: no output of this library depends on them, their gradient is
+        // identically zero and no kernel touches them), the FORCE path is Dense + num_atom residual layers, the lattice head this restatement's own
         const std::string p = "out_blocks." + std::to_string(i);
+        add(p + ".dense_rbf.weight", Ed, Rb);
+        add(p + ".scale_sum.scale_factor", 1, 1);
+        add(p + ".seq_energy.dense.weight", A, Ed);
+        res(p + ".seq_energy.res", g.num_atom, A);
+        add(p + ".out_energy.weight", 1, A);
         add(p + ".dense_F.weight", Ed, Ed);
-        res(p + ".res_F", 1, Ed);
+        res(p + ".res_F", g.num_atom, Ed);
         add(p + ".rbf_F.weight", Ed, Rb);
+        add(p + ".scale_rbf_F.scale_factor", 1, 1);
         add(p + ".out_F.weight", 1, Ed);
         add(p + ".dense_S.weight", Ed, Ed);
         add(p + ".rbf_S.weight", Ed, Rb);
@@ -2435,13 +2496,16 @@ int mi_gemnet_create(const mi_gemnet_config* cfg, mi_gemnet** out) {
         add(p + ".dense_ca.weight", Ed, Ed);
         add(p + ".dense_ba.weight", Ed, Ed);
         add(p + ".mlp_rbf.weight", Ed, Rb);
+        add(p + ".scale_rbf.scale_factor", 1, 1);
         add(p + ".down_projection.weight", Tr, Ed);
         add(p + ".bilinear.weight", Bl, Cb * Tr);
+        add(p + ".scale_cbf_sum.scale_factor", 1, 1);
         add(p + ".up_projection_ca.weight", Ed, Bl);
         add(p + ".up_projection_ac.weight", Ed, Bl);
         res(p + ".before_skip", g.num_before_skip, Ed);
         res(p + ".after_skip", g.num_after_skip, Ed);
         add(p + ".atom_update.rbf.weight", Ed, Rb);
+        add(p + ".atom_update.scale_sum.scale_factor", 1, 1);
         add(p + ".atom_update.dense.weight", A, Ed);
         res(p + ".atom_update.res", g.num_atom, A);
         add(p + ".concat.weight", Ed, 2 * A + Ed);
@@ -2523,7 +2587,25 @@ int mi_gemnet_set_params(mi_gemnet* net, const float* theta, void* stream) {
     {   // per-tensor plane scales on the host (2^floor(log2(16384 / absmax))); the lazily built weight plane sets are stale now
         std::vector<unsigned> bits(net->params.size());
         MI_HIP(hipMemcpyAsync(bits.data(), net->wamax, bits.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        std::vector<float> sf(net->params.size(), 1.f);
+        for (size_t i = 0; i < (size_t)net->n_real; ++i) {
+            const std::string& nm = net->params[i].name;
+            if (nm.size() > 13 && nm.compare(nm.size() - 13, 13, ".scale_factor") == 0)
+                MI_HIP(hipMemcpyAsync(&sf[i], theta + net->params[i].off, sizeof(float), hipMemcpyDeviceToHost, s));
+        }
         MI_HIP(hipStreamSynchronize(s));
+        {
+            uint64_t pat = 0xcbf29ce484222325ull;
+            bool unit = true;
+            for (size_t i = 0; i < sf.size(); ++i)
+                if (sf[i] != 1.f) {
+                    unit = false;
+                    pat = (pat ^ (uint64_t)(i + 1)) * 0x100000001b3ull;
+                }
+            net->sf_h = sf;
+            net->sf_all_unit = unit;
+            net->sf_pattern = unit ? 0 : pat;
+        }
         net->wscale_h.assign(bits.size(), 1.f);
         for (size_t i = 0; i < bits.size(); ++i) {
             float m;

@@ -255,11 +255,13 @@ class GemNetTDenoiser(nn.Module):
         for name, w in self.views().items():
             if name.endswith(".bias"):
                 w.zero_()
+            elif name.endswith(".scale_factor"):   # GemNet's ScalingFactor: a fitted constant upstream (a buffer, never trained); identity here
+                w.fill_(1.0)
             elif name == "atom_emb.weight":
                 w.copy_(torch.randn(w.shape))
             else:
                 w.copy_(torch.randn(w.shape) / math.sqrt(w.shape[1]))
-                if ".out_F." in name or ".out_S." in name or name == "fc_atom.weight":
+                if ".out_F." in name or ".out_S." in name or ".out_energy." in name or name == "fc_atom.weight":
                     w.mul_(cell_head_scale if (cell_head_scale is not None and ".out_S." in name) else head_scale)
         self._dirty = True
 

@@ -69,18 +69,26 @@ def param_list(hp: GemNetHParams):
         return r
 
     def out_block(i):
+        # GemNet-T's OutputBlock with direct forces [UPSTREAM-UNVERIFIED]: an ENERGY path (radial weighting, edge -> atom sum, ScalingFactor,
+        # Dense + num_atom residual layers, a one-column read-out: `E_t`, which the MatterGen denoiser computes and never reads) and a FORCE
+        # path (Dense + num_atom residual layers on the edge embedding, radial weighting, ScalingFactor, a one-column read-out); the
+        # lattice head (dense_S / rbf_S / out_S) is this restatement's form of the per-block lattice update
         p = f"out_blocks.{i}"
-        return ([(f"{p}.dense_F.weight", Ed, Ed)] + res(f"{p}.res_F", 1, Ed) + [(f"{p}.rbf_F.weight", Ed, Rb), (f"{p}.out_F.weight", 1, Ed),
-                (f"{p}.dense_S.weight", Ed, Ed), (f"{p}.rbf_S.weight", Ed, Rb), (f"{p}.out_S.weight", 1, Ed)])
+        return ([(f"{p}.dense_rbf.weight", Ed, Rb), (f"{p}.scale_sum.scale_factor", 1, 1), (f"{p}.seq_energy.dense.weight", A, Ed)]
+                + res(f"{p}.seq_energy.res", hp.num_atom, A) + [(f"{p}.out_energy.weight", 1, A)]
+                + [(f"{p}.dense_F.weight", Ed, Ed)] + res(f"{p}.res_F", hp.num_atom, Ed)
+                + [(f"{p}.rbf_F.weight", Ed, Rb), (f"{p}.scale_rbf_F.scale_factor", 1, 1), (f"{p}.out_F.weight", 1, Ed),
+                   (f"{p}.dense_S.weight", Ed, Ed), (f"{p}.rbf_S.weight", Ed, Rb), (f"{p}.out_S.weight", 1, Ed)])
 
     out += out_block(0)
     for i in range(hp.num_blocks):
         p = f"int_blocks.{i}"
-        out += [(f"{p}.dense_ca.weight", Ed, Ed), (f"{p}.dense_ba.weight", Ed, Ed), (f"{p}.mlp_rbf.weight", Ed, Rb),
-                (f"{p}.down_projection.weight", Tr, Ed), (f"{p}.bilinear.weight", Bl, Cb * Tr), (f"{p}.up_projection_ca.weight", Ed, Bl),
-                (f"{p}.up_projection_ac.weight", Ed, Bl)]
+        out += [(f"{p}.dense_ca.weight", Ed, Ed), (f"{p}.dense_ba.weight", Ed, Ed), (f"{p}.mlp_rbf.weight", Ed, Rb), (f"{p}.scale_rbf.scale_factor", 1, 1),
+                (f"{p}.down_projection.weight", Tr, Ed), (f"{p}.bilinear.weight", Bl, Cb * Tr), (f"{p}.scale_cbf_sum.scale_factor", 1, 1),
+                (f"{p}.up_projection_ca.weight", Ed, Bl), (f"{p}.up_projection_ac.weight", Ed, Bl)]
         out += res(f"{p}.before_skip", hp.num_before_skip, Ed) + res(f"{p}.after_skip", hp.num_after_skip, Ed)
-        out += [(f"{p}.atom_update.rbf.weight", Ed, Rb), (f"{p}.atom_update.dense.weight", A, Ed)] + res(f"{p}.atom_update.res", hp.num_atom, A)
+        out += [(f"{p}.atom_update.rbf.weight", Ed, Rb), (f"{p}.atom_update.scale_sum.scale_factor", 1, 1), (f"{p}.atom_update.dense.weight", A, Ed)]
+        out += res(f"{p}.atom_update.res", hp.num_atom, A)
         out += [(f"{p}.concat.weight", Ed, 2 * A + Ed)] + res(f"{p}.residual_m", hp.num_concat, Ed)
         out += out_block(i + 1)
     out += [("fc_atom.weight", NUM_CLASSES, A), ("fc_atom.bias", 1, NUM_CLASSES)]
@@ -94,13 +102,26 @@ def init_params(hp: GemNetHParams, seed: int = 0, head_scale: float = 1.0) -> Di
     for name, rows, cols in param_list(hp):
         if name.endswith(".bias"):
             P[name] = torch.zeros(cols)
+        elif name.endswith(".scale_factor"):   # GemNet's ScalingFactor: a fitted constant upstream (a buffer, never trained); identity here
+            P[name] = torch.ones(1, 1)
         elif name == "atom_emb.weight":
             P[name] = torch.randn(rows, cols, generator=g)
         else:
             P[name] = torch.randn(rows, cols, generator=g) / math.sqrt(cols)
-            if ".out_F." in name or ".out_S." in name or name == "fc_atom.weight":
+            if ".out_F." in name or ".out_S." in name or ".out_energy." in name or name == "fc_atom.weight":
                 P[name] = P[name] * head_scale
     return P
+
+
+def param_grads(loss, A: Dict[str, torch.Tensor]):
+    """d loss / d A as a list in A's order; entries no output depends on (the energy path, the ScalingFactor constants) are zeros."""
+    gs = torch.autograd.grad(loss, list(A.values()), allow_unused=True)
+    return [torch.zeros_like(v) if g is None else g for g, v in zip(gs, A.values())]
+
+
+def is_scale_factor(name: str) -> bool:
+    """The non-trainable scalars of the parameter list (their gradient entries are zero by definition)."""
+    return name.endswith(".scale_factor")
 
 
 # --------------------------------------------------------------------------------------------------------------------------
@@ -291,23 +312,32 @@ def gemnet_forward(P: Dict[str, torch.Tensor], hp: GemNetHParams, frac, cell, at
     if taps is not None:
         taps.update(rbf=rbf, h0=h, m0=m, D=D, V=V)
 
+    def sf(name):   # ScalingFactor: a constant (detached: it is a buffer upstream, never a trained parameter)
+        return P[name + ".scale_factor"].detach().reshape(())
+
     def out_block(i, m):
         p = f"out_blocks.{i}"
-        xF = _residual_stack(P, f"{p}.res_F", 1, _dense(P, f"{p}.dense_F", m, True))
-        F = (xF * (rbf_out @ P[f"{p}.rbf_F.weight"].t())) @ P[f"{p}.out_F.weight"].t()
+        # energy path (atom level): E_t is computed by the upstream denoiser and discarded by the score model -- restated for the parameter
+        # list's sake and returned under "energy"; the device path does not evaluate it (no output depends on it)
+        xE = _segment_sum(m * (rbf_out @ P[f"{p}.dense_rbf.weight"].t()), dst, N) * sf(f"{p}.scale_sum")
+        xE = _residual_stack(P, f"{p}.seq_energy.res", hp.num_atom, _dense(P, f"{p}.seq_energy.dense", xE, True))
+        En = xE @ P[f"{p}.out_energy.weight"].t()
+        # force path (edge level)
+        xF = _residual_stack(P, f"{p}.res_F", hp.num_atom, _dense(P, f"{p}.dense_F", m, True))
+        F = ((xF * (rbf_out @ P[f"{p}.rbf_F.weight"].t())) * sf(f"{p}.scale_rbf_F")) @ P[f"{p}.out_F.weight"].t()
         xS = _dense(P, f"{p}.dense_S", m, True)
         Sc = (xS * (rbf_out @ P[f"{p}.rbf_S.weight"].t())) @ P[f"{p}.out_S.weight"].t()
-        return F, Sc
+        return F, Sc, En
 
-    F, Sc = out_block(0, m)
+    F, Sc, En = out_block(0, m)
     for i in range(hp.num_blocks):
         p = f"int_blocks.{i}"
         x_ca = _dense(P, f"{p}.dense_ca", m, True)
-        x_ba = _dense(P, f"{p}.dense_ba", m, True) * (rbf3 @ P[f"{p}.mlp_rbf.weight"].t())
+        x_ba = _dense(P, f"{p}.dense_ba", m, True) * (rbf3 @ P[f"{p}.mlp_rbf.weight"].t()) * sf(f"{p}.scale_rbf")
         xd = x_ba @ P[f"{p}.down_projection.weight"].t()                                   # [E, Tr]
         sk = triplet_sum(xd, V, g, S)                                                      # [E, S, Tr]
         tm = torch.einsum("eli,elj->eij", cbfW, sk).reshape(E, Cb * Tr)                    # [e][i][j]
-        x3 = tm @ P[f"{p}.bilinear.weight"].t()                                            # [E, Bl]
+        x3 = (tm @ P[f"{p}.bilinear.weight"].t()) * sf(f"{p}.scale_cbf_sum")               # [E, Bl]
         if taps is not None:
             taps[f"x3_{i}"] = x3
         x3 = (_dense(P, f"{p}.up_projection_ca", x3, True) + _dense(P, f"{p}.up_projection_ac", x3, True)[swap]) * INV_SQRT_2
@@ -315,14 +345,14 @@ def gemnet_forward(P: Dict[str, torch.Tensor], hp: GemNetHParams, frac, cell, at
         x = _residual_stack(P, f"{p}.before_skip", hp.num_before_skip, x)
         m = (m + x) * INV_SQRT_2
         m = _residual_stack(P, f"{p}.after_skip", hp.num_after_skip, m)
-        h2 = _segment_sum(m * (rbf_h @ P[f"{p}.atom_update.rbf.weight"].t()), dst, N)
+        h2 = _segment_sum(m * (rbf_h @ P[f"{p}.atom_update.rbf.weight"].t()), dst, N) * sf(f"{p}.atom_update.scale_sum")
         h2 = _residual_stack(P, f"{p}.atom_update.res", hp.num_atom, _dense(P, f"{p}.atom_update.dense", h2, True))
         h = (h + h2) * INV_SQRT_2
         m2 = ssilu(torch.cat([h[src], h[dst], m], 1) @ P[f"{p}.concat.weight"].t())
         m2 = _residual_stack(P, f"{p}.residual_m", hp.num_concat, m2)
         m = (m + m2) * INV_SQRT_2
-        Fi, Si = out_block(i + 1, m)
-        F, Sc = F + Fi, Sc + Si
+        Fi, Si, Ei = out_block(i + 1, m)
+        F, Sc, En = F + Fi, Sc + Si, En + Ei
         if taps is not None:
             taps[f"h{i + 1}"], taps[f"m{i + 1}"] = h, m
     force = _segment_sum(F * V, dst, N)                                                    # [N,3] cartesian
@@ -331,7 +361,7 @@ def gemnet_forward(P: Dict[str, torch.Tensor], hp: GemNetHParams, frac, cell, at
     cnt = torch.zeros(B).index_add(0, eg, torch.ones(E)).clamp(min=1.0)
     stress = torch.zeros(B, 3, 3).index_add(0, eg, Sc[:, :, None] * outer) / cnt[:, None, None]
     logits = h @ P["fc_atom.weight"].t() + P["fc_atom.bias"]
-    return dict(pos=pos, cell=stress, atomic_numbers=logits)
+    return dict(pos=pos, cell=stress, atomic_numbers=logits, energy=En)
 
 
 # --------------------------------------------------------------------------------------------------------------------------

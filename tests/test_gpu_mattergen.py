@@ -48,7 +48,8 @@ def test_parameter_layout_matches_the_oracle_list():
     for (n, r, c), (k, (off, numel, shape)) in zip(names, m.decoder.layout.items()):
         assert numel == r * c and off % 4 == 0, n
     big = M.GemNetHParams()
-    assert sum(r * c for _, r, c in M.param_list(big)) == 28260965   # the 512-wide network of THIS restatement (upstream: ~46.8 M [UPSTREAM-UNVERIFIED])
+    assert sum(r * c for _, r, c in M.param_list(big)) == 42722427   # the 512-wide network of THIS restatement (upstream: ~46.8 M [UPSTREAM-UNVERIFIED]; 28.3 M before the
+    # output blocks took upstream's shape: energy path, num_atom residual layers on the force path, ScalingFactors -- round 5)
 
 
 @pytest.mark.parametrize("na,scale,hpk", [([4, 7, 1, 10], 5.0, {}), ([20, 20, 3], 3.2, dict(max_neighbors=12)), ([2, 5], 2.0, dict(cutoff=6.0, max_images=4))])
@@ -73,12 +74,27 @@ def test_periodic_graph_matches_the_oracle_exactly(na, scale, hpk):
 # the benchmark network's basis sizes (7 spherical orders, 16-wide circular basis, 64-wide triplet embedding: the branches of the triplet
 # kernels that the four-order TINY network does not reach) at widths the CPU oracle finishes in seconds
 BASIS7 = dict(M.TINY, emb_trip=64, emb_cbf=16, emb_rbf=16, emb_bil=64, num_spherical=7, num_radial=32)
+# GemNet's ScalingFactors with FITTED values (upstream ships them as constants of the checkpoint; identity-initialised here) and two residual layers
+# in the output blocks' stacks: the elementwise pass of op_scale and its gradient, which the identity case never launches
+FITTED = dict(M.TINY, num_atom=2)
+CASES = [(M.TINY, False), (BASIS7, False), (FITTED, True)]
+CASE_IDS = ["tiny", "benchmark-basis-sizes", "fitted-scale-factors"]
 
 
-@pytest.mark.parametrize("hpd", [M.TINY, BASIS7], ids=["tiny", "benchmark-basis-sizes"])
-def test_forward_matches_the_oracle_layer_by_layer(hpd):
+def _fit_scale_factors(P, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    for k in P:
+        if M.is_scale_factor(k):
+            P[k] = 0.6 + 0.9 * torch.rand(1, 1, generator=g)
+    return P
+
+
+@pytest.mark.parametrize("hpd,fitted", CASES, ids=CASE_IDS)
+def test_forward_matches_the_oracle_layer_by_layer(hpd, fitted):
     hp = M.GemNetHParams(**hpd)
     P = M.init_params(hp, seed=0, head_scale=0.3)
+    if fitted:
+        P = _fit_scale_factors(P)
     m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([4, 7, 1, 10, 20])
     taps = {}
@@ -102,10 +118,12 @@ def test_forward_matches_the_oracle_layer_by_layer(hpd):
         assert torch.equal(out[k], out2[k]), k
 
 
-@pytest.mark.parametrize("hpd", [M.TINY, BASIS7], ids=["tiny", "benchmark-basis-sizes"])
-def test_parameter_gradients_match_the_oracle_autograd(hpd):
+@pytest.mark.parametrize("hpd,fitted", CASES, ids=CASE_IDS)
+def test_parameter_gradients_match_the_oracle_autograd(hpd, fitted):
     hp = M.GemNetHParams(**hpd)
     P = M.init_params(hp, seed=2, head_scale=0.5)
+    if fitted:
+        P = _fit_scale_factors(P)
     m = _module(hpd, P)
     na, frac, cell, a, t, g = _case([5, 1, 12, 20, 3], seed=7)
     N, B = int(na.sum()), len(na)
@@ -117,8 +135,15 @@ def test_parameter_gradients_match_the_oracle_autograd(hpd):
     out = m.decoder(frac, cell, a, t, gb)
     ((out["pos"] * up.cuda()).sum() + (out["cell"] * uc.cuda()).sum() + (out["atomic_numbers"] * ul.cuda()).sum()).backward()
     th = m.decoder.theta
+    unused = 0
     for k, (o, n, shape) in m.decoder.layout.items():
+        if Pg[k].grad is None:   # the energy path (E_t feeds no output) and the ScalingFactors (constants): no gradient on either side
+            assert M.is_scale_factor(k) or ".seq_energy." in k or ".out_energy." in k or ".dense_rbf." in k or ".scale_sum." in k, k
+            assert not bool(th.grad[o:o + n].any()), k
+            unused += 1
+            continue
         _rel(th.grad[o:o + n].view(shape), Pg[k].grad, 5e-5, f"grad {k}")
+    assert unused > 0
     # `+=` semantics across backward calls, like .grad
     g1 = th.grad.clone()
     out = m.decoder(frac, cell, a, t, gb)
@@ -361,7 +386,7 @@ def test_fine_tune_step_through_the_pipeline_surface_vs_oracle():
         sl, _ = M.sample_loss(corr, ob, aux, pa)
         kl = M.calc_kl_reg(pa, pp, aux["node2graph"], B)
         loss = (rw * sl + 0.025 * kl * (1.1 - rw)).mean() / TS
-        gs = torch.autograd.grad(loss, list(A.values()))
+        gs = M.param_grads(loss, A)
         for k, gg in zip(A, gs):
             grads[k] += gg
         tot += float(loss) * TS
@@ -424,7 +449,7 @@ def large_tile_case():
     refg = M.gemnet_forward(Pg, hp, frac, cell, a, na, t)
     ((refg["pos"] * up).sum() + (refg["cell"] * uc).sum() + (refg["atomic_numbers"] * ul).sum()).backward()
     return dict(hpd=hpd, hp=hp, P=P, na=na, frac=frac, cell=cell, a=a, t=t, taps=taps, ref={k: v.detach() for k, v in ref.items()}, up=up, uc=uc, ul=ul,
-                grads={k: v.grad.clone() for k, v in Pg.items()})
+                grads={k: (torch.zeros_like(v) if v.grad is None else v.grad.clone()) for k, v in Pg.items()})
 
 
 @pytest.mark.parametrize("planes,f16,lean", [(1, 0, 1), (4, 0, 1), (5, 0, 1), (1, 0, 0), (2, 0, 1), (3, 0, 1), (0, 1, 1), (0, 0, 1)],
@@ -480,7 +505,7 @@ def test_forward_at_a_size_where_the_large_tile_products_run(planes, f16, lean, 
         _lib.load().mi_debug_set_rt_lean(1)
 
 
-# ---- the network at the size the benchmark times it: GemNetHParams() defaults (512 / 512 / 64 / 16 / 16, 4 blocks, 28.3 M parameters),
+# ---- the network at the size the benchmark times it: GemNetHParams() defaults (512 / 512 / 64 / 16 / 16, 4 blocks, 42.7 M parameters),
 # ---- 256 crystals x 20 atoms at physical density (~250 k edges) -- BASELINE configs[1]-[2] in their MatterGen-labelled form
 BENCH_B, BENCH_N = 256, 20
 
@@ -544,8 +569,10 @@ def _drop_handles(m):
     import gc
     m.__dict__.pop("_gb_cache", None)
     m.__dict__.pop("_gb_chain_cache", None)
+    m.__dict__.pop("_last_chain_batches", None)   # (the handles of the last sample() call, kept for graph_status())
     gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
 
 def test_benchmark_size_crystal_groups_vs_the_unsplit_batch(bench_net):
@@ -619,6 +646,8 @@ def test_benchmark_size_concurrent_forwards_are_bit_reproducible(bench_net):
     import threading
     from matinvent_amd.streams import concurrent_streams
     hp, P, m = bench_net
+    _drop_handles(m)   # (four inference arenas of 64 crystals at ~38 GB each follow)
+    print("free / total device memory before the four handles:", [round(x / 2**30, 1) for x in torch.cuda.mem_get_info()])
     G, Bg = 4, 64
     groups = []
     for k in range(G):
@@ -704,12 +733,17 @@ def test_benchmark_size_fine_tune_window_vs_the_oracle(bench_net):
             sl, _ = M.sample_loss(corr, ob, aux, pa)
             kl = M.calc_kl_reg(pa, pp, aux["node2graph"], CH)
             loss = (rw[c0:c1] * sl + 0.025 * kl * (1.1 - rw[c0:c1])).sum() / (B * TS)
-            gs = torch.autograd.grad(loss, list(A.values()))
+            gs = M.param_grads(loss, A)
             for k, gg in zip(A, gs):
                 grads[k] += gg
             tot += float(loss.detach()) * TS
             del pa, pp, sl, kl, loss, gs
-    assert abs(stats[0]["loss"] - tot / TS) <= 1e-4 * max(1.0, abs(tot / TS)), (stats[0]["loss"], tot / TS)
+    # (2e-3, not the forward's 2e-5: the device noises the structures itself, and its noised positions differ from the oracle's in the last bit
+    #  (`% 1.0` of a sum, 2e-6 allowed by test_add_noise_...).  128 radial Gaussians 0.055 A wide turn 7e-6 A into 1e-4 of a basis value, and this
+    #  randomly perturbed 42.7 M-parameter network (outputs of order 1e4) into up to 1 % of ONE crystal's loss -- measured with identical edge
+    #  lists on both sides, scripts/mg_loss_check.py: 8e-5 / 2.6e-4 of the summed sample loss, 4e-4 / 1e-3 of the KL term at the two timesteps.
+    #  On IDENTICAL inputs the same network agrees to 1e-5 per output: scripts/mg_scale_check.py and tests (i)-(iii).)
+    assert abs(stats[0]["loss"] - tot / TS) <= 2e-3 * max(1.0, abs(tot / TS)), (stats[0]["loss"], tot / TS)
     with torch.no_grad():
         Ad = {k: v.detach().clone() for k, v in A.items()}
         DO.adam_step(Ad, grads, {}, 1e-5)
