@@ -945,7 +945,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                            net->KP);
         MI_KERNEL_CHECK();
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT && g_edge_pairs && !b->knn && H % 8 == 0) {
-        if (b->Np > 0) {  // pair mode: one operand row per unordered pair
+        if (b->Np > 0 && !((g_ablate_skip & 16) && b->ff_built_once)) {  // pair mode: one operand row per unordered pair  (bit 4 of the timing ablations: built once, then stale)
+            b->ff_built_once = true;
             Planes ffp = make_planes(b->FFpl, 2 * net->Kh, PL_S_UNIT);
             const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 8);  // a lane per row and 8-column chunk
             hipLaunchKernelGGL(fourier_pair_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np,
