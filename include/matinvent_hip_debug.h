@@ -110,6 +110,10 @@ int mi_debug_set_node_cols(int mode);
  * run at the miss latency.  Default 64 (one chain of 256 crystals: +4.3 %; chains of 64 crystals measured -1 % and stay off); 0 = never.  Returns the
  * previous setting. */
 int mi_debug_set_node_touch(int min_blocks);
+/* Atom count from which the fused output heads (coordinate + type read-outs, models/diffcsp/cspnet.py:291-294) run on 16 rows per workgroup instead of 4
+ * (every workgroup streams the whole 213 KB weight block; same fp32 FMA chains per output, so the results do not depend on it).  Default: never (measured neutral / -2 %,
+ * profiles/r5_heads_rows16_ab.log).  Returns the previous setting. */
+int mi_debug_set_heads_rows16(int min_nodes);
 /* TIMING ABLATIONS ONLY -- the results of a forward are garbage while a bit is set: 1 = skip the node chain's launches, 2 = the first edge GEMM,
  * 4 = the second (what a chain's serial path and the chip's occupancy cost each other: DESIGN 19.1), 8 = every node chain launched twice, 16 = the
  * pair-mode Fourier operand built once per batch handle and then left stale.  Returns the previous mask. */

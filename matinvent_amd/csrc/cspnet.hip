@@ -27,6 +27,8 @@ int g_planes_rt = 2;              // register-tile kernel for every qualifying p
 int g_planes_rt_min_rows = 16384;
 int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
+int g_heads_rows16_min_nodes = 1 << 30;   // atoms from which the fused heads run on 16 rows per workgroup instead of 4 (a quarter of the weight streams; mi_debug_set_heads_rows16).
+                                          // OFF: measured neutral on the headline (53.9 / 54.0 / 54.4 against 53.7 / 53.8 / 54.2) and -2 % on the reference's default batch, profiles/r5_heads_rows16_ab.log
 int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0: two fp32-operand GEMM launches; mi_debug_set_node_priority(2))
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
@@ -642,13 +644,17 @@ __global__ void finalize_agg_kernel(const float* __restrict__ part, const int* _
 // LayerNorm's rows): the two [N, 3] / [N, 100] products were two fp32-operand GEMM launches plus their split-K reductions on every chain's
 // serial path (~60 us per evaluation for 67 MFLOP).  Four rows per block in LDS, a thread per output column, the 103 weight rows read
 // transposed ([H][104]: coalesced), plain fp32 FMA chains over k.
-constexpr int HEADS_LD = 104, HEADS_ROWS = 4;
+constexpr int HEADS_LD = 104;
 __global__ void pack_heads_kernel(const float* __restrict__ Wc, const float* __restrict__ Wt, float* __restrict__ WT, int H) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * HEADS_LD) return;
     const int k = idx / HEADS_LD, c = idx % HEADS_LD;
     WT[idx] = c < 3 ? Wc[(size_t)c * H + k] : c < 3 + MI_NUM_TYPES ? Wt[(size_t)(c - 3) * H + k] : 0.f;
 }
+// HEADS_ROWS rows per workgroup: every workgroup streams the whole [H][104] weight block (213 KB at H = 512) from L2, so 4 rows per workgroup made the
+// launch 320 such streams at 1 280 atoms (47 us beside the other chains' GEMMs, on every chain's serial path twice per step); 16 rows make it 80.  The
+// per-output fp32 FMA chains are unchanged (same k order, same four partial sums): the result does not depend on HEADS_ROWS.
+template <int HEADS_ROWS>
 __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf, const float* __restrict__ WT, const float* __restrict__ type_bias,
                                                     float* __restrict__ coord_out, float* __restrict__ type_out, int N, int H) {
     // 512 threads = 4 k-groups x 128 output columns (103 used): a k-group walks a quarter of H with eight weight loads in flight per
@@ -1228,8 +1234,16 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     }
     MI_KERNEL_CHECK();
     if (!train && net->WheadT && g_fused_heads && H % 64 == 0) {
-        hipLaunchKernelGGL(heads_kernel, dim3(cdiv(N, HEADS_ROWS)), dim3(512), (size_t)(HEADS_ROWS * H + 4 * HEADS_ROWS * 128) * sizeof(float), s, b->hf, net->WheadT,
-                           net->p("type_out.bias"), coord_out, type_out, N, H);
+        auto lds = [&](int rows) { return (size_t)(rows * H + 4 * rows * 128) * sizeof(float); };
+        if (N >= g_heads_rows16_min_nodes) {   // (16 rows per workgroup need 64.5 KB of LDS at H = 512: above the default ceiling)
+            static std::once_flag once;
+            static hipError_t attr_err = hipSuccess;
+            std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)heads_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+            MI_HIP(attr_err);
+            hipLaunchKernelGGL(heads_kernel<16>, dim3(cdiv(N, 16)), dim3(512), lds(16), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H);
+        } else {
+            hipLaunchKernelGGL(heads_kernel<4>, dim3(cdiv(N, 4)), dim3(512), lds(4), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H);
+        }
         MI_KERNEL_CHECK();
     } else {
         MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s, &b->sk));
@@ -1788,6 +1802,12 @@ int mi_debug_set_tn128(int on) {
     g_bwd_wgrad_planes = (on & 256) == 0;   // +256: edge_mlp.2's weight gradient from fp32 rows (split, SiLU and transposition on the way into LDS) instead of from the M1 / dZ2 plane sets
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
+}
+
+int mi_debug_set_heads_rows16(int min_nodes) {
+    const int was = g_heads_rows16_min_nodes;
+    g_heads_rows16_min_nodes = min_nodes;
+    return was;
 }
 
 int mi_debug_set_pair_wide(int on) {

@@ -7,6 +7,7 @@ same buffers (`beta_scheduler.*`, `sigma_scheduler.*`), same methods
 """
 import ctypes as C
 
+import os
 import torch
 import torch.nn as nn
 
@@ -248,17 +249,32 @@ class DiffCSPModule(nn.Module):
         self.decoder.sync()
         self._coefficients(step_lr)
         cur = torch.cuda.current_stream()
+        # ONE state for the whole batch, allocated (and, with `init`, copied) here on the caller's stream; every chain works in place on ITS rows
+        # of it.  (Each chain used to clone its slices on its own thread -- twelve small torch calls contending for the interpreter lock at the
+        # head of every call, 70-150 us apart on the GPU timeline -- and the call ended with five torch.cat launches: profiles/r5_window_steps.log.)
+        dev = self.device
+        n_tot, b_tot = n0[-1], g0[-1]
+        if init is not None:
+            state = tuple(v.to(dev, torch.float32).contiguous().clone() for v in init)
+        else:
+            state = (torch.empty(n_tot, 3, device=dev), torch.empty(b_tot, 3, 3, device=dev), torch.empty(n_tot, MAX_ATOMIC_NUM, device=dev))
         ready = cur.record_event()
         # long-lived worker threads, one per stream (streams.ChainWorkers): a call hands each its chain and waits -- no thread start per call
         from .streams import ChainWorkers
         workers = ChainWorkers.get(streams, self.device)
 
+        stagger = float(os.environ.get("MI_CHAIN_STAGGER_US", "0")) * 1e-6   # (experiment: chain k starts k x this later)
+
         def run(k, stream):
+            if stagger > 0 and k > 0:
+                import time as _t
+                _t.sleep(k * stagger)
             stream.wait_event(ready)
-            ini = None if init is None else (init[0][n0[k]:n0[k + 1]], init[1][g0[k]:g0[k + 1]], init[2][n0[k]:n0[k + 1]])
+            own = (state[0][n0[k]:n0[k + 1]], state[1][g0[k]:g0[k + 1]], state[2][n0[k]:n0[k + 1]])   # (contiguous row ranges: views, no copy)
             nz = None if noise is None else {"corr_x": noise["corr_x"][:, n0[k]:n0[k + 1]], "pred_x": noise["pred_x"][:, n0[k]:n0[k + 1]],
                                              "pred_t": noise["pred_t"][:, n0[k]:n0[k + 1]], "pred_l": noise["pred_l"][:, g0[k]:g0[k + 1]]}
-            r = self._sample_one(parts[k], step_lr, seed, nz, ini, record, t_start, t_stop, node_offset + n0[k], graph_offset + g0[k])
+            r = self._sample_one(parts[k], step_lr, seed, nz, None, record, t_start, t_stop, node_offset + n0[k], graph_offset + g0[k],
+                                 inplace=own, drawn=init is not None)
             cur.wait_event(stream.record_event())
             return r
 
@@ -276,10 +292,20 @@ class DiffCSPModule(nn.Module):
                 else:
                     m[name] = torch.cat([d[name] for d in ds])
             return m
-        traj = {t: merge([o[1][t] for o in out]) for t in out[0][1]}
+
+        def final_state():   # the chains' final states ARE the rows of `state`: nothing to concatenate
+            idx = getattr(batch, "_mi_batch_idx", None)
+            if idx is None or idx[0] != key:
+                idx = (key, torch.cat([o[0]["batch_idx"] + g0[k] for k, o in enumerate(out)]), torch.cat([o[0]["num_atoms"] for o in out]))
+                try:
+                    batch._mi_batch_idx = idx
+                except AttributeError:
+                    pass
+            return dict(atom_types=state[2], frac_coords=state[0], lattices=state[1], num_atoms=idx[2], batch_idx=idx[1])
+        traj = {t: (final_state() if t == t_stop else merge([o[1][t] for o in out])) for t in out[0][1]}
         return traj[t_stop], traj
 
-    def _sample_one(self, batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset):
+    def _sample_one(self, batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset, inplace=None, drawn=False):
         """One chain over one CrystalBatch on the current stream.
 
         Returns (traj[t_stop], traj) like the reference.  `traj` holds every step only when
@@ -295,7 +321,12 @@ class DiffCSPModule(nn.Module):
         cb = batch if isinstance(batch, CrystalBatch) else self.crystal_batch(batch, node_offset, graph_offset)
         B, N = cb.num_graphs, cb.num_nodes
         self.decoder.sync()
-        if init is None:
+        if inplace is not None:   # (a chain of a split batch: its rows of the caller's state, updated in place; `drawn`: they already hold the initial state)
+            x, l, a = inplace
+            assert x.is_contiguous() and l.is_contiguous() and a.is_contiguous() and x.shape[0] == N and l.shape[0] == B
+            if not drawn:
+                _lib.check(lib.mi_sampler_init_state(cb._h, seed, T, _ptr(a), _ptr(x), _ptr(l), _stream()), "mi_sampler_init_state")
+        elif init is None:
             x = torch.empty(N, 3, device=dev)
             l = torch.empty(B, 3, 3, device=dev)
             a = torch.empty(N, MAX_ATOMIC_NUM, device=dev)
