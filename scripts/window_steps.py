@@ -6,8 +6,10 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 out = "/tmp/window_steps"
 subprocess.run(["rm", "-rf", out])
 env = dict(os.environ, TMPDIR="/tmp")
-subprocess.run(["rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--", sys.executable, "bench.py", "--steps", str(K), "--warmup", str(W),
-                "--no-cpu-baseline", "--no-counters"] + sys.argv[3:], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+cmd = [sys.executable, "bench.py", "--steps", str(K), "--warmup", str(W), "--no-cpu-baseline", "--no-counters"] + sys.argv[3:]
+if os.environ.get("MI_WINDOW_CMD"):   # (another workload whose last K predictor kernels per queue are to be split into steps, e.g. scripts/two_calls.py)
+    cmd = [sys.executable] + os.environ["MI_WINDOW_CMD"].split()
+subprocess.run(["rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--"] + cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
 f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
