@@ -49,6 +49,16 @@
 #define MI_RING_WAIT(w) (void)0
 #endif
 
+// Cache policy of the LDS-DMA operand streams (the `aux` word of buffer_load ... lds: 2 = nt, "non-temporal"): M1 rows are read by the two column halves of a row
+// tile and are dead afterwards; the Fourier operand is read by the four column quarters of a row tile and again by the next layer ~400 us later.  A/B builds only
+// (scripts/build_variant.py): measured, see DESIGN 19.7.
+#ifndef MI_DMA_AUX_M1
+#define MI_DMA_AUX_M1 0
+#endif
+#ifndef MI_DMA_AUX_FF
+#define MI_DMA_AUX_FF 0
+#endif
+
 namespace mi {
 
 extern int g_edge2_train;
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; ++q) {
             const int piece = wave * 4 + q;   // plane = piece >> 3, rows 16 (piece & 7) .. + 15
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
-                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, MI_DMA_AUX_M1);
         }
     };
     dma_tile(0, 0);
@@ -1048,7 +1058,7 @@ __device__ __forceinline__ void edge_gemm1_body(const Planes& A, const u16* __re
         for (int q = 0; q < 4; ++q) {
             const int piece = wave * 4 + q;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + st * EG2B_STAGE + piece * 1024), 16, voffa,
-                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, 0);
+                                                     kt * 24576 + (piece >> 3) * 8192 + (piece & 7) * 1024, 0, MI_DMA_AUX_FF);
         }
     };
     dma_tile(0, 0);
