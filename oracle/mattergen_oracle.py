@@ -113,9 +113,9 @@ def init_params(hp: GemNetHParams, seed: int = 0, head_scale: float = 1.0) -> Di
     return P
 
 
-def param_grads(loss, A: Dict[str, torch.Tensor]):
+def param_grads(loss, A: Dict[str, torch.Tensor], retain_graph: bool = False):
     """d loss / d A as a list in A's order; entries no output depends on (the energy path, the ScalingFactor constants) are zeros."""
-    gs = torch.autograd.grad(loss, list(A.values()), allow_unused=True)
+    gs = torch.autograd.grad(loss, list(A.values()), allow_unused=True, retain_graph=retain_graph)
     return [torch.zeros_like(v) if g is None else g for g, v in zip(gs, A.values())]
 
 

@@ -228,6 +228,17 @@ def test_concurrent_streams_reproduce_the_single_stream_chain():
     g2, _ = m.sample(Box(na), step_lr=5e-6, seed=seed, init=init, streams=2)
     assert wrap_dist(g1["frac_coords"].cpu().numpy(), g2["frac_coords"].cpu().numpy()).max() < 2e-5
     np.testing.assert_allclose(g1["lattices"].cpu().numpy(), g2["lattices"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    # the chains of a split call work IN PLACE on one state the call allocates: the caller's `init` is copied, never written, a second call from the
+    # same `init` gives the same bits, and the returned state is ONE tensor per field in the batch's order (no per-group pieces to concatenate)
+    keep = tuple(v.clone() for v in init)
+    g3, _ = m.sample(Box(na), step_lr=5e-6, seed=seed, init=init, streams=2)
+    for a, b in zip(init, keep):
+        assert torch.equal(a, b)
+    for k in ("frac_coords", "lattices", "atom_types"):
+        assert torch.equal(g2[k], g3[k]), k
+        assert g3[k].is_contiguous() and g3[k].shape[0] == (int(na.sum()) if k != "lattices" else len(na))
+    assert g3["frac_coords"].data_ptr() != init[0].data_ptr()
+    assert torch.equal(g3["batch_idx"].cpu(), torch.repeat_interleave(torch.arange(len(na)), na)) and torch.equal(g3["num_atoms"].cpu(), na)
 
 
 def test_benchmark_workload_first_steps_vs_oracle():

@@ -122,6 +122,32 @@ def test_denoiser_invariances():
     assert torch.allclose(solo["atomic_numbers"], out["atomic_numbers"][sl], atol=1e-5)
 
 
+def test_energy_path_and_scale_factors_of_the_parameter_list():
+    """The output blocks carry upstream GemNet-T's energy path and ScalingFactors [UPSTREAM-UNVERIFIED]: E_t is returned (the score model never reads
+    it), no other output depends on the energy path's tensors, the ScalingFactors are constants (no gradient) that do scale what they stand in front
+    of, and param_grads() reports zeros for everything no output depends on."""
+    P = M.init_params(HP, seed=3, head_scale=0.5)
+    names = [n for n, _, _ in M.param_list(HP)]
+    sf = [n for n in names if M.is_scale_factor(n)]
+    assert len(sf) == 3 * HP.num_blocks + 2 * (HP.num_blocks + 1) and all(P[n].shape == (1, 1) and float(P[n]) == 1.0 for n in sf)
+    na, frac, cell, a, g = _case([5, 8, 3], seed=4)
+    t = torch.tensor([0.3, 0.6, 0.9])
+    A = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out = M.gemnet_forward(A, HP, frac, cell, a, na, t)
+    assert out["energy"].shape == (int(na.sum()), 1) and bool(torch.isfinite(out["energy"]).all())
+    gs = dict(zip(A, M.param_grads(out["pos"].square().sum() + out["cell"].square().sum() + out["atomic_numbers"].square().sum(), A, retain_graph=True)))
+    for n in names:
+        dead = M.is_scale_factor(n) or ".seq_energy." in n or ".out_energy." in n or ".dense_rbf." in n
+        assert bool(gs[n].any()) != dead, n
+    ge = dict(zip(A, M.param_grads(out["energy"].sum(), A)))
+    assert all(bool(ge[f"out_blocks.{i}.out_energy.weight"].any()) for i in range(HP.num_blocks + 1))
+    Q = {k: v.clone() for k, v in P.items()}
+    Q["out_blocks.0.scale_rbf_F.scale_factor"] = torch.full((1, 1), 1.5)
+    Q["int_blocks.0.atom_update.scale_sum.scale_factor"] = torch.full((1, 1), 0.5)
+    out2 = M.gemnet_forward(Q, HP, frac, cell, a, na, t)
+    assert not torch.allclose(out2["pos"], out["pos"].detach()) and not torch.allclose(out2["atomic_numbers"], out["atomic_numbers"].detach())
+
+
 def test_library_exposes_the_same_parameter_list():
     """Host-only entry points of the C ABI (no GPU needed): mi_gemnet_create / mi_gemnet_param_info list the oracle's tensors in the
     oracle's order, offsets padded to multiples of 4 floats."""
