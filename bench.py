@@ -36,6 +36,8 @@ SIGMAS_NORM = os.path.join(ROOT, "matinvent_amd", "data", "sigmas_norm_T1000_b0.
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the sparse figure is 2x)
+SUSTAINED_F16_MFMA_TFLOPS = 1620.0  # what a chip-filling loop of v_mfma_f32_32x32x16_f16 on operands with random bits holds on this part (1.69 GHz, ~1285 W:
+                                    # scripts/mfma_power.hip, profiles/r5_mfma_power.log) -- reported beside `peak`, never instead of it
 PEAK_HBM_TBPS = 8.0
 
 
@@ -900,6 +902,8 @@ def main():
                          "launches": int(n_launch.value), "avg_launch_ms": avg_ms, "concurrent_streams": S,
                          "stage_busy_ms": busy_ms, "stage_busy_share_of_timed_region": busy_ms / (elapsed * 1e3),
                          "achieved_fp32_equivalent": fp32_equiv,
+                         "peak_sustained_on_random_operands": SUSTAINED_F16_MFMA_TFLOPS if args.path == "split-gemm" else None,
+                         "frac_of_sustained": issued / SUSTAINED_F16_MFMA_TFLOPS if args.path == "split-gemm" else None,
                          "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg,
                          "achieved_section8d": n_launch.value * E * f_alg / (busy_ms * 1e-3) / 1e12,
                          "note": "one 'launch' = the per-edge MLP of one layer (Fourier block K=6F + 2nd linear K=H over the edges of one "
