@@ -26,6 +26,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                 hb &= 0xbfffbfffU;
             }
             if (MODE == 2) ha = hb = 0;
+            if (MODE == 3 || MODE == 4 || MODE == 5) {
+                ha &= 0xbfffbfffU;
+                hb &= 0xbfffbfffU;
+            }
+            if (MODE == 5) hb &= 0xffe0ffe0U;   // five of ten stored mantissa bits
             ra[p][i] = (int)ha;
             rb[p][i] = (int)hb;
         }
@@ -39,6 +44,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (MODE == 1) acci[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra[p], rb[(p + n) & 3], acci[n], 0, 0, 0);
+                else if (MODE == 3) accf[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[(p + n) & 3]), __builtin_bit_cast(f16x8, rb[(p + 3 * n + 1) & 3]), accf[n], 0, 0, 0);   // both operands change with every instruction
+                else if (MODE == 4) accf[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[p]), __builtin_bit_cast(f16x8, rb[p]), accf[n], 0, 0, 0);   // both operands held over four instructions
+                else if (MODE == 5) accf[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[p]), __builtin_bit_cast(f16x8, rb[(p + n) & 3]) , accf[n], 0, 0, 0);   // (mode 5: operand B with only its top five mantissa bits -- see main)
                 else accf[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[p]), __builtin_bit_cast(f16x8, rb[(p + n) & 3]), accf[n], 0, 0, 0);
             }
     }
@@ -55,6 +63,9 @@ int main(int argc, char** argv) {
     const int blocks = 256 * 2, iters = 20000;   // two four-wave workgroups per CU: two waves per SIMD
     auto launch = [&]() {
         if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters);
+        else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, iters);
+        else if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, iters);
+        else if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, iters);
         else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters);
         else hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters);
     };
@@ -79,6 +90,7 @@ int main(int argc, char** argv) {
     const double macs_per = mode == 1 ? 32.0 * 32 * 32 : 32.0 * 32 * 16;
     const double ops = 2.0 * macs_per * 16.0 * iters * (double)blocks * 4 * reps;
     printf("mode %d (%s): %d launches in %.1f ms -> %.3f P(FL)OP/s sustained over the run\n", mode,
-           mode == 1 ? "v_mfma_i32_32x32x32_i8, random bits" : mode == 2 ? "v_mfma_f32_32x32x16_f16, zero operands" : "v_mfma_f32_32x32x16_f16, random bits", reps, ms, ops / (ms * 1e-3) / 1e15);
+           mode == 1 ? "v_mfma_i32_32x32x32_i8, random bits" : mode == 2 ? "v_mfma_f32_32x32x16_f16, zero operands" : mode == 3 ? "f16, both operands change with every instruction" :
+           mode == 4 ? "f16, both operands held over four instructions" : mode == 5 ? "f16, operand B with five mantissa bits" : "v_mfma_f32_32x32x16_f16, random bits (A held over four instructions)", reps, ms, ops / (ms * 1e-3) / 1e15);
     return 0;
 }

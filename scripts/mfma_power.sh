@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5_mfma_power.log
 : > $O
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_power scripts/mfma_power.hip 2>>$O || { cat $O; exit 1; }
-for mode in 0 1 2; do
+for mode in ${MODES:-0 1 2}; do
   /tmp/mfma_power $mode 4 > /tmp/mp.txt 2>&1 &
   BP=$!
   sleep 1.2
