@@ -241,7 +241,10 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
 // cosine pairs and stores them into the sine tile and the matching cosine tile.
 template <bool F8>   // F8: F % 8 == 0 (the lane's eight columns share one coordinate)
 __global__ __launch_bounds__(256) void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi,
-                                                                  const int* __restrict__ pj, Planes FF, int64_t Np, int F, int Kh) {
+                                                                  const int* __restrict__ pj, Planes FF, int64_t Np, int F, int Kh,
+                                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0) {
+    // (`zero`: the per-evaluation absmax slots, cleared here instead of by a memset launch of their own in front of the kernels that raise them)
+    if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero[threadIdx.x] = 0u;
     const int F3 = 3 * F, kts = Kh / 32, lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t rows_pad = (Np + 127) / 128 * 128;
@@ -955,6 +958,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         eh.ld_row_bias = H;
         MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s, &b->sk));
     }
+    bool absmax_cleared = false;   // the pair-mode Fourier launch cleared b->absmax on the way (one launch fewer per evaluation)
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
@@ -966,8 +970,12 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             b->ff_built_once = true;
             Planes ffp = make_planes(b->FFpl, 2 * net->Kh, PL_S_UNIT);
             const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 8);  // a lane per row and 8-column chunk
-            if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh);
-            else hipLaunchKernelGGL(fourier_pair_planes_kernel<false>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh);
+            // (the launch also clears the evaluation's 2 L absmax slots: see below)
+            absmax_cleared = 2 * L <= 256 && B > 0 && L > 0;
+            unsigned* const zp = absmax_cleared ? b->absmax : nullptr;
+            const int zn = absmax_cleared ? 2 * L : 0;
+            if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn);
+            else hipLaunchKernelGGL(fourier_pair_planes_kernel<false>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn);
             MI_KERNEL_CHECK();
         }
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
@@ -991,7 +999,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const float* b0 = net->p("csp_layer_0.edge_mlp.0.bias");
         const int64_t lstride = L > 1 ? net->p("csp_layer_1.edge_mlp.0.weight") - w0 : 0;
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
-        MI_HIP(hipMemsetAsync(b->absmax, 0, 2 * L * sizeof(unsigned), s));
+        if (!absmax_cleared) MI_HIP(hipMemsetAsync(b->absmax, 0, 2 * L * sizeof(unsigned), s));
         if (g_node_cols == 2 && b->nc_flags) MI_HIP(hipMemsetAsync(b->nc_flags, 0, (size_t)(L + 1) * 2 * cdiv(N, 32) * sizeof(unsigned), s));
         hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
         MI_KERNEL_CHECK();
