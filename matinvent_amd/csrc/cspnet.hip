@@ -242,9 +242,10 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
 template <bool F8>   // F8: F % 8 == 0 (the lane's eight columns share one coordinate)
 __global__ __launch_bounds__(256) void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi,
                                                                   const int* __restrict__ pj, Planes FF, int64_t Np, int F, int Kh,
-                                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0) {
-    // (`zero`: the per-evaluation absmax slots, cleared here instead of by a memset launch of their own in front of the kernels that raise them)
-    if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero[threadIdx.x] = 0u;
+                                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0, int zero_even_only = 0) {
+    // (`zero`: the per-evaluation absmax slots, cleared here instead of by a memset launch of their own in front of the kernels that raise them;
+    //  zero_even_only: the node chain's slots alone -- the odd ones belong to the lattice term, which the caller keeps from the previous evaluation)
+    if (blockIdx.x == 0 && (int)threadIdx.x < nzero && !(zero_even_only && (threadIdx.x & 1))) zero[threadIdx.x] = 0u;
     const int F3 = 3 * F, kts = Kh / 32, lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t rows_pad = (Np + 127) / 128 * 128;
@@ -959,6 +960,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s, &b->sk));
     }
     bool absmax_cleared = false;   // the pair-mode Fourier launch cleared b->absmax on the way (one launch fewer per evaluation)
+    bool gram_kept = false;        // ... and left the lattice term's slots alone: G is the previous evaluation's
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
@@ -972,10 +974,13 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             const int64_t nthr = (b->Np + 127) / 128 * 128 * (int64_t)(net->Kh / 8);  // a lane per row and 8-column chunk
             // (the launch also clears the evaluation's 2 L absmax slots: see below)
             absmax_cleared = 2 * L <= 256 && B > 0 && L > 0;
+            // (reuse_embedding = the sampler's predictor evaluation: it differs from the corrector evaluation in front of it in the coordinates only,
+            //  diffusion.py:320-322 -- the lattice term G of every layer and its absmax slots are still valid: one more launch off the chain's serial path)
+            gram_kept = absmax_cleared && reuse_embedding && b->gram_valid;
             unsigned* const zp = absmax_cleared ? b->absmax : nullptr;
-            const int zn = absmax_cleared ? 2 * L : 0;
-            if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn);
-            else hipLaunchKernelGGL(fourier_pair_planes_kernel<false>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn);
+            const int zn = absmax_cleared ? 2 * L : 0, ze = gram_kept ? 1 : 0;
+            if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn, ze);
+            else hipLaunchKernelGGL(fourier_pair_planes_kernel<false>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn, ze);
             MI_KERNEL_CHECK();
         }
     } else if (b->E > 0 && g_gemm_mode == MI_GEMM_SPLIT) {
@@ -1001,7 +1006,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_CHECK(L == 1 || net->p("csp_layer_1.edge_mlp.0.bias") - b0 == lstride, MI_ESTATE, "layer parameters are not uniformly strided");
         if (!absmax_cleared) MI_HIP(hipMemsetAsync(b->absmax, 0, 2 * L * sizeof(unsigned), s));
         if (g_node_cols == 2 && b->nc_flags) MI_HIP(hipMemsetAsync(b->nc_flags, 0, (size_t)(L + 1) * 2 * cdiv(N, 32) * sizeof(unsigned), s));
-        hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
+        if (!gram_kept) hipLaunchKernelGGL(gram_term_all_kernel, dim3(cdiv(B, GRAM_GB), L), dim3(256), 0, s, lattices, w0, lstride, net->edge_in, b0, b->G, H, B, b->absmax + 1);
+        b->gram_valid = !train;   // (valid for a following reuse_embedding evaluation of this batch handle; a training forward's G is consumed by its own tape)
         MI_KERNEL_CHECK();
     }
     // Node-level kernels on a helper stream of the highest priority (experiment, `g_node_hi`): with four chains in flight a chain's short

@@ -143,6 +143,7 @@ struct mi_batch {
     float* dsc = nullptr;            // [6][2] {scale, 1/scale}: this layer's M1 / agg / X plane sets; backward pass: dZ2, the pair differences, the Fourier features (fp16 plane format)
     unsigned* absmax = nullptr;      // [2 L] bit patterns: [2l] = max |P_i, P_j, X_part| of layer l, [2l + 1] = max |G[l]| (zeroed per evaluation); [2L], [2L + 1] = max |d cat|, max |dM1| of the layer the backward pass is in
     int* e2_tab = nullptr;           // per-tile tables of the second edge GEMM (edge_stage.hip: EG2_TAB ints per 128-row tile), valid for graph_epoch == e2_tab_epoch
+    bool gram_valid = false;         // b->G and its absmax slots hold the lattice term of the previous (inference) evaluation of this handle
     bool ff_built_once = false;      // (timing ablation mi_debug_set_skip bit 4 only: the Fourier operand exists)
     int e2_tab_epoch = -1, graph_epoch = 0;   // graph_epoch: bumped whenever the edge list changes (knn: every forward)
     unsigned* nc_flags = nullptr;    // [L + 1][2 x row blocks] arrival counters of node_cols_kernel's in-launch hand-overs (zeroed per evaluation)
