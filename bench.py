@@ -230,7 +230,7 @@ def _apply_env_knobs(lib):
     """Experiment knobs (A/B runs of kernel choices); the defaults are what the library ships with."""
     for env, fn in (("MI_DB_MIN_TILES", lib.mi_debug_set_db_min_tiles), ("MI_NODE_PLANES_MIN_ROWS", lib.mi_debug_set_node_planes_min_rows),
                     ("MI_PLANES_SMALL_TILES", lib.mi_debug_set_planes_small_tiles), ("MI_TN128", lib.mi_debug_set_tn128), ("MI_TN_SPLIT_MIN_ROWS", lib.mi_debug_set_tn_split_min_rows), ("MI_TN_TILES", lib.mi_debug_set_tn_target_tiles),
-                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_NODE_TRAIN", lib.mi_debug_set_node_train), ("MI_NODE_SPLIT", lib.mi_debug_set_node_split), ("MI_NODE_COLS", lib.mi_debug_set_node_cols), ("MI_NODE_TOUCH", lib.mi_debug_set_node_touch), ("MI_HEADS_ROWS16", lib.mi_debug_set_heads_rows16), ("MI_SKIP", lib.mi_debug_set_skip), ("MI_RT_LEAN", lib.mi_debug_set_rt_lean), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused), ("MI_EDGE_FUSED", lib.mi_debug_set_edge_fused), ("MI_MG_NOSYNC", lib.mi_debug_set_mg_nosync)):
+                    ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_NODE_TRAIN", lib.mi_debug_set_node_train), ("MI_NODE_SPLIT", lib.mi_debug_set_node_split), ("MI_NODE_COLS", lib.mi_debug_set_node_cols), ("MI_NODE_TOUCH", lib.mi_debug_set_node_touch), ("MI_HEADS_ROWS16", lib.mi_debug_set_heads_rows16), ("MI_EVAL_REUSE", lib.mi_debug_set_eval_reuse), ("MI_SKIP", lib.mi_debug_set_skip), ("MI_RT_LEAN", lib.mi_debug_set_rt_lean), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused), ("MI_EDGE_FUSED", lib.mi_debug_set_edge_fused), ("MI_MG_NOSYNC", lib.mi_debug_set_mg_nosync)):
         if os.environ.get(env) is not None and os.environ[env] != "":
             fn(int(os.environ[env]))
     if os.environ.get("MI_PLANES_RT", "") != "":   # register-tile form of the large plane products: 0 off, 1 those with epilogue extensions (default), 2 all

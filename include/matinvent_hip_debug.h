@@ -114,6 +114,11 @@ int mi_debug_set_node_touch(int min_blocks);
  * (every workgroup streams the whole 213 KB weight block; same fp32 FMA chains per output, so the results do not depend on it).  Default: never (measured neutral / -2 %,
  * profiles/r5_heads_rows16_ab.log).  Returns the previous setting. */
 int mi_debug_set_heads_rows16(int min_nodes);
+/* What the sampler's predictor evaluation keeps from the corrector evaluation in front of it (models/diffcsp/diffusion.py:320-322: the corrector moves the
+ * coordinates only, so everything that depends on the lattice, the types and the time alone is still valid): bit 0 = the lattice term G of every layer, bit 1 =
+ * layer 0's LayerNorm + projections; bit 2 = the CORRECTOR evaluation computes the coordinate head alone (the Langevin corrector reads nothing else of it,
+ * diffusion.py:310-322).  Default 7; 0 = everything evaluated every time (the A/B).  Results are identical either way.  Returns the previous mask. */
+int mi_debug_set_eval_reuse(int mask);
 /* TIMING ABLATIONS ONLY -- the results of a forward are garbage while a bit is set: 1 = skip the node chain's launches, 2 = the first edge GEMM,
  * 4 = the second (what a chain's serial path and the chip's occupancy cost each other: DESIGN 19.1), 8 = every node chain launched twice, 16 = the
  * pair-mode Fourier operand built once per batch handle and then left stale.  Returns the previous mask. */

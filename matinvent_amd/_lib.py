@@ -85,6 +85,7 @@ SIGNATURES = {
     "mi_debug_set_node_cols": (_I, [_I]),
     "mi_debug_set_node_touch": (_I, [_I]),
     "mi_debug_set_heads_rows16": (_I, [_I]),
+    "mi_debug_set_eval_reuse": (_I, [_I]),
     "mi_debug_set_skip": (_I, [_I]),
     "mi_debug_rt_clock": (_I, [_P, _I, _I]),
     "mi_debug_set_rt_lean": (_I, [_I]),

@@ -29,6 +29,8 @@ int g_planes_big_seg_min_rows = 0;
 int g_planes_dma = 1;
 int g_heads_rows16_min_nodes = 1 << 30;   // atoms from which the fused heads run on 16 rows per workgroup instead of 4 (a quarter of the weight streams; mi_debug_set_heads_rows16).
                                           // OFF: measured neutral on the headline (53.9 / 54.0 / 54.4 against 53.7 / 53.8 / 54.2) and -2 % on the reference's default batch, profiles/r5_heads_rows16_ab.log
+int g_eval_reuse = 7;   // bits 0, 1: what the sampler's predictor evaluation keeps from the corrector evaluation in front of it (the lattice term G; layer 0's projections);
+                        // bit 2: the corrector evaluation computes the coordinate head alone (nothing else of it is read); mi_debug_set_eval_reuse
 int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0: two fp32-operand GEMM launches; mi_debug_set_node_priority(2))
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
@@ -242,10 +244,11 @@ __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const
 template <bool F8>   // F8: F % 8 == 0 (the lane's eight columns share one coordinate)
 __global__ __launch_bounds__(256) void fourier_pair_planes_kernel(const float* __restrict__ frac, const int* __restrict__ pi,
                                                                   const int* __restrict__ pj, Planes FF, int64_t Np, int F, int Kh,
-                                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0, int zero_even_only = 0) {
+                                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0, int zero_keep = 0) {
     // (`zero`: the per-evaluation absmax slots, cleared here instead of by a memset launch of their own in front of the kernels that raise them;
-    //  zero_even_only: the node chain's slots alone -- the odd ones belong to the lattice term, which the caller keeps from the previous evaluation)
-    if (blockIdx.x == 0 && (int)threadIdx.x < nzero && !(zero_even_only && (threadIdx.x & 1))) zero[threadIdx.x] = 0u;
+    //  zero_keep bit 0: the odd slots stay -- they belong to the lattice term, which the caller keeps from the previous evaluation; bit 1: slot 0 stays --
+    //  layer 0's projections, kept likewise)
+    if (blockIdx.x == 0 && (int)threadIdx.x < nzero && !((zero_keep & 1) && (threadIdx.x & 1)) && !((zero_keep & 2) && threadIdx.x == 0)) zero[threadIdx.x] = 0u;
     const int F3 = 3 * F, kts = Kh / 32, lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t rows_pad = (Np + 127) / 128 * 128;
@@ -671,7 +674,8 @@ __global__ void pack_heads_kernel(const float* __restrict__ Wc, const float* __r
 // per-output fp32 FMA chains are unchanged (same k order, same four partial sums): the result does not depend on HEADS_ROWS.
 template <int HEADS_ROWS>
 __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf, const float* __restrict__ WT, const float* __restrict__ type_bias,
-                                                    float* __restrict__ coord_out, float* __restrict__ type_out, int N, int H) {
+                                                    float* __restrict__ coord_out, float* __restrict__ type_out, int N, int H, int ncols = 3 + MI_NUM_TYPES) {
+    // (ncols = 3: the coordinate head alone -- the sampler's corrector evaluation reads nothing else, diffusion.py:310-322; same FMA chains for those columns)
     // 512 threads = 4 k-groups x 128 output columns (103 used): a k-group walks a quarter of H with eight weight loads in flight per
     // step (a single group with four was a chain of 128 load latencies: slower than the two GEMM launches it replaced); the four partial
     // sums of an output are added in a fixed order through LDS.
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf
 #pragma unroll
     for (int r = 0; r < HEADS_ROWS; ++r) acc[r] = 0.f;
     const int kq = H >> 2, k0 = kgp * kq, k1 = k0 + kq;
-    if (t < 3 + MI_NUM_TYPES) {
+    if (t < ncols) {
         for (int k = k0; k < k1; k += 16) {   // (H % 64 == 0: a k-group's quarter is a multiple of 16)
             float w[16];
 #pragma unroll
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(512) void heads_kernel(const float* __restrict__ hf
 #pragma unroll
     for (int r = 0; r < HEADS_ROWS; ++r) red[(kgp * HEADS_ROWS + r) * 128 + t] = acc[r];
     __syncthreads();
-    if (kgp != 0 || t >= 3 + MI_NUM_TYPES) return;
+    if (kgp != 0 || t >= ncols) return;
 #pragma unroll
     for (int r = 0; r < HEADS_ROWS; ++r) {
         const int row = r0 + r;
@@ -928,7 +932,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
 }
 
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
-                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train, bool reuse_embedding) {
+                const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train, bool reuse_embedding, bool coords_only) {
     MI_CHECK(net->theta != nullptr, MI_ESTATE, "mi_cspnet_forward before mi_net_set_params");
     const int H = net->H, L = net->L, N = b->N, B = b->B, TD = net->TD;
     if (N == 0 || B == 0) return MI_OK;
@@ -961,6 +965,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     }
     bool absmax_cleared = false;   // the pair-mode Fourier launch cleared b->absmax on the way (one launch fewer per evaluation)
     bool gram_kept = false;        // ... and left the lattice term's slots alone: G is the previous evaluation's
+    bool pq0_kept = false;         // ... and layer 0's slot: its [P_i | P_j | X_part] (b->PQ0) is the previous evaluation's as well
+    const bool fused_early = (!train || g_node_train) && !(g_node_hi && !train) && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 &&
+                             node_chain_supported(net);   // (= `fused` below: the node chain runs as node_chain.hip's launches)
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
@@ -976,9 +983,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             absmax_cleared = 2 * L <= 256 && B > 0 && L > 0;
             // (reuse_embedding = the sampler's predictor evaluation: it differs from the corrector evaluation in front of it in the coordinates only,
             //  diffusion.py:320-322 -- the lattice term G of every layer and its absmax slots are still valid: one more launch off the chain's serial path)
-            gram_kept = absmax_cleared && reuse_embedding && b->gram_valid;
+            gram_kept = absmax_cleared && reuse_embedding && b->gram_valid && (g_eval_reuse & 1);
+            pq0_kept = gram_kept && !train && fused_early && b->pq0_valid && b->PQ0 != nullptr && (g_eval_reuse & 2);
             unsigned* const zp = absmax_cleared ? b->absmax : nullptr;
-            const int zn = absmax_cleared ? 2 * L : 0, ze = gram_kept ? 1 : 0;
+            const int zn = absmax_cleared ? 2 * L : 0, ze = (gram_kept ? 1 : 0) | (pq0_kept ? 2 : 0);
             if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn, ze);
             else hipLaunchKernelGGL(fourier_pair_planes_kernel<false>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn, ze);
             MI_KERNEL_CHECK();
@@ -1039,7 +1047,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     // is ONE launch per layer boundary (node_chain.hip), for any batch size
     // training: the same launch, which then also writes what the backward pass reads (cat = [LayerNorm(h) | agg], the two pre-activations,
     // the LayerNorm statistics) -- five launches per layer fewer than layernorm + PQ product + finalize_agg + the two node-MLP products
-    const bool fused = (!train || g_node_train) && !use_hi && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 && node_chain_supported(net);
+    const bool fused = fused_early;   // (use_hi = g_node_hi && !train is part of it)
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const float* h_in = b->h + l * NH;
@@ -1054,8 +1062,11 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const Planes aggp = node_planes ? make_planes(b->aggpl, H, PL_S_ACT, b->dsc + 2) : Planes();
         const int ldpq = (node_planes || fused) ? 3 * H : 2 * H;
         MI_TRY(to(ns));
+        // layer l's [P_i | P_j | X_part]: layer 0's lives in a buffer of its own on the inference node-chain path (mi_batch::PQ0)
+        float* const PQl = (fused && !train && l == 0 && b->PQ0) ? b->PQ0 : b->PQ;
         if (fused) {
-            MI_TRY(node_chain(net, b, l, s, train));
+            if (!(l == 0 && pq0_kept)) MI_TRY(node_chain(net, b, l, s, train));
+            if (l == 0) b->pq0_valid = !train && b->PQ0 != nullptr;
         } else {
         if (net->cfg.ln) {
             hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, ns, h_in, net->p(p + "layer_norm.weight"),
@@ -1066,14 +1077,14 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         MI_KERNEL_CHECK();
         if (node_planes) {
             PlanesEpilogue pq;
-            pq.C = b->PQ;
+            pq.C = PQl;
             pq.ldc = ldpq;
             pq.absmax = MI_PLANES_FP16 ? b->absmax + 2 * l : nullptr;
             MI_TRY(gemm_planes(lnp, make_planes(net->Wlnpl + (size_t)l * planes_elems(3 * H, H), H), N, 3 * H, H, pq, ns));
         } else {
-            MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, b->PQ, 2 * H, N, 2 * H, H, GemmEpilogue(), ns, &b->sk));
+            MI_TRY(gemm_nt(cat, 2 * H, net->Whh + l * net->whh_stride(), H, PQl, 2 * H, N, 2 * H, H, GemmEpilogue(), ns, &b->sk));
             if (MI_PLANES_FP16 && net->edge_mode != 0 && g_gemm_mode == MI_GEMM_SPLIT && b->E > 0) {
-                hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, ns, b->PQ, (int64_t)N * 2 * H,
+                hipLaunchKernelGGL(absmax_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 256))), dim3(256), 0, ns, PQl, (int64_t)N * 2 * H,
                                    b->absmax + 2 * l);
                 MI_KERNEL_CHECK();
             }
@@ -1098,10 +1109,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             ProfSlot ps;
             MI_TRY(prof_begin(net, s, &ps));
             GemmEpilogue g1e;       // Z1 = FF Wff^T + P_i[src] + P_j[dst] + G[graph];  M1 = SiLU(Z1)
-            g1e.row_bias = b->PQ;
+            g1e.row_bias = PQl;
             g1e.row_group = b->src;
             g1e.ld_row_bias = ldpq;
-            g1e.row_bias2 = b->PQ + H;
+            g1e.row_bias2 = PQl + H;
             g1e.row_group2 = b->dst;
             g1e.ld_row_bias2 = ldpq;
             g1e.row_bias3 = b->G + (size_t)l * B * H;
@@ -1164,7 +1175,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                         MI_TRY(gemm_planes(make_planes(b->FFpl, Kp, PL_S_UNIT), make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp), (int)b->Np, H, Kp,
                                            pe1, s));
                     if (!fold) {
-                        hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, b->PQ, b->G + (size_t)l * B * H,
+                        hipLaunchKernelGGL(edge_diag_kernel, dim3(cdiv((int64_t)N * (H / 2), 256)), dim3(256), 0, s, PQl, b->G + (size_t)l * B * H,
                                            net->C0 + (size_t)l * H, b->node2graph, b->e_diag, g1e.pre_act, m1p, N, H, ldpq);
                         MI_KERNEL_CHECK();
                     }
@@ -1220,7 +1231,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         if (node_planes) {
             PlanesEpilogue p1;
             p1.ep = e1;
-            p1.ep.pre_add = b->PQ + 2 * H;  // LayerNorm(h) x W[:, :H], computed with P_i / P_j
+            p1.ep.pre_add = PQl + 2 * H;  // LayerNorm(h) x W[:, :H], computed with P_i / P_j
             p1.ep.ld_pre_add = ldpq;
             p1.Cp = make_planes(b->Xpl, H, PL_S_ACT, b->dsc + 4);
             MI_TRY(gemm_planes(aggp, make_planes(net->Waggpl + (size_t)l * planes_elems(H, H), H), N, H, H, p1, ns));
@@ -1258,26 +1269,32 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(NH, 256)), dim3(256), 0, s, h_last, b->hf, H, N, H);
     }
     MI_KERNEL_CHECK();
+    MI_CHECK(!(coords_only && train), MI_EINVAL, "a training forward evaluates every head");
     if (!train && net->WheadT && g_fused_heads && H % 64 == 0) {
+        const int ncols = (coords_only && (g_eval_reuse & 4)) ? 3 : 3 + MI_NUM_TYPES;
         auto lds = [&](int rows) { return (size_t)(rows * H + 4 * rows * 128) * sizeof(float); };
         if (N >= g_heads_rows16_min_nodes) {   // (16 rows per workgroup need 64.5 KB of LDS at H = 512: above the default ceiling)
             static std::once_flag once;
             static hipError_t attr_err = hipSuccess;
             std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)heads_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
             MI_HIP(attr_err);
-            hipLaunchKernelGGL(heads_kernel<16>, dim3(cdiv(N, 16)), dim3(512), lds(16), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H);
+            hipLaunchKernelGGL(heads_kernel<16>, dim3(cdiv(N, 16)), dim3(512), lds(16), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H, ncols);
         } else {
-            hipLaunchKernelGGL(heads_kernel<4>, dim3(cdiv(N, 4)), dim3(512), lds(4), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H);
+            hipLaunchKernelGGL(heads_kernel<4>, dim3(cdiv(N, 4)), dim3(512), lds(4), s, b->hf, net->WheadT, net->p("type_out.bias"), coord_out, type_out, N, H, ncols);
         }
         MI_KERNEL_CHECK();
     } else {
         MI_TRY(gemm_nt(b->hf, H, net->p("coord_out.weight"), H, coord_out, 3, N, 3, H, GemmEpilogue(), s, &b->sk));
-        GemmEpilogue et;
-        et.bias = net->p("type_out.bias");
-        MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
+        if (!(coords_only && (g_eval_reuse & 4))) {
+            GemmEpilogue et;
+            et.bias = net->p("type_out.bias");
+            MI_TRY(gemm_nt(b->hf, H, net->p("type_out.weight"), H, type_out, MI_NUM_TYPES, N, MI_NUM_TYPES, H, et, s, &b->sk));
+        }
     }
-    hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (2 * H + 12) * sizeof(float), s, b->hf, b->node_off,
-                       net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
+    // (coords_only -- the sampler's corrector evaluation, which reads the coordinate score alone, diffusion.py:310-322: no type columns above, no lattice head)
+    if (!(coords_only && (g_eval_reuse & 4)))
+        hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (2 * H + 12) * sizeof(float), s, b->hf, b->node_off,
+                           net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
     MI_KERNEL_CHECK();
     tp.valid = train;
     return MI_OK;
@@ -1602,6 +1619,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(h, (L + 1) * NH);
     A_(cat, 2 * NH);
     A_(PQ, 3 * NH);  // [N][2H] P_i | P_j, or [N][3H] with the LayerNorm(h) part of the node MLP's first product appended
+    A_(PQ0, 3 * NH);
     A_(G, (size_t)L * B * H);
     A_(part, nslots * NH);
     A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
@@ -1828,6 +1846,12 @@ int mi_debug_set_tn128(int on) {
     g_bwd_wgrad_planes = (on & 256) == 0;   // +256: edge_mlp.2's weight gradient from fp32 rows (split, SiLU and transposition on the way into LDS) instead of from the M1 / dZ2 plane sets
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
+}
+
+int mi_debug_set_eval_reuse(int mask) {
+    const int was = g_eval_reuse;
+    g_eval_reuse = mask;
+    return was;
 }
 
 int mi_debug_set_heads_rows16(int min_nodes) {

@@ -400,7 +400,7 @@ int edge_fused(mi_net* net, mi_batch* b, int l, hipStream_t s) {
     a.W1 = make_planes(net->Wffpl_pair + (size_t)l * planes_elems(H, Kp), Kp);
     a.W2f = net->Wnc + (size_t)l * node_chain_pack_elems(H) + (size_t)5 * H * H * 2;
     a.b2 = net->p("csp_layer_" + std::to_string(l) + ".edge_mlp.2.bias");
-    a.PQ = b->PQ;
+    a.PQ = (l == 0 && b->PQ0) ? b->PQ0 : b->PQ;   // (inference only: layer 0's projections live in mi_batch::PQ0)
     a.ldpq = 3 * H;
     a.G = b->G + (size_t)l * b->B * H;
     a.C0 = net->C0 + (size_t)l * H;

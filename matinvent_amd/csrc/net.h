@@ -128,6 +128,9 @@ struct mi_batch {
     float* h = nullptr;      // [L+1][N][H] node features before layer l / after the last
     float* cat = nullptr;    // [N][2H]  (LN(h) | agg)
     float* PQ = nullptr;     // [N][2H]
+    float* PQ0 = nullptr;    // layer 0's [P_i | P_j | X_part] of the INFERENCE node chain, in a buffer of its own: the sampler's predictor evaluation starts from
+                             // the same embedding as the corrector evaluation in front of it, so layer 0's LayerNorm + projections launch is not repeated (pq0_valid)
+    bool pq0_valid = false;
     float* G = nullptr;      // [B][H]
     float* part = nullptr;   // [nslots][N][H]
     float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order (fused path)
@@ -175,7 +178,7 @@ struct mi_batch {
 namespace mi {
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
                 const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train = false,
-                bool reuse_embedding = false);
+                bool reuse_embedding = false, bool coords_only = false);
 int net_tape_prepare(mi_net* net, mi_batch* b);
 int net_pack_transposes(mi_net* net, hipStream_t s);
 int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_coord, const float* d_type, float* grad, hipStream_t s);

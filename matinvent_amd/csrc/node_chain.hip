@@ -1063,7 +1063,7 @@ static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool 
             a.slotmask = b->ef_mask;
             a.nslots = b->ef_nslots;
         }
-        a.xpart = b->PQ + 2 * H;
+        a.xpart = ((!train && l == 1 && b->PQ0) ? b->PQ0 : b->PQ) + 2 * H;   // (layer l - 1's X_part: layer 0's is in its own buffer on the inference path, mi_batch::PQ0)
         a.ld_xpart = 3 * H;
         a.Wagg = base;
         a.Wn2 = base + (size_t)H * H * 2;
@@ -1080,7 +1080,7 @@ static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool 
         a.ln_w = net->p(p + "layer_norm.weight");
         a.ln_b = net->p(p + "layer_norm.bias");
         a.Wln = net->Wnc + (size_t)l * node_chain_pack_elems(H) + (size_t)2 * H * H * 2;
-        a.PQ = b->PQ;
+        a.PQ = (!train && l == 0 && b->PQ0) ? b->PQ0 : b->PQ;
         a.absmax = b->absmax + 2 * l;
     } else {
         a.ln_w = net->p("final_layer_norm.weight");

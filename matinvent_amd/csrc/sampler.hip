@@ -284,7 +284,8 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         hipLaunchKernelGGL(time_embedding_kernel, dim3(cdiv((int64_t)B * net->TD, 256)), dim3(256), 0, s, (const int*)nullptr, time_freqs, b->temb, B,
                            net->TD, t);
         // corrector
-        MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s));
+        // (the Langevin corrector reads the coordinate score alone, diffusion.py:310-322: the type columns of the heads and the lattice head are not evaluated)
+        MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s, false, false, true));
         hipLaunchKernelGGL(corrector_kernel, dim3(B), dim3(64), 0, s, frac, b->pred_x, noise ? noise->corr_x + t * n3 : nullptr,
                            b->coef, t, seed, b->node_offset, b->node_off, b->x_mid, b->lp_corr,
                            (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr, b->keep_coords);
