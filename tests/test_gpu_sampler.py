@@ -325,3 +325,29 @@ def test_chain_enqueue_does_not_synchronise_once_the_coefficients_are_resident()
     torch.cuda.synchronize()
     t_total = time.perf_counter() - t0
     assert t_total > 0.3 and t_enqueue < 0.5 * t_total, (t_enqueue, t_total)
+
+
+@pytest.mark.parametrize("H,streams", [(512, 1), (128, 2)])
+def test_what_the_predictor_evaluation_keeps_changes_no_bit(H, streams):
+    """The corrector half of a step moves the coordinates only (diffusion.py:320-322: l_t_minus_05 = l_t, t_t_minus_05 = t_t), so the predictor
+    evaluation keeps the embedding, the lattice term G of every layer and layer 0's LayerNorm + projections of the corrector evaluation in front of it,
+    and the corrector evaluation -- of which only pred_x is read (diffusion.py:326-331) -- computes the coordinate head alone.  With all of that switched
+    off (mi_debug_set_eval_reuse(0): everything evaluated every time) the recorded chain is the same, bit for bit."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    T, seed = 6, 17
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=3, num_freqs=16)
+    P = O.init_params(hp, seed=4, head_scale=0.1)
+    m = make_module(H, 3, 16, T, P, sigmas_norm=None)
+    na = torch.tensor([20] * 40 + [7, 3, 12]) if H == 512 else torch.tensor([5, 9, 2, 7, 11, 4])   # (H = 512: large enough for the register-tile edge GEMMs and the pair mode)
+    was = lib.mi_debug_set_eval_reuse(0)
+    try:
+        f0, t0 = m.sample(Box(na), step_lr=5e-6, seed=seed, record=True, streams=streams)
+        assert lib.mi_debug_set_eval_reuse(7) == 0
+        f1, t1 = m.sample(Box(na), step_lr=5e-6, seed=seed, record=True, streams=streams)
+    finally:
+        lib.mi_debug_set_eval_reuse(was)
+    assert sorted(t0) == sorted(t1)
+    for t in t0:
+        for k in t0[t]:
+            assert torch.equal(t0[t][k], t1[t][k]), (t, k)
