@@ -840,12 +840,16 @@ def main():
     final, _ = m.sample(cb, seed=SEED_NOISE, t_start=T, t_stop=T, **skw)
     state = (final["frac_coords"], final["lattices"], final["atom_types"])
     m._coefficients(STEP_LR)
+    import gc
+    gc.collect()
+    gc.disable()   # (as timeit does: a 20-step window is 0.1 s, a generation-2 collection of a torch process several ms of it; re-enabled right behind the window)
     barrier()
     _lib.check(lib.mi_profile_enable(m.decoder._h, 1))
     t0 = time.perf_counter()
     final, _ = m.sample(cb, seed=SEED_NOISE, init=state, t_start=T, t_stop=T - K, **skw)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     import ctypes as C
     n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.mi_profile_read(m.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
