@@ -121,7 +121,8 @@ int mi_debug_set_heads_rows16(int min_nodes);
 int mi_debug_set_eval_reuse(int mask);
 /* TIMING ABLATIONS ONLY -- the results of a forward are garbage while a bit is set: 1 = skip the node chain's launches, 2 = the first edge GEMM,
  * 4 = the second (what a chain's serial path and the chip's occupancy cost each other: DESIGN 19.1), 8 = every node chain launched twice, 16 = the
- * pair-mode Fourier operand built once per batch handle and then left stale.  Returns the previous mask. */
+ * pair-mode Fourier operand built once per batch handle and then left stale, 32 = an EMPTY launch in front of every edge GEMM (what a kernel boundary on a
+ * chain's serial path costs; results unaffected).  Returns the previous mask. */
 int mi_debug_set_skip(int mask);
 /* The second linear of the edge MLP with the edge -> node reduction (models/diffcsp/cspnet.py:73-79) of an inference forward at
  * hidden_dim 512 on 128-row x 512-column register tiles with the segmented sum as an MFMA product (csrc/edge_stage.hip):
