@@ -963,6 +963,12 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         eh.ld_row_bias = H;
         MI_TRY(gemm_nt(b->x1, H, net->p("atom_latent_emb.weight"), H + TD, b->h, H, N, H, H, eh, s, &b->sk));
     }
+    // what the previous evaluation of this handle left behind is valid for THIS call only if it says so (reuse_embedding); every forward re-earns the flags
+    // (a forward that takes another path -- a knob changed, a training forward -- leaves nothing a later call could mistake for its own)
+    const bool same_net = b->reuse_net == (const void*)net;
+    const bool had_gram = b->gram_valid && same_net, had_pq0 = b->pq0_valid && same_net;
+    b->gram_valid = b->pq0_valid = false;
+    b->reuse_net = net;
     bool absmax_cleared = false;   // the pair-mode Fourier launch cleared b->absmax on the way (one launch fewer per evaluation)
     bool gram_kept = false;        // ... and left the lattice term's slots alone: G is the previous evaluation's
     bool pq0_kept = false;         // ... and layer 0's slot: its [P_i | P_j | X_part] (b->PQ0) is the previous evaluation's as well
@@ -983,8 +989,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
             absmax_cleared = 2 * L <= 256 && B > 0 && L > 0;
             // (reuse_embedding = the sampler's predictor evaluation: it differs from the corrector evaluation in front of it in the coordinates only,
             //  diffusion.py:320-322 -- the lattice term G of every layer and its absmax slots are still valid: one more launch off the chain's serial path)
-            gram_kept = absmax_cleared && reuse_embedding && b->gram_valid && (g_eval_reuse & 1);
-            pq0_kept = gram_kept && !train && fused_early && b->pq0_valid && b->PQ0 != nullptr && (g_eval_reuse & 2);
+            gram_kept = absmax_cleared && reuse_embedding && had_gram && (g_eval_reuse & 1);
+            pq0_kept = gram_kept && !train && fused_early && had_pq0 && b->PQ0 != nullptr && (g_eval_reuse & 2);
             unsigned* const zp = absmax_cleared ? b->absmax : nullptr;
             const int zn = absmax_cleared ? 2 * L : 0, ze = (gram_kept ? 1 : 0) | (pq0_kept ? 2 : 0);
             if (net->F % 8 == 0) hipLaunchKernelGGL(fourier_pair_planes_kernel<true>, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->pair_i, b->pair_j, ffp, b->Np, net->F, net->Kh, zp, zn, ze);

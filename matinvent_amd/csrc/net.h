@@ -131,6 +131,7 @@ struct mi_batch {
     float* PQ0 = nullptr;    // layer 0's [P_i | P_j | X_part] of the INFERENCE node chain, in a buffer of its own: the sampler's predictor evaluation starts from
                              // the same embedding as the corrector evaluation in front of it, so layer 0's LayerNorm + projections launch is not repeated (pq0_valid)
     bool pq0_valid = false;
+    const void* reuse_net = nullptr;   // the network whose evaluation left G / PQ0 behind (another network's evaluation never reuses them)
     float* G = nullptr;      // [B][H]
     float* part = nullptr;   // [nslots][N][H]
     float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order (fused path)
