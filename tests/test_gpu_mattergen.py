@@ -309,6 +309,33 @@ def test_sampler_without_a_host_round_trip_equals_the_synchronising_form():
     assert _lib.saturation_events(reset=True) == 0
 
 
+def test_sampler_with_fitted_scale_factors_takes_the_synchronising_form():
+    """GemNet's ScalingFactors with values other than one are elementwise passes on fp32 rows (op_scale), which the plane-only program of the
+    no-round-trip forwards does not have: the chain then runs on the synchronising form whatever mi_debug_set_mg_nosync says (same samples both ways,
+    finite, reproducible), and differs from the identity-factor chain."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    hpd = dict(M.TINY, emb_atom=128, emb_edge=128)
+    hp = M.GemNetHParams(**hpd)
+    P = M.init_params(hp, seed=6, head_scale=20.0)
+    m1 = _module(hpd, P)
+    na = [20] * 40 + [7, 12, 1, 20]
+    s_id, m_id = m1.sample(na, n_steps=1000, seed=9, i_stop=2)
+    mf = _module(hpd, _fit_scale_factors({k: v.clone() for k, v in P.items()}))
+    try:
+        lib.mi_debug_set_mg_nosync(1)
+        sa, ma = mf.sample(na, n_steps=1000, seed=9, i_stop=2)
+        assert not bool(mf.last_sample_invalid().any())
+        lib.mi_debug_set_mg_nosync(0)
+        sb, mb = mf.sample(na, n_steps=1000, seed=9, i_stop=2)
+    finally:
+        lib.mi_debug_set_mg_nosync(1)
+    for key in ("pos", "cell", "atomic_numbers"):
+        assert torch.equal(ma[key], mb[key]) and torch.equal(sa[key], sb[key]), key
+    assert bool(torch.isfinite(ma["pos"]).all()) and bool(torch.isfinite(ma["cell"]).all())
+    assert not torch.equal(ma["cell"], m_id["cell"])
+
+
 def test_a_crystal_over_a_graph_capacity_is_dropped_alone():
     """A crystal with an in-degree above the graph's capacity (128 in-edges, the triplet kernels' LDS image; lowered to 24 here so that a
     dense cell exceeds it -- a collapsed cell is what would do it in a chain) fails the synchronising forward as a whole (MI_ECAPACITY).
