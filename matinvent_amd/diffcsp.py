@@ -7,7 +7,6 @@ same buffers (`beta_scheduler.*`, `sigma_scheduler.*`), same methods
 """
 import ctypes as C
 
-import os
 import torch
 import torch.nn as nn
 
@@ -263,12 +262,8 @@ class DiffCSPModule(nn.Module):
         from .streams import ChainWorkers
         workers = ChainWorkers.get(streams, self.device)
 
-        stagger = float(os.environ.get("MI_CHAIN_STAGGER_US", "0")) * 1e-6   # (experiment: chain k starts k x this later)
-
+        # (starting chain k later by k x 150 ... 1 200 us was measured and costs the delay: DESIGN 19.7, profiles/r5_chain_stagger.log)
         def run(k, stream):
-            if stagger > 0 and k > 0:
-                import time as _t
-                _t.sleep(k * stagger)
             stream.wait_event(ready)
             own = (state[0][n0[k]:n0[k + 1]], state[1][g0[k]:g0[k + 1]], state[2][n0[k]:n0[k + 1]])   # (contiguous row ranges: views, no copy)
             nz = None if noise is None else {"corr_x": noise["corr_x"][:, n0[k]:n0[k + 1]], "pred_x": noise["pred_x"][:, n0[k]:n0[k + 1]],
