@@ -99,8 +99,9 @@ __global__ __launch_bounds__(64) void corrector_kernel(const float* __restrict__
         x_mid[idx] = xm;
         float xmw = pymod1(xm);
         if (rec_mid && t > 1) rec_mid[idx] = xmw;
-        if (t > 1) lp += log_prob_wn(xmw, pymod1(drift), c.std_corr_sq);
+        if (lp_corr && t > 1) lp += log_prob_wn(xmw, pymod1(drift), c.std_corr_sq);   // (lp_corr = NULL: nothing records log-probabilities -- 21 exponentials per coordinate not spent)
     }
+    if (!lp_corr) return;
     lp = wave_sum(lp);
     // mean over the 3 coordinates, then mean over the atoms of the crystal
     if (lane == 0) lp_corr[b] = (n1 > n0) ? (lp / 3.0f) / (float)(n1 - n0) : 0.f;
@@ -128,6 +129,9 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
     const StepCoef c = load_coef(a.coef, t);
     const int n0 = a.node_off[b], n1 = a.node_off[b + 1], n = n1 - n0;
     const float cnt = (float)(n > 0 ? n : 1);
+    // the three log-probabilities of the step (diffusion.py:357-368) exist for a recording caller only: without one their arithmetic (21 exponentials per
+    // coordinate, a logarithm per logit) and block reductions are skipped -- the state update is the same instructions either way
+    const bool want_lp = t > 1 && (a.rec_lpl != nullptr || a.rec_lpt != nullptr || a.rec_lpx != nullptr);
 
     // lattice: l_{t-1} = c0 (l_t - c1 pred_l) + sigma z
     float lp_l = 0.f;
@@ -139,9 +143,9 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
         float v = a.keep_lattice ? a.lattices[idx] : mu + c.sigma * z;
         a.lattices[idx] = v;
         if (a.rec_lat) a.rec_lat[idx] = v;
-        if (t > 1) lp_l = normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+        if (want_lp) lp_l = normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
     }
-    lp_l = block_sum_256(lp_l, red);
+    if (want_lp) lp_l = block_sum_256(lp_l, red);
 
     // coordinates: x_{t-1} = (x_{t-1/2} - step * s + std z) % 1
     float lp_x = 0.f;
@@ -151,12 +155,12 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
         float px = a.pred_x[idx] * c.sqrt_sn;
         float drift = a.x_mid[idx] - c.step_pred * px;
         float v = pymod1(a.keep_coords ? a.x_mid[idx] : drift + c.std_pred * z);
-        if (t > 1) lp_x += log_prob_wn(v, pymod1(drift), c.std_pred_sq);
+        if (want_lp) lp_x += log_prob_wn(v, pymod1(drift), c.std_pred_sq);
         v = pymod1(v);  // traj[t-1]['frac_coords'] = x_{t-1} % 1  (:386)
         a.frac[idx] = v;
         if (a.rec_frac) a.rec_frac[idx] = v;
     }
-    lp_x = block_sum_256(lp_x, red);
+    if (want_lp) lp_x = block_sum_256(lp_x, red);
 
     // atom-type logits: one wave per atom; a lane owns a QUAD of consecutive logits = one Philox call (100 logits = 25 quads, and the
     // global element index of a logit row starts at a multiple of 4), instead of one call -- four Box-Muller normals -- per logit
@@ -181,14 +185,17 @@ __global__ __launch_bounds__(256) void predictor_kernel(PredictorArgs a) {
                 const float mu = c.c0 * (at[q] - c.c1 * pt[q]);
                 const float v = mu + c.sigma * z[q];
                 vout[q] = v;
-                if (t > 1) s += normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
+                if (want_lp) s += normal_log_prob(v, mu, c.sigma_sq, c.log_sigma);
             }
             *reinterpret_cast<f32x4*>(a.atom_types + idx0) = vout;
             if (a.rec_types) *reinterpret_cast<f32x4*>(a.rec_types + idx0) = vout;
         }
-        s = wave_sum(s);
-        lp_t += s / (float)MI_NUM_TYPES;  // mean over the 100 logits (:358)
+        if (want_lp) {
+            s = wave_sum(s);
+            lp_t += s / (float)MI_NUM_TYPES;  // mean over the 100 logits (:358)
+        }
     }
+    if (!want_lp) return;
     // every lane of a wave holds the same lp_t; add the four waves
     __syncthreads();
     if (lane == 0) red[wave] = lp_t;
@@ -287,7 +294,7 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         // (the Langevin corrector reads the coordinate score alone, diffusion.py:310-322: the type columns of the heads and the lattice head are not evaluated)
         MI_TRY(net_forward(net, b, b->temb, atom_types, frac, lattices, b->pred_l, b->pred_x, b->pred_t, s, false, false, true));
         hipLaunchKernelGGL(corrector_kernel, dim3(B), dim3(64), 0, s, frac, b->pred_x, noise ? noise->corr_x + t * n3 : nullptr,
-                           b->coef, t, seed, b->node_offset, b->node_off, b->x_mid, b->lp_corr,
+                           b->coef, t, seed, b->node_offset, b->node_off, b->x_mid, (rec && rec->log_prob_x) ? b->lp_corr : nullptr,
                            (rec && rec->frac_coords_mid) ? rec->frac_coords_mid + t * n3 : nullptr, b->keep_coords);
         MI_KERNEL_CHECK();
         // predictor
