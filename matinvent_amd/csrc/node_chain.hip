@@ -153,7 +153,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             const int nlines = bytes >> 7;
             for (int l0 = part * (64 * NW); l0 < nlines; l0 += nparts * (64 * NW)) {
                 const int line = l0 + tid;
-                if (line < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(touch_dummy) : "v"(reinterpret_cast<const char*>(base) + (size_t)line * 128));
+                // ("+v": EVERY touch writes the one VGPR that stays reserved until the closing s_waitcnt below -- a plain output would be a dead value whose
+                // register the allocator may reuse while the load is still in flight; scripts/scan_touch_regs.py checks the disassembly)
+                if (line < nlines) asm volatile("global_load_dword %0, %1, off" : "+v"(touch_dummy) : "v"(reinterpret_cast<const char*>(base) + (size_t)line * 128));
             }
         };
         const int wbytes = H * H * 4;

@@ -59,3 +59,17 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmatinvent_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_node_chain_touch_loads_share_one_reserved_register():
+    """The L2 warm-up loads of node_chain.hip are fire-and-forget inline asm; they are safe only when every one of them writes the single
+    VGPR that stays reserved until the closing s_waitcnt (advisor finding, round 5).  Checked on the device assembly of THIS source."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("scan_touch_regs", os.path.join(ROOT, "scripts", "scan_touch_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    report, bad = mod.scan()
+    assert len(report) >= 3, report     # the three widths of node_chain_kernel
+    assert not bad, bad
+    assert all(n == 3 and len(regs) == 1 for _, n, regs, _ in report), report
