@@ -71,7 +71,21 @@ def dist_setup(gpus=None):
     dist = None
     if gpus is not None and world != gpus:
         raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (or from a bare shell, which self-launches)")
-    if world > 1:
+    force = world == 1 and os.environ.get("MI_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if force:
+        # --force-dist: a WORLD-SIZE-1 RCCL process group, so that every line of the multi-GPU path -- init_process_group("nccl", device_id=...),
+        # barrier(device_ids=...), the all-reduce of the device-resident time, the flat-gradient all-reduce on the real 49.4 MB device buffer --
+        # runs with its real arguments on a one-GPU box.  The figures are those of a single GPU; `config.comm_backend` says "nccl".
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ["MI_DIST_FORCE_COLLECTIVES"] = "1"
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -92,14 +106,14 @@ def dist_setup(gpus=None):
 def dist_barrier(ctx):
     world, rank, local_rank, share, dist = ctx
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier() if share else dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
 
 
 def dist_max_time(ctx, elapsed):
     world, rank, local_rank, share, dist = ctx
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], device="cpu" if share else torch.device("cuda", local_rank), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -267,13 +281,31 @@ def measure_ft(args, K, W, ctx, cpu_budget_s=15.0):
     import ctypes as C
     lib = _lib.load()
     run(max(W, 1))
+    if getattr(args, "counter_child", False):   # (under rocprofv3 --pmc: the dispatches of K micro-steps are what is wanted, nothing is printed)
+        run(K)
+        return None
     _lib.check(lib.mi_profile_enable(agent.decoder._h, 1))
+    f16, f32 = C.c_double(), C.c_double()
+    _lib.check(lib.mi_debug_mfma_flops(None, None, 1))   # (host-side counters of the matrix-pipe work every launcher issues: reset)
     t0 = time.perf_counter()
     run(K)
     elapsed = dist_max_time(ctx, time.perf_counter() - t0)
+    _lib.check(lib.mi_debug_mfma_flops(C.byref(f16), C.byref(f32), 0))
     n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.mi_profile_read(agent.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
     _lib.check(lib.mi_profile_enable(agent.decoder._h, 0))
+    allreduce_ms = None
+    if dist is not None:   # the flat-gradient all-reduce on a buffer of the gradient's size (49.4 MB), timed on its own after the region
+        from matinvent_amd.dist import allreduce_flat_
+        gbuf = torch.zeros_like(agent.decoder.theta)
+        allreduce_flat_(gbuf)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(5):
+            allreduce_flat_(gbuf)
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - ta) / 5 * 1e3
+        del gbuf
     del agent, prior
     if rank != 0:
         return None
@@ -286,23 +318,40 @@ def measure_ft(args, K, W, ctx, cpu_budget_s=15.0):
     terms = 3 if lib.mi_plane_format() == 2 else 6
     busy_ms = union_ms.value if groups > 1 else tot_ms.value
     issued = terms * n_launch.value * E * f_exec / (busy_ms * 1e-3) / 1e12
+    # the WHOLE micro-step (noise, agent training forward, frozen-prior forward, loss, backward; Adam when it falls due): matrix-pipe flops
+    # ISSUED by every product of the timed region (the launchers count 2 M N K x MFMA terms as they enqueue: mi_debug_mfma_flops) / elapsed
+    whole16 = f16.value / elapsed / 1e12
+    whole32 = f32.value / elapsed / 1e12
+    traffic, traffic_src = None, {"measured": "skipped (--no-counters)" if getattr(args, "no_counters", False) else "not applicable to this world size"}
+    if world == 1 and not getattr(args, "no_counters", False):
+        traffic, traffic_src = measure_ft_traffic_live(args)
     out = {"metric": "fine-tune crystal-timesteps/sec", "value": nglob * K / elapsed, "unit": "crystal-timesteps/s",
            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None,
+           "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None,
            "dtype": "f32 (forward and edge-level backward products: 2-plane fp16 split, 3 MFMA terms; node-level backward products: 3-plane bf16 split, 6 terms; f32 accumulate)",
            "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: mat_invent fine-tune micro-steps (noise + agent fwd + frozen-prior fwd + agent bwd per "
-                                  "timestep), 256 crystals x 20 atoms per GPU, synthetic reward, accum_steps=50, fused Adam, one flat-gradient "
+                                  f"timestep), {getattr(args, 'batch_label', '256 crystals per GPU')} x 20 atoms, synthetic reward, accum_steps=50, fused Adam, one flat-gradient "
                                   "all-reduce (RCCL) per optimizer step when N>1; a bench step = one timestep over the batch",
                       "batch_per_gpu": B, "atoms_per_cell": NATOM, "accum_steps": 50, "concurrent_groups": groups,
                       "adam_steps_in_timed_region": K // 50 + (1 if K % 50 else 0),
-                      "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world},
-           "roofline": {"bound": "mfma", "kernel": "edge_gemm1b_kernel / gemm_planes_kernel<pair> + edge_gemm2b_kernel (agent forward, edge MLP of one layer; the "
-                                                      "largest single kernel of the micro-step)",
-                        "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_BF16_MFMA_TFLOPS,
-                        "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": tot_ms.value / max(1, n_launch.value),
-                        "concurrent_streams": groups, "stage_busy_ms": busy_ms,
-                        "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg},
+                      "comm_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
+                      "flat_gradient_allreduce_ms": allreduce_ms},
+           "roofline": {"bound": "mfma", "scope": "whole micro-step: every matrix product of noise + agent training forward + frozen-prior forward + loss + backward "
+                                                  "(+ Adam when due) over the timed region's elapsed time; one 'launch' = one timestep over the batch",
+                        "kernel": "all products of a micro-step (edge_gemm1b / edge_gemm2b / node_chain forward, gemm_rt dM1, gemm_tn_planes dW, node-level backward products)",
+                        "achieved": whole16, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole16 / PEAK_BF16_MFMA_TFLOPS,
+                        "traffic": traffic, "traffic_source": traffic_src, "launches": K, "avg_launch_ms": elapsed * 1e3 / K,
+                        "flops_per_launch_issued_16bit_pipe": f16.value / K, "flops_per_launch_f32_mfma": f32.value / K,
+                        "f32_mfma_achieved_tflops": whole32, "f32_mfma_frac_of_its_peak": whole32 / PEAK_F32_MFMA_TFLOPS,
+                        "algorithmic_section8d_flops_per_launch": 4 * 5.893e9 * nglob,
+                        "note": "achieved = 16-bit-pipe MFMA flops issued (3 terms per fp32 product on pre-split fp16 planes, 6 on bf16 planes split on the fly) / "
+                                "elapsed; the f32-input MFMA products (short weight-gradient contractions) are priced separately against their own 157.3 TF/s peak; "
+                                "traffic = FETCH_SIZE x2 + WRITE_SIZE of ALL kernels per timestep",
+                        "edge_stage_forward": {"kernel": "edge_gemm1b_kernel + edge_gemm2b_kernel (agent forward, edge MLP of one layer), HIP-event bracketed",
+                                               "achieved": issued, "frac": issued / PEAK_BF16_MFMA_TFLOPS, "launches": int(n_launch.value),
+                                               "avg_launch_ms": tot_ms.value / max(1, n_launch.value), "concurrent_streams": groups, "stage_busy_ms": busy_ms,
+                                               "flops_per_launch_executed": E * f_exec, "flops_per_launch_section8d": E * f_alg}},
            "end_to_end": {"tflops_section8d": flops / elapsed / 1e12,
                           "frac_of_f32_mfma_peak_section8d": flops / elapsed / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
     if not args.no_cpu_baseline and world == 1:
@@ -316,7 +365,7 @@ def main_ft(args):
     out = measure_ft(args, K, W, ctx)
     if out is not None:
         print(json.dumps(out), flush=True)
-    if ctx[0] > 1:
+    if ctx[4] is not None:
         dist_barrier(ctx)
         ctx[4].destroy_process_group()
 
@@ -575,7 +624,7 @@ def measure_mg(args, K, W, ctx=None):
                                    + "; SELF-CONSISTENT, PARITY-UNPINNED vs upstream",
                        "state": "held" if hold else "free-running",
                        "batch_per_gpu": Bm, "atoms_per_cell": NATOM, "T": T, "concurrent_chains": chains, "edges_first_step": E0, "edges_last_step": E,
-                       "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+                       "comm_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                        "parameters": nparams, "final_state_finite": finite, "fp16_plane_saturation_events": sat},
             "roofline": {"bound": "mfma", "kernel": "gemm_rt_kernel<lean> (edge-level dense layers of the interaction / output blocks)",
                          "achieved": terms * flops_eval * 2 * K / elapsed / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -595,7 +644,7 @@ def main_mg(args):
         if not args.no_cpu_baseline and ctx[0] == 1:
             out["cpu_baseline"] = cpu_baseline_mg()
         print(json.dumps(out), flush=True)
-    if ctx[0] > 1:
+    if ctx[4] is not None:
         dist_barrier(ctx)
         ctx[4].destroy_process_group()
 
@@ -658,6 +707,14 @@ def main_mg_ft(args):
     print(json.dumps(out), flush=True)
 
 
+def _child_env(**kw):
+    """Environment of a single-process child run of this file (counter passes, the TF32-class leg): never the parent's rendezvous."""
+    env = {k: v for k, v in os.environ.items() if k not in ("MI_BENCH_FORCE_DIST", "MI_DIST_FORCE_COLLECTIVES", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT",
+                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(kw)
+    return env
+
+
 def _counter_passes(extra_argv, timeout_s=240):
     """FETCH_SIZE and WRITE_SIZE of every kernel of `python bench.py <extra_argv> --counter-child`, from two rocprofv3 child runs (the
     counters in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Returns ({counter: {kernel: (dispatches,
@@ -678,7 +735,7 @@ def _counter_passes(extra_argv, timeout_s=240):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, here] + list(extra_argv) + ["--no-cpu-baseline", "--no-counters", "--counter-child"]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+                r = subprocess.run(cmd, cwd="/tmp", env=_child_env(TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
                 return None, f"no: the {counter} pass exceeded {timeout_s} s"
             dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
@@ -719,6 +776,25 @@ def measure_traffic_live(args, steps=3, warmup=1):
                    "steps_per_pass": steps, "per_kernel": kernels, "wall_s": round(time.perf_counter() - t0, 1), "correction": COUNTER_CORRECTION}
 
 
+def measure_ft_traffic_live(args, steps=4, warmup=1):
+    """roofline.traffic of the fine-tune line: HBM-side bytes of ALL kernels of a micro-step (FETCH_SIZE x2 + WRITE_SIZE over every dispatch of
+    a child run of `--mode ft`, divided by its timesteps), measured by this run.  Returns (bytes per timestep or None, provenance dict)."""
+    t0 = time.perf_counter()
+    argv = ["--mode", "ft", "--steps", str(steps), "--warmup", str(warmup)] + (["--ft-groups", str(args.ft_groups)] if getattr(args, "ft_groups", None) else [])
+    got, why = _counter_passes(argv, timeout_s=300)
+    if got is None:
+        return None, {"measured": why}
+    total = sum(2.0 * v * 1024.0 * n for n, v in got["FETCH_SIZE"].values()) + sum(v * 1024.0 * n for n, v in got["WRITE_SIZE"].values())
+    def kbytes(k):   # bytes of all dispatches of kernel k over the child run
+        nf, f = got["FETCH_SIZE"].get(k, (0, 0.0))
+        nw, w = got["WRITE_SIZE"].get(k, (0, 0.0))
+        return (2.0 * f * nf + w * nw) * 1024.0
+    top = sorted(((kbytes(k) / (steps + warmup), k[:60]) for k in set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"])), reverse=True)[:6]
+    return total / (steps + warmup), {"measured": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of `--mode ft`, every dispatch of the run (its set-up and "
+                                                  "one Adam step per call included)", "timesteps_per_pass": steps + warmup, "wall_s": round(time.perf_counter() - t0, 1),
+                                      "correction": COUNTER_CORRECTION, "largest_kernels_bytes_per_timestep": {k: b for b, k in top}}
+
+
 def measure_mg_traffic_live(args, steps=2, warmup=1):
     """HBM-side bytes of ALL kernels of the MatterGen-shaped sampler's step (FETCH_SIZE x2 + WRITE_SIZE, every dispatch of the child run),
     measured by this run.  Returns (bytes per step or None, provenance dict)."""
@@ -753,7 +829,7 @@ def tf32_class_leg(args, K, W):
     cmd = [sys.executable, os.path.abspath(__file__), "--path", "tf32-class", "--steps", str(K), "--warmup", str(W), "--streams", str(args.streams),
            "--no-cpu-baseline", "--no-counters"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_child_env())
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                 "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
@@ -771,7 +847,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ft-groups", type=int, default=None, help="--mode ft: crystal groups fine-tuned concurrently (default: automatic)")
     ap.add_argument("--streams", type=int, default=4, help="crystal groups of the batch sampled concurrently on separate HIP "
-                    "streams (same samples: the noise is indexed by global ids)")
+                    "streams (same samples: the noise is indexed by global ids); 0 = the sampler's automatic choice for the batch size")
     ap.add_argument("--path", choices=["split-gemm", "f32-gemm", "f32-fused", "tf32-class"], default="split-gemm",
                     help="arithmetic path: split-gemm (default) = fp32 products on the fp16 matrix pipe from two pre-split fp16 planes per operand "
                          "(three MFMA terms, f32 accumulate; a -DMI_PLANES_FP16=0 build uses three bf16 planes / six terms), fp32-class accuracy; "
@@ -783,11 +859,32 @@ def main():
                     "steps that each start from the physical-density state")
     ap.add_argument("--mg-chains", type=int, default=4, help="--mode mg-sample: crystal groups sampled concurrently on separate HIP streams (default 4, the "
                     "sampler's own automatic choice at this size; bit-reproducible since the library is built without packed-fp32 instructions, DESIGN 18)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): 256 crystals per GPU; strong: a global batch of 256 sharded over the ranks")
+    ap.add_argument("--batch", type=int, default=0, help="crystals per GPU (default 256; 256 / N with --scaling strong)")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: form a world-size-1 RCCL (\"nccl\") process group and run every collective of the "
+                    "multi-GPU path (barriers, max-over-ranks time, flat-gradient all-reduce) with its real arguments")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE child passes that fill roofline.traffic")
     ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)   # (the child of those passes: the timed chain only, no JSON)
     ap.add_argument("--mode", choices=["sample", "ft", "mg-sample", "mg-ft", "sample-default", "ft-default"], default="sample",
                     help="sample: headline metric (BASELINE configs[1]); ft: fine-tune micro-steps (configs[2]/[3]), secondary")
     args = ap.parse_args()
+    if args.force_dist:
+        os.environ["MI_BENCH_FORCE_DIST"] = "1"
+    # --scaling strong: ONE global batch of 256 crystals (north_star: "batch 256 ... >= 6x at 8 GPUs"), B / N crystals per rank, global ids in the noise
+    # counters as always (so the N-rank samples are the 1-rank samples).  --batch: the per-GPU batch directly -- the per-rank shapes of a strong-scaling
+    # run (128 / 64 / 32) measured on ONE GPU: profiles/r6_strong_shapes.json, DESIGN section 7.
+    global B
+    B_GLOBAL = B
+    if args.scaling == "strong":
+        assert B_GLOBAL % max(1, args.gpus) == 0, "--scaling strong: the global batch of 256 must divide over the ranks"
+        B = B_GLOBAL // max(1, args.gpus)
+    if args.batch:
+        B = int(args.batch)
+    args.batch_label = (f"global batch {B_GLOBAL} sharded over {args.gpus} rank(s): {B} crystals per GPU (strong scaling)" if args.scaling == "strong" and not args.batch
+                        else f"{B} crystals per GPU" + (" (a per-rank shape of the strong-scaling run, measured on one GPU)" if args.batch else ""))
+    if args.streams == 0:   # automatic: the sampler's own choice for the batch's edge count (DiffCSPModule.sample)
+        e_total = B * NATOM * NATOM
+        args.streams = 4 if e_total >= 98304 else 3 if e_total >= 49152 else 2 if e_total >= 16384 else 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not os.environ.get("MI_BENCH_SHARE_GPU") and torch.cuda.device_count() < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} starts one process per GPU over RCCL, but this node shows {torch.cuda.device_count()} GPU(s)")
@@ -843,13 +940,15 @@ def main():
     import gc
     gc.collect()
     gc.disable()   # (as timeit does: a 20-step window is 0.1 s, a generation-2 collection of a torch process several ms of it; re-enabled right behind the window)
-    barrier()
-    _lib.check(lib.mi_profile_enable(m.decoder._h, 1))
-    t0 = time.perf_counter()
-    final, _ = m.sample(cb, seed=SEED_NOISE, init=state, t_start=T, t_stop=T - K, **skw)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        barrier()
+        _lib.check(lib.mi_profile_enable(m.decoder._h, 1))
+        t0 = time.perf_counter()
+        final, _ = m.sample(cb, seed=SEED_NOISE, init=state, t_start=T, t_stop=T - K, **skw)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()   # (whatever happened in the window, the secondary legs run with the collector on)
     import ctypes as C
     n_launch, tot_ms, union_ms = C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.mi_profile_read(m.decoder._h, C.byref(n_launch), C.byref(tot_ms), C.byref(union_ms)))
@@ -893,14 +992,19 @@ def main():
         out = {
             "metric": "crystal structures/sec (1000-step reverse diffusion)", "value": value, "unit": "structures/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1000-step reverse sampler, batch=256 crystals x 20 atoms per GPU, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 1000-step reverse sampler, {args.batch_label} x 20 atoms, "
                                    "2 score-net evals/step (DiffCSP CSPNet H=512 L=6 F=128 fc edges; MatterGen arithmetic is "
                                    "un-vendored/parity-unpinned); a bench step = one denoising step over the batch",
                        "batch_per_gpu": B, "atoms_per_cell": NATOM, "T": T, "evals_per_step": 2, "path": args.path,
-                       "concurrent_chains": S, "comm_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+                       "concurrent_chains": S, "comm_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                        "weights": "random-init seed 0, heads x1e-2", "noise": "philox seed 1234", "final_state_finite": finite,
-                       "fp16_plane_saturation_events": sat},
+                       "fp16_plane_saturation_events": sat,
+                       "record": False,
+                       "record_note": "per-step log-probabilities not computed and the T+1 states not kept in the timed region (SURVEY 8(d) config 2: recording off "
+                                      "for timing, on for parity); the reference computes and keeps both on every step (models/diffcsp/diffusion.py:353-390) -- "
+                                      "extra.recording_chain is the same window with record=True",
+                       "gc_disabled_in_window": True},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": issued, "peak": peak,
                          "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(n_launch.value), "avg_launch_ms": avg_ms, "concurrent_streams": S,
@@ -938,6 +1042,24 @@ def main():
                                                     "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
                 set_gemm_mode("split")
                 m.decoder.set_edge_mode("gemm")
+                # what the timed region leaves out, priced: the same K steps from the same state with record=True -- every step's state kept on the
+                # device and its three log-probabilities computed (21-image wrapped-normal sums, block reductions), as diffusion.py:353-390 does
+                try:
+                    m.sample(cb, seed=SEED_NOISE + 1, t_start=T, t_stop=T - 2, record=True, **skw)
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter()
+                    fin_r, traj_r = m.sample(cb, seed=SEED_NOISE, init=state, t_start=T, t_stop=T - K, record=True, **skw)
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter() - tr
+                    same = all(bool(torch.equal(fin_r[k], final[k])) for k in ("frac_coords", "lattices", "atom_types"))
+                    kept = sorted(k for k in traj_r[T - K + 1]) if (T - K + 1) in traj_r else []
+                    out["extra"]["recording_chain"] = {"value": B * K / (T * tr), "unit": "structures/s", "steps": K, "ms_per_step": tr * 1e3 / K, "record": True,
+                                                       "relative_to_headline": (B * K / (T * tr)) / value, "states_kept": len(traj_r), "fields_per_state": kept,
+                                                       "final_state_bit_identical_to_timed_chain": same,
+                                                       "note": "record=True: states of all steps retained + log_prob_l / log_prob_t / log_prob_x per step (for t > 1)"}
+                    del fin_r, traj_r
+                except Exception as e:   # (never let the secondary figure take the headline down)
+                    out["extra"]["recording_chain"] = {"error": repr(e)}
                 # the arithmetic class the REFERENCE runs after its first fine-tune step (torch.set_float32_matmul_precision("high"),
                 # pipeline/mat_invent.py:127: TF32 on its hardware), as a LABELLED secondary line: the same command on the TF32-class library
                 # build (one term per plane-set product; its own tolerance is stated and tested in tests/test_gpu_tf32_class.py), in a child process
@@ -963,18 +1085,18 @@ def main():
                     out["extra"]["fine_tune"]["workload"] = ftl["config"]["workload"]
                     out["extra"]["fine_tune"]["adam_steps_in_timed_region"] = ftl["config"]["adam_steps_in_timed_region"]
                     # the same leg on rounds 2-3's protocol (20 timesteps per Adam step), so that the records stay comparable across rounds
-                    saved = args.no_cpu_baseline
-                    args.no_cpu_baseline = True
+                    saved = args.no_cpu_baseline, args.no_counters
+                    args.no_cpu_baseline = args.no_counters = True
                     try:
                         ft20 = measure_ft(args, 20, 3, ctx)
                         out["extra"]["fine_tune"]["value_20step"] = ft20["value"]
                     finally:
-                        args.no_cpu_baseline = saved
+                        args.no_cpu_baseline, args.no_counters = saved
                 except Exception as e:
                     out["extra"]["fine_tune"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         barrier()
         dist.destroy_process_group()
 

@@ -186,6 +186,11 @@ int mi_debug_set_mg_nosync(int on);
  * sampler's forwards (more workgroups per CU) at the price of flagging denser crystals; the tests use it to exercise the flag path.
  * Returns the previous value. */
 int mi_debug_set_mg_deg_cap(int cap);
+/* Matrix-pipe work ISSUED by every product this process has launched since the last reset (measurement only; host-side counters, so
+ * nothing is synchronised): *flops16 = sum over the products on the 16-bit pipe of 2 M N K x the MFMA terms each fp32 product is issued
+ * as (3: two pre-split fp16 planes; 6: three bf16 planes split on the fly; 1: the TF32-class build), *flops32 = 2 M N K of the
+ * f32-input MFMA products.  bench.py divides them by the elapsed time of a timed region: the whole step's matrix-pipe rate. */
+int mi_debug_mfma_flops(double* flops16, double* flops32, int reset);
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mi_set_edge_pairs": (_I, [_I]),
     "mi_plane_format": (_I, []),
     "mi_terms_per_product": (_I, []),
+    "mi_debug_mfma_flops": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
     "mi_debug_fourier_pairs": (_I, [_P, _P, _P, _L, _I, _P, _P]),
     "mi_debug_set_db_min_tiles": (_I, [_I]),
     "mi_debug_set_node_planes_min_rows": (_I, [_I]),

@@ -683,6 +683,7 @@ static int gemm_tn_planes(const Planes& A, int a_col0, const Planes& X, int x_co
     std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)gemm_tn_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TNP_NST * TNP_STAGE); });
     MI_HIP(attr_err);
     const int gy = Na / 256, gx = Kx / 128;
+    count_mfma(M, Na, Kx, MI_PLANES_TERMS);
     int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles * 2 / 3, gx * gy)));   // (one workgroup per CU: two rounds of the chip)
     while (nsplit > 1 && (size_t)nsplit * Na * Kx > scratch_floats) --nsplit;
     MI_CHECK((size_t)nsplit * Na * Kx <= scratch_floats, MI_ENOMEM, "gemm_tn_planes scratch too small");

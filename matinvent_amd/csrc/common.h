@@ -40,6 +40,15 @@ void set_error(const char* fmt, ...);
 
 #define MI_KERNEL_CHECK() MI_HIP(hipGetLastError())
 
+// ---- issued matrix-pipe work (measurement only) -----------------------------------------------------------------------------------
+// Every host launcher of a matrix product adds 2 M N K x (MFMA terms per fp32 product) to a process-wide counter (16-bit pipe: fp16 / bf16
+// MFMA) or, for the f32-input MFMA kernels, 2 M N K to a second one.  bench.py divides the counters of a timed region by its elapsed time:
+// the matrix-pipe rate of the WHOLE step (forwards + backward), not of one bracketed kernel pair.  mi_debug_mfma_flops reads / resets them.
+void count_mfma(int64_t M, int64_t N, int64_t K, int terms16);   // terms16 = 0: an f32-input MFMA product
+#if !defined(MI_PLANES_TERMS)
+#define MI_PLANES_TERMS (MI_PLANES_FP16 ? (MI_TF32_CLASS ? 1 : 3) : 6)   // MFMA terms of a product of two pre-split plane sets in this build
+#endif
+
 // ---- roctx ranges (tracing hooks around the sampler step, the fine-tune micro-step and the gradient all-reduce) --------
 // Off unless MI_ROCTX=1 is set when the library is loaded; the roctx library is opened at run time (no link dependency), so a
 // `rocprofv3 --marker-trace` run shows one named range per denoising step / micro-step / all-reduce over the kernels it enqueues.

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <atomic>
 
 #define MI_GEMM_OWNER   // this unit defines the GEMM launchers of gemm.h / gemm_split.h (and therefore carries their kernels); the others see prototypes
 #include "edge_mlp.h"
@@ -91,6 +92,14 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// issued matrix-pipe work of every product launched by this process (common.h): host-side counters, several enqueueing threads
+static std::atomic<uint64_t> g_mfma16_mflop{0}, g_mfma32_mflop{0};   // in units of 1e6 flops (2^64 of them outlast any run)
+void count_mfma(int64_t M, int64_t N, int64_t K, int terms16) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    const double f = 2.0 * (double)M * (double)N * (double)K * (terms16 > 0 ? terms16 : 1) * 1e-6;
+    (terms16 > 0 ? g_mfma16_mflop : g_mfma32_mflop).fetch_add((uint64_t)(f + 0.5), std::memory_order_relaxed);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -895,6 +904,7 @@ static int launch_edge(mi_net* net, mi_batch* b, int layer, const float* frac, f
     MI_TRY(prof_begin(net, s, &ps));
     const bool save = Z1 != nullptr;
     MI_CHECK((Z1 == nullptr) == (Z2 == nullptr), MI_EINVAL, "Z1 and Z2 must be given together");
+    count_mfma(b->E, net->H, 2 * net->KP + net->H, 0);   // (the register-chained f32-MFMA edge stage: Fourier block over KP (sin, cos) pairs + second linear)
 #define MI_EDGE_LAUNCH(HH)                                                                   \
     case HH:                                                                                 \
         if (save) hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH, true>), grid, block, 0, s, a); \
@@ -965,10 +975,11 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     }
     // what the previous evaluation of this handle left behind is valid for THIS call only if it says so (reuse_embedding); every forward re-earns the flags
     // (a forward that takes another path -- a knob changed, a training forward -- leaves nothing a later call could mistake for its own)
-    const bool same_net = b->reuse_net == (const void*)net;
+    const bool same_net = b->reuse_net == (const void*)net && b->reuse_epoch == net->param_epoch;   // (same network AND same parameter version)
     const bool had_gram = b->gram_valid && same_net, had_pq0 = b->pq0_valid && same_net;
     b->gram_valid = b->pq0_valid = false;
     b->reuse_net = net;
+    b->reuse_epoch = net->param_epoch;
     bool absmax_cleared = false;   // the pair-mode Fourier launch cleared b->absmax on the way (one launch fewer per evaluation)
     bool gram_kept = false;        // ... and left the lattice term's slots alone: G is the previous evaluation's
     bool pq0_kept = false;         // ... and layer 0's slot: its [P_i | P_j | X_part] (b->PQ0) is the previous evaluation's as well
@@ -1426,6 +1437,7 @@ int mi_net_set_params(mi_net* n, const float* theta, const float* freqs_host, vo
     MI_CHECK((((uintptr_t)theta) & 15) == 0, MI_EINVAL, "theta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int H = n->H;
+    ++n->param_epoch;   // (what earlier evaluations left on their batch handles for reuse belongs to the previous parameter version)
     if (!n->Whh) {
         MI_HIP(hipMalloc((void**)&n->Whh, n->L * n->whh_stride() * sizeof(float)));
         MI_HIP(hipMalloc((void**)&n->Wff_p, n->L * n->wff_stride() * sizeof(float)));
@@ -1841,6 +1853,15 @@ int mi_debug_set_planes_dma(int mode) {
 
 int mi_plane_format(void) { return NPL; }
 int mi_terms_per_product(void) { return MI_TF32_CLASS ? 1 : 3; }
+int mi_debug_mfma_flops(double* flops16, double* flops32, int reset) {
+    if (flops16) *flops16 = 1e6 * (double)mi::g_mfma16_mflop.load();
+    if (flops32) *flops32 = 1e6 * (double)mi::g_mfma32_mflop.load();
+    if (reset) {
+        mi::g_mfma16_mflop.store(0);
+        mi::g_mfma32_mflop.store(0);
+    }
+    return MI_OK;
+}
 
 int mi_debug_set_tn128(int on) {
     g_tn128 = (on & 1) != 0;

@@ -1453,6 +1453,7 @@ int edge_gemm1(mi_net* net, const Planes& A, int layer, int M, PlanesEpilogue pe
     });
     MI_HIP(attr_err);
     const int H = net->H, K = 2 * net->Kh;
+    count_mfma(M, H, K, MI_PLANES_TERMS);   // (pair rows x [sine block | cosine block] of the Fourier columns)
     pe.out_scale = 1.f / (A.scale * PL_SW);
 #if MI_HAVE_ABLATION_KERNELS
     if (g_edge1_fused == 4 && H % 256 == 0 && net->Wffc2 && (K / 32) % 4 == 0) {   // form E: one accumulator set, 128 x 256 tiles, the sine half twice
@@ -1525,6 +1526,7 @@ int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2) {
     });
     MI_HIP(attr_err);
     const int H = net->H;
+    count_mfma(b->E, H, H, MI_PLANES_TERMS);
     EdgeGemm2Args a;
     a.A = make_planes(b->m1_cur ? b->m1_cur : b->M1pl, H, PL_S_ACT, b->dsc);
     a.W2f = net->Wnc + (size_t)layer * node_chain_pack_elems(H) + (size_t)5 * H * H * 2;
@@ -1586,6 +1588,7 @@ int gemm_rt(const Planes& A, const u16* Wfrag, int M, int N, int K, const Planes
     MI_HIP(attr_err);
     MI_CHECK(Wfrag && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && A.KT >= K / 32, MI_EINVAL, "gemm_rt: N % 256, K % 64, K >= 128 and a fragment-order W operand");
     if (M <= 0) return MI_OK;
+    count_mfma(M, N, K, MI_PLANES_TERMS);
     const dim3 grid((N >> 8) * ((cdiv(M, 128) + 7) / 8 * 8));
     static const bool trace = getenv("MI_RT_TRACE") != nullptr;   // (debugging aid: which epilogue features each launch carries)
     if (trace)

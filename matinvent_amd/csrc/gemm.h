@@ -171,6 +171,7 @@ int gemm_nt_f32(const float* A, int lda, const float* W, int ldw, float* C, int 
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt: K/lda/ldw must be multiples of 4 (%d,%d,%d)", K, lda, ldw);
     MI_CHECK((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, MI_EINVAL, "gemm_nt: operands must be 16-byte aligned");
     if (M <= 0 || N <= 0) return MI_OK;
+    count_mfma(M, N, K, 0);
     // 128x64 tiles once there are enough of them to fill 256 CUs twice; 64x64 otherwise
     if ((int64_t)cdiv(M, 128) * cdiv(N, 64) >= 512) {
         dim3 grid(cdiv(N, 64), cdiv(M, 128));
@@ -408,6 +409,7 @@ extern int g_tn_target_tiles;  // workgroups a long weight-gradient contraction 
 int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int ldc, int M, int Na, int Kx, float* scratch,
                        size_t scratch_floats, hipStream_t s) {
     if (M <= 0 || Na <= 0 || Kx <= 0) return MI_OK;
+    count_mfma(M, Na, Kx, 0);   // (gemm_tn_kernel / gemm_tn128_kernel: f32-input MFMA)
     if (g_tn128 && Na >= 128 && Kx >= 128 && M >= 8192) {  // the edge / pair-list contractions
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
         int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles, gx * gy)));

@@ -421,6 +421,7 @@ int gemm_nt_split(const float* A, int lda, const float* W, int ldw, float* C, in
                          hipStream_t s, const SplitK* sk = nullptr, const unsigned* amax_a = nullptr, const unsigned* amax_w = nullptr) {
     MI_CHECK(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, MI_EINVAL, "gemm_nt_split: K/lda/ldw must be multiples of 4");
     if (M <= 0 || N <= 0) return MI_OK;
+    count_mfma(M, N, K, (amax_a && amax_w && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 256) ? (MI_TF32_CLASS ? 1 : 3) : (MI_TF32_CLASS ? 1 : 6));
     if ((int64_t)cdiv(M, 128) * cdiv(N, 128) >= 256) {
         constexpr int BM = 128, BN = 128;
         if (amax_a && amax_w)   // two fp16 planes split on the fly, three MFMA terms (scales from the operands' exact absmax)
@@ -2242,6 +2243,7 @@ int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int
         nsplit = cdiv(M, rows);
         const dim3 grid(gx * gy * ((nsplit + 7) / 8 * 8));
         const bool f16 = MI_PLANES_FP16 && sa && sx;
+        count_mfma(M, Na, Kx, MI_TF32_CLASS ? 1 : f16 ? 3 : 6);
         if (f16 && x_silu) hipLaunchKernelGGL((gemm_tn_split_kernel<true, true>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
         else if (f16) hipLaunchKernelGGL((gemm_tn_split_kernel<false, true>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
         else if (x_silu) hipLaunchKernelGGL((gemm_tn_split_kernel<true, false>), grid, dim3(256), 0, s, A, lda, X, ldx, scratch, M, Na, Kx, rows, gx, gy, nsplit, sa, sx);
@@ -2277,6 +2279,7 @@ int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const Pla
     // A may be a wider plane set of which the first K columns are used (A.KT is then only the row-tile stride)
     MI_CHECK(A.KT >= (K + 31) / 32 && W.KT == (K + 31) / 32 && (A.KT == W.KT || K % 32 == 0), MI_EINVAL, "gemm_planes: operand plane sets do not match K");
     if (M <= 0 || N <= 0) return MI_OK;
+    count_mfma(M, N, K, MI_PLANES_TERMS);
     PlanesEpilogue pe = pe_in;
     pe.out_scale = 1.f / ((A.dscale ? 1.f : A.scale) * W.scale);
     pe.a_dinv = A.dscale ? A.dscale + 1 : nullptr;

@@ -18,6 +18,7 @@ struct mi_net {
     std::vector<ParamInfo> params;
     int64_t nparams = 0;
     const float* theta = nullptr;  // caller-owned flat parameters (device)
+    uint64_t param_epoch = 0;      // bumped by every mi_net_set_params: what an evaluation left behind for a later one (mi_batch::G, PQ0) is valid for ONE parameter version
     float* freqs = nullptr;        // [F] device
     bool have_freqs = false;
     // packed copies, rebuilt by mi_net_set_params
@@ -132,6 +133,7 @@ struct mi_batch {
                              // the same embedding as the corrector evaluation in front of it, so layer 0's LayerNorm + projections launch is not repeated (pq0_valid)
     bool pq0_valid = false;
     const void* reuse_net = nullptr;   // the network whose evaluation left G / PQ0 behind (another network's evaluation never reuses them)
+    uint64_t reuse_epoch = 0;          // ... and its parameter version (mi_net::param_epoch): an optimizer step in between invalidates both
     float* G = nullptr;      // [B][H]
     float* part = nullptr;   // [nslots][N][H]
     float* FFp = nullptr;    // [tiles][KP/4][64][4] Fourier operand, B-fragment order (fused path)
@@ -177,6 +179,10 @@ struct mi_batch {
 };
 
 namespace mi {
+// reuse_embedding -- the CONTRACT (internal; the only caller is mi_sampler_run's predictor evaluation, diffusion.py:320-322): this evaluation has the same
+// t_emb, atom_types AND lattices as the previous evaluation of this batch handle by this network at this parameter version; only the coordinates moved.
+// It keeps h[0], and (inference, pair mode) the lattice term G of every layer and layer 0's [P_i | P_j | X_part].  The handle remembers the network and
+// its parameter epoch, so another network or an mi_net_set_params in between falls back to recomputing G / PQ0; unchanged lattices are the caller's promise.
 int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_types, const float* frac,
                 const float* lattices, float* lattice_out, float* coord_out, float* type_out, hipStream_t s, bool train = false,
                 bool reuse_embedding = false, bool coords_only = false);

@@ -1034,6 +1034,8 @@ int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
 }
 static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     const int H = net->H, L = net->L, N = b->N;
+    if (l > 0) count_mfma(N, 2 * H, H, MI_PLANES_TERMS);   // agg . Wagg^T and X . Wn2^T of layer l - 1
+    if (l < L) count_mfma(N, 3 * H, H, MI_PLANES_TERMS);   // LayerNorm(h) . [W_Pi; W_Pj; W_node0[:, :H]]^T of layer l
     const size_t NH = (size_t)N * H;
     NodeChainArgs a;
     a.N = N;

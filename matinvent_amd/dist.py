@@ -9,6 +9,14 @@ def is_dist():
     return dist.is_available() and dist.is_initialized()
 
 
+def collectives_on():
+    """True when the collectives of this module really run: a process group exists and it has more than one rank -- or it has ONE rank and
+    MI_DIST_FORCE_COLLECTIVES=1 asks for them anyway.  A world-size-1 RCCL group executes every line of the multi-GPU path with its real
+    arguments (device buffers, device ids) on a one-GPU box: tests/test_gpu_multirank.py::test_world_size_one_rccl_group_runs_every_collective."""
+    import os
+    return is_dist() and (dist.get_world_size() > 1 or os.environ.get("MI_DIST_FORCE_COLLECTIVES", "0") not in ("", "0"))
+
+
 def rank_world():
     return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
 
@@ -50,7 +58,7 @@ def allreduce_flat_(buf: torch.Tensor):
     """In-place SUM all-reduce of one flat buffer (the whole gradient: 4P bytes, one message; pipeline/mat_invent.py:166,177 is where the
     reference steps its optimizer -- the all-reduce sits right in front).  ONE code path for every backend: stage (a no-op under RCCL),
     reduce, unstage; the only line a gloo run does not execute with the arguments of an RCCL run is the collective itself."""
-    if not (is_dist() and dist.get_world_size() > 1):
+    if not collectives_on():
         return buf
     assert buf.is_contiguous() and buf.dtype == torch.float32, "the flat gradient / accumulator buffer is one contiguous fp32 vector"
     lib = _trace_lib()
@@ -66,7 +74,7 @@ def allreduce_flat_(buf: torch.Tensor):
 
 
 def all_gather_objects(obj):
-    if not is_dist() or dist.get_world_size() == 1:
+    if not collectives_on():
         return [obj]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
@@ -74,7 +82,7 @@ def all_gather_objects(obj):
 
 
 def broadcast_object(obj, src=0):
-    if not is_dist() or dist.get_world_size() == 1:
+    if not collectives_on():
         return obj
     box = [obj]
     dist.broadcast_object_list(box, src=src)

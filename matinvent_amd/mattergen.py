@@ -321,6 +321,13 @@ class GemNetTDenoiser(nn.Module):
             self._lib.mi_gemnet_destroy(h)
 
 
+def weighted_field_sum(fields, weights=None):
+    """SampleLoss.__call__'s aggregation (loss.py:71-73): stack of w_field * loss_field over the fields in the loss functions' order, summed -> [B]
+    (pinned by tests/golden/g12_mattergen_adapter.npz, generated from the reference's own loss.py)."""
+    w = WEIGHTS if weights is None else weights
+    return torch.stack([w[k] * v for k, v in fields.items()], dim=0).sum(0)
+
+
 def _scatter_mean(src, index, dim_size):
     out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
     cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
@@ -445,8 +452,7 @@ class MatterGenModule(nn.Module):
         x0 = batch.atomic_numbers.to(logp.device).long()
         nll = -logp.gather(1, (x0 - 1)[:, None])[:, 0]
         l_types = _scatter_mean(aux["masked"].to(nll.dtype) * nll / aux["tau"] + D3PM_LAMBDA * nll, n2g, B)
-        loss = WEIGHTS["atomic_numbers"] * l_types + WEIGHTS["cell"] * l_cell + WEIGHTS["pos"] * l_pos
-        return loss, pred
+        return weighted_field_sum(dict(pos=l_pos, cell=l_cell, atomic_numbers=l_types)), pred
 
     def calc_kl_reg(self, agent_pred, prior_pred, batch):
         """pl_module.py:83-102."""

@@ -52,7 +52,8 @@ class DiffCSPSampler:
         rank, world = int(kwargs.get("rank", 0)), int(kwargs.get("world_size", 1))
         model.eval()
         dataset = SampleDataset(total_num=batch_size * num_batches, dataset=self.num_atoms_distribution)
-        if world > 1:
+        from .dist import collectives_on
+        if world > 1 or collectives_on():
             # the atom counts come from numpy's unseeded GLOBAL generator (sample.py:123): every rank would draw a different
             # vector, while the shard ranges and the global noise offsets below assume ONE.  Rank 0's draw is the batch.
             from .dist import broadcast_object
@@ -86,7 +87,7 @@ class DiffCSPSampler:
             d.geometry = {"max_cell_edge": float(geom[i, 0]), "min_distance": float(geom[i, 1]), "volume": float(geom[i, 2])}
             data_list.append(d)
             struc_list.append(data2struc(d))
-        if world > 1:
+        if world > 1 or collectives_on():
             from .dist import all_gather_objects
             parts = all_gather_objects((data_list, struc_list))
             data_list = [d for p in parts for d in p[0]]

@@ -78,7 +78,6 @@ class ChainWorkers:
         self.streams = concurrent_streams(n, device)
         self.device = self.streams[0].device
         self._q = [queue.SimpleQueue() for _ in range(n)]
-        self._done = queue.SimpleQueue()
         self._busy = threading.Lock()   # one sample() call at a time per pool (the chains of two calls would share streams)
         self._threads = [threading.Thread(target=self._loop, args=(k,), name=f"mi-chain-{k}", daemon=True) for k in range(n)]
         for t in self._threads:
@@ -87,26 +86,37 @@ class ChainWorkers:
     def _loop(self, k):
         torch.cuda.set_device(self.device)
         while True:
-            fn = self._q[k].get()
-            if fn is None:
+            item = self._q[k].get()
+            if item is None:
                 return
+            fn, done = item   # (every call brings its OWN result queue: what an interrupted call left behind can never reach a later one)
             try:
                 with torch.cuda.stream(self.streams[k]):
-                    self._done.put((k, fn(k, self.streams[k]), None))
+                    done.put((k, fn(k, self.streams[k]), None))
             except BaseException as e:  # noqa: BLE001 -- handed to the caller
-                self._done.put((k, None, e))
+                done.put((k, None, e))
 
     def run(self, fn, n=None):
         """fn(k, stream) on worker k = 0 .. n-1 (each under its stream); returns the list of results in worker order."""
+        import queue
         n = len(self._q) if n is None else n
+        done = queue.SimpleQueue()
         with self._busy:
             for k in range(n):
-                self._q[k].put(fn)
-            out, err = [None] * n, None
-            for _ in range(n):
-                k, r, e = self._done.get()
-                out[k] = r
-                err = err or e
+                self._q[k].put((fn, done))
+            out, err, got = [None] * n, None, 0
+            try:
+                while got < n:
+                    k, r, e = done.get()
+                    got += 1
+                    out[k] = r
+                    err = err or e
+            finally:
+                # interrupted while waiting (KeyboardInterrupt in a notebook): the workers are still enqueueing on their streams.  Wait for
+                # them before the pool is released, so the next call neither shares a stream with a half-enqueued chain nor sees its results.
+                while got < n:
+                    done.get()
+                    got += 1
         if err is not None:
             raise err
         return out

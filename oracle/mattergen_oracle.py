@@ -461,7 +461,15 @@ def sample_loss(corr: Corruption, batch, aux, pred):
     logp = torch.log_softmax(pred["atomic_numbers"][:, :NUM_CLASSES - 1], dim=1)
     nll = -logp.gather(1, (batch["atomic_numbers"] - 1)[:, None])[:, 0]
     l_types = _scatter_mean(aux["masked"].to(nll.dtype) * nll / aux["tau"] + D3PM_LAMBDA * nll, n2g, B)
-    return WEIGHTS["atomic_numbers"] * l_types + WEIGHTS["cell"] * l_cell + WEIGHTS["pos"] * l_pos, dict(pos=l_pos, cell=l_cell, atomic_numbers=l_types)
+    fields = dict(pos=l_pos, cell=l_cell, atomic_numbers=l_types)
+    return weighted_field_sum(fields), fields
+
+
+def weighted_field_sum(fields, weights=None):
+    """SampleLoss.__call__'s aggregation (loss.py:71-73): stack of w_field * loss_field over the fields, summed -> [B].  Pinned by the reference-generated
+    fixture tests/golden/g12_mattergen_adapter.npz (the per-field losses themselves are upstream arithmetic and stay unpinned)."""
+    w = WEIGHTS if weights is None else weights
+    return torch.stack([w[k] * v for k, v in fields.items()], dim=0).sum(0)
 
 
 def calc_kl_reg(agent_pred, prior_pred, node2graph, B):

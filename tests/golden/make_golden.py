@@ -493,6 +493,140 @@ def g11_noise_sampled_times():
         loss=loss, pred_l=pred[0], pred_x=pred[1], pred_t=pred[2], time_freqs=time_freqs(256), **sd)
 
 
+def g12_mattergen_adapter():
+    """The IN-TREE arithmetic of the MatterGen adapter, run from the reference's own files (models/mattergen/pl_module.py, loss.py).  The network and
+    the corruptions live in the un-vendored package `mattergen @ 5bb2b397` (env.yml:31) and stay parity-unpinned; what the reference itself computes
+    around them does not need that package's arithmetic -- only names to import.  The names are given as EMPTY class stand-ins (no arithmetic of
+    ours in them): `DiffusionLightningModule` keeps the diffusion module it is handed, `MaterialsLoss` keeps the weights it is handed and one
+    key per included field, `apply` returns the per-field losses the harness planted.  Recorded:
+      (a) MatterGenModule.calc_kl_reg (pl_module.py:83-102) on random agent / prior predictions with a ragged batch index;
+      (b) MatterGenModule.add_noise's time grid (pl_module.py:55-67): the `t` it hands the corruption, for timestep 0 / 1 / 500 / 998 / 999, T_max 1.0 and 0.8;
+      (c) SampleLoss.__call__ (loss.py:36-78): default weights and the weighted stack-sum over planted per-field, per-sample losses."""
+    import typing
+    mods = {}
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        mods[name] = m
+        return m
+
+    class BatchedData:   # a type bound only
+        pass
+
+    class DiffusionLightningModule(torch.nn.Module):   # upstream: a LightningModule that owns the diffusion module
+        def __init__(self, diffusion_module=None, optimizer_partial=None, scheduler_partials=None):
+            super().__init__()
+            self.diffusion_module = diffusion_module
+
+    class MaterialsLoss:   # upstream builds one loss function per included field and keeps the weights; the functions themselves are upstream arithmetic
+        def __init__(self, reduce="sum", d3pm_hybrid_lambda=0.01, include_pos=True, include_cell=True, include_atomic_numbers=True, weights=None):
+            self.loss_weights = dict(weights)
+            self.d3pm_hybrid_lambda = d3pm_hybrid_lambda
+            self.loss_fns = {k: None for k, inc in (("pos", include_pos), ("cell", include_cell), ("atomic_numbers", include_atomic_numbers)) if inc}
+
+    T_ = typing.TypeVar("T_")
+
+    class MultiCorruption(typing.Generic[T_]):
+        pass
+
+    planted = {}
+
+    def apply(fns, corruption, x, noisy_x, score_model_output, batch_idx, broadcast, node_is_unmasked):
+        assert set(fns) == set(planted) and set(batch_idx) == set(fns)
+        return {k: planted[k] for k in fns}   # (dict order = the order of the loss functions, as upstream's apply keeps it)
+
+    mod("omegaconf", DictConfig=dict)
+    mod("mattergen")
+    mod("mattergen.common")
+    mod("mattergen.common.loss", MaterialsLoss=MaterialsLoss)
+    mod("mattergen.diffusion")
+    mod("mattergen.diffusion.config", Config=object)
+    mod("mattergen.diffusion.data")
+    mod("mattergen.diffusion.data.batched_data", BatchedData=BatchedData)
+    mod("mattergen.diffusion.diffusion_module", DiffusionModule=object)
+    mod("mattergen.diffusion.lightning_module", DiffusionLightningModule=DiffusionLightningModule)
+    mod("mattergen.diffusion.corruption")
+    mod("mattergen.diffusion.corruption.multi_corruption", MultiCorruption=MultiCorruption, apply=apply)
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        import importlib
+        pl = importlib.import_module("models.mattergen.pl_module")
+        ls = importlib.import_module("models.mattergen.loss")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    gen = torch.Generator().manual_seed(1212)
+    out = {}
+    # ---- (a) calc_kl_reg ------------------------------------------------------------------------------------------------------------------
+    na = torch.tensor([3, 1, 7, 20, 2])
+    N, Bn = int(na.sum()), len(na)
+    n2g = torch.repeat_interleave(torch.arange(Bn), na)
+
+    class Batch:
+        def get_batch_idx(self, key):
+            assert key in ("pos", "cell", "atomic_numbers")
+            return n2g if key != "cell" else None
+
+        def get_batch_size(self):
+            return Bn
+
+    agent = {"pos": torch.randn(N, 3, generator=gen), "cell": torch.randn(Bn, 3, 3, generator=gen), "atomic_numbers": torch.randn(N, 101, generator=gen)}
+    prior = {k: v + 0.3 * torch.randn(v.shape, generator=gen) for k, v in agent.items()}
+
+    class Corr:
+        T = 1.0
+
+        def sample_marginal(self, batch, t):
+            return ("noisy", batch)
+
+    class DM:
+        corruption = Corr()
+
+        @staticmethod
+        def pre_corruption_fn(b):
+            return b
+
+        @staticmethod
+        def _get_device(b):
+            return torch.device("cpu")
+    m = pl.MatterGenModule(diffusion_module=DM())
+    kl = m.calc_kl_reg(agent, prior, Batch())
+    assert kl.shape == (Bn,)
+    out.update(kl_num_atoms=na, kl_agent_pos=agent["pos"], kl_agent_cell=agent["cell"], kl_agent_types=agent["atomic_numbers"],
+               kl_prior_pos=prior["pos"], kl_prior_cell=prior["cell"], kl_prior_types=prior["atomic_numbers"], kl_out=kl)
+    # ---- (b) the time grid of add_noise -----------------------------------------------------------------------------------------------------
+    steps = [0, 1, 500, 998, 999]
+    for tmax in (1.0, 0.8):
+        DM.corruption.T = tmax
+        ts = []
+        for k in steps:
+            noisy, b2, t = m.add_noise(Batch(), k)
+            assert t.shape == (Bn,) and bool((t == t[0]).all()) and noisy == ("noisy", b2)
+            ts.append(t[0])
+        out["grid_t_Tmax%s" % str(tmax).replace(".", "p")] = torch.stack(ts)
+    out["grid_timesteps"] = torch.tensor(steps)
+    # ---- (c) SampleLoss ------------------------------------------------------------------------------------------------------------------------
+    sl = ls.SampleLoss()
+    planted.update({k: torch.rand(Bn, generator=gen) * s for k, s in (("pos", 3.0), ("cell", 0.7), ("atomic_numbers", 5.0))})
+    agg, metrics = sl(multi_corruption=types.SimpleNamespace(corruptions=None), batch=Batch(), noisy_batch=None, score_model_output=None, t=torch.zeros(Bn))
+    assert agg.shape == (Bn,)
+    out.update(loss_fields=np.array(list(sl.loss_fns.keys())), loss_weights=np.array([sl.loss_weights[k] for k in sl.loss_fns]),
+               loss_d3pm_hybrid_lambda=np.float64(sl.d3pm_hybrid_lambda), loss_pos=planted["pos"], loss_cell=planted["cell"], loss_types=planted["atomic_numbers"],
+               loss_agg=agg, loss_metric_means=torch.stack([metrics[k] for k in sl.loss_fns]))
+    # custom weights travel through unchanged
+    sl2 = ls.SampleLoss(weights={"atomic_numbers": 2.0, "cell": 0.5, "pos": 0.25})
+    agg2, _ = sl2(multi_corruption=types.SimpleNamespace(corruptions=None), batch=Batch(), noisy_batch=None, score_model_output=None, t=torch.zeros(Bn))
+    out.update(loss_agg_custom=agg2, loss_weights_custom=np.array([sl2.loss_weights[k] for k in sl2.loss_fns]))
+    npz("g12_mattergen_adapter", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # only the named fixtures, e.g. `make_golden.py g10_csp_mode g11_noise_sampled_times`
         for name in sys.argv[1:]:
@@ -510,3 +644,4 @@ if __name__ == "__main__":
     g9_host_glue()
     g10_csp_mode()
     g11_noise_sampled_times()
+    g12_mattergen_adapter()

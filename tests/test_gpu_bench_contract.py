@@ -30,3 +30,13 @@ def test_bench_line_has_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "structures/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
     assert d["config"]["final_state_finite"] is True
+    # what the timed region leaves out is said in the line, and priced (round 6): recording off in the window, a record=True figure beside it
+    assert d["config"]["record"] is False and "log-probabilities" in d["config"]["record_note"] and d["config"]["gc_disabled_in_window"] is True
+    rc = d["extra"]["recording_chain"]
+    assert "error" not in rc, rc
+    assert rc["record"] is True and rc["value"] > 0 and rc["states_kept"] >= 4 and rc["final_state_bit_identical_to_timed_chain"] is True
+    assert {"log_prob_l", "log_prob_t", "log_prob_x"} <= set(rc["fields_per_state"])
+    # BASELINE configs[2] rides along with a roofline object over the WHOLE micro-step
+    ft = d["extra"]["fine_tune"]
+    assert "error" not in ft, ft
+    assert ft["roofline"]["scope"].startswith("whole micro-step") and 0 < ft["roofline"]["frac"] < 1

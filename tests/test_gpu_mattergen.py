@@ -781,3 +781,44 @@ def test_benchmark_size_fine_tune_window_vs_the_oracle(bench_net):
         bad += int((d > 1e-6).sum())
         tot_n += d.numel()
     assert bad <= 0.02 * tot_n, f"{bad} of {tot_n} parameters differ by more than 1e-6 after the Adam step"
+
+
+def test_adapter_arithmetic_on_the_device_against_the_reference_generated_fixture():
+    """The product adapter (matinvent_amd/mattergen.py, tensors on the GPU) against tests/golden/g12_mattergen_adapter.npz -- outputs of the reference's own
+    pl_module.py / loss.py (tests/golden/make_golden.py::g12_mattergen_adapter): anchor penalty on a ragged batch, the time grid add_noise hands the corruption,
+    the default loss weights and the weighted stack-sum.  Row a17 reads "adapter arithmetic pinned, network unpinned"."""
+    import os
+    from matinvent_amd import mattergen as MG
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_mattergen_adapter.npz"))
+    dev = torch.device("cuda", 0)
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    m = _module(M.TINY)
+    na = torch.from_numpy(g["kl_num_atoms"])
+    n2g = torch.repeat_interleave(torch.arange(len(na)), na)
+
+    class Batch:
+        num_atoms = na
+
+        def get_batch_idx(self, key):
+            return n2g
+
+    agent = dict(pos=t("kl_agent_pos"), cell=t("kl_agent_cell"), atomic_numbers=t("kl_agent_types"))
+    prior = dict(pos=t("kl_prior_pos"), cell=t("kl_prior_cell"), atomic_numbers=t("kl_prior_types"))
+    kl = m.calc_kl_reg(agent, prior, Batch())
+    assert kl.is_cuda
+    _rel(kl, g["kl_out"], 2e-6, "anchor penalty vs the reference's calc_kl_reg")
+    # add_noise's t (every crystal gets linspace(T_max, 1/1000, 1000)[timestep]): bit-equal float32
+    gen = torch.Generator().manual_seed(3)
+    N, B = int(na.sum()), len(na)
+    cell = 6.0 * torch.eye(3)[None].repeat(B, 1, 1)
+    batch = _batch_obj(na, torch.rand(N, 3, generator=gen), cell, torch.randint(1, 101, (N,), generator=gen))
+    for tmax, key in ((1.0, "grid_t_Tmax1p0"), (0.8, "grid_t_Tmax0p8")):
+        m.T = tmax
+        for k, want in zip(g["grid_timesteps"], g[key]):
+            _, _, tt = m.add_noise(batch, int(k))
+            assert tt.is_cuda and tt.shape == (B,) and np.array_equal(tt.cpu().numpy(), np.full(B, want, dtype=np.float32)), (tmax, k)
+    # SampleLoss: weights and aggregation
+    assert [MG.WEIGHTS[k] for k in g["loss_fields"]] == list(g["loss_weights"]) and MG.D3PM_LAMBDA == float(g["loss_d3pm_hybrid_lambda"])
+    fields = dict(pos=t("loss_pos"), cell=t("loss_cell"), atomic_numbers=t("loss_types"))
+    assert torch.equal(MG.weighted_field_sum(fields).cpu(), torch.from_numpy(g["loss_agg"]))
+    assert torch.equal(MG.weighted_field_sum(fields, dict(zip(g["loss_fields"], g["loss_weights_custom"]))).cpu(), torch.from_numpy(g["loss_agg_custom"]))

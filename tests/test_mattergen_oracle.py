@@ -200,3 +200,31 @@ def test_scalar_heads_through_the_derived_radial_tensors_identity():
     Q = (w[:, None] * Wr).t()            # [Rb, Ed]
     got = (rbf * (x @ Q.t())).sum(1)
     assert torch.allclose(ref, got, rtol=1e-12, atol=1e-12)
+
+
+def test_adapter_arithmetic_against_the_reference_generated_fixture():
+    """g12_mattergen_adapter.npz was produced by the reference's OWN models/mattergen/pl_module.py and loss.py (imported in the build container through empty
+    class stand-ins for the un-vendored `mattergen` package, tests/golden/make_golden.py::g12_mattergen_adapter): the anchor penalty, add_noise's time grid and
+    SampleLoss's weighted stack-sum.  The network and the corruptions stay parity-unpinned; this pins what the reference itself computes around them."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_mattergen_adapter.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    na = t("kl_num_atoms")
+    n2g = torch.repeat_interleave(torch.arange(len(na)), na)
+    agent = dict(pos=t("kl_agent_pos"), cell=t("kl_agent_cell"), atomic_numbers=t("kl_agent_types"))
+    prior = dict(pos=t("kl_prior_pos"), cell=t("kl_prior_cell"), atomic_numbers=t("kl_prior_types"))
+    kl = M.calc_kl_reg(agent, prior, n2g, len(na))
+    assert torch.allclose(kl, t("kl_out"), rtol=2e-6, atol=0), (kl - t("kl_out")).abs().max()
+    # the time grid: the very float32 values the reference hands its corruption
+    for tmax, key in ((1.0, "grid_t_Tmax1p0"), (0.8, "grid_t_Tmax0p8")):
+        corr = M.Corruption(T=tmax)
+        got = np.array([M.time_grid(corr, int(k)) for k in g["grid_timesteps"]], dtype=np.float32)
+        assert np.array_equal(got, g[key]), (got, g[key])
+    # SampleLoss: field order, default weights, the hybrid-loss lambda, and the aggregation
+    assert list(g["loss_fields"]) == ["pos", "cell", "atomic_numbers"]
+    assert [M.WEIGHTS[k] for k in g["loss_fields"]] == list(g["loss_weights"]) and M.D3PM_LAMBDA == float(g["loss_d3pm_hybrid_lambda"])
+    fields = dict(pos=t("loss_pos"), cell=t("loss_cell"), atomic_numbers=t("loss_types"))
+    assert torch.equal(M.weighted_field_sum(fields), t("loss_agg"))
+    wc = dict(zip(g["loss_fields"], g["loss_weights_custom"]))
+    assert torch.equal(M.weighted_field_sum(fields, wc), t("loss_agg_custom"))
+    assert torch.allclose(torch.stack([v.mean() for v in fields.values()]), t("loss_metric_means"))
