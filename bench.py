@@ -247,6 +247,8 @@ def _apply_env_knobs(lib):
                     ("MI_EDGE_PAIRS", lib.mi_set_edge_pairs), ("MI_PLANES_DMA", lib.mi_debug_set_planes_dma), ("MI_PLANES_BIG_SEG", lib.mi_debug_set_planes_big_seg), ("MI_NODE_PRIORITY", lib.mi_debug_set_node_priority), ("MI_PLANES_LATENCY", lib.mi_debug_set_planes_latency), ("MI_NODE_FUSED", lib.mi_debug_set_node_fused), ("MI_NODE_TRAIN", lib.mi_debug_set_node_train), ("MI_NODE_SPLIT", lib.mi_debug_set_node_split), ("MI_NODE_COLS", lib.mi_debug_set_node_cols), ("MI_NODE_TOUCH", lib.mi_debug_set_node_touch), ("MI_HEADS_ROWS16", lib.mi_debug_set_heads_rows16), ("MI_EVAL_REUSE", lib.mi_debug_set_eval_reuse), ("MI_SKIP", lib.mi_debug_set_skip), ("MI_RT_LEAN", lib.mi_debug_set_rt_lean), ("MI_EDGE2_FUSED", lib.mi_debug_set_edge2_fused), ("MI_EDGE1_FUSED", lib.mi_debug_set_edge1_fused), ("MI_EDGE_FUSED", lib.mi_debug_set_edge_fused), ("MI_MG_NOSYNC", lib.mi_debug_set_mg_nosync)):
         if os.environ.get(env) is not None and os.environ[env] != "":
             fn(int(os.environ[env]))
+    if os.environ.get("MI_NODE_BWD", "") != "":   # the fused node-level backward chain of the fine-tune step: 1 (default) / 0 = seven launches per layer
+        lib.mi_debug_set_node_bwd(int(os.environ["MI_NODE_BWD"]), int(os.environ.get("MI_NODE_BWD_MIN_BLOCKS", "0")))
     if os.environ.get("MI_PLANES_RT", "") != "":   # register-tile form of the large plane products: 0 off, 1 those with epilogue extensions (default), 2 all
         lib.mi_debug_set_planes_rt(int(os.environ["MI_PLANES_RT"]), 0)
     if os.environ.get("MI_WGRAD_WINDOW", "") != "":   # micro-steps per node-level weight-gradient contraction of the fine-tune loop (0: off)

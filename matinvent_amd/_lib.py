@@ -82,6 +82,7 @@ SIGNATURES = {
     "mi_debug_node_chain_clock": (_I, [_P]),
     "mi_debug_set_edge2_fused": (_I, [_I]),
     "mi_debug_set_node_train": (_I, [_I]),
+    "mi_debug_set_node_bwd": (_I, [_I, _I]),
     "mi_debug_set_node_split": (_I, [_I]),
     "mi_debug_set_node_cols": (_I, [_I]),
     "mi_debug_set_node_touch": (_I, [_I]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmatinvent_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
-SOURCES = ["cspnet.hip", "node_chain.hip", "edge_stage.hip", "edge_fused.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
+SOURCES = ["cspnet.hip", "node_chain.hip", "node_bwd.hip", "edge_stage.hip", "edge_fused.hip", "sampler.hip", "backward.hip", "graph.hip", "gemnet.hip"]
 ARCH = ["--offload-arch=gfx950"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 # NO packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) in device code.  Measured on MI355X

@@ -379,6 +379,58 @@ __global__ void row_broadcast_add_kernel(const float* __restrict__ v, float* __r
     gW[(size_t)(idx / ncols) * ld + idx % ncols] += v[idx / ncols];
 }
 
+// gW[f][c] += sum_z P[z][f] for c < ncols: the column sums of part_reduce_kernel (same reduction order) broadcast over a row block straight away --
+// one launch instead of a memset, the reduction and row_broadcast_add_kernel.  32 columns f per block.
+__global__ __launch_bounds__(256) void part_reduce_bcast_kernel(const float* __restrict__ P, int nsplit, int ldp, float* __restrict__ gW, int ld, int H, int ncols) {
+    __shared__ float red[8][32];
+    __shared__ float tot[32];
+    const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, rg = threadIdx.x >> 5;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < H) {
+        int z = rg;
+        for (; z + 24 < nsplit; z += 32) {
+            s0 += P[(size_t)z * ldp + c];
+            s1 += P[(size_t)(z + 8) * ldp + c];
+            s2 += P[(size_t)(z + 16) * ldp + c];
+            s3 += P[(size_t)(z + 24) * ldp + c];
+        }
+        for (; z < nsplit; z += 8) s0 += P[(size_t)z * ldp + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0) tot[cl] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * ncols; idx += 256) {
+        const int f = blockIdx.x * 32 + idx / ncols;
+        if (f < H) gW[(size_t)f * ld + idx % ncols] += tot[idx / ncols];
+    }
+}
+
+// part_reduce_kernel over `gridDim.y` independent problems of one shape: problem y reads P + y * p_stride and adds into out + y * out_stride
+// (the LayerNorm weight / bias gradients of all layers in one launch: every layer's parameter block has the same size)
+__global__ __launch_bounds__(256) void part_reduce_batched_kernel(const float* __restrict__ P, size_t p_stride, int nsplit, int ldp, float* __restrict__ out,
+                                                                  size_t out_stride, int Nc) {
+    __shared__ float red[8][32];
+    P += (size_t)blockIdx.y * p_stride;
+    out += (size_t)blockIdx.y * out_stride;
+    const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, rg = threadIdx.x >> 5;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < Nc) {
+        int z = rg;
+        for (; z + 24 < nsplit; z += 32) {
+            s0 += P[(size_t)z * ldp + c];
+            s1 += P[(size_t)(z + 8) * ldp + c];
+            s2 += P[(size_t)(z + 16) * ldp + c];
+            s3 += P[(size_t)(z + 24) * ldp + c];
+        }
+        for (; z < nsplit; z += 8) s0 += P[(size_t)z * ldp + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < Nc)
+        out[c] += ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+}
+
 // general edge lists (knn branch): out-edges of i are its CSR row, in-edges are listed in `inedge` at the same offsets
 __global__ void edge_dpq_csr_kernel(const float* __restrict__ dZ1, const int* __restrict__ rowptr, const int* __restrict__ inedge,
                                     float* __restrict__ dPQ, int N, int H) {
@@ -711,6 +763,7 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
     T_(Ypre, L * N * H);
     T_(lnstat, (L + 1) * N * 2);
     T_(dsc_layers, L * 8);
+    T_(lnpart, L * (size_t)cdiv(N, 32) * 2 * H);
     T_(gf, B * H);
     T_(atom_types, N * MI_NUM_TYPES);
     T_(t_emb, B * TD);
@@ -833,7 +886,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     MI_CHECK(!defer || t.wcur < t.wslots, MI_ESTATE, "wgrad window overrun");
 
     // ---------------- heads ----------------
-    hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.lattices, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
+    hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.in_lat, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
     MI_KERNEL_CHECK();
     MI_TRY(gemm_tn_auto(t.dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
     hipLaunchKernelGGL(heads_bwd_kernel, g1(NH), dim3(256), 0, s, d_type, d_coord, t.dgf, net->p("type_out.weight"),
@@ -864,11 +917,33 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     const bool pairs = g_edge_pairs && !b->knn && H % 4 == 0;
     const int64_t Np = b->Np;
     if (pairs && Np > 0) {
-        hipLaunchKernelGGL(fourier_kernel, g1(Np * 3 * F), dim3(256), 0, s, t.frac, (const float*)nullptr, b->pair_i, b->pair_j, t.FF, Np, F);
+        hipLaunchKernelGGL(fourier_kernel, g1(Np * 3 * F), dim3(256), 0, s, t.in_frac, (const float*)nullptr, b->pair_i, b->pair_j, t.FF, Np, F);
         MI_KERNEL_CHECK();
     } else if (!pairs && E > 0) {
-        hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.frac, b->fd, b->src, b->dst, t.FF, E, F);
+        hipLaunchKernelGGL(fourier_kernel, g1(E * 3 * F), dim3(256), 0, s, t.in_frac, b->fd, b->src, b->dst, t.FF, E, F);
         MI_KERNEL_CHECK();
+    }
+
+    // The node-level part of the pass as ONE launch per layer boundary (node_bwd.hip): launch l runs what follows layer l's edge stage (the h_i / h_j
+    // projections' data gradient, the LayerNorm gradient into the residual stream) and what precedes layer l - 1's (its node MLP's data gradients).
+    const bool nb = net->cfg.ln && node_bwd_supported(net, b) && (size_t)cdiv(N, 32) * 2 * H <= scf;
+    // the chain's per-workgroup partial sums of d ln_w | d ln_b: every layer's in a slot of its own (Tape::lnpart) -- ONE reduction launch for all layers behind the loop
+    const size_t ln_slot = (size_t)cdiv(N, 32) * 2 * H;
+    const bool ln_batched = nb && L >= 2 && t.lnpart != nullptr;
+    float* const ln_tail = t.lnpart;
+    // (the operand rows of layer `layer`'s node-level weight gradients: slot t.wcur of the deferred window, or the tape's single buffers)
+    auto w_rows = [&](int layer, float** dYp, float** Xap, float** dXap) {
+        const size_t r = defer ? (size_t)layer * t.wslots * N + (size_t)t.wcur * N : 0;
+        *dYp = defer ? t.w_dY + r * H : t.dY;
+        *Xap = defer ? t.w_Xa + r * H : t.Xa;
+        *dXap = defer ? t.w_dXa + r * H : t.dXa;
+    };
+    if (nb) {
+        // one pair of absmax slots per layer {max |d cat|, max |dM1|}, cleared once per pass (the seven-launch form clears its single pair per layer)
+        MI_HIP(hipMemsetAsync(b->absmax + 2 * L + 2, 0, 2 * L * sizeof(unsigned), s));
+        float *dY1, *Xa1, *dXa1;
+        w_rows(L - 1, &dY1, &Xa1, &dXa1);
+        MI_TRY(node_bwd(net, b, L, nullptr, dY1, dXa1, Xa1, nullptr, b->absmax + 2 * L + 2 + 2 * (L - 1), s));
     }
 
     // ---------------- layers, last to first ----------------
@@ -881,11 +956,20 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         float* Xa = defer ? t.w_Xa + wr * H : t.Xa;
         float* dXa = defer ? t.w_dXa + wr * H : t.dXa;
         float* dPQ = defer ? t.w_dPQ + wr * 2 * H : t.dPQ;
+        unsigned* const am = nb ? b->absmax + 2 * L + 2 + 2 * l : b->absmax + 2 * L;   // this layer's {max |d cat|, max |dM1|}
         float* Z1 = t.Z1 + (size_t)l * E * H;
         float* Z2 = t.Z2 + (size_t)l * E * H;
         const float* Xpre = t.Xpre + (size_t)l * NH;
         const float* Ypre = t.Ypre + (size_t)l * NH;
         // node MLP (cspnet.py:80-82)
+        if (nb) {   // (dY, Xa, dXa of this layer and d cat were written by the chain launch above this layer's edge stage)
+            if (!defer) {
+                MI_TRY(gemm_tn_auto(dYl, H, Xa, H, G(p + "node_mlp.2.weight"), H, N, H, H, sc, scf, s));
+                MI_TRY(colsum_acc(dYl, H, G(p + "node_mlp.2.bias"), N, H, sc, scf, s));
+                MI_TRY(gemm_tn_auto(dXa, H, cat, 2 * H, G(p + "node_mlp.0.weight"), 2 * H, N, H, 2 * H, sc, scf, s));
+                MI_TRY(colsum_acc(dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
+            }
+        } else {
         hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, dYl, (int64_t)NH);
         hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, Xa, (int64_t)NH);
         MI_KERNEL_CHECK();
@@ -903,6 +987,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             MI_TRY(colsum_acc(dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
         }
         MI_TRY(gemm_nt(dXa, H, net->Wn1T + l * (size_t)2 * H * H, H, t.dcat, 2 * H, N, 2 * H, H, GemmEpilogue(), s, &b->sk));
+        }
         // edge stage (cspnet.py:59-79)
         bool edge_sums_done = false;  // dPQ and dG already produced by the fused pair-mode kernel
         if (E > 0) {
@@ -919,9 +1004,10 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             Planes dzp;
             if (dz2_planes) {
                 dzp = make_planes(b->M1pl, H, 1.f, b->dsc + 6);
-                MI_HIP(hipMemsetAsync(b->absmax + 2 * L, 0, 2 * sizeof(unsigned), s));
-                hipLaunchKernelGGL(absmax_bwd_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 1024))), dim3(256), 0, s, t.dcat, (int64_t)N * 2 * H,
-                                   b->absmax + 2 * L);
+                if (!nb) {   // (the fused chain raised max |d cat| in the epilogue of the product that wrote it; its slots were cleared once per pass)
+                    MI_HIP(hipMemsetAsync(am, 0, 2 * sizeof(unsigned), s));
+                    hipLaunchKernelGGL(absmax_bwd_kernel, dim3(std::min<int64_t>(256, cdiv((int64_t)N * 2 * H, 1024))), dim3(256), 0, s, t.dcat, (int64_t)N * 2 * H, am);
+                }
             }
             // (both consumers of dZ2 on its plane set -- the data gradient below and edge_mlp.2's weight gradient: its fp32 rows are dead)
             bool w2_planes = false;
@@ -931,7 +1017,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 #endif
             if (dz2_sums) {
                 hipLaunchKernelGGL(edge_dz2_colsum_kernel, dim3(1, nchunk), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, sc, E, H, crows, dzp,
-                                   b->absmax + 2 * L, b->dsc + 6, w2_planes ? 0 : 1);
+                                   am, b->dsc + 6, w2_planes ? 0 : 1);
                 hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, nchunk, H, G(p + "edge_mlp.2.bias"), H);
             } else {
                 hipLaunchKernelGGL(edge_dz2_kernel, g1(E * H), dim3(256), 0, s, t.dcat, b->src, b->rowptr, Z2, E, H);
@@ -956,7 +1042,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 PlanesEpilogue pd;
                 pd.C = t.dM1;
                 pd.ldc = H;
-                pd.absmax = b->absmax + 2 * L + 1;  // max |dM1|: bounds the pair-mode weight gradient's operands
+                pd.absmax = am + 1;  // max |dM1|: bounds the pair-mode weight gradient's operands
                 Planes w2t = make_planes(net->W2Tpl + (size_t)l * planes_elems(H, H), H);
                 if (net->W2Tf) w2t.frag = net->W2Tf + (size_t)l * frag_elems(H, H);   // (from 16384 edges up: the 128 x 256 register-tile kernel)
                 MI_TRY(gemm_planes(dzp, w2t, (int)E, H, H, pd, s));
@@ -973,7 +1059,9 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 float* gWff = G(p + "edge_mlp.0.weight") + 2 * H + 9;
                 float *Dm = t.M1, *Dp = t.M1 + (size_t)Np * H;
                 float* dsum = sc + scf - H;  // the tail of the scratch: the reductions below use its head
-                MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
+                // (the LDS-tile pair pass: its per-crystal partial sums of the self edges' dZ1 go into the cosine block in ONE launch -- no dsum, no memset)
+                const bool dsum_folded = fused_pairs && b->nmax_fc <= PAIRS_NMAX && g_bwd_pairs_tile;
+                if (!dsum_folded) MI_HIP(hipMemsetAsync(dsum, 0, H * sizeof(float), s));
                 const bool wff_f16 = dz2_planes && fused_pairs && g_bwd_wgrad_f16;  // two-plane fp16 operands for the Fourier-block weight gradient
                 bool wff_planes = false;   // ... and from plane sets: the pass below writes Dm / Dp as such, the Fourier operand is the forward's pair-mode plane set
 #if MI_PLANES_FP16
@@ -990,17 +1078,17 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 #if MI_PLANES_FP16
                     if (wff_planes)
                         hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
-                                           Dp, dPQ, t.dG, sc, H, b->absmax + 2 * L + 1, b->dsc + 8, dmp, dpp);
+                                           Dp, dPQ, t.dG, sc, H, am + 1, b->dsc + 8, dmp, dpp);
                     else
 #endif
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
-                                       Dp, dPQ, t.dG, sc, H, wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
-                    hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
+                                       Dp, dPQ, t.dG, sc, H, wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
+                    hipLaunchKernelGGL(part_reduce_bcast_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, sc, B, H, gWff + 3 * F, net->edge_in, H, 3 * F);
                     MI_KERNEL_CHECK();
                 } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
                                        Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, dPQ, t.dG, sc, H,
-                                       wff_f16 ? b->absmax + 2 * L + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
+                                       wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
                 } else {
@@ -1010,7 +1098,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                     }
                     MI_TRY(colsum_acc(t.dM1, H, dsum, N, H, sc, scf - H, s, b->e_diag));
                 }
-                hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
+                if (!dsum_folded) hipLaunchKernelGGL(row_broadcast_add_kernel, g1((int64_t)H * 3 * F), dim3(256), 0, s, dsum, gWff + 3 * F, net->edge_in, H, 3 * F);
                 MI_KERNEL_CHECK();
 #if MI_PLANES_FP16
                 if (Np > 0 && wff_planes) {
@@ -1037,12 +1125,21 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             MI_HIP(hipMemsetAsync(dPQ, 0, NH * 2 * 4, s));
         }
         if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dPQ, 2 * H, b->node_off, t.dG, B, H);
-        hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.lattices, G(p + "edge_mlp.0.weight"), net->edge_in,
+        hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.in_lat, G(p + "edge_mlp.0.weight"), net->edge_in,
                            G(p + "edge_mlp.0.bias"), B, H);
         MI_KERNEL_CHECK();
         if (!defer) {
             MI_TRY(gemm_tn_auto(dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
             MI_TRY(gemm_tn_auto(dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, N, H, H, sc, scf, s));
+        }
+        if (nb) {
+            // d hn = dcat[:, :H] + dPQ Whh, dh_l = dh_{l+1} + LN'(d hn) -- and the node MLP's data gradients of the layer below, in the same launch
+            float *dY1 = nullptr, *Xa1 = nullptr, *dXa1 = nullptr;
+            if (l > 0) w_rows(l - 1, &dY1, &Xa1, &dXa1);
+            MI_TRY(node_bwd(net, b, l, dPQ, dY1, dXa1, Xa1, ln_batched ? ln_tail + (size_t)l * ln_slot : sc, l > 0 ? b->absmax + 2 * L + 2 + 2 * (l - 1) : nullptr, s));
+            if (!ln_batched) hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(2 * H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, cdiv(N, 32), 2 * H, G(p + "layer_norm.weight"), 2 * H);
+            MI_KERNEL_CHECK();
+            continue;
         }
         // d hn = dcat[:, :H] + dPQ * Whh   -> dY (reuse)
         GemmEpilogue er;
@@ -1058,15 +1155,21 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         }
     }
 
+    if (ln_batched) {   // (every layer's parameter block has the same size: a constant stride between the layers' LayerNorm weights)
+        const size_t stride = net->off("csp_layer_1.layer_norm.weight") - net->off("csp_layer_0.layer_norm.weight");
+        hipLaunchKernelGGL(part_reduce_batched_kernel, dim3(cdiv(2 * H, 32), L), dim3(256), 0, s, ln_tail, ln_slot, cdiv(N, 32), 2 * H,
+                           G("csp_layer_0.layer_norm.weight"), stride, 2 * H);
+        MI_KERNEL_CHECK();
+    }
     // ---------------- embedding (cspnet.py:265-271) ----------------
     const int WA = H + TD;
     MI_TRY(gemm_tn_auto(t.dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
     hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dh, H, b->node_off, t.dtproj, B, H);
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_auto(t.dtproj, H, t.t_emb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dtproj, H, t.in_temb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
     MI_TRY(colsum_acc(t.dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
     MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
-    MI_TRY(gemm_tn_auto(t.dXa, H, t.atom_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
+    MI_TRY(gemm_tn_auto(t.dXa, H, t.in_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
     if (defer && ++t.wcur == t.wslots) MI_TRY(net_wgrad_flush(net, b, grad, s));
     return MI_OK;
@@ -1150,6 +1253,7 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
         MI_HIP(hipMalloc((void**)&n->WaT, (size_t)H * H * 4));
         if (MI_PLANES_FP16 && H % 32 == 0) MI_HIP(hipMalloc((void**)&n->W2Tpl, (size_t)L * planes_elems(H, H) * sizeof(u16)));
         if (MI_PLANES_FP16 && H % 256 == 0) MI_HIP(hipMalloc((void**)&n->W2Tf, (size_t)L * frag_elems(H, H) * sizeof(u16)));
+        if (MI_PLANES_FP16 && n->cfg.ln && (H == 128 || H == 256 || H == 512)) MI_HIP(hipMalloc((void**)&n->Wbw, (size_t)L * node_bwd_pack_elems(H) * sizeof(u16)));
     }
     for (int l = 0; l < L; ++l) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
@@ -1165,6 +1269,7 @@ int net_pack_transposes(mi_net* n, hipStream_t s) {
                            n->Wn1T + (size_t)l * 2 * H * H);
         hipLaunchKernelGGL(transpose_kernel, g1(2 * H * H), dim3(256), 0, s, n->Whh + l * n->whh_stride(), H, 2 * H, H,
                            n->WhhT + (size_t)l * 2 * H * H);
+        if (n->Wbw) MI_TRY(node_bwd_pack(n, l, n->p(p + "edge_mlp.0.weight"), n->p(p + "node_mlp.0.weight"), n->p(p + "node_mlp.2.weight"), s));
     }
     hipLaunchKernelGGL(transpose_kernel, g1(H * H), dim3(256), 0, s, n->p("atom_latent_emb.weight"), H + n->TD, H, H, n->WaT);
     MI_KERNEL_CHECK();
@@ -1389,10 +1494,16 @@ static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* p
         MI_HIP(hipStreamWaitEvent(s2, pb->ev_fork, 0));
         MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s2, false));
         MI_HIP(hipEventRecord(pb->ev_join, s2));
-        MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
+        tp.borrow_inputs = true;   // (the noised inputs live in this tape and the time embedding in this batch until the backward below has run)
+        const int rc = net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
+        tp.borrow_inputs = false;
+        MI_TRY(rc);
         MI_HIP(hipStreamWaitEvent(s, pb->ev_join, 0));
     } else {
-        MI_TRY(net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true));
+        tp.borrow_inputs = true;
+        const int rc = net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
+        tp.borrow_inputs = false;
+        MI_TRY(rc);
         MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
     }
     LossArgs la{ab->pred_l, ab->pred_x, ab->pred_t, pb->pred_l, pb->pred_x, pb->pred_t, tp.rnd_l, tp.tar_x, tp.rnd_t, reward, ab->node_off,

@@ -952,10 +952,15 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     if (b->knn) MI_TRY(knn_build(b, frac, lattices, s));  // cspnet.py:243-257: the edge list follows the coordinates
     if (train) {
         MI_CHECK(tp.allocated, MI_ESTATE, "training forward without tape");
-        MI_HIP(hipMemcpyAsync(tp.atom_types, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
-        MI_HIP(hipMemcpyAsync(tp.t_emb, t_emb, (size_t)B * TD * 4, hipMemcpyDeviceToDevice, s));
-        MI_HIP(hipMemcpyAsync(tp.lattices, lattices, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, s));
-        MI_HIP(hipMemcpyAsync(tp.frac, frac, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
+        if (tp.borrow_inputs) {   // (the fused micro-step's own arrays: see Tape::in_types)
+            tp.in_types = atom_types, tp.in_temb = t_emb, tp.in_lat = lattices, tp.in_frac = frac;
+        } else {
+            MI_HIP(hipMemcpyAsync(tp.atom_types, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
+            MI_HIP(hipMemcpyAsync(tp.t_emb, t_emb, (size_t)B * TD * 4, hipMemcpyDeviceToDevice, s));
+            MI_HIP(hipMemcpyAsync(tp.lattices, lattices, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, s));
+            MI_HIP(hipMemcpyAsync(tp.frac, frac, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
+            tp.in_types = tp.atom_types, tp.in_temb = tp.t_emb, tp.in_lat = tp.lattices, tp.in_frac = tp.frac;
+        }
     }
     // ---- embedding (cspnet.py:265-271) ----
     // (reuse_embedding: same t_emb and atom_types as this batch's previous evaluation -- the sampler's predictor evaluation
@@ -1407,6 +1412,7 @@ void mi_net_destroy(mi_net* n) {
     if (n->W2pl) (void)hipFree(n->W2pl);
     if (n->W2Tpl) (void)hipFree(n->W2Tpl);
     if (n->W2Tf) (void)hipFree(n->W2Tf);
+    if (n->Wbw) (void)hipFree(n->Wbw);
     if (n->Wlnpl) (void)hipFree(n->Wlnpl);
     if (n->Waggpl) (void)hipFree(n->Waggpl);
     if (n->Wn2pl) (void)hipFree(n->Wn2pl);
@@ -1659,7 +1665,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(aggpl, planes_elems(N, H));
     A_(Xpl, planes_elems(N, H));
     A_(dsc, 16);
-    A_(absmax, 2 * L + 2);
+    A_(absmax, 4 * L + 2);   // [0, 2L): the forward's per-layer slots; [2L, 2L + 2): the backward's (seven-launch form); [2L + 2, 4L + 2): one pair per layer (fused backward chain)
     A_(nc_flags, (size_t)(L + 1) * 2 * cdiv(N, 32));
     A_(X, NH);
     A_(x1, NH);
@@ -1686,7 +1692,7 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
         hipMemset(b->lnpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->aggpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
         hipMemset(b->Xpl, 0, planes_elems(N, H) * sizeof(unsigned short)) != hipSuccess ||
-        hipMemset(b->absmax, 0, (2 * L + 2) * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(b->absmax, 0, (4 * L + 2) * sizeof(unsigned)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {   // (the handle will be used on non-blocking side streams: its set-up on the null stream must have finished)
         mi_batch_destroy(b);
         set_error("hipMemset failed");

@@ -50,6 +50,7 @@ struct mi_net {
     float* Wn1T = nullptr;   // [L][2H][H]
     float* WhhT = nullptr;   // [L][H][2H]
     float* WaT = nullptr;    // [H][H]   (atom_latent_emb.weight[:, :H])^T
+    unsigned short* Wbw = nullptr;   // [L] fragment-order packs of the TRANSPOSED node-level weights [WhhA | WhhB | Wn2^T | Wn0^T]: the fused backward chain (node_bwd.hip)
     float* WheadT = nullptr; // [H][104] coord_out.weight (3 rows) and type_out.weight (100 rows) transposed side by side (inference heads)
     // profiling of the dominant kernel (event pairs; launches may come from several host threads / streams)
     bool prof = false;
@@ -70,11 +71,17 @@ struct Tape {
     bool allocated = false, valid = false;
     float *cat = nullptr, *Z1 = nullptr, *Z2 = nullptr, *Xpre = nullptr, *Ypre = nullptr, *lnstat = nullptr, *gf = nullptr;
     float *atom_types = nullptr, *t_emb = nullptr, *lattices = nullptr, *frac = nullptr;
+    // what the backward reads of the forward's INPUTS: the tape's copies above (mi_cspnet_forward_train: the caller may overwrite its arrays before the
+    // backward), or -- `borrow_inputs`, set by the fused micro-step around its own training forward -- the caller's arrays themselves (they are the
+    // tape's noised inputs and the batch's time embedding, alive until the micro-step's backward has run: four copy launches fewer per micro-step)
+    const float *in_types = nullptr, *in_temb = nullptr, *in_lat = nullptr, *in_frac = nullptr;
+    bool borrow_inputs = false;
     float *dh = nullptr, *dY = nullptr, *dXa = nullptr, *Xa = nullptr, *dcat = nullptr, *dPQ = nullptr, *dG = nullptr, *dgf = nullptr,
           *dlo = nullptr, *dtproj = nullptr, *M1 = nullptr, *dM1 = nullptr, *FF = nullptr, *scratch = nullptr;
     // fused fine-tune micro-step: noised inputs, targets, gradient seeds, per-crystal losses
     float *nz_lat = nullptr, *nz_frac = nullptr, *nz_types = nullptr, *tar_x = nullptr, *rnd_l = nullptr, *rnd_t = nullptr, *d_l = nullptr,
           *d_x = nullptr, *d_t = nullptr, *Lb = nullptr, *KLb = nullptr;
+    float* lnpart = nullptr;      // [L][ceil(N / 32)][2H] per-workgroup partial sums of d ln_w | d ln_b of the fused backward chain (node_bwd.hip), reduced for all layers at once
     float* dsc_layers = nullptr;  // [L][8] each layer's activation scales of the training forward (fp16 plane format, folded launch)
     // fp16 plane format: every layer's M1 plane set of the training forward, kept for edge_mlp.2's weight gradient (gemm_tn_planes, backward.hip:
     // the product reads both operands as the plane sets their producers wrote instead of re-splitting -- and re-evaluating SiLU on -- fp32 rows)
@@ -194,6 +201,12 @@ int net_wgrad_flush(mi_net* net, mi_batch* b, float* grad, hipStream_t s);   // 
 template <typename T>
 int dev_alloc(mi_batch* b, T** p, size_t n);
 int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node);
+// node_bwd.hip: the node-level BACKWARD chain between two edge stages of the backward pass as one launch per layer boundary
+extern int g_node_bwd, g_node_bwd_min_blocks;
+size_t node_bwd_pack_elems(int H);
+bool node_bwd_supported(const mi_net* net, const mi_batch* b);
+int node_bwd_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s);
+int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dY, float* dXa, float* Xa, float* lnpart, unsigned* dcat_absmax, hipStream_t s);
 // node_chain.hip: the node-level chain between two edge stages of an inference forward as one launch
 bool node_chain_supported(const mi_net* net);
 size_t node_chain_pack_elems(int H);

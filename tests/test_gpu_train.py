@@ -151,18 +151,75 @@ def test_gradients_vs_oracle_autograd_ragged(H):
     assert torch.allclose(m.decoder.theta.grad, 2 * g1, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("node_train,tn", [(1, 3), (0, 3), (1, 3 + 256)], ids=["node-chain-writes-the-tape", "seven-launch-node-level", "edge-weight-gradients-from-fp32-rows"])
+def _grad_case(H, L, F, na, seed, tol=2e-5):
+    """Parameter gradients of random upstream gradients on the three heads: the device's backward vs torch autograd through the oracle.  Returns the flat gradient."""
+    hp = O.CSPNetHParams(hidden_dim=H, num_layers=L, num_freqs=F)
+    P = O.init_params(hp, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 100)
+    for k in P:
+        if "layer_norm" in k:
+            P[k] = P[k] + 0.1 * torch.randn(P[k].shape, generator=gen)
+    m = make_module(H, L, F, 20, P)
+    na = torch.as_tensor(na)
+    B, N = len(na), int(na.sum())
+    n2g = torch.repeat_interleave(torch.arange(B), na)
+    t_emb = O.time_embedding(torch.randint(1, 20, (B,), generator=gen), 256)
+    at, fr = torch.randn(N, 100, generator=gen), torch.rand(N, 3, generator=gen)
+    lat = 4 * torch.eye(3) + torch.randn(B, 3, 3, generator=gen)
+    ul, ux, ut = torch.randn(B, 3, 3, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(N, 100, generator=gen)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ol, ox, ot = O.cspnet_forward(Pg, hp, t_emb, at, fr, lat, na, n2g)
+    ((ol * ul).sum() + (ox * ux).sum() + (ot * ut).sum()).backward()
+    pl, px, pt = m.decoder(t_emb.cuda(), at.cuda(), fr.cuda(), lat.cuda(), na)
+    ((pl * ul.cuda()).sum() + (px * ux.cuda()).sum() + (pt * ut.cuda()).sum()).backward()
+    th = m.decoder.theta
+    for k, (o, cnt, shape) in m.decoder.layout.items():
+        _rel(th.grad[o:o + cnt].view(shape), Pg["decoder." + k].grad, tol, f"grad {k}")
+    return th.grad.detach().clone(), m.decoder.layout
+
+
+@pytest.mark.parametrize("H,F", [(128, 16), (256, 16), (512, 32)], ids=["H128-four-waves", "H256", "H512-benchmark-width"])
+def test_node_level_backward_chain_vs_oracle_and_vs_the_seven_launch_form(H, F):
+    """The fused node-level backward chain (node_bwd.hip: one launch per layer boundary -- the h_i / h_j projections' data gradient, the LayerNorm gradient, the node
+    MLP's two data gradients, with per-tile fp16 plane scales) against torch autograd through the oracle, on a ragged batch whose atom count is NOT a multiple of the
+    32-row blocks (a partial last block, 1-atom crystals) and three layers (so a middle launch runs both phases); then the seven-launch form on the same case, and
+    the two against each other; and the fused form twice (bit-reproducible: a tile's scale comes from its own workgroup)."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    na = torch.randint(1, 21, (40,), generator=gen)
+    na[:3] = torch.tensor([1, 20, 1])
+    if int(na.sum()) % 32 == 0:
+        na[3] += 1
+    assert int(na.sum()) >= 256 and int(na.sum()) % 32 != 0
+    was = lib.mi_debug_set_node_bwd(1, 1)
+    try:
+        g_fused, layout = _grad_case(H, 3, F, na, seed=31)
+        g_again, _ = _grad_case(H, 3, F, na, seed=31)
+        assert torch.equal(g_fused, g_again)
+        lib.mi_debug_set_node_bwd(0, 0)
+        g_seven, _ = _grad_case(H, 3, F, na, seed=31)
+    finally:
+        lib.mi_debug_set_node_bwd(was, 8)
+    assert not torch.equal(g_fused, g_seven)    # (the two forms really are different code: three fp16 terms with tile scales vs six bf16 terms)
+    for k, (o, cnt, shape) in layout.items():
+        _rel(g_fused[o:o + cnt].cpu(), g_seven[o:o + cnt].cpu(), 1e-5, f"fused vs seven-launch, grad {k}")
+
+
+@pytest.mark.parametrize("node_train,tn", [(1, 3), (0, 3), (1, 3 + 256), (1, 3 + 4096)], ids=["node-chain-writes-the-tape", "seven-launch-node-level", "edge-weight-gradients-from-fp32-rows", "seven-launch-node-level-backward"])
 def test_gradients_vs_oracle_autograd_mid_size(node_train, tn):
     """The same check at a size where the large-problem kernels run in the training forward and the backward (B=96 x 20 atoms,
     E=38 400, H=512, L=2, F=128: pair-mode Fourier GEMM and its pair-mode weight gradient, 256-row double-buffered GEMM).  The node-level
     work between two edge stages runs as the one-launch chain that also writes the backward's tape (default) and as the seven-launch form."""
     from matinvent_amd import _lib
     was = _lib.load().mi_debug_set_node_train(node_train)
-    _lib.check(_lib.load().mi_debug_set_tn128(tn))   # (+256: edge_mlp.2's weight gradient from fp32 rows instead of the M1 / dZ2 plane sets)
+    nbw = _lib.load().mi_debug_set_node_bwd(0 if tn & 4096 else 1, 0)   # (+4096, this test's own flag: the node-level backward as seven launches per layer)
+    _lib.check(_lib.load().mi_debug_set_tn128(tn & 4095))   # (+256: edge_mlp.2's weight gradient from fp32 rows instead of the M1 / dZ2 plane sets)
     try:
         _mid_size_case()
     finally:
         _lib.load().mi_debug_set_node_train(was)
+        _lib.load().mi_debug_set_node_bwd(nbw, 0)
         _lib.check(_lib.load().mi_debug_set_tn128(3))
 
 
