@@ -309,6 +309,12 @@ int mi_net_set_edge_mode(mi_net* net, int mode);
 /* fc edge style on the plane-GEMM path: run the Fourier-block GEMM over unordered node pairs (default on).  The reversed edge's
  * features are (-sin, +cos) of the same arguments, so one operand row yields both directed edges; off = one row per edge. */
 int mi_set_edge_pairs(int on);
+/* How many crystal groups of one fine-tune set the caller runs CONCURRENTLY on separate streams (matinvent_amd/finetune.py: the data-parallel
+ * arithmetic of pipeline/mat_invent.py:150-177 inside one GPU; default 1).  The weight-gradient contractions split their row lists into enough
+ * workgroups to fill the chip; with n groups in flight each launch needs 1 / n of them, and every split it does not make saves a partial tile's
+ * write and re-read (measured at 256 crystals x 20 atoms on four groups: 21.1k -> 22.0k crystal-timesteps/s).  Results change by fp32
+ * summation order only.  Returns the previous value. */
+int mi_set_concurrent_groups(int n);
 
 /* Element format of the pre-split plane sets this library was built with: 2 = two fp16 planes with per-class power-of-two scales
  * (three MFMA terms per product; the default), 3 = three bf16 planes (six terms, no range limits; build with -DMI_PLANES_FP16=0). */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mi_structure_check_offsets": (_I, [_P, _I, _P, _P, _P, _P]),
     "mi_debug_spin": (_I, [C.c_longlong, _P]),
     "mi_set_edge_pairs": (_I, [_I]),
+    "mi_set_concurrent_groups": (_I, [_I]),
     "mi_plane_format": (_I, []),
     "mi_terms_per_product": (_I, []),
     "mi_debug_mfma_flops": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),

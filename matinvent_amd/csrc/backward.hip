@@ -380,7 +380,8 @@ __global__ void row_broadcast_add_kernel(const float* __restrict__ v, float* __r
 }
 
 // gW[f][c] += sum_z P[z][f] for c < ncols: the column sums of part_reduce_kernel (same reduction order) broadcast over a row block straight away --
-// one launch instead of a memset, the reduction and row_broadcast_add_kernel.  32 columns f per block.
+// one launch instead of a memset, the reduction and row_broadcast_add_kernel.  32 columns f per block; gridDim.y blocks share a row block's `ncols` target columns
+// (each repeats the small reduction -- nsplit x 32 floats from L2 -- and adds into its own column slice: 16 blocks alone took 27 us for 32 x 384 updates each).
 __global__ __launch_bounds__(256) void part_reduce_bcast_kernel(const float* __restrict__ P, int nsplit, int ldp, float* __restrict__ gW, int ld, int H, int ncols) {
     __shared__ float red[8][32];
     __shared__ float tot[32];
@@ -400,9 +401,10 @@ __global__ __launch_bounds__(256) void part_reduce_bcast_kernel(const float* __r
     __syncthreads();
     if (rg == 0) tot[cl] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * ncols; idx += 256) {
-        const int f = blockIdx.x * 32 + idx / ncols;
-        if (f < H) gW[(size_t)f * ld + idx % ncols] += tot[idx / ncols];
+    const int cper = (ncols + gridDim.y - 1) / gridDim.y, cbeg = blockIdx.y * cper, cw = min(ncols, cbeg + cper) - cbeg;   // this block's column slice
+    for (int idx = threadIdx.x; idx < 32 * cw; idx += 256) {
+        const int f = blockIdx.x * 32 + idx / cw;
+        if (f < H) gW[(size_t)f * ld + cbeg + idx % cw] += tot[idx / cw];
     }
 }
 
@@ -736,7 +738,7 @@ static int gemm_tn_planes(const Planes& A, int a_col0, const Planes& X, int x_co
     MI_HIP(attr_err);
     const int gy = Na / 256, gx = Kx / 128;
     count_mfma(M, Na, Kx, MI_PLANES_TERMS);
-    int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles * 2 / 3, gx * gy)));   // (one workgroup per CU: two rounds of the chip)
+    int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(tn_target_tiles() * 2 / 3, gx * gy)));   // (one workgroup per CU: two rounds of the chip -- of this launch's share of it)
     while (nsplit > 1 && (size_t)nsplit * Na * Kx > scratch_floats) --nsplit;
     MI_CHECK((size_t)nsplit * Na * Kx <= scratch_floats, MI_ENOMEM, "gemm_tn_planes scratch too small");
     const int rows = cdiv(cdiv(M, nsplit), 32) * 32;
@@ -1083,7 +1085,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 #endif
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
                                        Dp, dPQ, t.dG, sc, H, wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
-                    hipLaunchKernelGGL(part_reduce_bcast_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, sc, B, H, gWff + 3 * F, net->edge_in, H, 3 * F);
+                    hipLaunchKernelGGL(part_reduce_bcast_kernel, dim3(cdiv(H, 32), 12), dim3(256), 0, s, sc, B, H, gWff + 3 * F, net->edge_in, H, 3 * F);
                     MI_KERNEL_CHECK();
                 } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,

@@ -39,6 +39,7 @@ int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles 
 extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile, g_bwd_wgrad_planes;
 int g_tn128 = 1;
 int g_tn_target_tiles = 768;      // three workgroups per CU for a contraction that has the chip to itself
+int g_concurrent_groups = 1;      // crystal groups the caller fine-tunes concurrently (mi_set_concurrent_groups): a contraction's share of the chip is 1 / this
 int g_tn_split = 1;
 int g_tn_split_min_rows = 4096;  // (at 5120 rows: 43 -> 39 us for 512 x 512, 71 -> 56 us for 512 x 1024; no gain below)
 int g_edge_pairs = 1;  // first edge GEMM over unordered pairs (fc edge style, plane-GEMM edge stage)
@@ -1896,6 +1897,12 @@ int mi_debug_set_heads_rows16(int min_nodes) {
 int mi_debug_set_pair_wide(int on) {
     const int was = g_pair_wide_force;
     g_pair_wide_force = on != 0;
+    return was;
+}
+
+int mi_set_concurrent_groups(int n) {
+    const int was = g_concurrent_groups;
+    g_concurrent_groups = n < 1 ? 1 : (n > 16 ? 16 : n);
     return was;
 }
 

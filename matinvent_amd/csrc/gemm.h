@@ -403,6 +403,9 @@ void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, in
 void tn_reduce(const float* P, int nsplit, int PN, int PK, float* C, int ldc, int Na, int Kx, hipStream_t s);
 #endif
 extern int g_tn_target_tiles;  // workgroups a long weight-gradient contraction is split into (over its row list); the partial tiles are summed by tn_reduce
+extern int g_concurrent_groups;
+// ... when it has the chip to itself; with n crystal groups fine-tuned concurrently (mi_set_concurrent_groups) a launch's share is 1 / n of that
+static inline int tn_target_tiles() { return std::max(64, g_tn_target_tiles / std::max(1, g_concurrent_groups)); }
 
 // C[Na,Kx] (ldc) += A^T X.  `scratch` must hold nsplit * ceil64(Na) * ceil64(Kx) floats.
 #ifdef MI_GEMM_OWNER   // (defined once, in the owning translation unit: every unit that defined it also carried its kernels)
@@ -412,7 +415,7 @@ int gemm_tn_acc(const float* A, int lda, const float* X, int ldx, float* C, int 
     count_mfma(M, Na, Kx, 0);   // (gemm_tn_kernel / gemm_tn128_kernel: f32-input MFMA)
     if (g_tn128 && Na >= 128 && Kx >= 128 && M >= 8192) {  // the edge / pair-list contractions
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
-        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles, gx * gy)));
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(tn_target_tiles(), gx * gy)));
         while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
         MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;

@@ -2236,7 +2236,7 @@ int gemm_tn_auto(const float* A, int lda, const float* X, int ldx, float* C, int
                         size_t scratch_floats, hipStream_t s, bool x_silu = false, const float* sa = nullptr, const float* sx = nullptr) {
     if (gemm_tn_is_split(A, lda, X, ldx, M, Na, Kx)) {
         const int gy = cdiv(Na, 128), gx = cdiv(Kx, 128);
-        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(g_tn_target_tiles, gx * gy)));
+        int nsplit = std::max(1, std::min(cdiv(M, 256), cdiv(tn_target_tiles(), gx * gy)));
         while (nsplit > 1 && (size_t)nsplit * gy * 128 * gx * 128 > scratch_floats) --nsplit;
         MI_CHECK((size_t)nsplit * gy * 128 * gx * 128 <= scratch_floats, MI_ENOMEM, "gemm_tn scratch too small");
         const int rows = cdiv(cdiv(M, nsplit), 32) * 32;

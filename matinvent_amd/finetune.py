@@ -426,11 +426,13 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
         for st in streams:
             st.wait_event(ready)
 
+    was_groups = _lib.load().mi_set_concurrent_groups(groups)   # (each group's weight-gradient contractions take their share of the chip, not all of it)
     try:
         return _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma,
                                        device, noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats)
     finally:
         import sys
+        _lib.load().mi_set_concurrent_groups(was_groups)
         failing = sys.exc_info()[0] is not None
         try:   # (nothing pending unless an exception cut a window short -- and then its own error must not replace that exception)
             flush_wgrads()
