@@ -101,6 +101,12 @@ int mi_batch_create_knn(const mi_net* net, const int* num_atoms_host, int B, int
                         int max_neighbors, int edge_cap_per_node, mi_batch** out);
 /* Build the list for the given coordinates without running the network (one host synchronisation); *num_edges = E''. */
 int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* stream, int64_t* num_edges);
+/* The reverse sampler (mi_sampler_run) rebuilds a knn batch's list in every evaluation WITHOUT a host round trip: its launches are sized for the capacity
+ * and read the edge count on the device (the reference pays a host synchronisation per evaluation, models/diffcsp/cspnet.py:243-257 -> utils.py:335-514:
+ * nonzero / masked_select).  A list over capacity cannot raise in the middle of an enqueued chain; it sets a sticky flag instead and contributes no edges.
+ * This call synchronises `stream`, returns MI_ECAPACITY (and clears the flag) if any build since the last call exceeded the capacity, MI_OK otherwise.
+ * matinvent_amd.diffcsp asks it wherever a chain's results are about to be read. */
+int mi_knn_graph_status(mi_batch* b, void* stream);
 /* Copy out the current list: edges [2][E''] int32 (row 0 = aggregation/source node, row 1 = neighbour) and
  * edge_vec [E''][3] (the `frac_diff` CSPNet.forward consumes).  MI_EDGE_ORDER_REFERENCE reproduces gen_edges' order
  * bit for bit; MI_EDGE_ORDER_CSR is the source-sorted order the kernels iterate in.  Either pointer may be NULL. */

@@ -98,6 +98,9 @@ int mi_debug_set_node_train(int on);
  * `min_blocks` 32-row blocks (<= 0: keep the current threshold), 0 = the seven-launch form (three fp32-operand products, three streaming
  * passes and the LayerNorm gradient per layer).  Both are fp32-class; the gradient tests run both.  Returns the previous setting. */
 int mi_debug_set_node_bwd(int on, int min_blocks);
+/* knn edge style inside mi_sampler_run: 1 (default) = every evaluation rebuilds the list without a host round trip (consumers sized by capacity, edge
+ * count read on the device), 0 = the synchronising build of rounds 1-5.  Same results bit for bit; the tests run both.  Returns the previous setting. */
+int mi_debug_set_knn_nosync(int on);
 /* The same chain as TWO launches for small and medium batches (at most 85 row blocks of 32 atoms per chain): phase A, then LayerNorm + the
  * three projection passes on three workgroups per row block -- the chain is bound by the weight planes a workgroup streams through its CU's
  * L2 port, and the passes are independent given LayerNorm(h') (models/diffcsp/cspnet.py:87-88,61).  1 (default) = on, 0 = one launch.

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mi_debug_spin": (_I, [C.c_longlong, _P]),
     "mi_set_edge_pairs": (_I, [_I]),
     "mi_set_concurrent_groups": (_I, [_I]),
+    "mi_knn_graph_status": (_I, [_P, _P]),
     "mi_plane_format": (_I, []),
     "mi_terms_per_product": (_I, []),
     "mi_debug_mfma_flops": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "mi_debug_set_edge2_fused": (_I, [_I]),
     "mi_debug_set_node_train": (_I, [_I]),
     "mi_debug_set_node_bwd": (_I, [_I, _I]),
+    "mi_debug_set_knn_nosync": (_I, [_I]),
     "mi_debug_set_node_split": (_I, [_I]),
     "mi_debug_set_node_cols": (_I, [_I]),
     "mi_debug_set_node_touch": (_I, [_I]),

@@ -117,6 +117,7 @@ class CSPNet(nn.Module):
         # `cutoff` is accepted and, as in the reference, has no effect: radius_graph_pbc overwrites it with the smallest
         # inter-plane spacing + 0.01 (utils.py:463-471)
         self.edge_style, self.cutoff, self.max_neighbors = edge_style, cutoff, max_neighbors
+        self.edge_cap_per_node = 48   # knn edge style: kept neighbours per centre atom the batch handles are sized for (exceeding it is an error, never a truncation)
         self.hidden_dim, self.latent_dim, self.num_layers, self.num_freqs, self.ln = hidden_dim, latent_dim, num_layers, num_freqs, ln
         lib = _lib.load()
         self._lib = lib
@@ -209,7 +210,8 @@ class CSPNet(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     def make_batch(self, num_atoms, node_offset=0, graph_offset=0) -> CrystalBatch:
-        return CrystalBatch(self, num_atoms, node_offset, graph_offset, edge_style=self.edge_style, max_neighbors=self.max_neighbors)
+        return CrystalBatch(self, num_atoms, node_offset, graph_offset, edge_style=self.edge_style, max_neighbors=self.max_neighbors,
+                            edge_cap_per_node=self.edge_cap_per_node)
 
     def forward(self, t, atom_types, frac_coords, lattices, num_atoms, node2graph=None, batch: CrystalBatch = None):
         """Same positional signature as the reference CSPNet.forward (cspnet.py:260); `batch`

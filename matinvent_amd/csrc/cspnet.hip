@@ -38,6 +38,7 @@ int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per 
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
 extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile, g_bwd_wgrad_planes;
 int g_tn128 = 1;
+int g_knn_nosync = 1;             // knn edge style inside the sampler's chain: the per-evaluation graph build without a host round trip (0: synchronising, as rounds 1-5)
 int g_tn_target_tiles = 768;      // three workgroups per CU for a contraction that has the chip to itself
 int g_concurrent_groups = 1;      // crystal groups the caller fine-tunes concurrently (mi_set_concurrent_groups): a contraction's share of the chip is 1 / this
 int g_tn_split = 1;
@@ -184,7 +185,8 @@ __global__ void fourier_kernel(const float* __restrict__ frac, const float* __re
 // sine and cosine of an argument are produced together and stored to column ck and column 3F + ck.  Pad columns (>= 6F)
 // and pad rows (>= E) are written as zero.  Needs 3F even (F even); the per-column kernel below covers odd F.
 __global__ void fourier_planes_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
-                                      const int* __restrict__ dst, Planes FF, int64_t E, int F) {
+                                      const int* __restrict__ dst, Planes FF, int64_t E, int F, const int* __restrict__ e_dev = nullptr) {
+    if (e_dev) E = min(E, (int64_t)*e_dev);   // (the launch is sized for a capacity: the list's length lives on the device, knn_build nosync)
     const int F3 = 3 * F, np = F3 / 2, npad = (FF.KT * 32 - 2 * F3) / 2, per_row = np + npad;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rows_pad = (E + 127) / 128 * 128;
@@ -218,7 +220,8 @@ __global__ void fourier_planes_kernel(const float* __restrict__ frac, const floa
 
 // per-column-pair form (any F)
 __global__ void fourier_planes_cols_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
-                                           const int* __restrict__ dst, Planes FF, int64_t E, int F) {
+                                           const int* __restrict__ dst, Planes FF, int64_t E, int F, const int* __restrict__ e_dev = nullptr) {
+    if (e_dev) E = min(E, (int64_t)*e_dev);
     const int cp = FF.KT * 16;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rows_pad = (E + 127) / 128 * 128;
@@ -950,7 +953,9 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     const size_t NH = (size_t)N * H;
     Tape& tp = b->tape;
     tp.valid = false;  // this forward overwrites h / hf / x1, which a pending backward would read
-    if (b->knn) MI_TRY(knn_build(b, frac, lattices, s));  // cspnet.py:243-257: the edge list follows the coordinates
+    // cspnet.py:243-257: the edge list follows the coordinates.  Inside the sampler's chain (mi_batch::knn_nosync) on the plane-GEMM path the build does not
+    // synchronise: b->E is then the capacity, b->e_dev the device-side edge count every consumer below takes its row count from
+    if (b->knn) MI_TRY(knn_build(b, frac, lattices, s, b->knn_nosync && !train && g_knn_nosync && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0));
     if (train) {
         MI_CHECK(tp.allocated, MI_ESTATE, "training forward without tape");
         if (tp.borrow_inputs) {   // (the fused micro-step's own arrays: see Tape::in_types)
@@ -1019,10 +1024,10 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const int64_t rows_pad = (b->E + 127) / 128 * 128;
         if (net->F % 2 == 0) {
             const int64_t nthr = rows_pad * (int64_t)(ffp.KT * 16 - 3 * net->F / 2);
-            hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
+            hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F, b->e_dev);
         } else {
             const int64_t nthr = rows_pad * (int64_t)ffp.KT * 16;
-            hipLaunchKernelGGL(fourier_planes_cols_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F);
+            hipLaunchKernelGGL(fourier_planes_cols_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F, b->e_dev);
         }
         MI_KERNEL_CHECK();
     } else if (b->E > 0) {
@@ -1162,6 +1167,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 PlanesEpilogue pe1;
                 pe1.ep = g1e;
                 pe1.Cp = m1p;
+                pe1.m_dev = b->e_dev;   // (knn lists built without a host round trip: E is the capacity)
                 if (g_edge_pairs && !b->knn && H % 8 == 0) {  // (the pair epilogue moves 8 columns per lane)
                     // symmetric edge list: sin(2 pi k (1 - d)) = -sin(2 pi k d), cos unchanged, so one operand row per unordered
                     // pair yields both directed edges (half the MFMA work of this GEMM); self edges (d = 0) are a constant
@@ -1223,6 +1229,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_src = b->src;
                 pe2.seg_rowptr = b->rowptr;
                 pe2.seg_nodes = N;
+                pe2.m_dev = b->e_dev;
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
                 b->seg_shift = 5;
                 }
@@ -1897,6 +1904,12 @@ int mi_debug_set_heads_rows16(int min_nodes) {
 int mi_debug_set_pair_wide(int on) {
     const int was = g_pair_wide_force;
     g_pair_wide_force = on != 0;
+    return was;
+}
+
+int mi_debug_set_knn_nosync(int on) {
+    const int was = g_knn_nosync;
+    g_knn_nosync = on != 0;
     return was;
 }
 

@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
     }
 }
 
-// eoff[b] = 2 * sum_{b' < b} mcount[b'];  rowptr = exclusive scan of deg;  meta = {E, max degree, overflow flag}
+// eoff[b] = 2 * sum_{b' < b} mcount[b'];  rowptr = exclusive scan of deg;  meta = {E, max degree, overflow flag, STICKY capacity flag}
+// meta[3] is never cleared by a build: a chain of forwards that rebuilds the list without a host round trip (knn_build nosync) leaves the verdict there, and
+// mi_knn_graph_status reads it once behind the chain.  A build over capacity publishes E = 0, so that the consumers sized by capacity touch nothing.
 __global__ __launch_bounds__(1024) void knn_scan_kernel(const int* __restrict__ mcount, const int* __restrict__ deg, int B, int N,
-                                                         int* __restrict__ eoff, int* __restrict__ rowptr, int* __restrict__ meta) {
+                                                         int* __restrict__ eoff, int* __restrict__ rowptr, int* __restrict__ meta, int64_t E_cap, int deg_cap) {
     __shared__ int part[1024];
     __shared__ int pmax[1024];
     const int tid = threadIdx.x;
@@ -192,7 +194,20 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const int* __restrict__ 
     };
     scan(mcount, B, 2, eoff, false);
     scan(deg, N, 1, rowptr, true);
-    if (tid == 0) meta[0] = rowptr[N];
+    if (tid == 0) {
+        const int E = rowptr[N];
+        const bool over = meta[2] != 0 || (int64_t)E > E_cap || meta[1] > deg_cap;
+        meta[0] = E;
+        if (over) {
+            meta[3] = 1;
+            meta[4] = E;          // (what the host reports; the edge count the consumers see is zeroed below, after the emit kernel's own test)
+            meta[5] = meta[1];
+        }
+    }
+}
+// behind the emit kernel of a build without a host round trip: a list over capacity was not emitted -- its consumers (sized by capacity, row count from meta[0]) get none
+__global__ void knn_publish_kernel(int* __restrict__ meta, int64_t E_cap, int deg_cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (meta[2] != 0 || (int64_t)meta[0] > E_cap || meta[1] > deg_cap)) meta[0] = 0;
 }
 
 __global__ __launch_bounds__(256) void knn_emit_kernel(const float* __restrict__ frac, const int* __restrict__ node_off,
@@ -345,7 +360,7 @@ int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node) {
     A_(kn_deg, N);
     A_(kn_mcount, B);
     A_(kn_eoff, B + 1);
-    A_(kn_meta, 4);
+    A_(kn_meta, 8);
     A_(kn_refpos, EC);
     A_(r_src, EC);
     A_(r_dst, EC);
@@ -358,26 +373,38 @@ int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node) {
 
 // Rebuild the edge list of a knn batch from the current coordinates.  One host synchronisation (the edge count
 // sizes every later launch).
-int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s) {
+int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s, bool nosync) {
     MI_CHECK(b->knn, MI_ESTATE, "batch was not created with the knn edge style");
     b->E = 0;
+    b->e_dev = nullptr;
     if (b->N == 0 || b->B == 0) return MI_OK;
-    MI_HIP(hipMemsetAsync(b->kn_meta, 0, 4 * sizeof(int), s));
+    MI_HIP(hipMemsetAsync(b->kn_meta, 0, 3 * sizeof(int), s));   // (meta[3..5]: the sticky capacity verdict of a chain of builds, cleared by mi_knn_graph_status)
     hipLaunchKernelGGL(knn_select_kernel, dim3(b->B), dim3(256), select_lds(b->nmax), s, frac, lattices, b->node_off, b->max_neighbors,
                        b->cap_per_node, b->nmax, b->kn_ent, b->kn_acnt, b->kn_deg, b->kn_mcount, b->kn_meta);
-    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, s, b->kn_mcount, b->kn_deg, b->B, b->N, b->kn_eoff, b->rowptr, b->kn_meta);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, s, b->kn_mcount, b->kn_deg, b->B, b->N, b->kn_eoff, b->rowptr, b->kn_meta, b->E_cap, b->deg_cap);
     hipLaunchKernelGGL(knn_emit_kernel, dim3(b->B), dim3(256), emit_lds(b->nmax, b->cap_per_node), s, frac, b->node_off, b->kn_ent, b->kn_acnt,
                        b->kn_eoff, b->rowptr, b->cap_per_node, b->nmax, b->E_cap, b->r_src, b->r_dst, b->r_vec, b->src, b->dst, b->fd,
                        b->edge_graph, b->kn_refpos, b->inedge, b->kn_meta);
     MI_KERNEL_CHECK();
+    ++b->graph_epoch;   // (tables derived from the edge list -- edge_stage.hip's per-tile tables -- are rebuilt at their next use)
+    if (nosync) {
+        // No host round trip: the consumers are launched for the CAPACITY and take the row count from meta[0] on the device (PlanesEpilogue::m_dev, the
+        // Fourier operand's e_dev); tiles past the count exit at once.  A list over capacity sets the sticky flag meta[3] and publishes zero edges; the
+        // caller of the chain asks mi_knn_graph_status once behind it (the error is the same MI_ECAPACITY, raised later instead of never).
+        hipLaunchKernelGGL(knn_publish_kernel, dim3(1), dim3(64), 0, s, b->kn_meta, b->E_cap, b->deg_cap);
+        MI_KERNEL_CHECK();
+        b->E = b->E_cap;
+        b->e_dev = b->kn_meta;
+        return MI_OK;
+    }
     int meta[4];
     MI_HIP(hipMemcpyAsync(meta, b->kn_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
+    if (meta[3] != 0) MI_HIP(hipMemsetAsync(b->kn_meta + 3, 0, 3 * sizeof(int), s));   // (this build reports for itself, right here)
     MI_CHECK(meta[2] == 0 && meta[0] <= b->E_cap && meta[1] <= b->deg_cap, MI_ECAPACITY,
              "knn graph exceeds its capacity (edges %d of %lld, max degree %d of %d): raise edge_cap_per_node", meta[0], (long long)b->E_cap,
              meta[1], b->deg_cap);
     b->E = meta[0];
-    ++b->graph_epoch;   // (tables derived from the edge list -- edge_stage.hip's per-tile tables -- are rebuilt at their next use)
     return MI_OK;
 }
 
@@ -391,6 +418,22 @@ int mi_knn_graph(mi_batch* b, const float* frac, const float* lattices, void* st
     MI_CHECK(b && frac && lattices, MI_EINVAL, "null argument");
     MI_TRY(knn_build(b, frac, lattices, (hipStream_t)stream));
     if (num_edges) *num_edges = b->E;
+    return MI_OK;
+}
+
+int mi_knn_graph_status(mi_batch* b, void* stream) {
+    MI_CHECK(b && b->knn, MI_ESTATE, "batch was not created with the knn edge style");
+    if (b->N == 0 || b->B == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int meta[8];
+    MI_HIP(hipMemcpyAsync(meta, b->kn_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (meta[3] != 0) {
+        MI_HIP(hipMemsetAsync(b->kn_meta + 3, 0, 3 * sizeof(int), s));
+        mi::set_error("a knn graph built inside the chain exceeded its capacity (edges %d of %lld, max degree %d of %d): the chain's results are invalid; raise edge_cap_per_node",
+                      meta[4], (long long)b->E_cap, meta[5], b->deg_cap);
+        return MI_ECAPACITY;
+    }
     return MI_OK;
 }
 

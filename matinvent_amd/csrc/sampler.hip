@@ -286,6 +286,11 @@ int mi_sampler_run(mi_net* net, mi_batch* b, const float* coef_host, int T, int 
         if (rec->frac_coords)
             hipLaunchKernelGGL(wrap_copy_kernel, dim3(cdiv(n3, 256)), dim3(256), 0, s, frac, rec->frac_coords + t_start * n3, (int64_t)n3);
     }
+    struct NoSyncScope {   // the chain's graph builds (knn edge style) do not synchronise: see mi_knn_graph_status
+        mi_batch* b;
+        explicit NoSyncScope(mi_batch* b_) : b(b_) { b->knn_nosync = true; }
+        ~NoSyncScope() { b->knn_nosync = false; }
+    } nosync_scope(b);
     for (int t = t_start; t > t_stop; --t) {
         TraceRange range("mi_sampler_step");
         hipLaunchKernelGGL(time_embedding_kernel, dim3(cdiv((int64_t)B * net->TD, 256)), dim3(256), 0, s, (const int*)nullptr, time_freqs, b->temb, B,

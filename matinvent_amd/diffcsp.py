@@ -207,6 +207,8 @@ class DiffCSPModule(nn.Module):
         samples are the same as those of the unsplit batch): the node-level kernels and the partial last round of one
         group's edge GEMMs overlap the other groups' edge GEMMs.  None = automatic (2-4 for large batches).
         """
+        if self.__dict__.get("_knn_pending"):
+            self.check_graph()   # (the verdict of the previous call's chains: by now they have long finished)
         if isinstance(batch, CrystalBatch):
             return self._sample_one(batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset)
         if (self.keep_lattice or self.keep_coords) and init is None:
@@ -300,6 +302,15 @@ class DiffCSPModule(nn.Module):
         traj = {t: (final_state() if t == t_stop else merge([o[1][t] for o in out])) for t in out[0][1]}
         return traj[t_stop], traj
 
+    def check_graph(self):
+        """knn edge style: wait for the chains enqueued by `sample` and raise (MI_ECAPACITY, as a RuntimeError) if a neighbour list built inside one of them
+        exceeded its capacity -- the results of that chain are invalid.  Called by `sample` for the chains of EARLIER calls, by DiffCSPSampler.generate before
+        it unpacks a batch, and by any caller about to read a chain's results.  A no-op for the fc edge style."""
+        pending, self.__dict__["_knn_pending"] = self.__dict__.get("_knn_pending", []), []
+        lib = _lib.load()
+        for cb, stream in pending:
+            _lib.check(lib.mi_knn_graph_status(cb._h, C.c_void_p(stream.cuda_stream)), "mi_knn_graph_status")
+
     def _sample_one(self, batch, step_lr, seed, noise, init, record, t_start, t_stop, node_offset, graph_offset, inplace=None, drawn=False):
         """One chain over one CrystalBatch on the current stream.
 
@@ -347,6 +358,10 @@ class DiffCSPModule(nn.Module):
                                       _ptr(self.time_embedding.freqs), seed, C.byref(nz) if nz is not None else None,
                                       C.byref(rec) if rec is not None else None, _ptr(a), _ptr(x), _ptr(l), _stream()),
                    "mi_sampler_run")
+        if cb.edge_style == "knn":
+            # the chain rebuilt its periodic neighbour list in every evaluation WITHOUT a host round trip (the reference synchronises per evaluation:
+            # cspnet.py:243-257); a list over capacity could not raise inside the enqueued chain -- its verdict waits on the batch handle for check_graph()
+            self.__dict__.setdefault("_knn_pending", []).append((cb, torch.cuda.current_stream()))
         final = dict(atom_types=a, frac_coords=x, lattices=l, num_atoms=cb.num_atoms, batch_idx=cb.batch)
         traj = {t_stop: final}
         if record:

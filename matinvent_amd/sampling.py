@@ -69,6 +69,8 @@ class DiffCSPSampler:
             counts = _AtomCounts(na[lo:hi])
             outputs, _ = model.sample(counts, step_lr=step_lr, seed=self.seed, node_offset=node_off, graph_offset=lo)
         from . import _lib
+        if hasattr(model, "check_graph"):
+            model.check_graph()   # (knn edge style: the chains' neighbour lists stayed inside their capacity -- the device is about to be drained anyway)
         _lib.check_saturation("DiffCSPSampler.generate")  # (the results are about to be copied to the host: the device is drained anyway)
         # geometric validity quantities of the final state, computed where it lives (K18); the filter step thresholds them
         from .structure import check_structures
