@@ -99,7 +99,9 @@ int mi_debug_set_node_train(int on);
  * passes and the LayerNorm gradient per layer).  Both are fp32-class; the gradient tests run both.  Returns the previous setting. */
 int mi_debug_set_node_bwd(int on, int min_blocks);
 /* knn edge style inside mi_sampler_run: 1 (default) = every evaluation rebuilds the list without a host round trip (consumers sized by capacity, edge
- * count read on the device), 0 = the synchronising build of rounds 1-5.  Same results bit for bit; the tests run both.  Returns the previous setting. */
+ * count read on the device; the FIRST build of a batch handle still synchronises once, so that the host knows the list's size when it picks kernel forms),
+ * 0 = the synchronising build of rounds 1-5, 2 = no synchronisation at all (forms picked for the capacity; the tests use it to reach the deferred capacity
+ * report).  Same results bit for bit; the tests run all three.  Returns the previous setting. */
 int mi_debug_set_knn_nosync(int on);
 /* The same chain as TWO launches for small and medium batches (at most 85 row blocks of 32 atoms per chain): phase A, then LayerNorm + the
  * three projection passes on three workgroups per row block -- the chain is bound by the weight planes a workgroup streams through its CU's

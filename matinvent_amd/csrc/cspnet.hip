@@ -186,36 +186,38 @@ __global__ void fourier_kernel(const float* __restrict__ frac, const float* __re
 // and pad rows (>= E) are written as zero.  Needs 3F even (F even); the per-column kernel below covers odd F.
 __global__ void fourier_planes_kernel(const float* __restrict__ frac, const float* __restrict__ fd, const int* __restrict__ src,
                                       const int* __restrict__ dst, Planes FF, int64_t E, int F, const int* __restrict__ e_dev = nullptr) {
-    if (e_dev) E = min(E, (int64_t)*e_dev);   // (the launch is sized for a capacity: the list's length lives on the device, knn_build nosync)
+    // (e_dev: the list's length lives on the device, knn_build nosync -- E is then its CAPACITY, the launch a fixed number of workgroups that stride
+    //  over the rows that exist, instead of one thread per element of the capacity: 94 M mostly idle threads at 256 crystals)
+    if (e_dev) E = min(E, (int64_t)*e_dev);
     const int F3 = 3 * F, np = F3 / 2, npad = (FF.KT * 32 - 2 * F3) / 2, per_row = np + npad;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t rows_pad = (E + 127) / 128 * 128;
-    if (idx >= rows_pad * per_row) return;
-    const int64_t e = idx / per_row;
-    const int m = (int)(idx % per_row);
-    if (m >= np) {  // zero padding of the K direction
-        const int col = 2 * F3 + 2 * (m - np);
+    const int64_t rows_pad = (E + 127) / 128 * 128, total = rows_pad * per_row, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t e = idx / per_row;
+        const int m = (int)(idx % per_row);
+        if (m >= np) {  // zero padding of the K direction
+            const int col = 2 * F3 + 2 * (m - np);
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, col, k)) = 0u;
-        return;
-    }
-    float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
-    if (e < E) {
-        const int i = src[e], j = dst[e];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ck = 2 * m + u, c = ck / F, k = ck - c * F;
-            const float d = edge_diff(frac, fd, e, i, j, c);
-            sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn[u], &cs[u]);
+            for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, col, k)) = 0u;
+            continue;
         }
+        float sn[2] = {0.f, 0.f}, cs[2] = {0.f, 0.f};
+        if (e < E) {
+            const int i = src[e], j = dst[e];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ck = 2 * m + u, c = ck / F, k = ck - c * F;
+                const float d = edge_diff(frac, fd, e, i, j, c);
+                sincos_bounded(d * ((float)k * 6.28318530717958647692f), &sn[u], &cs[u]);
+            }
+        }
+        unsigned p[3];
+        pl_split_pair(sn[0], sn[1], FF.s(), p);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
+        pl_split_pair(cs[0], cs[1], FF.s(), p);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, F3 + 2 * m, k)) = p[k];
     }
-    unsigned p[3];
-    pl_split_pair(sn[0], sn[1], FF.s(), p);
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, 2 * m, k)) = p[k];
-    pl_split_pair(cs[0], cs[1], FF.s(), p);
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) *reinterpret_cast<unsigned*>(FF.base + FF.elem((int)e, F3 + 2 * m, k)) = p[k];
 }
 
 // per-column-pair form (any F)
@@ -1024,7 +1026,8 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
         const int64_t rows_pad = (b->E + 127) / 128 * 128;
         if (net->F % 2 == 0) {
             const int64_t nthr = rows_pad * (int64_t)(ffp.KT * 16 - 3 * net->F / 2);
-            hipLaunchKernelGGL(fourier_planes_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F, b->e_dev);
+            const unsigned nblk = (unsigned)(b->e_dev ? std::min<int64_t>(cdiv(nthr, 256), 16384) : cdiv(nthr, 256));   // (a device-side length: a fixed, striding launch)
+            hipLaunchKernelGGL(fourier_planes_kernel, dim3(nblk), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F, b->e_dev);
         } else {
             const int64_t nthr = rows_pad * (int64_t)ffp.KT * 16;
             hipLaunchKernelGGL(fourier_planes_cols_kernel, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, frac, b->fd, b->src, b->dst, ffp, b->E, net->F, b->e_dev);
@@ -1168,6 +1171,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe1.ep = g1e;
                 pe1.Cp = m1p;
                 pe1.m_dev = b->e_dev;   // (knn lists built without a host round trip: E is the capacity)
+                pe1.m_hint = (int)std::min<int64_t>(b->e_hint, INT32_MAX);
                 if (g_edge_pairs && !b->knn && H % 8 == 0) {  // (the pair epilogue moves 8 columns per lane)
                     // symmetric edge list: sin(2 pi k (1 - d)) = -sin(2 pi k d), cos unchanged, so one operand row per unordered
                     // pair yields both directed edges (half the MFMA work of this GEMM); self edges (d = 0) are a constant
@@ -1230,6 +1234,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
                 pe2.seg_rowptr = b->rowptr;
                 pe2.seg_nodes = N;
                 pe2.m_dev = b->e_dev;
+                pe2.m_hint = (int)std::min<int64_t>(b->e_hint, INT32_MAX);
                 MI_TRY(gemm_planes(m1p, w2p, E, H, H, pe2, s));
                 b->seg_shift = 5;
                 }
@@ -1909,7 +1914,7 @@ int mi_debug_set_pair_wide(int on) {
 
 int mi_debug_set_knn_nosync(int on) {
     const int was = g_knn_nosync;
-    g_knn_nosync = on != 0;
+    g_knn_nosync = on < 0 ? 0 : (on > 2 ? 2 : on);
     return was;
 }
 

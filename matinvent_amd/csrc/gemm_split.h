@@ -610,6 +610,7 @@ struct PlanesEpilogue {
     // Lets a chain of launches whose row count is produced on the device (the periodic graph's edge count) run without a host
     // round trip per evaluation (gemnet.hip, the sampler's forwards).
     const int* m_dev = nullptr;
+    int m_hint = 0;         // with m_dev: the row count the host expects (the last one it has seen) -- chooses the kernel form, never the rows processed
     __device__ __forceinline__ int rows(int M) const {
         if (!m_dev) return M;
         const int md = __builtin_amdgcn_readfirstlane(*m_dev);
@@ -2290,6 +2291,9 @@ int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const Pla
     MI_CHECK(!pair || (A.KT % 2 == 0 && pe.Cp.base && pe.ep.row_bias && pe.ep.row_bias2 && pe.ep.row_bias3 && (N & 7) == 0 && !pe.ep.bias), MI_EINVAL,
              "gemm_planes: pair mode needs an even k-tile count, a plane-set output, the three gathered addends and no column bias");
     const int nct = cdiv(N, 128);
+    // Ms: the row count the FORM of the product is chosen for.  With a device-side count (pe.m_dev) M is a capacity -- several times the rows that exist
+    // for a knn list -- and the caller's expectation pe.m_hint (the last count the host has seen) picks the form; the grids below still cover M.
+    const int Ms = (pe.m_dev && pe.m_hint > 0) ? std::min(M, pe.m_hint) : M;
 #if MI_PLANES_FP16
     {
         static bool dma_attr_set = false;
@@ -2337,12 +2341,12 @@ int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const Pla
             else if (lat) hipLaunchKernelGGL((gemm_planes_lat_kernel<1>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
             else hipLaunchKernelGGL((gemm_planes_kernel<1, 2>), dim3(nblk), dim3(256), planes_lds_bytes(1, 2), s, A, W, M, N, K, pe, 0);
         }
-    } else if (MI_PLANES_FP16 && W.frag && g_planes_rt && (g_planes_rt > 1 || ext) && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && M >= g_planes_rt_min_rows &&
+    } else if (MI_PLANES_FP16 && W.frag && g_planes_rt && (g_planes_rt > 1 || ext) && (N & 255) == 0 && (K & 63) == 0 && K >= 128 && Ms >= g_planes_rt_min_rows &&
                planes_epilogue_is_rows(pe, N)) {
         return gemm_rt(A, W.frag, M, N, K, pe, ext, s);
     } else if (MI_PLANES_FP16 && (N & 255) == 0 &&
-               ((g_planes_big && (g_planes_big > 1 || !ext) && M >= g_planes_big_min_rows && planes_epilogue_is_rows(pe, N)) ||
-                (MI_HAVE_ABLATION_KERNELS && g_planes_big_seg_min_rows > 0 && M >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act &&
+               ((g_planes_big && (g_planes_big > 1 || !ext) && Ms >= g_planes_big_min_rows && planes_epilogue_is_rows(pe, N)) ||
+                (MI_HAVE_ABLATION_KERNELS && g_planes_big_seg_min_rows > 0 && Ms >= g_planes_big_seg_min_rows && !ext && pe.seg_part && !pe.ep.pre_act &&
                  !planes_epilogue_is_rows(pe, N)))) {
 #if MI_PLANES_FP16
         static bool attr_set = false;
@@ -2362,20 +2366,20 @@ int gemm_planes(const Planes& A, const Planes& W, int M, int N, int K, const Pla
         if (ext) hipLaunchKernelGGL(gemm_planes_big_kernel<true>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
         else hipLaunchKernelGGL(gemm_planes_big_kernel<false>, grid, dim3(512), GEMM_BIG_LDS, s, A, W, M, N, K, pe);
 #endif
-    } else if (cdiv(M, 128) * nct < g_planes_small_tiles) {
+    } else if (cdiv(Ms, 128) * nct < g_planes_small_tiles) {
         // few tiles (node-level products): 64-row tiles -- twice the workgroups, half the serial MFMA work in each
         if (ext) hipLaunchKernelGGL((gemm_planes_kernel<0, 1, true>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_kernel<0, 1>), dim3(nct * ((cdiv(M, 64) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 1), s, A, W, M, N, K, pe, 0);
 #if MI_HAVE_ABLATION_KERNELS
-    } else if (g_planes_dma >= 4 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= 256) {   // mode 4: one-round launches on the four-waves-per-SIMD build
+    } else if (g_planes_dma >= 4 && nct * ((cdiv(Ms, 128) + 7) / 8 * 8) <= 256) {   // mode 4: one-round launches on the four-waves-per-SIMD build
         if (ext) hipLaunchKernelGGL((gemm_planes_slim_kernel<true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_slim_kernel<false>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
 #endif
-    } else if (MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) ||
-                                  (g_planes_dma >= 3 && nct * ((cdiv(M, 128) + 7) / 8 * 8) > 256))) {   // (modes 3 / 4: the LDS-DMA form for the LARGE launches only)
+    } else if (MI_PLANES_FP16 && (g_planes_dma == 2 || (g_planes_dma == 1 && nct * ((cdiv(Ms, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) ||
+                                  (g_planes_dma >= 3 && nct * ((cdiv(Ms, 128) + 7) / 8 * 8) > 256))) {   // (modes 3 / 4: the LDS-DMA form for the LARGE launches only)
         if (ext) hipLaunchKernelGGL((gemm_planes_dma_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_dma_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), PLANES_DMA_LDS, s, A, W, M, N, K, pe, 0);
-    } else if (nct * ((cdiv(M, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) {   // at most one round: the latency form
+    } else if (nct * ((cdiv(Ms, 128) + 7) / 8 * 8) <= g_planes_lat_max_blocks) {   // at most one round: the latency form
         if (ext) hipLaunchKernelGGL((gemm_planes_lat_kernel<0, true>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
         else hipLaunchKernelGGL((gemm_planes_lat_kernel<0>), dim3(nct * ((cdiv(M, 128) + 7) / 8 * 8)), dim3(256), planes_lds_bytes(0, 2), s, A, W, M, N, K, pe, 0);
     } else {

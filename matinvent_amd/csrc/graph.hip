@@ -368,6 +368,7 @@ int knn_alloc(mi_batch* b, int max_neighbors, int cap_per_node) {
     A_(fd, EC * 3);
     A_(inedge, EC);
 #undef A_
+    if (rc == MI_OK && b->kn_meta && hipMemset(b->kn_meta, 0, 8 * sizeof(int)) != hipSuccess) rc = MI_EHIP;   // (the sticky verdict meta[3..5] starts clean: a build clears meta[0..2] only)
     return rc;
 }
 
@@ -387,7 +388,7 @@ int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t
                        b->edge_graph, b->kn_refpos, b->inedge, b->kn_meta);
     MI_KERNEL_CHECK();
     ++b->graph_epoch;   // (tables derived from the edge list -- edge_stage.hip's per-tile tables -- are rebuilt at their next use)
-    if (nosync) {
+    if (nosync && (b->e_hint > 0 || g_knn_nosync == 2)) {   // (the very first build of a handle synchronises once: the host learns the list's size, which picks the kernel forms from then on; 2 = not even that one, tests)
         // No host round trip: the consumers are launched for the CAPACITY and take the row count from meta[0] on the device (PlanesEpilogue::m_dev, the
         // Fourier operand's e_dev); tiles past the count exit at once.  A list over capacity sets the sticky flag meta[3] and publishes zero edges; the
         // caller of the chain asks mi_knn_graph_status once behind it (the error is the same MI_ECAPACITY, raised later instead of never).
@@ -405,6 +406,7 @@ int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t
              "knn graph exceeds its capacity (edges %d of %lld, max degree %d of %d): raise edge_cap_per_node", meta[0], (long long)b->E_cap,
              meta[1], b->deg_cap);
     b->E = meta[0];
+    b->e_hint = std::max<int64_t>(meta[0], 1);
     return MI_OK;
 }
 
@@ -434,6 +436,7 @@ int mi_knn_graph_status(mi_batch* b, void* stream) {
                       meta[4], (long long)b->E_cap, meta[5], b->deg_cap);
         return MI_ECAPACITY;
     }
+    b->e_hint = std::max<int64_t>(meta[0], 1);   // (the size of the chain's last list: the form hint of the next chain's launches)
     return MI_OK;
 }
 

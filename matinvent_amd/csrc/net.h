@@ -107,6 +107,7 @@ struct mi_batch {
     int64_t E = 0;      // edges of the current graph (fixed for fc; rewritten by every forward for knn)
     int64_t E_cap = 0;  // edge capacity every per-edge buffer is sized for (= E for fc)
     const int* e_dev = nullptr;   // knn lists rebuilt WITHOUT a host round trip (knn_build nosync): E above is the capacity the launches are sized for, *e_dev the edge count
+    int64_t e_hint = 0;           // the last edge count the HOST has seen (a synchronising build, mi_knn_graph_status): picks kernel forms for capacity-sized launches
     bool knn_nosync = false;      // set by mi_sampler_run around its forwards: the chain's graph builds do not synchronise (mi_knn_graph_status reads the verdict behind it)
     int nslots = 1;
     int seg_shift = 5;  // log2 of the row-block size behind the partial sums currently in `part` (5: plane GEMM epilogue; 7: edge_stage.hip; -1: edge_fused.hip, slots by mask)
@@ -225,5 +226,6 @@ int edge_fused(mi_net* net, mi_batch* b, int layer, hipStream_t s);   // edge_fu
 bool edge_fused_supported(const mi_net* net, const mi_batch* b);
 int edge_gemm2(mi_net* net, mi_batch* b, int layer, hipStream_t s, float* Z2 = nullptr);   // Z2: optional pre-activation output (training forward)
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train = false);
+extern int g_knn_nosync;
 int knn_build(mi_batch* b, const float* frac, const float* lattices, hipStream_t s, bool nosync = false);
 }  // namespace mi

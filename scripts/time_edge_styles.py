@@ -6,6 +6,9 @@ import torch, numpy as np
 import bench
 from matinvent_amd.diffcsp import DiffCSPModule
 dev = torch.device('cuda')
+if os.environ.get("MI_KNN_NOSYNC", "") != "":   # 0: the synchronising graph build of rounds 1-5 inside the chain (A/B of round 6's sync-free build)
+    from matinvent_amd import _lib
+    _lib.load().mi_debug_set_knn_nosync(int(os.environ["MI_KNN_NOSYNC"]))
 def build(style):
     torch.manual_seed(bench.SEED_W)
     m = DiffCSPModule(decoder=dict(hidden_dim=bench.H, num_layers=bench.L, num_freqs=bench.F, ln=True, edge_style=style, max_neighbors=20),
@@ -28,4 +31,6 @@ for style in ("fc", "knn"):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.sample(cb, seed=2, t_start=bench.T, t_stop=bench.T - K, step_lr=bench.STEP_LR, streams=S)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+        if style == "knn":
+            m.check_graph()
         print(f"{style} streams {S}: {dt*1e3:.2f} ms per denoising step -> {bench.B/(dt*bench.T):.1f} structures/s")

@@ -232,15 +232,18 @@ def test_knn_chain_without_a_host_round_trip_equals_the_synchronising_chain_and_
     was = lib.mi_debug_set_knn_nosync(0)
     try:
         f0, t0 = m.sample(Box(na), step_lr=5e-6, seed=seed, record=True)
-        assert lib.mi_debug_set_knn_nosync(1) == 0
-        f1, t1 = m.sample(Box(na), step_lr=5e-6, seed=seed, record=True)
-        m.check_graph()
+        trajs = []
+        for mode in (1, 2):   # 1: the first build of the handle synchronises once (form hint), 2: none does
+            lib.mi_debug_set_knn_nosync(mode)
+            trajs.append(m.sample(Box(na), step_lr=5e-6, seed=seed, record=True)[1])
+            m.check_graph()
     finally:
         lib.mi_debug_set_knn_nosync(was)
-    assert sorted(t0) == sorted(t1)
-    for t in t0:
-        for k in t0[t]:
-            assert torch.equal(t0[t][k], t1[t][k]), (t, k)
+    for t1 in trajs:
+        assert sorted(t0) == sorted(t1)
+        for t in t0:
+            for k in t0[t]:
+                assert torch.equal(t0[t][k], t1[t][k]), (t, k)
     # (2) no synchronisation inside the enqueue
     box = Box(na)
     m.sample(box, step_lr=5e-6, seed=1)
@@ -259,17 +262,27 @@ def test_knn_chain_without_a_host_round_trip_equals_the_synchronising_chain_and_
 def test_knn_capacity_error_inside_a_chain_is_raised_behind_it():
     """A list over capacity cannot raise in the middle of an enqueued chain: it contributes no edges, sets a sticky flag, and check_graph() -- which sample() runs
     for the previous call's chains and DiffCSPSampler.generate before it unpacks -- raises the same capacity error.  Never a silent truncation."""
+    from matinvent_amd import _lib
     from tests.gpu_util import Box
+    lib = _lib.load()
     T = 4
     hp = O.CSPNetHParams(hidden_dim=64, num_layers=2, num_freqs=8, edge_style="knn")
     P = O.init_params(hp, seed=1, head_scale=0.1)
     m = _knn_module(T, torch.ones(T + 1), P)
     m.decoder.edge_cap_per_node = 4
     box = Box(torch.tensor([20, 20]))
-    m.sample(box, step_lr=5e-6, seed=3)          # enqueues; dense 20-atom cells overflow 4 kept neighbours per atom at once
+    # the very first build of a batch handle synchronises once (the host learns the list's size): an overflow there raises at once
     with pytest.raises(RuntimeError, match="capacity"):
-        m.check_graph()
-    m.check_graph()                               # (the flag was cleared with the report)
-    m.sample(box, step_lr=5e-6, seed=4)
-    with pytest.raises(RuntimeError, match="capacity"):
-        m.sample(box, step_lr=5e-6, seed=5)      # the next call reports the previous call's chains first
+        m.sample(box, step_lr=5e-6, seed=3)
+    was = lib.mi_debug_set_knn_nosync(2)          # no synchronisation at all: what every LATER build of a handle does
+    try:
+        m.sample(box, step_lr=5e-6, seed=3)      # enqueues; dense 20-atom cells overflow 4 kept neighbours per atom at once
+        with pytest.raises(RuntimeError, match="capacity"):
+            m.check_graph()
+        m.check_graph()                           # (the flag was cleared with the report)
+        m.sample(box, step_lr=5e-6, seed=4)
+        with pytest.raises(RuntimeError, match="capacity"):
+            m.sample(box, step_lr=5e-6, seed=5)  # the next call reports the previous call's chains first
+    finally:
+        lib.mi_debug_set_knn_nosync(was)
+        m.__dict__["_knn_pending"] = []
