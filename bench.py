@@ -251,6 +251,9 @@ def _apply_env_knobs(lib):
         lib.mi_debug_set_node_bwd(int(os.environ["MI_NODE_BWD"]), int(os.environ.get("MI_NODE_BWD_MIN_BLOCKS", "0")))
     if os.environ.get("MI_PLANES_RT", "") != "":   # register-tile form of the large plane products: 0 off, 1 those with epilogue extensions (default), 2 all
         lib.mi_debug_set_planes_rt(int(os.environ["MI_PLANES_RT"]), 0)
+    if os.environ.get("MI_FT_PRIOR_AUX", "") != "":
+        from matinvent_amd import finetune
+        finetune.FT_PRIOR_AUX = bool(int(os.environ["MI_FT_PRIOR_AUX"]))
     if os.environ.get("MI_WGRAD_WINDOW", "") != "":   # micro-steps per node-level weight-gradient contraction of the fine-tune loop (0: off)
         from matinvent_amd import finetune
         finetune.WGRAD_WINDOW = int(os.environ["MI_WGRAD_WINDOW"])

@@ -110,6 +110,7 @@ def _stacked_micro_steps(agent, prior, batch, time_idxs, noises, sigma, n_global
 
 
 MAX_STACK = 16  # MI_MAX_STACK of the C ABI
+FT_PRIOR_AUX = False  # grouped path: the frozen prior's forward of every group on an auxiliary stream (measured: see DESIGN 20)
 WGRAD_WINDOW = 16  # micro-steps whose node-level weight gradients are contracted together (mi_batch_set_wgrad_window); 0 = off
 
 
@@ -378,6 +379,8 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     main = torch.cuda.current_stream()
     from .streams import concurrent_streams
     streams = concurrent_streams(groups, device)
+    # FT_PRIOR_AUX (experiment, MI_FT_PRIOR_AUX=1): every group forks its frozen prior's forward onto a stream of its own, as the single-group path does
+    aux_streams = concurrent_streams(2 * groups, device)[groups:] if FT_PRIOR_AUX else [None] * groups
     if theta.grad is None:
         theta.grad = torch.zeros_like(theta)
     grads = [theta.grad] + [torch.zeros_like(theta) for _ in range(groups - 1)]
@@ -429,7 +432,7 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     was_groups = _lib.load().mi_set_concurrent_groups(groups)   # (each group's weight-gradient contractions take their share of the chip, not all of it)
     try:
         return _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma,
-                                       device, noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats)
+                                       device, noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats, aux_streams)
     finally:
         import sys
         _lib.load().mi_set_concurrent_groups(was_groups)
@@ -444,7 +447,7 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
 
 
 def _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_lo, n_global, groups, accum_steps, epochs, timesteps, sigma, device,
-                            noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats):
+                            noise_fn, log, rank, theta, grads, streams, main, optimizer_step, stats, aux_streams=None):
     for epoch in range(epochs):
         agent.train()
         theta.grad.zero_()
@@ -465,7 +468,8 @@ def _ft_step_grouped_epochs(agent, prior, batches, cuts, nodes, offs, lo, node_l
                     nz = (noise[0][g0:g1], noise[1][n0:n1], noise[2][n0:n1])
                 agent.shard_offsets = prior.shard_offsets = offs[k]
                 with torch.cuda.stream(streams[k]):
-                    _fused_micro_step(agent, prior, batches[k], t, nz, sigma, n_global, accum_steps, grads[k], accs[k], call_id=agent._noise_calls)
+                    _fused_micro_step(agent, prior, batches[k], t, nz, sigma, n_global, accum_steps, grads[k], accs[k], call_id=agent._noise_calls,
+                                      aux_stream=None if aux_streams is None else aux_streams[k])
             if (t + 1) % accum_steps == 0:
                 optimizer_step()
         if (t + 1) % accum_steps != 0:

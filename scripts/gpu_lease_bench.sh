@@ -3,7 +3,7 @@
 # usage (through gpurun): bash scripts/gpu_lease_bench.sh <n>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 N=${1:-1}
-O=gpurun_out/r5_bench_lease$N
+O=gpurun_out/r6_bench_lease$N
 { rocm-smi --showclocks 2>/dev/null | grep -iE "sclk|mclk|fclk|socclk" | head -4; rocm-smi --showpower 2>/dev/null | grep -i "power" | head -1; rocm-smi --showperflevel 2>/dev/null | grep -i "perf" | head -1; } > $O.box 2>&1
 T0=$(date +%s%N)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O.json 2> $O.err
