@@ -998,6 +998,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     bool pq0_kept = false;         // ... and layer 0's slot: its [P_i | P_j | X_part] (b->PQ0) is the previous evaluation's as well
     const bool fused_early = (!train || g_node_train) && !(g_node_hi && !train) && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0 && b->E > 0 &&
                              node_chain_supported(net);   // (= `fused` below: the node chain runs as node_chain.hip's launches)
+    if (fused_early && !train && !b->PQ0) MI_TRY(dev_alloc(b, &b->PQ0, (size_t)3 * N * H));   // (first inference forward on the fused path: once per handle)
     // ---- Fourier operand: identical in every layer (cspnet.py:65-66), built once per evaluation ----
     if (b->E > 0 && net->edge_mode == 0) {
         const int64_t nf4 = (int64_t)cdiv(b->E, 32) * (net->KP / 4) * 64;
@@ -1656,7 +1657,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(h, (L + 1) * NH);
     A_(cat, 2 * NH);
     A_(PQ, 3 * NH);  // [N][2H] P_i | P_j, or [N][3H] with the LayerNorm(h) part of the node MLP's first product appended
-    A_(PQ0, 3 * NH);
+    // (PQ0 -- layer 0's projections of the INFERENCE node chain, 3 N H floats -- is allocated by the first forward that takes that path: training-only, knn and
+    //  non-fp16 handles never pay for it)
     A_(G, (size_t)L * B * H);
     A_(part, nslots * NH);
     A_(FFp, (size_t)cdiv(E, 32) * (net->KP / 4) * 256);
