@@ -844,6 +844,28 @@ def tf32_class_leg(args, K, W):
         return {"error": repr(e)}
 
 
+def resolve_batch(args):
+    """--scaling strong: ONE global batch of 256 crystals (north_star: "batch 256 ... >= 6x at 8 GPUs"), B / N crystals per rank, global ids in the noise
+    counters as always (so the N-rank samples are the 1-rank samples).  --batch: the per-GPU batch directly -- the per-rank shapes of a strong-scaling run
+    (128 / 64 / 32) measured on ONE GPU: profiles/r6_strong_shapes.json, DESIGN section 7.  --streams 0: the sampler's automatic chain count for the batch.
+    Rebinds the module's per-GPU batch B; returns it."""
+    global B
+    b_global = 256
+    B = b_global
+    if args.scaling == "strong":
+        if b_global % max(1, args.gpus) != 0:
+            raise SystemExit(f"bench.py: --scaling strong: the global batch of {b_global} does not divide over {args.gpus} ranks")
+        B = b_global // max(1, args.gpus)
+    if args.batch:
+        B = int(args.batch)
+    args.batch_label = (f"global batch {b_global} sharded over {args.gpus} rank(s): {B} crystals per GPU (strong scaling)" if args.scaling == "strong" and not args.batch
+                        else f"{B} crystals per GPU" + (" (a per-rank shape of the strong-scaling run, measured on one GPU)" if args.batch else ""))
+    if args.streams == 0:   # automatic: the sampler's own choice for the batch's edge count (DiffCSPModule.sample)
+        e_total = B * NATOM * NATOM
+        args.streams = 4 if e_total >= 98304 else 3 if e_total >= 49152 else 2 if e_total >= 16384 else 1
+    return B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -875,21 +897,7 @@ def main():
     args = ap.parse_args()
     if args.force_dist:
         os.environ["MI_BENCH_FORCE_DIST"] = "1"
-    # --scaling strong: ONE global batch of 256 crystals (north_star: "batch 256 ... >= 6x at 8 GPUs"), B / N crystals per rank, global ids in the noise
-    # counters as always (so the N-rank samples are the 1-rank samples).  --batch: the per-GPU batch directly -- the per-rank shapes of a strong-scaling
-    # run (128 / 64 / 32) measured on ONE GPU: profiles/r6_strong_shapes.json, DESIGN section 7.
-    global B
-    B_GLOBAL = B
-    if args.scaling == "strong":
-        assert B_GLOBAL % max(1, args.gpus) == 0, "--scaling strong: the global batch of 256 must divide over the ranks"
-        B = B_GLOBAL // max(1, args.gpus)
-    if args.batch:
-        B = int(args.batch)
-    args.batch_label = (f"global batch {B_GLOBAL} sharded over {args.gpus} rank(s): {B} crystals per GPU (strong scaling)" if args.scaling == "strong" and not args.batch
-                        else f"{B} crystals per GPU" + (" (a per-rank shape of the strong-scaling run, measured on one GPU)" if args.batch else ""))
-    if args.streams == 0:   # automatic: the sampler's own choice for the batch's edge count (DiffCSPModule.sample)
-        e_total = B * NATOM * NATOM
-        args.streams = 4 if e_total >= 98304 else 3 if e_total >= 49152 else 2 if e_total >= 16384 else 1
+    resolve_batch(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not os.environ.get("MI_BENCH_SHARE_GPU") and torch.cuda.device_count() < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} starts one process per GPU over RCCL, but this node shows {torch.cuda.device_count()} GPU(s)")
@@ -937,13 +945,18 @@ def main():
 
     # W untimed denoising steps on a throwaway state, then exactly K timed steps of the chain that
     # starts at t = T (its Philox initial state is generated outside the timed region: inputs resident)
-    if W > 0:
-        m.sample(cb, seed=SEED_NOISE + 1, t_start=T, t_stop=T - W, **skw)
+    import gc
+    gc_early = os.environ.get("MI_BENCH_GC_EARLY", "1") not in ("", "0")
     final, _ = m.sample(cb, seed=SEED_NOISE, t_start=T, t_stop=T, **skw)
     state = (final["frac_coords"], final["lattices"], final["atom_types"])
     m._coefficients(STEP_LR)
-    import gc
-    gc.collect()
+    if gc_early:
+        gc.collect()   # (everything the host has to do between the warm-up and the window is done BEFORE the warm-up: a generation-2 collection of a torch
+        #  process takes tens of ms, during which an idle part drops its power state -- the warm-up steps are meant to be the last thing the GPU did)
+    if W > 0:
+        m.sample(cb, seed=SEED_NOISE + 1, t_start=T, t_stop=T - W, **skw)
+    if not gc_early:
+        gc.collect()
     gc.disable()   # (as timeit does: a 20-step window is 0.1 s, a generation-2 collection of a torch process several ms of it; re-enabled right behind the window)
     try:
         barrier()

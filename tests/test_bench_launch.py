@@ -91,3 +91,21 @@ def test_the_all_reduce_helper_stages_only_what_the_backend_cannot_read(monkeypa
     seen.clear()
     D.allreduce_flat_(buf)
     assert not seen   # a single rank never enters the collective
+
+
+def test_strong_scaling_shards_one_global_batch_of_256(bench):
+    """`--scaling strong`: the global batch of 256 crystals is cut over the ranks (north_star's "batch 256 ... at 8 GPUs"); weak (default) keeps 256 per rank;
+    `--batch` measures a per-rank shape on one GPU; `--streams 0` takes the sampler's automatic chain count for that shape."""
+    ns = lambda **kw: types.SimpleNamespace(**dict(dict(gpus=1, scaling="weak", batch=0, streams=4), **kw))
+    a = ns(gpus=8)
+    assert bench.resolve_batch(a) == 256 and "256 crystals per GPU" in a.batch_label
+    a = ns(gpus=8, scaling="strong")
+    assert bench.resolve_batch(a) == 32 and bench.B == 32 and "sharded over 8 rank(s): 32 crystals per GPU" in a.batch_label
+    a = ns(gpus=2, scaling="strong", streams=0)
+    assert bench.resolve_batch(a) == 128 and a.streams == 3
+    a = ns(batch=64, streams=0)
+    assert bench.resolve_batch(a) == 64 and a.streams == 2 and "per-rank shape" in a.batch_label
+    with pytest.raises(SystemExit, match="does not divide"):
+        bench.resolve_batch(ns(gpus=3, scaling="strong"))
+    bench.resolve_batch(ns())     # (back to the default for whoever imports the module next)
+    assert bench.B == 256
