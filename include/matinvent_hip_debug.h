@@ -44,7 +44,9 @@ int mi_debug_set_node_planes_min_rows(int n);
  * dZ1-consumer kernels instead of the fused fc pair-mode backward pass, +16 = a separate silu(Z1) pass instead of forming M1 inside
  * the weight-gradient product's operand load, +32 = the dM1 data gradient on the on-the-fly three-plane bf16 split instead of the
  * pre-split fp16 plane GEMM, +64 = the edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes /
- * three, +128 = the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form (ablations). */
+ * three, +128 = the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form, +256 = edge_mlp.2's weight gradient
+ * from fp32 rows instead of the M1 / dZ2 plane sets, +512 = the head / embedding weight gradients contracted in every backward instead of in the
+ * deferred window of mi_batch_set_wgrad_window (applies to windows sized afterwards) (ablations). */
 int mi_debug_set_tn128(int on);
 /* Tuning knob: shortest row list (contraction length) for which the bf16-pipe weight-gradient kernel is used (default 4096). */
 int mi_debug_set_tn_split_min_rows(int n);

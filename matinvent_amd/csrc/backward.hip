@@ -18,6 +18,7 @@ int g_bwd_pairs_tile = 1;   // crystals of at most 24 atoms: the LDS-tile form o
 int g_bwd_pairs_fused = 1;  // fc pair mode: one fused pass for every consumer of dZ1 (0: the separate kernels, ablation)
 int g_bwd_dz2_planes = 1;   // fp16 plane format: dZ2 also as a plane set, its data gradient on the pre-split plane GEMM (0: on-the-fly bf16 split)
 int g_bwd_wgrad_planes = 1; // fp16 plane format: edge_mlp.2's weight gradient from the plane sets of M1 (kept per layer by the training forward) and dZ2 (0: fp32 rows re-split on the way into LDS)
+int g_bwd_head_window = 1;  // the head / embedding weight gradients join the deferred window of the node-level ones (0: contracted in every backward; read when a window is sized)
 int g_bwd_wgrad_f16 = 1;    // fp16 plane format: edge-level weight gradients on two fp16 planes / three terms (0: three bf16 planes / six)
 }
 
@@ -826,7 +827,8 @@ int net_wgrad_window(mi_net* net, mi_batch* b, int slots) {
     }
     MI_TRY(alloc_tape(net, b));
     if (slots > t.wcap) {
-        for (float** q : {&t.w_dY, &t.w_Xa, &t.w_dXa, &t.w_cat, &t.w_dPQ})
+        for (float** q : {&t.w_dY, &t.w_Xa, &t.w_dXa, &t.w_cat, &t.w_dPQ, &t.w_dlo, &t.w_gf, &t.w_dtype, &t.w_dcoord, &t.w_hf, &t.w_dh, &t.w_x1, &t.w_dtproj, &t.w_temb,
+                          &t.w_eXa, &t.w_types})
             if (*q) {
                 b->allocs.erase(std::remove(b->allocs.begin(), b->allocs.end(), (void*)*q), b->allocs.end());
                 (void)hipFree(*q);
@@ -840,6 +842,21 @@ int net_wgrad_window(mi_net* net, mi_batch* b, int slots) {
         if (rc == MI_OK) rc = dev_alloc(b, &t.w_dXa, rows * H);
         if (rc == MI_OK) rc = dev_alloc(b, &t.w_cat, rows * 2 * H);
         if (rc == MI_OK) rc = dev_alloc(b, &t.w_dPQ, rows * 2 * H);
+        // the head / embedding operands of the same window (see Tape): [slots][N or B][width]
+        const size_t sn = (size_t)slots * b->N, sb = (size_t)slots * b->B;
+        if (g_bwd_head_window) {
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_dlo, sb * 12);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_gf, sb * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_dtype, sn * MI_NUM_TYPES);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_dcoord, sn * 3);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_hf, sn * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_dh, sn * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_x1, sn * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_dtproj, sb * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_temb, sb * net->TD);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_eXa, sn * H);
+            if (rc == MI_OK) rc = dev_alloc(b, &t.w_types, sn * MI_NUM_TYPES);
+        }
         if (rc != MI_OK) {
             t.wslots = 0;
             return rc;
@@ -868,6 +885,18 @@ int net_wgrad_flush(mi_net* net, mi_batch* b, float* grad, hipStream_t s) {
         MI_TRY(gemm_tn_auto(dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, M, H, H, sc, scf, s));
         MI_TRY(gemm_tn_auto(dPQ + H, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight") + H, net->edge_in, M, H, H, sc, scf, s));
     }
+    if (t.head_window()) {   // heads and embedding over the same rows (net_backward skipped them micro-step by micro-step)
+        const int MB = t.wcur * b->B, TD = net->TD, WA = H + TD;
+        MI_TRY(gemm_tn_auto(t.w_dlo, 12, t.w_gf, H, G("lattice_out.weight"), H, MB, 9, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.w_dtype, MI_NUM_TYPES, t.w_hf, H, G("type_out.weight"), H, M, MI_NUM_TYPES, H, sc, scf, s));
+        MI_TRY(colsum_acc(t.w_dtype, MI_NUM_TYPES, G("type_out.bias"), M, MI_NUM_TYPES, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.w_dcoord, 3, t.w_hf, H, G("coord_out.weight"), H, M, 3, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.w_dh, H, t.w_x1, H, G("atom_latent_emb.weight"), WA, M, H, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.w_dtproj, H, t.w_temb, TD, G("atom_latent_emb.weight") + H, WA, MB, H, TD, sc, scf, s));
+        MI_TRY(colsum_acc(t.w_dh, H, G("atom_latent_emb.bias"), M, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(t.w_eXa, H, t.w_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, M, H, MI_NUM_TYPES, sc, scf, s));
+        MI_TRY(colsum_acc(t.w_eXa, H, G("node_embedding.bias"), M, H, sc, scf, s));
+    }
     t.wcur = 0;
     return MI_OK;
 }
@@ -887,16 +916,29 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     const bool defer = t.wslots > 0;
     MI_CHECK(!defer || t.wcur < t.wslots, MI_ESTATE, "wgrad window overrun");
 
+    // Head / embedding weight gradients in the deferred window (Tape::w_hf ...): this micro-step's operand rows live in slot t.wcur -- the training forward wrote
+    // x1 / hf / gf / the inputs there, this pass writes dlo / d h / dtproj / the embedding's dXa there -- and net_wgrad_flush contracts them with the rest
+    const bool hw = defer && t.head_window();
+    const size_t hs = hw ? (size_t)t.wcur : 0;
+    float* const dlo = hw ? t.w_dlo + hs * B * 12 : t.dlo;
+    float* const dh = hw ? t.w_dh + hs * NH : t.dh;
     // ---------------- heads ----------------
-    hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.in_lat, net->p("lattice_out.weight"), t.dlo, t.dgf, H);
+    hipLaunchKernelGGL(lattice_head_bwd_kernel, dim3(B), dim3(256), 0, s, d_lat, t.in_lat, net->p("lattice_out.weight"), dlo, t.dgf, H);
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_auto(t.dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
     hipLaunchKernelGGL(heads_bwd_kernel, g1(NH), dim3(256), 0, s, d_type, d_coord, t.dgf, net->p("type_out.weight"),
                        net->p("coord_out.weight"), b->node2graph, b->node_off, t.dY, N, H);  // dY = d hf
     MI_KERNEL_CHECK();
-    MI_TRY(gemm_tn_auto(d_type, MI_NUM_TYPES, b->hf, H, G("type_out.weight"), H, N, MI_NUM_TYPES, H, sc, scf, s));
-    MI_TRY(colsum_acc(d_type, MI_NUM_TYPES, G("type_out.bias"), N, MI_NUM_TYPES, sc, scf, s));
-    MI_TRY(gemm_tn_auto(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
+    if (hw) {   // (the fused micro-step seeds d_type / d_coord straight into the slot; any other caller's arrays are copied there)
+        float* const dts = t.w_dtype + hs * N * MI_NUM_TYPES;
+        float* const dcs = t.w_dcoord + hs * N * 3;
+        if (d_type != dts) MI_HIP(hipMemcpyAsync(dts, d_type, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
+        if (d_coord != dcs) MI_HIP(hipMemcpyAsync(dcs, d_coord, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        MI_TRY(gemm_tn_auto(dlo, 12, t.gf, H, G("lattice_out.weight"), H, B, 9, H, sc, scf, s));
+        MI_TRY(gemm_tn_auto(d_type, MI_NUM_TYPES, b->hf, H, G("type_out.weight"), H, N, MI_NUM_TYPES, H, sc, scf, s));
+        MI_TRY(colsum_acc(d_type, MI_NUM_TYPES, G("type_out.bias"), N, MI_NUM_TYPES, sc, scf, s));
+        MI_TRY(gemm_tn_auto(d_coord, 3, b->hf, H, G("coord_out.weight"), H, N, 3, H, sc, scf, s));
+    }
 
     auto ln_bwd = [&](const float* dy, int ld_dy, const float* x, const float* stats, const std::string& wname, float* dx, int accumulate) {
         const int rows_per_block = N >= 16384 ? 64 : (N >= 2048 ? 16 : 4), nblk = cdiv(N, rows_per_block);  // >= ~256 blocks when possible
@@ -910,9 +952,9 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     };
     // final LayerNorm: d h_L
     if (net->cfg.ln) {
-        MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)L * NH, t.lnstat + (size_t)L * N * 2, "final_layer_norm", t.dh, 0));
+        MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)L * NH, t.lnstat + (size_t)L * N * 2, "final_layer_norm", dh, 0));
     } else {
-        MI_HIP(hipMemcpyAsync(t.dh, t.dY, NH * 4, hipMemcpyDeviceToDevice, s));
+        MI_HIP(hipMemcpyAsync(dh, t.dY, NH * 4, hipMemcpyDeviceToDevice, s));
     }
 
     // Fourier features are the same for every layer; in pair mode one row per unordered atom pair
@@ -949,7 +991,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_HIP(hipMemsetAsync(b->absmax + 2 * L + 2, 0, 2 * L * sizeof(unsigned), s));
         float *dY1, *Xa1, *dXa1;
         w_rows(L - 1, &dY1, &Xa1, &dXa1);
-        MI_TRY(node_bwd(net, b, L, nullptr, dY1, dXa1, Xa1, nullptr, b->absmax + 2 * L + 2 + 2 * (L - 1), s));
+        MI_TRY(node_bwd(net, b, L, nullptr, dh, dY1, dXa1, Xa1, nullptr, b->absmax + 2 * L + 2 + 2 * (L - 1), s));
     }
 
     // ---------------- layers, last to first ----------------
@@ -976,7 +1018,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
                 MI_TRY(colsum_acc(dXa, H, G(p + "node_mlp.0.bias"), N, H, sc, scf, s));
             }
         } else {
-        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, t.dh, Ypre, dYl, (int64_t)NH);
+        hipLaunchKernelGGL(silu_bwd_kernel, g1(NH), dim3(256), 0, s, dh, Ypre, dYl, (int64_t)NH);
         hipLaunchKernelGGL(silu_fwd_kernel, g1(NH), dim3(256), 0, s, Xpre, Xa, (int64_t)NH);
         MI_KERNEL_CHECK();
         if (!defer) {
@@ -1144,7 +1186,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
             // d hn = dcat[:, :H] + dPQ Whh, dh_l = dh_{l+1} + LN'(d hn) -- and the node MLP's data gradients of the layer below, in the same launch
             float *dY1 = nullptr, *Xa1 = nullptr, *dXa1 = nullptr;
             if (l > 0) w_rows(l - 1, &dY1, &Xa1, &dXa1);
-            MI_TRY(node_bwd(net, b, l, dPQ, dY1, dXa1, Xa1, ln_batched ? ln_tail + (size_t)l * ln_slot : sc, l > 0 ? b->absmax + 2 * L + 2 + 2 * (l - 1) : nullptr, s));
+            MI_TRY(node_bwd(net, b, l, dPQ, dh, dY1, dXa1, Xa1, ln_batched ? ln_tail + (size_t)l * ln_slot : sc, l > 0 ? b->absmax + 2 * L + 2 + 2 * (l - 1) : nullptr, s));
             if (!ln_batched) hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(2 * H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, cdiv(N, 32), 2 * H, G(p + "layer_norm.weight"), 2 * H);
             MI_KERNEL_CHECK();
             continue;
@@ -1156,9 +1198,9 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         MI_TRY(gemm_nt(dPQ, 2 * H, net->WhhT + l * (size_t)2 * H * H, 2 * H, t.dY, H, N, H, 2 * H, er, s, &b->sk));
         // LayerNorm + residual stream: dh_l = dh_{l+1} + LN'(d hn)
         if (net->cfg.ln) {
-            MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)l * NH, t.lnstat + (size_t)l * N * 2, p + "layer_norm", t.dh, 1));
+            MI_TRY(ln_bwd(t.dY, H, b->h + (size_t)l * NH, t.lnstat + (size_t)l * N * 2, p + "layer_norm", dh, 1));
         } else {
-            hipLaunchKernelGGL(axpy_kernel, g1(NH), dim3(256), 0, s, t.dY, t.dh, (int64_t)NH);
+            hipLaunchKernelGGL(axpy_kernel, g1(NH), dim3(256), 0, s, t.dY, dh, (int64_t)NH);
             MI_KERNEL_CHECK();
         }
     }
@@ -1171,14 +1213,20 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     }
     // ---------------- embedding (cspnet.py:265-271) ----------------
     const int WA = H + TD;
-    MI_TRY(gemm_tn_auto(t.dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
-    hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, t.dh, H, b->node_off, t.dtproj, B, H);
+    if (hw) {   // the data path only: d tproj and the embedding's dXa into the slot; the five contractions and three column sums run in net_wgrad_flush
+        hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dh, H, b->node_off, t.w_dtproj + hs * B * H, B, H);
+        MI_KERNEL_CHECK();
+        MI_TRY(gemm_nt(dh, H, net->WaT, H, t.w_eXa + hs * NH, H, N, H, H, GemmEpilogue(), s, &b->sk));
+    } else {
+    MI_TRY(gemm_tn_auto(dh, H, b->x1, H, G("atom_latent_emb.weight"), WA, N, H, H, sc, scf, s));
+    hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dh, H, b->node_off, t.dtproj, B, H);
     MI_KERNEL_CHECK();
     MI_TRY(gemm_tn_auto(t.dtproj, H, t.in_temb, TD, G("atom_latent_emb.weight") + H, WA, B, H, TD, sc, scf, s));
-    MI_TRY(colsum_acc(t.dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
-    MI_TRY(gemm_nt(t.dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
+    MI_TRY(colsum_acc(dh, H, G("atom_latent_emb.bias"), N, H, sc, scf, s));
+    MI_TRY(gemm_nt(dh, H, net->WaT, H, t.dXa, H, N, H, H, GemmEpilogue(), s, &b->sk));
     MI_TRY(gemm_tn_auto(t.dXa, H, t.in_types, MI_NUM_TYPES, G("node_embedding.weight"), MI_NUM_TYPES, N, H, MI_NUM_TYPES, sc, scf, s));
     MI_TRY(colsum_acc(t.dXa, H, G("node_embedding.bias"), N, H, sc, scf, s));
+    }
     if (defer && ++t.wcur == t.wslots) MI_TRY(net_wgrad_flush(net, b, grad, s));
     return MI_OK;
 }
@@ -1468,7 +1516,15 @@ static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* p
     if (B == 0 || N == 0) return MI_OK;
     MI_TRY(net_tape_prepare(agent, ab));
     Tape& tp = ab->tape;
-    NoiseArgs na{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, ab->node_off, tp.nz_lat, tp.nz_frac, tp.nz_types, tp.tar_x,
+    // with the head / embedding weight gradients deferred over a window (Tape::w_hf ...), what their contractions read of this micro-step is written straight
+    // into the window's slot: the noised types, the time embedding, the gradient seeds of the type and coordinate heads
+    const bool hw = tp.head_window();
+    const size_t hs = hw ? (size_t)tp.wcur : 0;
+    float* const nz_types = hw ? tp.w_types + hs * N * MI_NUM_TYPES : tp.nz_types;
+    float* const temb = hw ? tp.w_temb + hs * B * agent->TD : ab->temb;
+    float* const d_t = hw ? tp.w_dtype + hs * N * MI_NUM_TYPES : tp.d_t;
+    float* const d_x = hw ? tp.w_dcoord + hs * N * 3 : tp.d_x;
+    NoiseArgs na{lengths, angles, frac0, atom_types, rand_l, rand_x, rand_t, ab->node_off, tp.nz_lat, tp.nz_frac, nz_types, tp.tar_x,
                  tp.rnd_l, tp.rnd_t, c0, c1, sigma_t, sigma_norm, seed, noise_step, ab->node_offset, ab->graph_offset};
     if (copies > 0) {
         MI_CHECK(copies <= MI_MAX_STACK && B % copies == 0 && N % copies == 0 && ts && c0s && c1s && sigmas && sigma_norms, MI_EINVAL,
@@ -1487,7 +1543,7 @@ static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* p
     } else {
         hipLaunchKernelGGL(fill_int_kernel2, dim3(cdiv(B, 256)), dim3(256), 0, s, ab->times, t, B);
     }
-    MI_TRY(mi_time_embedding(ab->times, time_freqs, B, agent->TD, ab->temb, stream));
+    MI_TRY(mi_time_embedding(ab->times, time_freqs, B, agent->TD, temb, stream));
     hipLaunchKernelGGL(add_noise_kernel, dim3(B), dim3(256), 0, s, na);
     MI_KERNEL_CHECK();
     if (aux_stream && aux_stream != stream) {
@@ -1500,29 +1556,29 @@ static int ft_micro_impl(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* p
         }
         MI_HIP(hipEventRecord(pb->ev_fork, s));
         MI_HIP(hipStreamWaitEvent(s2, pb->ev_fork, 0));
-        MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s2, false));
+        MI_TRY(net_forward(prior, pb, temb, nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s2, false));
         MI_HIP(hipEventRecord(pb->ev_join, s2));
         tp.borrow_inputs = true;   // (the noised inputs live in this tape and the time embedding in this batch until the backward below has run)
-        const int rc = net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
+        const int rc = net_forward(agent, ab, temb, nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
         tp.borrow_inputs = false;
         MI_TRY(rc);
         MI_HIP(hipStreamWaitEvent(s, pb->ev_join, 0));
     } else {
         tp.borrow_inputs = true;
-        const int rc = net_forward(agent, ab, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
+        const int rc = net_forward(agent, ab, temb, nz_types, tp.nz_frac, tp.nz_lat, ab->pred_l, ab->pred_x, ab->pred_t, s, true);
         tp.borrow_inputs = false;
         MI_TRY(rc);
-        MI_TRY(net_forward(prior, pb, ab->temb, tp.nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
+        MI_TRY(net_forward(prior, pb, temb, nz_types, tp.nz_frac, tp.nz_lat, pb->pred_l, pb->pred_x, pb->pred_t, s, false));
     }
     LossArgs la{ab->pred_l, ab->pred_x, ab->pred_t, pb->pred_l, pb->pred_x, pb->pred_t, tp.rnd_l, tp.tar_x, tp.rnd_t, reward, ab->node_off,
-                tp.d_l, tp.d_x, tp.d_t, tp.Lb, tp.KLb, cost_lattice, cost_coord, cost_type, kl_sigma,
+                tp.d_l, d_x, d_t, tp.Lb, tp.KLb, cost_lattice, cost_coord, cost_type, kl_sigma,
                 1.0f / ((float)b_global * (float)accum_steps)};
     hipLaunchKernelGGL(ft_loss_kernel, dim3(B), dim3(256), 0, s, la);
     if (stats) hipLaunchKernelGGL(ft_stats_kernel, dim3(1), dim3(64), 0, s, tp.Lb, tp.KLb, reward, B, kl_sigma, 1.0f / (float)b_global, stats);
     MI_KERNEL_CHECK();
     if (out_sample_loss) MI_HIP(hipMemcpyAsync(out_sample_loss, tp.Lb, B * 4, hipMemcpyDeviceToDevice, s));
     if (out_kl) MI_HIP(hipMemcpyAsync(out_kl, tp.KLb, B * 4, hipMemcpyDeviceToDevice, s));
-    return net_backward(agent, ab, tp.d_l, tp.d_x, tp.d_t, grad_theta, s);
+    return net_backward(agent, ab, tp.d_l, d_x, d_t, grad_theta, s);
 }
 
 int mi_ft_micro_step(mi_net* agent, mi_batch* ab, mi_net* prior, mi_batch* pb, const float* lengths, const float* angles,

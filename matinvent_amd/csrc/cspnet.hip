@@ -36,7 +36,7 @@ int g_fused_heads = 1;  // inference: coordinate and type heads in one launch (0
 int g_node_hi = 0;  // 1: the node-level kernels of an inference forward on a helper stream of the highest priority (joined by events)
 int g_planes_lat_max_blocks = 256;  // plane GEMMs of at most one workgroup per CU: the deep-prefetch latency form (gemm_split.h)
 int g_planes_small_tiles = 0;  // off: with concurrent chains the 128-row tiles win (31.3 vs 30.8 structures/s); one chain alone gains 2.7 % from 64-row tiles
-extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile, g_bwd_wgrad_planes;
+extern int g_bwd_pairs_fused, g_tn_xsilu, g_bwd_dz2_planes, g_bwd_wgrad_f16, g_bwd_pairs_tile, g_bwd_wgrad_planes, g_bwd_head_window;
 int g_tn128 = 1;
 int g_knn_nosync = 1;             // knn edge style inside the sampler's chain: the per-evaluation graph build without a host round trip (0: synchronising, as rounds 1-5)
 int g_tn_target_tiles = 768;      // three workgroups per CU for a contraction that has the chip to itself
@@ -958,16 +958,23 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     // cspnet.py:243-257: the edge list follows the coordinates.  Inside the sampler's chain (mi_batch::knn_nosync) on the plane-GEMM path the build does not
     // synchronise: b->E is then the capacity, b->e_dev the device-side edge count every consumer below takes its row count from
     if (b->knn) MI_TRY(knn_build(b, frac, lattices, s, b->knn_nosync && !train && g_knn_nosync && MI_PLANES_FP16 && g_gemm_mode == MI_GEMM_SPLIT && net->edge_mode != 0));
+    // Head / embedding weight gradients deferred over a window of micro-steps (Tape::w_hf ...): this forward's x1 and hf ARE the window slot's rows
+    const bool hw = train && tp.allocated && tp.head_window();
+    const size_t hslot = hw ? (size_t)tp.wcur : 0;
+    b->x1 = hw ? tp.w_x1 + hslot * N * H : b->x1_base;
+    b->hf = hw ? tp.w_hf + hslot * N * H : b->hf_base;
     if (train) {
         MI_CHECK(tp.allocated, MI_ESTATE, "training forward without tape");
-        if (tp.borrow_inputs) {   // (the fused micro-step's own arrays: see Tape::in_types)
+        if (tp.borrow_inputs) {   // (the fused micro-step's own arrays: see Tape::in_types; with an open window it hands over the slot's rows)
             tp.in_types = atom_types, tp.in_temb = t_emb, tp.in_lat = lattices, tp.in_frac = frac;
         } else {
-            MI_HIP(hipMemcpyAsync(tp.atom_types, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
-            MI_HIP(hipMemcpyAsync(tp.t_emb, t_emb, (size_t)B * TD * 4, hipMemcpyDeviceToDevice, s));
+            float* const types_dst = hw ? tp.w_types + hslot * N * MI_NUM_TYPES : tp.atom_types;   // (what the deferred contraction reads must outlive this micro-step)
+            float* const temb_dst = hw ? tp.w_temb + hslot * B * TD : tp.t_emb;
+            MI_HIP(hipMemcpyAsync(types_dst, atom_types, (size_t)N * MI_NUM_TYPES * 4, hipMemcpyDeviceToDevice, s));
+            MI_HIP(hipMemcpyAsync(temb_dst, t_emb, (size_t)B * TD * 4, hipMemcpyDeviceToDevice, s));
             MI_HIP(hipMemcpyAsync(tp.lattices, lattices, (size_t)B * 9 * 4, hipMemcpyDeviceToDevice, s));
             MI_HIP(hipMemcpyAsync(tp.frac, frac, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
-            tp.in_types = tp.atom_types, tp.in_temb = tp.t_emb, tp.in_lat = tp.lattices, tp.in_frac = tp.frac;
+            tp.in_types = types_dst, tp.in_temb = temb_dst, tp.in_lat = tp.lattices, tp.in_frac = tp.frac;
         }
     }
     // ---- embedding (cspnet.py:265-271) ----
@@ -1330,7 +1337,7 @@ int net_forward(mi_net* net, mi_batch* b, const float* t_emb, const float* atom_
     // (coords_only -- the sampler's corrector evaluation, which reads the coordinate score alone, diffusion.py:310-322: no type columns above, no lattice head)
     if (!(coords_only && (g_eval_reuse & 4)))
         hipLaunchKernelGGL(lattice_head_kernel, dim3(B), dim3(256), (2 * H + 12) * sizeof(float), s, b->hf, b->node_off,
-                           net->p("lattice_out.weight"), lattices, lattice_out, train ? tp.gf : (float*)nullptr, H);
+                           net->p("lattice_out.weight"), lattices, lattice_out, train ? (hw ? tp.w_gf + hslot * B * H : tp.gf) : (float*)nullptr, H);
     MI_KERNEL_CHECK();
     tp.valid = train;
     return MI_OK;
@@ -1686,6 +1693,8 @@ static int batch_create_impl(const mi_net* net, const int* num_atoms_host, int B
     A_(x1, NH);
     A_(tproj, (size_t)B * H);
     A_(hf, NH);
+    b->x1_base = b->x1;   // (x1 / hf point into the weight-gradient window's slot while a training forward with an open window runs: net_forward)
+    b->hf_base = b->hf;
     A_(temb, (size_t)B * net->TD);
     A_(times, B);
     A_(pred_l, (size_t)B * 9);
@@ -1892,6 +1901,7 @@ int mi_debug_set_tn128(int on) {
     g_bwd_dz2_planes = (on & 32) == 0;  // +32: dM1 data gradient on the on-the-fly three-plane bf16 split instead of the fp16 plane GEMM
     g_bwd_pairs_tile = (on & 128) == 0;  // +128: the thread-per-column form of the fused pair-mode backward pass instead of the LDS-tile form
     g_bwd_wgrad_planes = (on & 256) == 0;   // +256: edge_mlp.2's weight gradient from fp32 rows (split, SiLU and transposition on the way into LDS) instead of from the M1 / dZ2 plane sets
+    g_bwd_head_window = (on & 512) == 0;   // +512: the head / embedding weight gradients in every backward instead of in the deferred window (applies to windows sized afterwards)
     g_bwd_wgrad_f16 = (on & 64) == 0;   // +64: edge-level weight gradients on three bf16 planes / six terms instead of two fp16 planes / three
     return MI_OK;
 }

@@ -100,6 +100,16 @@ struct Tape {
     // dPQ; net_wgrad_flush contracts rows 0 .. wcur x N and resets wcur (automatically when the window is full).
     int wslots = 0, wcap = 0, wcur = 0;
     float *w_dY = nullptr, *w_Xa = nullptr, *w_dXa = nullptr, *w_cat = nullptr, *w_dPQ = nullptr;
+    // ... and (round 6) the HEAD and EMBEDDING weight gradients in the same window -- six short contractions + three column sums per micro-step, each with its
+    // own partial reduction (18 launches), become the same nine over wslots x the rows.  Their operand rows, layout [wslots][rows][width], slot `wcur`:
+    //   w_dlo [B,12] | w_gf [B,H] -> lattice_out.weight      w_dtype [N,100] | w_hf [N,H] -> type_out.weight / bias      w_dcoord [N,3] | w_hf -> coord_out.weight
+    //   w_dh [N,H] | w_x1 [N,H] -> atom_latent_emb.weight[:, :H] / bias      w_dtproj [B,H] | w_temb [B,TD] -> atom_latent_emb.weight[:, H:]
+    //   w_eXa [N,H] | w_types [N,100] -> node_embedding.weight / bias
+    // The training forward and the backward write them IN PLACE: while a window is open, the batch's x1 / hf, the tape's gf / dlo / dtproj / d h and the
+    // micro-step's noised types, time embedding and gradient seeds LIVE in the slot (the pointer accessors below); nothing is copied on the fused route.
+    float *w_dlo = nullptr, *w_gf = nullptr, *w_dtype = nullptr, *w_dcoord = nullptr, *w_hf = nullptr, *w_dh = nullptr, *w_x1 = nullptr, *w_dtproj = nullptr,
+          *w_temb = nullptr, *w_eXa = nullptr, *w_types = nullptr;
+    bool head_window() const { return wslots > 0 && w_hf != nullptr; }
 };
 
 struct mi_batch {
@@ -136,6 +146,7 @@ struct mi_batch {
     int *num_atoms = nullptr, *node_off = nullptr /*[B+1]*/, *node2graph = nullptr, *src = nullptr, *dst = nullptr,
         *rowptr = nullptr /*[N+1]*/, *edge_graph = nullptr /*[E]*/;
     // forward workspace (device)
+    float *x1_base = nullptr, *hf_base = nullptr;   // the handle's own x1 / hf buffers (x1 / hf point into the weight-gradient window's slot while a training forward with an open window runs)
     float* h = nullptr;      // [L+1][N][H] node features before layer l / after the last
     float* cat = nullptr;    // [N][2H]  (LN(h) | agg)
     float* PQ = nullptr;     // [N][2H]
@@ -209,7 +220,7 @@ extern int g_node_bwd, g_node_bwd_min_blocks;
 size_t node_bwd_pack_elems(int H);
 bool node_bwd_supported(const mi_net* net, const mi_batch* b);
 int node_bwd_pack(mi_net* net, int l, const float* W1, const float* Wn0, const float* Wn2, hipStream_t s);
-int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dY, float* dXa, float* Xa, float* lnpart, unsigned* dcat_absmax, hipStream_t s);
+int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dh, float* dY, float* dXa, float* Xa, float* lnpart, unsigned* dcat_absmax, hipStream_t s);
 // node_chain.hip: the node-level chain between two edge stages of an inference forward as one launch
 bool node_chain_supported(const mi_net* net);
 size_t node_chain_pack_elems(int H);

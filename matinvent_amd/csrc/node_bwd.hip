@@ -487,13 +487,13 @@ int node_bwd_pack(mi_net* net, int l, const float* W1, const float* Wn0, const f
 
 // The launch at the boundary below layer `l` (l = L: the first launch of a backward pass, phase A of layer L - 1 only; l = 0: phase B of layer 0 only).
 //   dPQ / cat-side operands of layer l, the window-slot pointers of layer l - 1 (dY, dXa, Xa) and the LayerNorm partial sums' scratch come from the caller.
-int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dY, float* dXa, float* Xa, float* lnpart, unsigned* dcat_absmax, hipStream_t s) {
+int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dh, float* dY, float* dXa, float* Xa, float* lnpart, unsigned* dcat_absmax, hipStream_t s) {
     const int H = net->H, L = net->L, N = b->N;
     Tape& t = b->tape;
     const size_t NH = (size_t)N * H, one = (size_t)H * H * 2;
     NodeBwdArgs a;
     a.N = N;
-    a.dh = t.dh;
+    a.dh = dh;
     if (l < L) {
         const std::string p = "csp_layer_" + std::to_string(l) + ".";
         const u16* base = net->Wbw + (size_t)l * node_bwd_pack_elems(H);
@@ -529,7 +529,7 @@ int node_bwd(mi_net* net, mi_batch* b, int l, const float* dPQ, float* dY, float
 size_t node_bwd_pack_elems(int) { return 0; }
 bool node_bwd_supported(const mi_net*, const mi_batch*) { return false; }
 int node_bwd_pack(mi_net*, int, const float*, const float*, const float*, hipStream_t) { return MI_OK; }
-int node_bwd(mi_net*, mi_batch*, int, const float*, float*, float*, float*, float*, unsigned*, hipStream_t) { return MI_ESTATE; }
+int node_bwd(mi_net*, mi_batch*, int, const float*, float*, float*, float*, float*, float*, unsigned*, hipStream_t) { return MI_ESTATE; }
 #endif
 
 }  // namespace mi

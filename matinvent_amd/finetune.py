@@ -391,7 +391,8 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     # agent's batch handles keep the operand rows of up to WGRAD_WINDOW micro-steps (see include/matinvent_hip.h).
     window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
     dec = agent.decoder
-    slot_bytes = 7 * max(nodes[k + 1] - nodes[k] for k in range(groups)) * dec.hidden_dim * dec.num_layers * 4   # operand rows of one micro-step
+    nmax_ = max(nodes[k + 1] - nodes[k] for k in range(groups))
+    slot_bytes = (7 * dec.hidden_dim * dec.num_layers + 4 * dec.hidden_dim + 203) * nmax_ * 4   # operand rows of one micro-step: node-level linears + heads / embedding
     # at most 8 GB of kept rows per group AND 24 GB over all groups (the windows of the groups are live together)
     window = max(0, min(window, (8 << 30) // max(1, slot_bytes), (24 << 30) // max(1, slot_bytes * groups)))
     handles = []

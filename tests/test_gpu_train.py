@@ -519,8 +519,9 @@ def test_add_noise_sampled_times_golden(golden):
     _rel(loss, g["loss"], 3e-5, "sample loss")
 
 
+@pytest.mark.parametrize("head_window", [True, False], ids=["heads-and-embedding-in-the-window", "node-level-linears-only"])
 @pytest.mark.parametrize("H,L,F,na", [(64, 2, 8, [5, 1, 7, 3, 4]), (512, 2, 16, [20] * 12 + [7, 1, 13])], ids=["small-ragged", "benchmark-width"])
-def test_node_level_weight_gradients_over_a_window_of_micro_steps(H, L, F, na):
+def test_node_level_weight_gradients_over_a_window_of_micro_steps(H, L, F, na, head_window):
     """mi_batch_set_wgrad_window: the node-level linears' weight gradients of k micro-steps contracted together (rows of all k
     micro-steps in ONE product per weight, include/matinvent_hip.h) against the immediate form, five micro-steps with a window of
     three -- one automatic contraction when the window is full, one by mi_cspnet_wgrad_flush for the two left over.  Same sums in
@@ -534,6 +535,8 @@ def test_node_level_weight_gradients_over_a_window_of_micro_steps(H, L, F, na):
     rewards = torch.rand(len(na), generator=gen).numpy()
     ds = CrystalDataset(data, rewards)
     out = []
+    from matinvent_amd import _lib
+    _lib.check(_lib.load().mi_debug_set_tn128(3 if head_window else 3 + 512))   # (+512: the head / embedding weight gradients stay in every backward; round 6 put them into the window)
     for window in (0, 3):
         agent, prior = make_module(H, L, F, 1000, O.init_params(hp, seed=5)), make_module(H, L, F, 1000, O.init_params(hp, seed=6))
         prior.requires_grad_(False)
@@ -553,9 +556,13 @@ def test_node_level_weight_gradients_over_a_window_of_micro_steps(H, L, F, na):
         torch.cuda.synchronize()
         gc = grad.cpu()
         out.append((gc, acc.cpu(), {k: gc[o:o + n].view(shape) for k, (o, n, shape) in agent.decoder.layout.items()}))
+    _lib.check(_lib.load().mi_debug_set_tn128(3))
     (g0, a0, v0), (g1, a1, v1) = out
     assert torch.equal(a0, a1)   # losses do not depend on the gradient route
     deferred = ("node_mlp.0.weight", "node_mlp.0.bias", "node_mlp.2.weight", "node_mlp.2.bias", "edge_mlp.0.weight")
+    if head_window:
+        deferred += ("lattice_out.weight", "type_out.weight", "type_out.bias", "coord_out.weight", "atom_latent_emb.weight", "atom_latent_emb.bias",
+                     "node_embedding.weight", "node_embedding.bias")
     for k in v0:
         scale = float(v0[k].abs().max())
         err = float((v0[k] - v1[k]).abs().max())
