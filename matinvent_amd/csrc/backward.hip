@@ -463,9 +463,14 @@ __global__ void graph_sum_kernel(const float* __restrict__ X, int ldx, const int
 // gram term backward: gW1[f][2H+m] += sum_b dG[b][f] * gram_b[m];  gb1[f] += sum_b dG[b][f]
 // 32 features x 8 graph groups per block (graph sums combined through LDS in a fixed order): with one thread per feature looping
 // over all graphs the whole job was two workgroups and 96 us of latency.
+// gridDim.y > 1: one layer per blockIdx.y -- dG of layer y at dG + y * dg_stride, its weight / bias gradient at gW1 / gb1 + y * w_stride (every layer's
+// parameter block has the same size): all layers of a backward pass in ONE launch behind the loop instead of one launch per layer.
 __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ lattices, float* __restrict__ gW1,
-                                                       int edge_in, float* __restrict__ gb1, int B, int H) {
+                                                       int edge_in, float* __restrict__ gb1, int B, int H, size_t dg_stride = 0, size_t w_stride = 0) {
     __shared__ float red[8][10][32];
+    dG += (size_t)blockIdx.y * dg_stride;
+    gW1 += (size_t)blockIdx.y * w_stride;
+    gb1 += (size_t)blockIdx.y * w_stride;
     const int fl = threadIdx.x & 31, bg = threadIdx.x >> 5, f = blockIdx.x * 32 + fl;
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = 0.f;
     if (f < H)
@@ -778,7 +783,7 @@ static int alloc_tape(mi_net* net, mi_batch* b) {
     T_(Xa, N * H);
     T_(dcat, N * 2 * H);
     T_(dPQ, N * 2 * H);
-    T_(dG, B * H);
+    T_(dG, L * B * H);   // one [B][H] slot per layer: the lattice term's weight gradient of all layers is one launch behind the loop
     T_(dgf, B * H);
     T_(dlo, B * 12);
     T_(dtproj, B * H);
@@ -979,6 +984,8 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
     const size_t ln_slot = (size_t)cdiv(N, 32) * 2 * H;
     const bool ln_batched = nb && L >= 2 && t.lnpart != nullptr;
     float* const ln_tail = t.lnpart;
+    const bool gram_batched = L >= 2 && net->off("csp_layer_1.edge_mlp.0.bias") - net->off("csp_layer_0.edge_mlp.0.bias") ==
+                                            net->off("csp_layer_1.edge_mlp.0.weight") - net->off("csp_layer_0.edge_mlp.0.weight");
     // (the operand rows of layer `layer`'s node-level weight gradients: slot t.wcur of the deferred window, or the tape's single buffers)
     auto w_rows = [&](int layer, float** dYp, float** Xap, float** dXap) {
         const size_t r = defer ? (size_t)layer * t.wslots * N + (size_t)t.wcur * N : 0;
@@ -1005,6 +1012,7 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         float* dXa = defer ? t.w_dXa + wr * H : t.dXa;
         float* dPQ = defer ? t.w_dPQ + wr * 2 * H : t.dPQ;
         unsigned* const am = nb ? b->absmax + 2 * L + 2 + 2 * l : b->absmax + 2 * L;   // this layer's {max |d cat|, max |dM1|}
+        float* const dGl = t.dG + (size_t)l * B * H;   // this layer's d G (per crystal): kept until the batched lattice-term weight gradient behind the loop
         float* Z1 = t.Z1 + (size_t)l * E * H;
         float* Z2 = t.Z2 + (size_t)l * E * H;
         const float* Xpre = t.Xpre + (size_t)l * NH;
@@ -1126,16 +1134,16 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
 #if MI_PLANES_FP16
                     if (wff_planes)
                         hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
-                                           Dp, dPQ, t.dG, sc, H, am + 1, b->dsc + 8, dmp, dpp);
+                                           Dp, dPQ, dGl, sc, H, am + 1, b->dsc + 8, dmp, dpp);
                     else
 #endif
                     hipLaunchKernelGGL(edge_bwd_pairs_tile_kernel, dim3(B, cdiv(H, PAIRS_W)), dim3(256), sh, s, t.dM1, Z1, b->node_off, b->rowptr, b->pair_off, Dm,
-                                       Dp, dPQ, t.dG, sc, H, wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
+                                       Dp, dPQ, dGl, sc, H, wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_bcast_kernel, dim3(cdiv(H, 32), 12), dim3(256), 0, s, sc, B, H, gWff + 3 * F, net->edge_in, H, 3 * F);
                     MI_KERNEL_CHECK();
                 } else if (fused_pairs) {
                     hipLaunchKernelGGL(edge_bwd_pairs_kernel, dim3(B, cdiv(H, 128)), dim3(128), (size_t)2 * b->nmax_fc * 128 * sizeof(float), s, t.dM1,
-                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, dPQ, t.dG, sc, H,
+                                       Z1, b->node_off, b->rowptr, b->pair_off, Dm, Dp, dPQ, dGl, sc, H,
                                        wff_f16 ? am + 1 : nullptr, wff_f16 ? b->dsc + 8 : nullptr);
                     hipLaunchKernelGGL(part_reduce_kernel<>, dim3(cdiv(H, PART_REDUCE_COLS)), dim3(256), 0, s, sc, B, H, dsum, H);
                     MI_KERNEL_CHECK();
@@ -1174,9 +1182,9 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         } else {
             MI_HIP(hipMemsetAsync(dPQ, 0, NH * 2 * 4, s));
         }
-        if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dPQ, 2 * H, b->node_off, t.dG, B, H);
-        hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, t.dG, t.in_lat, G(p + "edge_mlp.0.weight"), net->edge_in,
-                           G(p + "edge_mlp.0.bias"), B, H);
+        if (!edge_sums_done) hipLaunchKernelGGL(graph_sum_kernel, g1((int64_t)B * H), dim3(256), 0, s, dPQ, 2 * H, b->node_off, dGl, B, H);
+        if (!gram_batched) hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32)), dim3(256), 0, s, dGl, t.in_lat, G(p + "edge_mlp.0.weight"), net->edge_in,
+                                              G(p + "edge_mlp.0.bias"), B, H, (size_t)0, (size_t)0);
         MI_KERNEL_CHECK();
         if (!defer) {
             MI_TRY(gemm_tn_auto(dPQ, 2 * H, cat, 2 * H, G(p + "edge_mlp.0.weight"), net->edge_in, N, H, H, sc, scf, s));
@@ -1205,6 +1213,12 @@ int net_backward(mi_net* net, mi_batch* b, const float* d_lat, const float* d_co
         }
     }
 
+    if (gram_batched) {   // the lattice term's weight / bias gradient of every layer: one launch (gridDim.y = L) over the per-layer d G slots
+        const size_t stride = net->off("csp_layer_1.edge_mlp.0.weight") - net->off("csp_layer_0.edge_mlp.0.weight");
+        hipLaunchKernelGGL(gram_bwd_kernel, dim3(cdiv(H, 32), L), dim3(256), 0, s, t.dG, t.in_lat, G("csp_layer_0.edge_mlp.0.weight"), net->edge_in,
+                           G("csp_layer_0.edge_mlp.0.bias"), B, H, (size_t)B * H, stride);
+        MI_KERNEL_CHECK();
+    }
     if (ln_batched) {   // (every layer's parameter block has the same size: a constant stride between the layers' LayerNorm weights)
         const size_t stride = net->off("csp_layer_1.layer_norm.weight") - net->off("csp_layer_0.layer_norm.weight");
         hipLaunchKernelGGL(part_reduce_batched_kernel, dim3(cdiv(2 * H, 32), L), dim3(256), 0, s, ln_tail, ln_slot, cdiv(N, 32), 2 * H,
