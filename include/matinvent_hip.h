@@ -234,10 +234,12 @@ int mi_cspnet_backward(mi_net* net, mi_batch* b, const float* d_lattice_out, con
  * `.backward()` on its own, pipeline/mat_invent.py:164; between two optimizer steps, :166-167, the weights are constant, so the
  * gradient of a linear over k micro-steps is one contraction over k x N rows).  mi_batch_set_wgrad_window(net, b, k), k in 1..64:
  * training forwards / backwards on `b` keep the operand rows of node_mlp.{0,2} and of the node part of edge_mlp.0 per micro-step
- * (7 N H floats per layer and micro-step) and contract them when k micro-steps are pending -- into the grad_theta of THAT backward
- * call -- or when mi_cspnet_wgrad_flush is called (before anything reads grad_theta: the optimizer step, an all-reduce).  k = 0
- * (default) restores the immediate form.  Every other gradient is accumulated by mi_cspnet_backward as before.  Same sums up to
- * fp32 summation order.  mi_batch_wgrad_pending: micro-steps not yet contracted. */
+ * (7 N H floats per layer and micro-step) -- and, since round 6, those of the heads and the embedding (lattice_out, type_out, coord_out,
+ * atom_latent_emb, node_embedding: (4 H + 203) N floats per micro-step, written in place into the window by the forward and the backward) -- and
+ * contract them when k micro-steps are pending -- into the grad_theta of THAT backward call -- or when mi_cspnet_wgrad_flush is called (before
+ * anything reads grad_theta: the optimizer step, an all-reduce).  k = 0 (default) restores the immediate form.  Every other gradient (the edge-level
+ * weights, the LayerNorms, the lattice term) is accumulated by mi_cspnet_backward as before.  Same sums up to fp32 summation order.
+ * mi_batch_wgrad_pending: micro-steps not yet contracted. */
 int mi_batch_set_wgrad_window(mi_net* net, mi_batch* b, int micro_steps);
 int mi_cspnet_wgrad_flush(mi_net* net, mi_batch* b, float* grad_theta, void* stream);
 int mi_batch_wgrad_pending(const mi_batch* b);
