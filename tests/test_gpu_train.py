@@ -206,6 +206,19 @@ def test_node_level_backward_chain_vs_oracle_and_vs_the_seven_launch_form(H, F):
         _rel(g_fused[o:o + cnt].cpu(), g_seven[o:o + cnt].cpu(), 1e-5, f"fused vs seven-launch, grad {k}")
 
 
+@pytest.mark.parametrize("na", [[7], [1, 1, 1], [20, 13]], ids=["one-partial-block", "three-single-atom-crystals", "33-atoms-two-blocks"])
+def test_node_level_backward_chain_on_batches_smaller_than_a_row_block(na):
+    """The fused backward chain forced onto batches of one or two 32-row blocks (it is off there by default: mi_debug_set_node_bwd's threshold): rows past the
+    atom count are masked in every phase -- the tile scale, the LayerNorm partial sums, the stores."""
+    from matinvent_amd import _lib
+    lib = _lib.load()
+    was = lib.mi_debug_set_node_bwd(1, 1)
+    try:
+        _grad_case(128, 2, 8, na, seed=17)
+    finally:
+        lib.mi_debug_set_node_bwd(was, 8)
+
+
 @pytest.mark.parametrize("node_train,tn", [(1, 3), (0, 3), (1, 3 + 256), (1, 3 + 4096)], ids=["node-chain-writes-the-tape", "seven-launch-node-level", "edge-weight-gradients-from-fp32-rows", "seven-launch-node-level-backward"])
 def test_gradients_vs_oracle_autograd_mid_size(node_train, tn):
     """The same check at a size where the large-problem kernels run in the training forward and the backward (B=96 x 20 atoms,
