@@ -117,7 +117,9 @@ WGRAD_WINDOW = 16  # micro-steps whose node-level weight gradients are contracte
 def auto_groups(e_total: int) -> int:
     """Concurrent crystal groups ft_step picks for a local set with `e_total` directed edges (measured at 256 x 20 atoms, round 3:
     16.1k / 16.7k / 17.3k / 13.9k / 11.7k crystal-timesteps/s with 2 / 3 / 4 / 6 / 8 groups)."""
-    return 4 if e_total >= 90000 else 2 if e_total >= 40000 else 1
+    # (round 6, after the fused backward chain and the contractions' share of the chip: 128 crystals x 20 atoms on 1 / 2 / 3 groups 16.3k / 17.0k / 17.6k,
+    #  64 crystals 12.65k / 12.46k / 12.1k, 256 crystals on 3 / 4 / 5 groups 21.3k / 21.7k / 17.0k: profiles/r6_strong_shapes.json)
+    return 4 if e_total >= 90000 else 3 if e_total >= 40000 else 1
 
 
 def _stack_plan(e_one, accum_steps, timesteps, stack):
