@@ -1029,6 +1029,7 @@ int node_chain_pack(mi_net* net, int l, const float* W1, const float* Wn0, const
 static int node_chain_once(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train);
 int node_chain(mi_net* net, mi_batch* b, int l, hipStream_t s, bool train) {
     if (g_ablate_skip & 1) return MI_OK;
+    if ((g_ablate_skip & 64) && !train) return MI_OK;   // (timing ablation: the INFERENCE forwards' chains only -- in a fine-tune micro-step: the frozen prior's)
     if (g_ablate_skip & 8) MI_TRY(node_chain_once(net, b, l, s, train));   // (timing experiment: every chain launched TWICE -- the second finds its weights in L2)
     return node_chain_once(net, b, l, s, train);
 }

@@ -391,12 +391,16 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
     # The weights only change at the optimizer step, so the node-level linears' weight gradients of a run of micro-steps are ONE
     # contraction over all their rows instead of one short contraction (1.7k rows per group at 256 x 20 atoms) per micro-step: the
     # agent's batch handles keep the operand rows of up to WGRAD_WINDOW micro-steps (see include/matinvent_hip.h).
-    window = min(accum_steps, timesteps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
+    # `cap`: the window a LATER call on these handles may ask for (its timesteps are not known here) -- the buffers are sized for it once, so that a short first
+    # call (a warm-up of three timesteps) is not followed by a reallocation -- sixteen hipFree / hipMalloc pairs per group, each a device synchronisation -- at the
+    # start of the next one (measured: a 20-timestep call behind a 3-timestep warm-up ran at 13.1 k instead of 19-21 k crystal-timesteps/s)
+    cap = min(accum_steps, WGRAD_WINDOW) if groups <= 8 else 0   # (_batch_for caches eight handles per module)
     dec = agent.decoder
     nmax_ = max(nodes[k + 1] - nodes[k] for k in range(groups))
     slot_bytes = (7 * dec.hidden_dim * dec.num_layers + 4 * dec.hidden_dim + 203) * nmax_ * 4   # operand rows of one micro-step: node-level linears + heads / embedding
     # at most 8 GB of kept rows per group AND 24 GB over all groups (the windows of the groups are live together)
-    window = max(0, min(window, (8 << 30) // max(1, slot_bytes), (24 << 30) // max(1, slot_bytes * groups)))
+    cap = max(0, min(cap, (8 << 30) // max(1, slot_bytes), (24 << 30) // max(1, slot_bytes * groups)))
+    window = min(cap, timesteps)
     handles = []
     for k in range(groups):
         agent.shard_offsets = offs[k]
@@ -404,6 +408,8 @@ def _ft_step_grouped(agent, prior, dataset, lo, hi, node_lo, n_global, groups, l
         handles.append(ab)
     try:
         for ab in handles:
+            if cap > window > 1:
+                ab.set_wgrad_window(agent.decoder, cap)   # (reserves the buffers; the line below only lowers the slot count)
             ab.set_wgrad_window(agent.decoder, window if window > 1 else 0)
     except _lib.MIError as e:   # the window is an optimisation: out of memory for it -> the immediate form, not a failed fine-tune step
         if e.code != _lib.MI_ENOMEM:
