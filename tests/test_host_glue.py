@@ -184,3 +184,41 @@ def test_reward_scaling_modes_follow_the_reference(tmp_path):
     d = PyMatGen(task="density").calc(([s], None))
     assert abs(d[0] - (55.845 + 15.999) * 1.66053906660 / 64.0) < 1e-6
     assert np.isnan(PyMatGen(task="hhi").calc(([s], None))[0])  # no table offline -> failed sample, like the reference's except branch
+
+
+_W1 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from matinvent_amd import dist as D
+dist.init_process_group("gloo", rank=0, world_size=1)
+x = torch.arange(10, dtype=torch.float32)
+calls = []
+orig = dist.all_reduce
+dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+assert not D.collectives_on()                       # a one-rank group runs no collective by default
+D.allreduce_flat_(x)
+assert D.all_gather_objects("a") == ["a"] and D.broadcast_object(3) == 3 and calls == []
+os.environ["MI_DIST_FORCE_COLLECTIVES"] = "1"       # ... unless asked to: how the RCCL lines are executed on a one-GPU box
+assert D.collectives_on()
+y = D.allreduce_flat_(x.clone())
+assert torch.equal(y, x) and calls == [10]          # SUM over one rank = identity, and the collective really ran
+assert D.all_gather_objects({"k": 1}) == [{"k": 1}] and D.broadcast_object([1, 2]) == [1, 2]
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_forced_collectives_on_a_one_rank_group(tmp_path):
+    """matinvent_amd.dist.collectives_on: a world-size-1 process group skips its collectives unless MI_DIST_FORCE_COLLECTIVES=1 -- the switch that lets ONE GPU execute
+    every line of the RCCL path (tests/test_gpu_multirank.py::test_world_size_one_rccl_group_runs_every_collective, bench.py --force-dist).  Here on gloo / CPU."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "w1.py"
+    script.write_text(_W1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("MI_DIST_FORCE_COLLECTIVES", None)
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
