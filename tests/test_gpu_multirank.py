@@ -205,6 +205,10 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
                {"MI_BENCH_SHARE_GPU": "1"})
     assert g["n_gpus"] == 2 and g["value"] > 0 and g["config"]["comm_backend"] == "gloo" and g["config"]["world_size"] == 2
     assert g["hbm_roofline"]["frac"] > 0 and g["hbm_roofline"]["algorithmic_bytes_per_crystal_evaluation"] > 1e6
+    # strong scaling: ONE global batch of 256 cut over the two ranks (128 crystals each, global ids in the noise counters); value = all crystals / max-over-ranks time
+    st = _bench(["--gpus", "2", "--scaling", "strong", "--steps", "3", "--warmup", "1"], {"MI_BENCH_SHARE_GPU": "1"})
+    assert st["n_gpus"] == 2 and st["scaling"] == "strong" and st["config"]["batch_per_gpu"] == 128 and "sharded over 2 rank(s)" in st["config"]["workload"]
+    assert abs(st["value"] - 2 * 128 * 3 / (1000 * st["ms_per_step"] * 3e-3)) < 1e-6 * st["value"]
 
 
 def test_bench_refuses_more_ranks_than_gpus_with_a_message():
