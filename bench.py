@@ -950,6 +950,10 @@ def main():
     final, _ = m.sample(cb, seed=SEED_NOISE, t_start=T, t_stop=T, **skw)
     state = (final["frac_coords"], final["lattices"], final["atom_types"])
     m._coefficients(STEP_LR)
+    preheat = int(os.environ.get("MI_BENCH_PREHEAT_STEPS", "0") or 0)
+    if preheat > 0:   # (experiment: untimed steps of a throwaway chain in front of everything -- does a FIRST process of a lease then measure like a later one?)
+        m.sample(cb, seed=SEED_NOISE + 3, t_start=T, t_stop=max(0, T - preheat), **skw)
+        torch.cuda.synchronize()
     if gc_early:
         gc.collect()   # (everything the host has to do between the warm-up and the window is done BEFORE the warm-up: a generation-2 collection of a torch
         #  process takes tens of ms, during which an idle part drops its power state -- the warm-up steps are meant to be the last thing the GPU did)
